@@ -1,0 +1,155 @@
+/*
+ * include/somar_amd.h -- C ABI of libsomar_amd.so: MI355X-native (gfx950, HIP) drop-in for
+ * the pressure-projection hot path of UNC-CFD/somar.
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  Every entry point returns 0 on
+ * success and a negative code on failure (somar_last_error() gives the text); nothing
+ * aborts the process -- the reference's MayDay::Error sites ("kaboom",
+ * MappedAMRMultiGrid.H:1136,1144) are reported through somar_stats_t.status instead.
+ *
+ * What each group replaces in the reference (paths relative to /root/reference/src):
+ *
+ *  somar_solver_create / _set_metric_ortho / _finalize
+ *      AMRPressureSolver::levelDefine / define          projection/AMRPressureSolver.cpp:163-314, 321-463
+ *      MappedAMRPoissonOpFactory::define                calculus/AMRElliptic/MappedAMRPoissonOpFactory.cpp:95-205
+ *      MappedAMRMultiGrid<T>::define                    calculus/AMRElliptic/MappedAMRMultiGrid.H:1407-1492
+ *      (metric arrays = LevelGeometry::getFCJgupPtr / getCCJinvPtr, geometry/LevelGeometry.H:139-286)
+ *  somar_params_t
+ *      AMRPressureSolver::setAMRMGParameters / setBottomParameters   projection/AMRPressureSolver.H:53-77
+ *  somar_solver_solve / somar_solver_solve_host
+ *      AMREllipticSolver<LevelData<FArrayBox>>::solve(phi, rhs, l_max, l_base, zeroPhi, forceHomogeneous)
+ *                                                       calculus/AMRElliptic/AMREllipticSolver.H:33-48
+ *      as called from AMRPressureSolver::solve          projection/AMRPressureSolver.cpp:494-561
+ *  somar_stats_t.exit_status
+ *      MappedAMRMultiGrid<T>::m_exitStatus              calculus/AMRElliptic/MappedAMRMultiGrid.H:545, 1148
+ *  somar_level_relax / _residual / _apply_op / _restrict_residual / _prolong_increment / _precond
+ *      RelaxationMethod::relax                          calculus/AMRElliptic/RelaxationMethods/RelaxationMethod.H:34-52
+ *      MappedAMRPoissonOp::residual/applyOp/restrictResidual/preCond
+ *                                                       calculus/AMRElliptic/MappedAMRPoissonOp.cpp:628-765, 1281-1304, 684-734
+ *      ProlongationStrategy::prolongIncrement           calculus/AMRElliptic/MGStrategies/ProlongationStrategy.H:35-48
+ *  somar_vcycle
+ *      MappedMultiGrid<T>::oneCycle                     calculus/AMRElliptic/MappedMultiGrid.H:528-548
+ *
+ * Host arrays use the Chombo BaseFab layout the Fortran kernels see (FORT_PROTO FRA):
+ * column-major, inclusive [lo,hi] box, i fastest; a face-centred array in direction a spans
+ * faces(valid, a) = valid with hi[a]+1, face i being the LOW face of cell i.
+ * Ownership: host buffers stay caller-owned; device buffers belong to the handle.
+ * Threading: one host thread drives one handle; distinct handles are independent.
+ */
+#ifndef SOMAR_AMD_H
+#define SOMAR_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOMAR_AMD_ABI_VERSION 1
+
+/* BCType codes, calculus/BCInterface/BCDescriptor.H:34-39 */
+#define SOMAR_BC_NONE (-1)
+#define SOMAR_BC_NEUM 0
+#define SOMAR_BC_DIRI 1
+
+/* RelaxMode / PrecondMode, utils/ProblemContext.H:322-340 */
+#define SOMAR_RELAX_JACOBI 0
+#define SOMAR_RELAX_LEVEL_GSRB 1
+#define SOMAR_PRECOND_NONE (-1)
+#define SOMAR_PRECOND_DIAG_RELAX 0
+
+typedef struct somar_solver somar_solver_t; /* opaque */
+
+typedef struct somar_params {
+    /* AMRMG.* (utils/ProblemContext.cpp:1147-1201) */
+    int imin, imax;
+    double eps, hang, norm_thresh;
+    int num_smooth_down, num_smooth_up, num_smooth_bottom, num_smooth_precond;
+    int num_mg, max_depth, precond_mode, relax_mode, verbosity;
+    /* bottom.* (utils/ProblemContext.cpp:1207-1231) */
+    int bottom_imax, bottom_num_restarts, bottom_norm_type, bottom_verbosity;
+    double bottom_eps, bottom_reps, bottom_hang, bottom_small;
+} somar_params_t;
+
+#define SOMAR_MAX_HISTORY 64
+typedef struct somar_stats {
+    int iters;
+    int exit_status; /* !goRedu + 2*!goIter + 4*!goHang + 8*!goNorm */
+    int status;      /* 0 ok, 1 "kaboom" (residual grew 10x), 2 "solver blew up" */
+    int bottom_iters, bottom_exit;
+    int nhistory;
+    double initial_rnorm, final_rnorm;
+    double history[SOMAR_MAX_HISTORY]; /* max-norm residual: [0] initial, [k] after V-cycle k */
+} somar_stats_t;
+
+/* resident field handles: which | (depth << 8) */
+#define SOMAR_F_PHI 0     /* depth 0: the solution        */
+#define SOMAR_F_RHS 1     /* depth 0: the right-hand side */
+#define SOMAR_F_RES 2     /* residual   at this depth (depth 0: uberResidual)   */
+#define SOMAR_F_CORR 3    /* correction at this depth (depth 0: uberCorrection) */
+#define SOMAR_F_BEST 4    /* depth 0: bestPhi */
+#define SOMAR_F_SCRATCH 5 /* per-depth scratch (fine residual before restriction) */
+#define SOMAR_FIELD(depth, which) (((depth) << 8) | (which))
+
+int somar_abi_version(void);
+const char* somar_last_error(void);
+int somar_device_count(int* count);
+int somar_params_default(somar_params_t* p);
+
+/* boxes: nboxes*6 ints {lo0,lo1,lo2,hi0,hi1,hi2}; owner: rank per box or NULL (all rank 0);
+ * bc_type: {loX,hiX,loY,hiY,loZ,hiZ}; comm: handle from somar_comm_* or NULL (single GPU). */
+int somar_solver_create(somar_solver_t** out, const int* domain_lo, const int* domain_hi, const int* periodic,
+                        const double* dx, const int* bc_type, int nboxes, const int* boxes, const int* owner,
+                        double alpha, double beta, const somar_params_t* prm, void* comm);
+int somar_solver_destroy(somar_solver_t* s);
+int somar_solver_num_local_patches(somar_solver_t* s, int* n);
+int somar_solver_patch_box(somar_solver_t* s, int depth, int patch, int* box6, int* global_index);
+/* Diagonal metric of local patch `patch`: Jg^{aa} over faces(valid,a) (1 comp), Jinv over valid. */
+int somar_solver_set_metric_ortho(somar_solver_t* s, int patch, const double* jg0, const double* jg1,
+                                  const double* jg2, const double* jinv);
+int somar_solver_finalize(somar_solver_t* s);
+int somar_solver_depth(somar_solver_t* s, int* depth);
+int somar_solver_mg_ref_ratio(somar_solver_t* s, int depth, int* r3); /* depth -> depth+1 */
+int somar_solver_zero_avg(somar_solver_t* s, int depth, int* flag);
+int somar_solver_level_info(somar_solver_t* s, int depth, int* domain6, double* dx3, long long* cells,
+                            long long* field_elems);
+
+/* host <-> HBM, one local patch; host array spans valid.grow(ghost). */
+int somar_field_upload(somar_solver_t* s, int field, int patch, const double* host, const int* ghost);
+int somar_field_download(somar_solver_t* s, int field, int patch, double* host, const int* ghost);
+int somar_field_set(somar_solver_t* s, int field, double value);
+int somar_field_fill_hash(somar_solver_t* s, int field, unsigned long long seed);
+int somar_field_norm(somar_solver_t* s, int field, int ord, double* out);
+int somar_field_dot(somar_solver_t* s, int field_a, int field_b, double* out);
+
+/* the solve on resident PHI/RHS */
+int somar_solver_solve(somar_solver_t* s, int zero_phi, int force_homogeneous, somar_stats_t* stats);
+/* AMREllipticSolver::solve on caller-owned host LevelData (one pointer per local patch). */
+int somar_solver_solve_host(somar_solver_t* s, double* const* phi, const int* phi_ghost,
+                            const double* const* rhs, const int* rhs_ghost, int l_max, int l_base,
+                            int zero_phi, int force_homogeneous, somar_stats_t* stats);
+
+/* level-operator pieces on resident fields (all fields must belong to `depth`) */
+int somar_level_relax(somar_solver_t* s, int depth, int phi_field, int rhs_field, int iters);
+int somar_level_residual(somar_solver_t* s, int depth, int out_field, int phi_field, int rhs_field);
+int somar_level_apply_op(somar_solver_t* s, int depth, int out_field, int phi_field);
+int somar_level_restrict_residual(somar_solver_t* s, int depth, int coarse_res_field, int phi_field, int rhs_field);
+int somar_level_prolong_increment(somar_solver_t* s, int depth, int phi_field, int coarse_corr_field);
+int somar_level_precond(somar_solver_t* s, int depth, int phi_field, int rhs_field);
+int somar_vcycle(somar_solver_t* s, int corr_field, int res_field);
+int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* iters, int* exit_code);
+
+/* stream control + HIP-event timing on the solver's own stream */
+int somar_sync(somar_solver_t* s);
+int somar_timer_start(somar_solver_t* s);
+int somar_timer_stop(somar_solver_t* s, double* milliseconds);
+
+/* one-process-per-GPU transport (RCCL over xGMI).  The unique id is created on rank 0 and
+ * distributed by the launcher (torch.distributed store / MPI / file). */
+#define SOMAR_COMM_ID_BYTES 128
+int somar_comm_unique_id(unsigned char* id128);
+int somar_comm_create(void** comm, const unsigned char* id128, int rank, int nranks, int device);
+int somar_comm_destroy(void* comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOMAR_AMD_H */

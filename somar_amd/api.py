@@ -1,0 +1,346 @@
+"""ctypes binding of libsomar_amd.so + a Python mirror of the reference's AMRPressureSolver interface
+(projection/AMRPressureSolver.H:42-172: setAMRMGParameters, setBottomParameters, define, solve, undefine)
+so the parity tests read like calls into the reference.  No computation happens here and there is no
+CPU fallback: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+BC_NONE, BC_NEUM, BC_DIRI = -1, 0, 1
+F_PHI, F_RHS, F_RES, F_CORR, F_BEST, F_SCRATCH = 0, 1, 2, 3, 4, 5
+MAX_HISTORY = 64
+COMM_ID_BYTES = 128
+
+
+def FIELD(depth, which):
+    return (depth << 8) | which
+
+
+class SomarError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("imin", C.c_int), ("imax", C.c_int), ("eps", C.c_double), ("hang", C.c_double),
+                ("norm_thresh", C.c_double), ("num_smooth_down", C.c_int), ("num_smooth_up", C.c_int),
+                ("num_smooth_bottom", C.c_int), ("num_smooth_precond", C.c_int), ("num_mg", C.c_int),
+                ("max_depth", C.c_int), ("precond_mode", C.c_int), ("relax_mode", C.c_int), ("verbosity", C.c_int),
+                ("bottom_imax", C.c_int), ("bottom_num_restarts", C.c_int), ("bottom_norm_type", C.c_int),
+                ("bottom_verbosity", C.c_int), ("bottom_eps", C.c_double), ("bottom_reps", C.c_double),
+                ("bottom_hang", C.c_double), ("bottom_small", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iters", C.c_int), ("exit_status", C.c_int), ("status", C.c_int), ("bottom_iters", C.c_int),
+                ("bottom_exit", C.c_int), ("nhistory", C.c_int), ("initial_rnorm", C.c_double),
+                ("final_rnorm", C.c_double), ("history", C.c_double * MAX_HISTORY)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libsomar_amd.so")
+
+
+# name -> argtypes; every function returns int (0 ok) except somar_last_error
+_PD, _PI = C.POINTER(C.c_double), C.POINTER(C.c_int)
+_H = C.c_void_p
+_SIGS = {
+    "somar_abi_version": [],
+    "somar_device_count": [_PI],
+    "somar_params_default": [C.POINTER(Params)],
+    "somar_solver_create": [C.POINTER(_H), _PI, _PI, _PI, _PD, _PI, C.c_int, _PI, _PI, C.c_double, C.c_double,
+                            C.POINTER(Params), _H],
+    "somar_solver_destroy": [_H],
+    "somar_solver_num_local_patches": [_H, _PI],
+    "somar_solver_patch_box": [_H, C.c_int, C.c_int, _PI, _PI],
+    "somar_solver_set_metric_ortho": [_H, C.c_int, _PD, _PD, _PD, _PD],
+    "somar_solver_finalize": [_H],
+    "somar_solver_depth": [_H, _PI],
+    "somar_solver_mg_ref_ratio": [_H, C.c_int, _PI],
+    "somar_solver_zero_avg": [_H, C.c_int, _PI],
+    "somar_solver_level_info": [_H, C.c_int, _PI, _PD, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)],
+    "somar_field_upload": [_H, C.c_int, C.c_int, _PD, _PI],
+    "somar_field_download": [_H, C.c_int, C.c_int, _PD, _PI],
+    "somar_field_set": [_H, C.c_int, C.c_double],
+    "somar_field_fill_hash": [_H, C.c_int, C.c_ulonglong],
+    "somar_field_norm": [_H, C.c_int, C.c_int, _PD],
+    "somar_field_dot": [_H, C.c_int, C.c_int, _PD],
+    "somar_solver_solve": [_H, C.c_int, C.c_int, C.POINTER(Stats)],
+    "somar_solver_solve_host": [_H, C.POINTER(_PD), _PI, C.POINTER(_PD), _PI, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.POINTER(Stats)],
+    "somar_level_relax": [_H, C.c_int, C.c_int, C.c_int, C.c_int],
+    "somar_level_residual": [_H, C.c_int, C.c_int, C.c_int, C.c_int],
+    "somar_level_apply_op": [_H, C.c_int, C.c_int, C.c_int],
+    "somar_level_restrict_residual": [_H, C.c_int, C.c_int, C.c_int, C.c_int],
+    "somar_level_prolong_increment": [_H, C.c_int, C.c_int, C.c_int],
+    "somar_level_precond": [_H, C.c_int, C.c_int, C.c_int],
+    "somar_vcycle": [_H, C.c_int, C.c_int],
+    "somar_bottom_solve": [_H, C.c_int, C.c_int, _PI, _PI],
+    "somar_sync": [_H],
+    "somar_timer_start": [_H],
+    "somar_timer_stop": [_H, _PD],
+    "somar_comm_unique_id": [C.POINTER(C.c_ubyte)],
+    "somar_comm_create": [C.POINTER(_H), C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int],
+    "somar_comm_destroy": [_H],
+}
+EXPORTS = sorted(list(_SIGS) + ["somar_last_error"])
+
+
+def lib():
+    """Load libsomar_amd.so (fails loudly if it has not been built: there is no fallback)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise SomarError("%s is missing: run `python -m somar_amd.build` (hipcc, gfx950). "
+                             "somar_amd has no CPU fallback." % p)
+        L = C.CDLL(p)
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        L.somar_last_error.restype = C.c_char_p
+        L.somar_last_error.argtypes = []
+        _LIB = L
+    return _LIB
+
+
+def _ck(rc):
+    if rc != 0:
+        raise SomarError("libsomar_amd error %d: %s" % (rc, lib().somar_last_error().decode()))
+
+
+def _ia(v):
+    return (C.c_int * len(v))(*[int(x) for x in v])
+
+
+def _da(v):
+    return (C.c_double * len(v))(*[float(x) for x in v])
+
+
+def _dp(a):
+    assert a.dtype == np.float64 and a.flags["F_CONTIGUOUS"]
+    return a.ctypes.data_as(_PD)
+
+
+class AMRPressureSolver:
+    """Mirror of projection/AMRPressureSolver.H.  Boxes are (lo, hi) integer 3-tuples; host FABs are
+    Fortran-ordered numpy arrays over valid.grow(ghost)."""
+
+    def __init__(self):
+        self._p = Params()
+        _ck(lib().somar_params_default(C.byref(self._p)))
+        self._h = None
+        self._comm = None
+        self.exitStatus = 0
+        self.stats = None
+
+    # -- AMRPressureSolver.H:53-77 ----------------------------------------------------------------
+    def setAMRMGParameters(self, imin, imax, eps, maxDepth, num_precond_iters, num_smooth_down, num_smooth_up,
+                           num_smooth_bottom, precondMode, relaxMode, numMG, hang, norm_thresh, verbosity):
+        assert self._h is None, "setAMRMGParameters can only be called before define"
+        p = self._p
+        p.imin, p.imax, p.eps, p.max_depth = imin, imax, eps, maxDepth
+        p.num_smooth_precond, p.num_smooth_down, p.num_smooth_up = num_precond_iters, num_smooth_down, num_smooth_up
+        p.num_smooth_bottom, p.precond_mode, p.relax_mode, p.num_mg = num_smooth_bottom, precondMode, relaxMode, numMG
+        p.hang, p.norm_thresh, p.verbosity = hang, norm_thresh, verbosity
+
+    def setBottomParameters(self, imax, numRestarts, eps, reps, hang, small, normType, verbosity):
+        assert self._h is None, "setBottomParameters can only be called before define"
+        p = self._p
+        p.bottom_imax, p.bottom_num_restarts, p.bottom_eps, p.bottom_reps = int(imax), numRestarts, eps, reps
+        p.bottom_hang, p.bottom_small, p.bottom_norm_type, p.bottom_verbosity = hang, small, normType, verbosity
+
+    # -- define: what MappedAMRPoissonOpFactory::define receives (Factory.cpp:95-108), single level ---
+    def define(self, domain_lo, domain_hi, periodic, dx, boxes, bc_type=None, owner=None, alpha=0.0, beta=1.0,
+               comm=None):
+        assert self._h is None, "already defined (call undefine first)"
+        bc = bc_type if bc_type is not None else [BC_NEUM] * 6
+        flat = []
+        for lo, hi in boxes:
+            flat += list(lo) + list(hi)
+        h = _H()
+        _ck(lib().somar_solver_create(C.byref(h), _ia(domain_lo), _ia(domain_hi), _ia([int(bool(x)) for x in periodic]),
+                                      _da(dx), _ia(bc), len(boxes), _ia(flat), _ia(owner) if owner is not None else None,
+                                      float(alpha), float(beta), C.byref(self._p), comm))
+        self._h = h
+        self._comm = comm
+        n = C.c_int()
+        _ck(lib().somar_solver_num_local_patches(h, C.byref(n)))
+        self.num_local_patches = n.value
+
+    def patch_box(self, patch, depth=0):
+        b = (C.c_int * 6)()
+        g = C.c_int()
+        _ck(lib().somar_solver_patch_box(self._h, depth, patch, b, C.byref(g)))
+        return tuple(b[0:3]), tuple(b[3:6]), g.value
+
+    def setMetricOrtho(self, patch, jg0, jg1, jg2, jinv):
+        _ck(lib().somar_solver_set_metric_ortho(self._h, patch, _dp(jg0), _dp(jg1), _dp(jg2), _dp(jinv)))
+
+    def finalize(self):
+        _ck(lib().somar_solver_finalize(self._h))
+
+    def isDefined(self):
+        return self._h is not None
+
+    def undefine(self):
+        if self._h is not None:
+            _ck(lib().somar_solver_destroy(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.undefine()
+        except Exception:
+            pass
+
+    # -- hierarchy inspection ---------------------------------------------------------------------
+    def depth(self):
+        d = C.c_int()
+        _ck(lib().somar_solver_depth(self._h, C.byref(d)))
+        return d.value
+
+    def mgRefRatios(self):
+        out = []
+        for d in range(self.depth() - 1):
+            r = (C.c_int * 3)()
+            _ck(lib().somar_solver_mg_ref_ratio(self._h, d, r))
+            out.append(tuple(r))
+        return out
+
+    def zeroAvg(self, depth):
+        f = C.c_int()
+        _ck(lib().somar_solver_zero_avg(self._h, depth, C.byref(f)))
+        return bool(f.value)
+
+    def levelInfo(self, depth):
+        dom, dx = (C.c_int * 6)(), (C.c_double * 3)()
+        cells, elems = C.c_longlong(), C.c_longlong()
+        _ck(lib().somar_solver_level_info(self._h, depth, dom, dx, C.byref(cells), C.byref(elems)))
+        return {"domain": (tuple(dom[0:3]), tuple(dom[3:6])), "dx": tuple(dx), "cells": cells.value,
+                "field_elems": elems.value}
+
+    # -- fields -------------------------------------------------------------------------------------
+    def upload(self, field, patch, host, ghost):
+        _ck(lib().somar_field_upload(self._h, field, patch, _dp(host), _ia(ghost)))
+
+    def download(self, field, patch, ghost, depth=None):
+        depth = field >> 8 if depth is None else depth
+        lo, hi, _ = self.patch_box(patch, depth)
+        shape = tuple(h - l + 1 + 2 * g for l, h, g in zip(lo, hi, ghost))
+        out = np.zeros(shape, dtype=np.float64, order="F")
+        _ck(lib().somar_field_download(self._h, field, patch, _dp(out), _ia(ghost)))
+        return out
+
+    def setVal(self, field, value):
+        _ck(lib().somar_field_set(self._h, field, float(value)))
+
+    def fillHash(self, field, seed):
+        _ck(lib().somar_field_fill_hash(self._h, field, int(seed)))
+
+    def norm(self, field, order):
+        v = C.c_double()
+        _ck(lib().somar_field_norm(self._h, field, order, C.byref(v)))
+        return v.value
+
+    def dotProduct(self, a, b):
+        v = C.c_double()
+        _ck(lib().somar_field_dot(self._h, a, b, C.byref(v)))
+        return v.value
+
+    # -- solve (AMRPressureSolver::solve, projection/AMRPressureSolver.cpp:494-561) -----------------------
+    def solve(self, phi, rhs, lmin=0, lmax=0, zeroPhi=True, forceHomogeneous=False, phi_ghost=(1, 1, 1),
+              rhs_ghost=(0, 0, 0)):
+        """phi, rhs: lists (one per local patch) of Fortran-ordered float64 arrays; phi is updated in place."""
+        n = self.num_local_patches
+        assert len(phi) == n and len(rhs) == n
+        P = (_PD * n)(*[_dp(a) for a in phi])
+        R = (_PD * n)(*[_dp(a) for a in rhs])
+        st = Stats()
+        # note the reference's call order solve(phi, rhs, a_lmax, a_lmin, ...) (AMRPressureSolver.cpp:529-534)
+        _ck(lib().somar_solver_solve_host(self._h, P, _ia(phi_ghost), R, _ia(rhs_ghost), lmax, lmin, int(zeroPhi),
+                                          int(forceHomogeneous), C.byref(st)))
+        return self._stats(st)
+
+    def solveResident(self, zeroPhi=True, forceHomogeneous=False):
+        st = Stats()
+        _ck(lib().somar_solver_solve(self._h, int(zeroPhi), int(forceHomogeneous), C.byref(st)))
+        return self._stats(st)
+
+    def _stats(self, st):
+        self.exitStatus = st.exit_status
+        self.stats = {"iters": st.iters, "exitStatus": st.exit_status, "status": st.status,
+                      "bottom_iters": st.bottom_iters, "bottom_exit": st.bottom_exit,
+                      "initial_rnorm": st.initial_rnorm, "final_rnorm": st.final_rnorm,
+                      "history": [st.history[i] for i in range(st.nhistory)]}
+        if st.status == 1:
+            raise SomarError("kaboom: solver seems to have blown up (MappedAMRMultiGrid.H:1134-1137)")
+        if st.status == 2:
+            raise SomarError("MappedAMRMultiGrid solver blew up (MappedAMRMultiGrid.H:1141-1145)")
+        return self.stats
+
+    # -- level-operator pieces on resident fields ---------------------------------------------------
+    def relax(self, depth, phi_field, rhs_field, iters):
+        _ck(lib().somar_level_relax(self._h, depth, phi_field, rhs_field, iters))
+
+    def residual(self, depth, out_field, phi_field, rhs_field):
+        _ck(lib().somar_level_residual(self._h, depth, out_field, phi_field, rhs_field))
+
+    def applyOp(self, depth, out_field, phi_field):
+        _ck(lib().somar_level_apply_op(self._h, depth, out_field, phi_field))
+
+    def restrictResidual(self, depth, coarse_res_field, phi_field, rhs_field):
+        _ck(lib().somar_level_restrict_residual(self._h, depth, coarse_res_field, phi_field, rhs_field))
+
+    def prolongIncrement(self, depth, phi_field, coarse_corr_field):
+        _ck(lib().somar_level_prolong_increment(self._h, depth, phi_field, coarse_corr_field))
+
+    def preCond(self, depth, phi_field, rhs_field):
+        _ck(lib().somar_level_precond(self._h, depth, phi_field, rhs_field))
+
+    def vcycle(self, corr_field=F_CORR, res_field=F_RES):
+        _ck(lib().somar_vcycle(self._h, corr_field, res_field))
+
+    def bottomSolve(self, phi_field, rhs_field):
+        it, ex = C.c_int(), C.c_int()
+        _ck(lib().somar_bottom_solve(self._h, phi_field, rhs_field, C.byref(it), C.byref(ex)))
+        return it.value, ex.value
+
+    def sync(self):
+        _ck(lib().somar_sync(self._h))
+
+    def timerStart(self):
+        _ck(lib().somar_timer_start(self._h))
+
+    def timerStop(self):
+        ms = C.c_double()
+        _ck(lib().somar_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+
+def device_count():
+    n = C.c_int()
+    _ck(lib().somar_device_count(C.byref(n)))
+    return n.value
+
+
+def comm_unique_id():
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    _ck(lib().somar_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_create(id_bytes, rank, nranks, device):
+    h = _H()
+    buf = (C.c_ubyte * COMM_ID_BYTES)(*id_bytes)
+    _ck(lib().somar_comm_create(C.byref(h), buf, rank, nranks, device))
+    return h
+
+
+def comm_destroy(h):
+    _ck(lib().somar_comm_destroy(h))

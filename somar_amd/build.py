@@ -1,0 +1,49 @@
+"""Builds somar_amd/libsomar_amd.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m somar_amd.build [--force]
+
+-ffp-contract=off: the kernels reproduce the reference's Fortran operation order bit for bit
+(no FMA contraction); they are HBM-bound, so the extra multiply-add issue slots are free.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libsomar_amd.so")
+SOURCES = ["kernels.hip", "level.cpp", "solver.cpp", "comm_rccl.cpp", "capi.cpp"]
+HEADERS = ["common.h", "kernels.h", "level.h", "solver.h", os.path.join("..", "..", "include", "somar_amd.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-result", "-I/opt/rocm/include"]
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not (force or _stale()):
+        return OUT
+    objs = []
+    for f in SOURCES:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(CSRC, os.path.splitext(f)[0] + ".o")
+        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if f.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,462 @@
+// somar_amd/csrc/capi.cpp -- extern "C" boundary of libsomar_amd.so (include/somar_amd.h).
+#include <cstring>
+#include <string>
+
+#include "../../include/somar_amd.h"
+#include "solver.h"
+
+namespace somar {
+void rccl_unique_id(unsigned char* id128);
+Comm* rccl_create(const unsigned char* id128, int rank, int nranks, int device);
+}  // namespace somar
+
+using namespace somar;
+
+struct somar_solver {
+    PressureSolver* ps = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static thread_local std::string g_err;
+
+#define API_BEGIN try {
+#define API_END                              \
+    }                                        \
+    catch (const somar::Error& e)            \
+    {                                        \
+        g_err = e.what();                    \
+        return e.code;                       \
+    }                                        \
+    catch (const std::exception& e)          \
+    {                                        \
+        g_err = e.what();                    \
+        return -99;                          \
+    }                                        \
+    return 0;
+
+static double* field_ptr(somar_solver* s, int field, int* depth_out = nullptr)
+{
+    const int which = field & 0xff, depth = field >> 8;
+    PressureSolver& ps = *s->ps;
+    SOMAR_CHECK(depth >= 0 && depth < ps.depth(), "field depth out of range");
+    if (depth_out) *depth_out = depth;
+    double* p = ps.field(depth, which);
+    SOMAR_CHECK(p != nullptr, "no such resident field at this depth");
+    return p;
+}
+
+extern "C" {
+
+int somar_abi_version(void) { return SOMAR_AMD_ABI_VERSION; }
+const char* somar_last_error(void) { return g_err.c_str(); }
+
+int somar_device_count(int* count)
+{
+    API_BEGIN
+    int n = 0;
+    SOMAR_HIP(hipGetDeviceCount(&n));
+    *count = n;
+    API_END
+}
+
+int somar_params_default(somar_params_t* p)
+{
+    API_BEGIN
+    SolverParams d;
+    p->imin = d.imin; p->imax = d.imax; p->eps = d.eps; p->hang = d.hang; p->norm_thresh = d.normThresh;
+    p->num_smooth_down = d.num_smooth_down; p->num_smooth_up = d.num_smooth_up;
+    p->num_smooth_bottom = d.num_smooth_bottom; p->num_smooth_precond = d.num_smooth_precond;
+    p->num_mg = d.numMG; p->max_depth = d.maxDepth; p->precond_mode = d.precondMode; p->relax_mode = d.relaxMode;
+    p->verbosity = d.verbosity;
+    p->bottom_imax = d.bottom_imax; p->bottom_num_restarts = d.bottom_numRestarts;
+    p->bottom_norm_type = d.bottom_normType; p->bottom_verbosity = d.bottom_verbosity;
+    p->bottom_eps = d.bottom_eps; p->bottom_reps = d.bottom_reps; p->bottom_hang = d.bottom_hang;
+    p->bottom_small = d.bottom_small;
+    API_END
+}
+
+static SolverParams to_params(const somar_params_t* p)
+{
+    SolverParams d;
+    if (!p) return d;
+    d.imin = p->imin; d.imax = p->imax; d.eps = p->eps; d.hang = p->hang; d.normThresh = p->norm_thresh;
+    d.num_smooth_down = p->num_smooth_down; d.num_smooth_up = p->num_smooth_up;
+    d.num_smooth_bottom = p->num_smooth_bottom; d.num_smooth_precond = p->num_smooth_precond;
+    d.numMG = p->num_mg; d.maxDepth = p->max_depth; d.precondMode = p->precond_mode; d.relaxMode = p->relax_mode;
+    d.verbosity = p->verbosity;
+    d.bottom_imax = p->bottom_imax; d.bottom_numRestarts = p->bottom_num_restarts;
+    d.bottom_normType = p->bottom_norm_type; d.bottom_verbosity = p->bottom_verbosity;
+    d.bottom_eps = p->bottom_eps; d.bottom_reps = p->bottom_reps; d.bottom_hang = p->bottom_hang;
+    d.bottom_small = p->bottom_small;
+    return d;
+}
+
+int somar_solver_create(somar_solver_t** out, const int* domain_lo, const int* domain_hi, const int* periodic,
+                        const double* dx, const int* bc_type, int nboxes, const int* boxes, const int* owner,
+                        double alpha, double beta, const somar_params_t* prm, void* comm)
+{
+    API_BEGIN
+    SOMAR_CHECK(out && domain_lo && domain_hi && periodic && dx && bc_type && boxes && nboxes > 0, "null/empty argument");
+    IBox dom(domain_lo, domain_hi);
+    bool per[3] = {periodic[0] != 0, periodic[1] != 0, periodic[2] != 0};
+    int bct[3][2] = {{bc_type[0], bc_type[1]}, {bc_type[2], bc_type[3]}, {bc_type[4], bc_type[5]}};
+    std::vector<IBox> bx;
+    std::vector<int> own;
+    for (int b = 0; b < nboxes; ++b) {
+        IBox q(boxes + 6 * b, boxes + 6 * b + 3);
+        SOMAR_CHECK(!q.empty(), "empty box");
+        bx.push_back(q);
+        own.push_back(owner ? owner[b] : 0);
+    }
+    // disjointness + containment (DisjointBoxLayout contract)
+    for (size_t a = 0; a < bx.size(); ++a) {
+        for (int d = 0; d < 3; ++d)
+            SOMAR_CHECK(bx[a].lo[d] >= dom.lo[d] && bx[a].hi[d] <= dom.hi[d], "box outside the domain");
+        for (size_t b = a + 1; b < bx.size(); ++b) SOMAR_CHECK((bx[a] & bx[b]).empty(), "boxes overlap");
+    }
+    somar_solver* s = new somar_solver;
+    try {
+        s->ps = new PressureSolver(static_cast<Comm*>(comm));
+        s->ps->define(dom, per, dx, bct, bx, own, alpha, beta, to_params(prm));
+        SOMAR_HIP(hipEventCreate(&s->ev0));
+        SOMAR_HIP(hipEventCreate(&s->ev1));
+    } catch (...) {
+        delete s->ps;
+        delete s;
+        throw;
+    }
+    *out = s;
+    API_END
+}
+
+int somar_solver_destroy(somar_solver_t* s)
+{
+    API_BEGIN
+    if (s) {
+        if (s->ev0) hipEventDestroy(s->ev0);
+        if (s->ev1) hipEventDestroy(s->ev1);
+        delete s->ps;
+        delete s;
+    }
+    API_END
+}
+
+int somar_solver_num_local_patches(somar_solver_t* s, int* n)
+{
+    API_BEGIN
+    *n = s->ps->level(0).npatches();
+    API_END
+}
+
+int somar_solver_patch_box(somar_solver_t* s, int depth, int patch, int* box6, int* global_index)
+{
+    API_BEGIN
+    SOMAR_CHECK(depth >= 0 && depth < s->ps->depth(), "depth out of range");
+    Level& L = s->ps->level(depth);
+    SOMAR_CHECK(patch >= 0 && patch < L.npatches(), "patch out of range");
+    const IBox& b = L.boxes[L.local[patch]];
+    for (int d = 0; d < 3; ++d) { box6[d] = b.lo[d]; box6[3 + d] = b.hi[d]; }
+    if (global_index) *global_index = L.local[patch];
+    API_END
+}
+
+int somar_solver_set_metric_ortho(somar_solver_t* s, int patch, const double* jg0, const double* jg1,
+                                  const double* jg2, const double* jinv)
+{
+    API_BEGIN
+    SOMAR_CHECK(jg0 && jg1 && jg2 && jinv, "null metric pointer");
+    s->ps->set_metric_ortho(patch, jg0, jg1, jg2, jinv);
+    API_END
+}
+
+int somar_solver_finalize(somar_solver_t* s)
+{
+    API_BEGIN
+    s->ps->finalize();
+    API_END
+}
+
+int somar_solver_depth(somar_solver_t* s, int* depth)
+{
+    API_BEGIN
+    *depth = s->ps->depth();
+    API_END
+}
+
+int somar_solver_mg_ref_ratio(somar_solver_t* s, int depth, int* r3)
+{
+    API_BEGIN
+    SOMAR_CHECK(depth >= 0 && depth < (int)s->ps->mgRefRatios.size(), "no coarser depth");
+    for (int d = 0; d < 3; ++d) r3[d] = s->ps->mgRefRatios[depth][d];
+    API_END
+}
+
+int somar_solver_zero_avg(somar_solver_t* s, int depth, int* flag)
+{
+    API_BEGIN
+    SOMAR_CHECK(depth >= 0 && depth < s->ps->depth(), "depth out of range");
+    *flag = s->ps->level(depth).zeroAvg ? 1 : 0;
+    API_END
+}
+
+int somar_solver_level_info(somar_solver_t* s, int depth, int* domain6, double* dx3, long long* cells,
+                            long long* field_elems)
+{
+    API_BEGIN
+    SOMAR_CHECK(depth >= 0 && depth < s->ps->depth(), "depth out of range");
+    Level& L = s->ps->level(depth);
+    for (int d = 0; d < 3; ++d) {
+        if (domain6) { domain6[d] = L.domain.lo[d]; domain6[3 + d] = L.domain.hi[d]; }
+        if (dx3) dx3[d] = L.dx[d];
+    }
+    if (cells) *cells = L.valid_cells_global;
+    if (field_elems) *field_elems = L.field_elems;
+    API_END
+}
+
+int somar_field_upload(somar_solver_t* s, int field, int patch, const double* host, const int* ghost)
+{
+    API_BEGIN
+    int depth;
+    double* f = field_ptr(s, field, &depth);
+    Level& L = s->ps->level(depth);
+    SOMAR_CHECK(patch >= 0 && patch < L.npatches() && host && ghost, "bad patch / null pointer");
+    for (int d = 0; d < 3; ++d) SOMAR_CHECK(ghost[d] >= 0 && ghost[d] <= FRAME, "ghost wider than device frame");
+    const IBox valid = L.boxes[L.local[patch]];
+    const IBox hb = valid.grow(ghost);
+    L.upload(f, patch, host, hb, hb, s->ps->stream());
+    s->ps->sync();
+    API_END
+}
+
+int somar_field_download(somar_solver_t* s, int field, int patch, double* host, const int* ghost)
+{
+    API_BEGIN
+    int depth;
+    double* f = field_ptr(s, field, &depth);
+    SOMAR_CHECK(host && ghost, "null pointer");
+    s->ps->download_field(f, depth, patch, host, ghost);
+    API_END
+}
+
+int somar_field_set(somar_solver_t* s, int field, double value)
+{
+    API_BEGIN
+    int depth;
+    double* f = field_ptr(s, field, &depth);
+    launch_set(s->ps->stream(), f, s->ps->level(depth).field_elems, value);
+    API_END
+}
+
+int somar_field_fill_hash(somar_solver_t* s, int field, unsigned long long seed)
+{
+    API_BEGIN
+    int depth;
+    double* f = field_ptr(s, field, &depth);
+    s->ps->fill_hash(depth, f, seed);
+    API_END
+}
+
+int somar_field_norm(somar_solver_t* s, int field, int ord, double* out)
+{
+    API_BEGIN
+    int depth;
+    double* f = field_ptr(s, field, &depth);
+    *out = s->ps->norm(depth, f, ord);
+    API_END
+}
+
+int somar_field_dot(somar_solver_t* s, int field_a, int field_b, double* out)
+{
+    API_BEGIN
+    int da, db;
+    double* a = field_ptr(s, field_a, &da);
+    double* b = field_ptr(s, field_b, &db);
+    SOMAR_CHECK(da == db, "fields of different depths");
+    *out = s->ps->dot(da, a, b);
+    API_END
+}
+
+static void fill_stats(const SolveStats& st, somar_stats_t* o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->iters = st.iters;
+    o->exit_status = st.exitStatus;
+    o->status = st.status;
+    o->bottom_iters = st.bottom_iters_last;
+    o->bottom_exit = st.bottom_exit_last;
+    o->initial_rnorm = st.initial_rnorm;
+    o->final_rnorm = st.final_rnorm;
+    o->nhistory = (int)std::min<size_t>(st.history.size(), SOMAR_MAX_HISTORY);
+    for (int i = 0; i < o->nhistory; ++i) o->history[i] = st.history[i];
+}
+
+int somar_solver_solve(somar_solver_t* s, int zero_phi, int force_homogeneous, somar_stats_t* stats)
+{
+    API_BEGIN
+    SolveStats st;
+    s->ps->solve(zero_phi != 0, force_homogeneous != 0, st);
+    fill_stats(st, stats);
+    API_END
+}
+
+int somar_solver_solve_host(somar_solver_t* s, double* const* phi, const int* phi_ghost,
+                            const double* const* rhs, const int* rhs_ghost, int l_max, int l_base,
+                            int zero_phi, int force_homogeneous, somar_stats_t* stats)
+{
+    API_BEGIN
+    SOMAR_CHECK(l_max == 0 && l_base == 0, "multi-level AMR solves are not implemented yet (l_max = l_base = 0 only)");
+    SOMAR_CHECK(phi && rhs && phi_ghost && rhs_ghost, "null pointer");
+    PressureSolver& ps = *s->ps;
+    const int np = ps.level(0).npatches();
+    for (int p = 0; p < np; ++p) {
+        ps.upload_rhs(p, rhs[p], rhs_ghost);
+        if (!zero_phi) ps.upload_phi(p, phi[p], phi_ghost);
+    }
+    SolveStats st;
+    ps.solve(zero_phi != 0, force_homogeneous != 0, st);
+    for (int p = 0; p < np; ++p) ps.download_phi(p, phi[p], phi_ghost);
+    fill_stats(st, stats);
+    API_END
+}
+
+int somar_level_relax(somar_solver_t* s, int depth, int phi_field, int rhs_field, int iters)
+{
+    API_BEGIN
+    int d1, d2;
+    double* phi = field_ptr(s, phi_field, &d1);
+    double* rhs = field_ptr(s, rhs_field, &d2);
+    SOMAR_CHECK(d1 == depth && d2 == depth, "field/depth mismatch");
+    s->ps->relax(depth, phi, rhs, iters);
+    API_END
+}
+
+int somar_level_residual(somar_solver_t* s, int depth, int out_field, int phi_field, int rhs_field)
+{
+    API_BEGIN
+    int d0, d1, d2;
+    double* out = field_ptr(s, out_field, &d0);
+    double* phi = field_ptr(s, phi_field, &d1);
+    double* rhs = field_ptr(s, rhs_field, &d2);
+    SOMAR_CHECK(d0 == depth && d1 == depth && d2 == depth && out != rhs && out != phi, "field/depth mismatch or aliasing");
+    s->ps->residual(depth, out, phi, rhs);
+    API_END
+}
+
+int somar_level_apply_op(somar_solver_t* s, int depth, int out_field, int phi_field)
+{
+    API_BEGIN
+    int d0, d1;
+    double* out = field_ptr(s, out_field, &d0);
+    double* phi = field_ptr(s, phi_field, &d1);
+    SOMAR_CHECK(d0 == depth && d1 == depth && out != phi, "field/depth mismatch or aliasing");
+    s->ps->apply_op(depth, out, phi);
+    API_END
+}
+
+int somar_level_restrict_residual(somar_solver_t* s, int depth, int coarse_res_field, int phi_field, int rhs_field)
+{
+    API_BEGIN
+    int dc, d1, d2;
+    double* rc = field_ptr(s, coarse_res_field, &dc);
+    double* phi = field_ptr(s, phi_field, &d1);
+    double* rhs = field_ptr(s, rhs_field, &d2);
+    SOMAR_CHECK(dc == depth + 1 && d1 == depth && d2 == depth, "field/depth mismatch");
+    s->ps->restrict_residual(depth, rc, phi, rhs);
+    API_END
+}
+
+int somar_level_prolong_increment(somar_solver_t* s, int depth, int phi_field, int coarse_corr_field)
+{
+    API_BEGIN
+    int dc, d1;
+    double* phi = field_ptr(s, phi_field, &d1);
+    double* cc = field_ptr(s, coarse_corr_field, &dc);
+    SOMAR_CHECK(dc == depth + 1 && d1 == depth, "field/depth mismatch");
+    s->ps->prolong_increment(depth, phi, cc);
+    API_END
+}
+
+int somar_level_precond(somar_solver_t* s, int depth, int phi_field, int rhs_field)
+{
+    API_BEGIN
+    int d1, d2;
+    double* phi = field_ptr(s, phi_field, &d1);
+    double* rhs = field_ptr(s, rhs_field, &d2);
+    SOMAR_CHECK(d1 == depth && d2 == depth && phi != rhs, "field/depth mismatch or aliasing");
+    s->ps->pre_cond(depth, phi, rhs);
+    API_END
+}
+
+int somar_vcycle(somar_solver_t* s, int corr_field, int res_field)
+{
+    API_BEGIN
+    int d1, d2;
+    double* e = field_ptr(s, corr_field, &d1);
+    double* r = field_ptr(s, res_field, &d2);
+    SOMAR_CHECK(d1 == 0 && d2 == 0 && e != r, "V-cycle starts at depth 0");
+    s->ps->vcycle(e, r);
+    API_END
+}
+
+int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* iters, int* exit_code)
+{
+    API_BEGIN
+    int d1, d2;
+    double* phi = field_ptr(s, phi_field, &d1);
+    double* rhs = field_ptr(s, rhs_field, &d2);
+    SOMAR_CHECK(d1 == s->ps->depth() - 1 && d2 == d1 && phi != rhs, "bottom solve runs on the coarsest depth");
+    s->ps->bottom_solve(phi, rhs);
+    if (iters) *iters = s->ps->bottom_iters;
+    if (exit_code) *exit_code = s->ps->bottom_exit;
+    API_END
+}
+
+int somar_sync(somar_solver_t* s)
+{
+    API_BEGIN
+    s->ps->sync();
+    API_END
+}
+
+int somar_timer_start(somar_solver_t* s)
+{
+    API_BEGIN
+    SOMAR_HIP(hipEventRecord(s->ev0, s->ps->stream()));
+    API_END
+}
+
+int somar_timer_stop(somar_solver_t* s, double* milliseconds)
+{
+    API_BEGIN
+    SOMAR_HIP(hipEventRecord(s->ev1, s->ps->stream()));
+    SOMAR_HIP(hipEventSynchronize(s->ev1));
+    float ms = 0.f;
+    SOMAR_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    *milliseconds = ms;
+    API_END
+}
+
+int somar_comm_unique_id(unsigned char* id128)
+{
+    API_BEGIN
+    rccl_unique_id(id128);
+    API_END
+}
+
+int somar_comm_create(void** comm, const unsigned char* id128, int rank, int nranks, int device)
+{
+    API_BEGIN
+    *comm = rccl_create(id128, rank, nranks, device);
+    API_END
+}
+
+int somar_comm_destroy(void* comm)
+{
+    API_BEGIN
+    delete static_cast<Comm*>(comm);
+    API_END
+}
+
+}  // extern "C"

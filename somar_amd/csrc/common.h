@@ -1,0 +1,83 @@
+// somar_amd/csrc/common.h -- shared host/device declarations for the MI355X (gfx950)
+// implementation of SOMAR's pressure-projection multigrid.  HIP only; no CUDA paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace somar {
+
+// Error convention of the C ABI (include/somar_amd.h): 0 ok, <0 failure.  Inside the
+// library failures are C++ exceptions, translated at the ABI boundary.
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define SOMAR_HIP(call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            throw ::somar::Error(-2, std::string("HIP error ") + hipGetErrorString(e_) + " at " \
+                                         + __FILE__ + ":" + std::to_string(__LINE__));          \
+    } while (0)
+
+#define SOMAR_CHECK(cond, msg)                                                      \
+    do {                                                                            \
+        if (!(cond))                                                                \
+            throw ::somar::Error(-1, std::string(msg) + " (" #cond ") at " + __FILE__ + \
+                                         ":" + std::to_string(__LINE__));         \
+    } while (0)
+
+// BCType codes, reference calculus/BCInterface/BCDescriptor.H:34-39
+enum { BC_UNDEFINED = -2, BC_NONE = -1, BC_NEUM = 0, BC_DIRI = 1, BC_PERIODIC = 2, BC_CF = 3 };
+
+// Ghost frame allocated around every patch, in cells.  All fields of a level (cell- and
+// face-centred alike) share one shape so a single offset addresses every array; face
+// index i is the LOW face of cell i (reference convention, MappedAMRPoissonOpF.ChF:412-415).
+constexpr int FRAME = 2;
+
+// One box of a level as stored in HBM.  Element (i,j,k) (local, 0-based from the valid
+// low corner; ghosts are negative) of any field lives at  base[off + i + pj*j + pk*k].
+struct PatchDesc {
+    int lo[3];  // global index of the valid low corner
+    int n[3];   // valid cells per direction
+    int pj;     // j pitch (elements), even => 16-byte aligned rows
+    int pad_;
+    long long pk;   // k pitch
+    long long off;  // offset of local cell (0,0,0)
+};
+
+// Work item of a sweep kernel: a (128 x 4 x nk) brick of one patch.
+struct Tile {
+    int patch;
+    int i0, j0, k0;  // local start
+    int nk;
+    int pad_[3];
+};
+constexpr int TILE_I = 128;  // cells in i per block (64 lanes x double2)
+constexpr int TILE_J = 4;
+constexpr int TILE_K = 8;
+
+// One box-to-box ghost copy ("motion item" of a Chombo Copier).
+struct CopyItem {
+    int src_patch, dst_patch;
+    int src_lo[3];  // local start in the source patch
+    int dst_lo[3];  // local start in the destination patch
+    int n[3];
+    int pad_;
+};
+
+// Per-level constants handed to the stencil kernels by value.
+struct StencilParams {
+    int dom_lo[3], dom_hi[3];  // domain box at this depth
+    int neum[3][2];            // 1 = homogeneous-Neumann physical face (no ghost, no flux)
+    int active[3];             // activeDirs
+    double dx[3];
+    double alpha, beta;
+};
+
+}  // namespace somar

@@ -1,0 +1,46 @@
+// somar_amd/csrc/kernels.h -- launcher prototypes for kernels.hip
+#pragma once
+#include "common.h"
+
+namespace somar {
+
+// Device-side view of one (AMR level, MG depth): tables + coefficient planes in HBM.
+struct LevelDev {
+    const Tile* tiles = nullptr;        // XCD-contiguous order
+    int ntiles = 0;
+    const PatchDesc* patches = nullptr;
+    int npatches = 0;
+    double* jg[3] = {nullptr, nullptr, nullptr};  // J g^{aa} on a-faces
+    double* jinv = nullptr;
+    double* lapdiag = nullptr;
+    StencilParams P;
+};
+
+void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color);
+void launch_op_ortho(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* rhs, int mode);
+void launch_lapdiag(hipStream_t st, const LevelDev& L);
+void launch_diag(hipStream_t st, const LevelDev& L, double* phi, const double* r, int mode);
+void launch_restrict(hipStream_t st, const LevelDev& C, const LevelDev& F, double* crse, const double* fine,
+                     const int r[3]);
+void launch_prolong(hipStream_t st, const LevelDev& F, const LevelDev& C, double* fine, const double* crse,
+                    const int r[3], bool zeroAvg, double dxProduct, double* partials, double* sums,
+                    long long fieldElems);
+void launch_sub_mean(hipStream_t st, double* f, long long n, const double* sums);
+void launch_avg_harmonic(hipStream_t st, const LevelDev& C, const LevelDev& F, double* crse, const double* fine,
+                         const int r[3]);
+void launch_avg_face(hipStream_t st, const LevelDev& C, const LevelDev& F, int patch, const int cn[3], double* crse,
+                     const double* fine, int dir, const int r[3]);
+void launch_copy_items(hipStream_t st, const LevelDev& L, const CopyItem* items, int nitems, double* f);
+void launch_pack(hipStream_t st, const LevelDev& L, const CopyItem* items, const long long* bufoff, int nitems,
+                 double* f, double* buf, bool pack);
+void launch_set(hipStream_t st, double* a, long long n, double v);
+void launch_copy(hipStream_t st, double* d, const double* s, long long n);
+void launch_incr(hipStream_t st, double* y, const double* x, double a, long long n);
+void launch_scale(hipStream_t st, double* y, double a, long long n);
+void launch_axby(hipStream_t st, double* z, const double* x, const double* y, double a, double b, long long n);
+// mode 0: sum a*b, 1: max|a|, 2: sum|a|, 3: signed max a  -> out[0] (device)
+void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const double* b, int mode, double* partials,
+                   double* out);
+void launch_fill_hash(hipStream_t st, const LevelDev& L, double* f, unsigned long long seed);
+
+}  // namespace somar

@@ -1,0 +1,684 @@
+// somar_amd/csrc/kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4).
+//
+// The hot path of SOMAR's pressure projection is a 7-point variable-coefficient stencil:
+// every kernel here is HBM-bandwidth bound (0.1-0.4 flop/byte), so there is no MFMA
+// anywhere; what matters is 64-lane-wide unit-stride access along i, one shared index
+// computation for all coefficient planes, XCD-contiguous tile order (done on the host when
+// the tile table is built) and no temporaries in HBM (flux + divergence + subtract fused).
+//
+// Arithmetic mirrors the reference's Fortran operation order term by term and the file is
+// compiled with -ffp-contract=off, so results are bit-identical to oracle/kernels.c
+// (reductions excepted: those are tree sums, documented at each kernel).
+//
+// Reference kernels restated here (paths relative to /root/reference/src):
+//   GSRBITER3DORTHO            calculus/AMRElliptic/RelaxationMethods/GSRBF.ChF:545-701
+//   GSRBBOUNDARYITER3DORTHO    .../GSRBF.ChF:1362-1505          (fused into the same launch)
+//   MAPPEDGETFLUXORTHO         calculus/AMRElliptic/MappedAMRPoissonOpOrthoF.ChF:33-82
+//   MAPPEDFLUXDIVERGENCE3D     calculus/DivCurlGrad/DivCurlGradF.ChF:1122-1215
+//   SUBTRACTOP/AXBYIP/DIAGPRECOND  calculus/AMRElliptic/MappedAMRPoissonOpF.ChF:36-85, 284-328
+//   FILLMAPPEDLAPDIAG3D        .../MappedAMRPoissonOpF.ChF:215-274
+//   MAPPEDAVERAGE2, UNMAPPEDAVERAGEHARMONIC, UNMAPPEDAVERAGEFACE
+//                              MappedChombo/MappedCoarseAverageF.ChF:132-167, 48-82, 182-221
+//   ConstInterpPS / ConstInterpWithAvgPS  calculus/AMRElliptic/MGStrategies/ProlongationStrategyF.ChF:36-160
+//   JACOBIITER                 calculus/AMRElliptic/RelaxationMethods/JacobiF.ChF
+#include "common.h"
+#include "kernels.h"
+
+namespace somar {
+
+// ------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ long long cidx(const PatchDesc& p, int i, int j, int k)
+{
+    return p.off + i + (long long)p.pj * j + p.pk * k;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// 256-thread block reduction (4 waves). Result valid in thread 0.
+template <bool MAX>
+__device__ __forceinline__ double block_reduce(double v)
+{
+    __shared__ double s[8];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    v = MAX ? wave_max(v) : wave_sum(v);
+    __syncthreads();  // protect s[] against a previous use
+    if (lane == 0) s[w] = v;
+    __syncthreads();
+    if (tid == 0) {
+        const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+        double r = s[0];
+        for (int q = 1; q < nw; ++q) r = MAX ? fmax(r, s[q]) : r + s[q];
+        v = r;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------
+// GSRB, diagonal metric, one colour.  Interior cells follow GSRBITER3DORTHO, cells that
+// touch a DOMAIN face (periodic ones included: GSRB.cpp:76,87-92) follow
+// GSRBBOUNDARYITER3DORTHO with a Neumann face contributing neither flux nor diagonal.
+// Both in one launch: the reference's 26 one-cell-thick boundary sub-box calls per box
+// become a per-lane branch that only diverges on the shell.
+// Thread = one i-pair; exactly one cell of the pair has this colour.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gsrb_ortho(const Tile* __restrict__ tiles,
+                                                    const PatchDesc* __restrict__ patches,
+                                                    double* __restrict__ phi,
+                                                    const double* __restrict__ rhs,
+                                                    const double* __restrict__ jgx,
+                                                    const double* __restrict__ jgy,
+                                                    const double* __restrict__ jgz,
+                                                    const double* __restrict__ jinv,
+                                                    const double* __restrict__ lapd,
+                                                    StencilParams P, int color)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1] || li0 >= p.n[0]) return;
+    const double xxScale = 1.0 / (P.dx[0] * P.dx[0]);
+    const double yyScale = 1.0 / (P.dx[1] * P.dx[1]);
+    const double zzScale = 1.0 / (P.dx[2] * P.dx[2]);
+    const int gj = p.lo[1] + lj;
+    const bool bj = (gj == P.dom_lo[1]) || (gj == P.dom_hi[1]);
+    const long long sj = p.pj, sk = p.pk;
+    for (int kk = 0; kk < t.nk; ++kk) {
+        const int lk = t.k0 + kk;
+        const int gk = p.lo[2] + lk;
+        const int li = li0 + ((p.lo[0] + li0 + gj + gk + color) & 1);
+        if (li >= p.n[0]) continue;
+        const int gi = p.lo[0] + li;
+        const long long c = cidx(p, li, lj, lk);
+        const bool onb = bj || (gk == P.dom_lo[2]) || (gk == P.dom_hi[2]) || (gi == P.dom_lo[0]) ||
+                         (gi == P.dom_hi[0]);
+        const double Ji = jinv[c];
+        double out;
+        if (!onb) {
+            const double JDxx = xxScale * (jgx[c + 1] * phi[c + 1] + jgx[c] * phi[c - 1]);
+            const double JDyy = yyScale * (jgy[c + sj] * phi[c + sj] + jgy[c] * phi[c - sj]);
+            const double JDzz = zzScale * (jgz[c + sk] * phi[c + sk] + jgz[c] * phi[c - sk]);
+            const double lphi = P.beta * Ji * (JDxx + JDyy + JDzz);
+            out = (rhs[c] - lphi) / (P.alpha + P.beta * lapd[c]);
+        } else {
+            const bool nxl = (gi == P.dom_lo[0]) && P.neum[0][0];
+            const bool nxh = (gi == P.dom_hi[0]) && P.neum[0][1];
+            const bool nyl = (gj == P.dom_lo[1]) && P.neum[1][0];
+            const bool nyh = (gj == P.dom_hi[1]) && P.neum[1][1];
+            const bool nzl = (gk == P.dom_lo[2]) && P.neum[2][0];
+            const bool nzh = (gk == P.dom_hi[2]) && P.neum[2][1];
+            double JDloX = 0, JDhiX = 0, JDloY = 0, JDhiY = 0, JDloZ = 0, JDhiZ = 0, ld = 0.0;
+            if (!nxl) { JDloX = jgx[c] * phi[c - 1];        ld = ld - xxScale * jgx[c]; }
+            if (!nyl) { JDloY = jgy[c] * phi[c - sj];       ld = ld - yyScale * jgy[c]; }
+            if (!nzl) { JDloZ = jgz[c] * phi[c - sk];       ld = ld - zzScale * jgz[c]; }
+            if (!nxh) { JDhiX = jgx[c + 1] * phi[c + 1];    ld = ld - xxScale * jgx[c + 1]; }
+            if (!nyh) { JDhiY = jgy[c + sj] * phi[c + sj];  ld = ld - yyScale * jgy[c + sj]; }
+            if (!nzh) { JDhiZ = jgz[c + sk] * phi[c + sk];  ld = ld - zzScale * jgz[c + sk]; }
+            ld = ld * Ji;
+            const double lphi = P.beta * Ji *
+                                ((JDloX + JDhiX) * xxScale + (JDloY + JDhiY) * yyScale +
+                                 (JDloZ + JDhiZ) * zzScale);
+            out = (rhs[c] - lphi) / (P.alpha + P.beta * ld);
+        }
+        phi[c] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Operator / residual, diagonal metric: flux (MAPPEDGETFLUXORTHO) + zero Neumann boundary
+// flux (EllipticConstNeumBCFluxClass) + "flux *= beta" + MAPPEDFLUXDIVERGENCE3D + AXBYIP
+// + SUBTRACTOP fused; the reference's three flux temporaries never exist.
+// MODE 0: out = rhs - L[phi]   MODE 1: out = L[phi]
+// Thread = one i-pair (both cells), k-loop over the tile.
+// ------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_op_ortho(const Tile* __restrict__ tiles,
+                                                  const PatchDesc* __restrict__ patches,
+                                                  double* __restrict__ out,
+                                                  const double* __restrict__ phi,
+                                                  const double* __restrict__ rhs,
+                                                  const double* __restrict__ jgx,
+                                                  const double* __restrict__ jgy,
+                                                  const double* __restrict__ jgz,
+                                                  const double* __restrict__ jinv, StencilParams P)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1] || li0 >= p.n[0]) return;
+    const double sx = 1.0 / P.dx[0], sy = 1.0 / P.dx[1], sz = 1.0 / P.dx[2];  // scale = ref/dx, dxinv
+    const int gj = p.lo[1] + lj;
+    const long long sj = p.pj, sk = p.pk;
+    const bool zyl = (gj == P.dom_lo[1]) && P.neum[1][0];
+    const bool zyh = (gj == P.dom_hi[1]) && P.neum[1][1];
+    const int npair = (li0 + 1 < p.n[0]) ? 2 : 1;
+    for (int kk = 0; kk < t.nk; ++kk) {
+        const int lk = t.k0 + kk;
+        const int gk = p.lo[2] + lk;
+        const bool zzl = (gk == P.dom_lo[2]) && P.neum[2][0];
+        const bool zzh = (gk == P.dom_hi[2]) && P.neum[2][1];
+        for (int q = 0; q < npair; ++q) {
+            const int li = li0 + q;
+            const int gi = p.lo[0] + li;
+            const long long c = cidx(p, li, lj, lk);
+            const double pc = phi[c];
+            double fxl = jgx[c] * sx * (pc - phi[c - 1]);
+            double fxh = jgx[c + 1] * sx * (phi[c + 1] - pc);
+            double fyl = jgy[c] * sy * (pc - phi[c - sj]);
+            double fyh = jgy[c + sj] * sy * (phi[c + sj] - pc);
+            double fzl = jgz[c] * sz * (pc - phi[c - sk]);
+            double fzh = jgz[c + sk] * sz * (phi[c + sk] - pc);
+            if ((gi == P.dom_lo[0]) && P.neum[0][0]) fxl = 0.0;
+            if ((gi == P.dom_hi[0]) && P.neum[0][1]) fxh = 0.0;
+            if (zyl) fyl = 0.0;
+            if (zyh) fyh = 0.0;
+            if (zzl) fzl = 0.0;
+            if (zzh) fzh = 0.0;
+            fxl *= P.beta; fxh *= P.beta; fyl *= P.beta; fyh *= P.beta; fzl *= P.beta; fzh *= P.beta;
+            double l = jinv[c] * ((fxh - fxl) * sx + (fyh - fyl) * sy + (fzh - fzl) * sz);
+            if (P.alpha != 0.0) l = P.alpha * pc + 1.0 * l;
+            out[c] = (MODE == 0) ? (rhs[c] - l) : l;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// lapDiag fill (setup).  FILLMAPPEDLAPDIAG3D
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lapdiag(const Tile* __restrict__ tiles,
+                                                 const PatchDesc* __restrict__ patches,
+                                                 double* __restrict__ lap,
+                                                 const double* __restrict__ jgx,
+                                                 const double* __restrict__ jgy,
+                                                 const double* __restrict__ jgz,
+                                                 const double* __restrict__ jinv, StencilParams P)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1]) return;
+    const double s0 = 1.0 / (P.dx[0] * P.dx[0]), s1 = 1.0 / (P.dx[1] * P.dx[1]),
+                 s2 = 1.0 / (P.dx[2] * P.dx[2]);
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int li = li0 + q;
+            if (li >= p.n[0]) continue;
+            const long long c = cidx(p, li, lj, t.k0 + kk);
+            lap[c] = -jinv[c] * ((jgx[c + 1] + jgx[c]) * s0 + (jgy[c + p.pj] + jgy[c]) * s1 +
+                                 (jgz[c + p.pk] + jgz[c]) * s2);
+        }
+}
+
+// ------------------------------------------------------------------------------------
+// pointwise: DIAGPRECOND  phi = rhs/(alpha+beta*lapDiag);  JACOBIITER phi += 0.5*res/(..)
+// ------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_diag(const Tile* __restrict__ tiles,
+                                              const PatchDesc* __restrict__ patches,
+                                              double* __restrict__ phi, const double* __restrict__ r,
+                                              const double* __restrict__ lapd, double alpha, double beta)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1]) return;
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int li = li0 + q;
+            if (li >= p.n[0]) continue;
+            const long long c = cidx(p, li, lj, t.k0 + kk);
+            if (MODE == 0) phi[c] = r[c] / (alpha + beta * lapd[c]);
+            else           phi[c] = phi[c] + 0.5 * r[c] / (alpha + beta * lapd[c]);
+        }
+}
+
+// ------------------------------------------------------------------------------------
+// Restriction (tiles run over the COARSE level; patch index is shared fine<->coarse
+// because the coarse layout is coarsen(fine layout)).  MAPPEDAVERAGE2, loop ii2,ii1,ii0.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_restrict(const Tile* __restrict__ ctiles,
+                                                  const PatchDesc* __restrict__ cpatches,
+                                                  const PatchDesc* __restrict__ fpatches,
+                                                  double* __restrict__ crse,
+                                                  const double* __restrict__ fine,
+                                                  const double* __restrict__ fjinv, int r0, int r1, int r2)
+{
+    const Tile t = ctiles[blockIdx.x];
+    const PatchDesc cp = cpatches[t.patch];
+    const PatchDesc fp = fpatches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= cp.n[1]) return;
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int li = li0 + q;
+            if (li >= cp.n[0]) continue;
+            const int lk = t.k0 + kk;
+            double s = 0.0, sj = 0.0;
+            for (int ii2 = 0; ii2 < r2; ++ii2)
+                for (int ii1 = 0; ii1 < r1; ++ii1)
+                    for (int ii0 = 0; ii0 < r0; ++ii0) {
+                        const long long f = cidx(fp, li * r0 + ii0, lj * r1 + ii1, lk * r2 + ii2);
+                        const double ji = fjinv[f];
+                        s = s + fine[f] / ji;
+                        sj = sj + 1.0 / ji;
+                    }
+            crse[cidx(cp, li, lj, lk)] = s / sj;
+        }
+}
+
+// ------------------------------------------------------------------------------------
+// Prolongation: fine += coarse(i/m).  AVG also emits per-block partial sums of
+// dvol*fine and dvol (dvol = dxProduct/Jinv) for the zero-average variant; the mean is
+// removed by k_sub_mean without the value ever visiting the host.  (Tree sum: differs
+// from the reference's sequential sum in the last bits -- the one non-bit-exact step.)
+// ------------------------------------------------------------------------------------
+template <bool AVG>
+__global__ __launch_bounds__(256) void k_prolong(const Tile* __restrict__ ftiles,
+                                                 const PatchDesc* __restrict__ fpatches,
+                                                 const PatchDesc* __restrict__ cpatches,
+                                                 double* __restrict__ fine,
+                                                 const double* __restrict__ crse,
+                                                 const double* __restrict__ jinv, int r0, int r1, int r2,
+                                                 double dxProduct, double* __restrict__ partials)
+{
+    const Tile t = ftiles[blockIdx.x];
+    const PatchDesc fp = fpatches[t.patch];
+    const PatchDesc cp = cpatches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    double s = 0.0, v = 0.0;
+    if (lj < fp.n[1]) {
+        for (int kk = 0; kk < t.nk; ++kk)
+            for (int q = 0; q < 2; ++q) {
+                const int li = li0 + q;
+                if (li >= fp.n[0]) continue;
+                const int lk = t.k0 + kk;
+                const long long f = cidx(fp, li, lj, lk);
+                const double nv = fine[f] + crse[cidx(cp, li / r0, lj / r1, lk / r2)];
+                fine[f] = nv;
+                if (AVG) {
+                    const double dvol = dxProduct / jinv[f];
+                    s = s + dvol * nv;
+                    v = v + dvol;
+                }
+            }
+    }
+    if (AVG) {
+        s = block_reduce<false>(s);
+        v = block_reduce<false>(v);
+        if (threadIdx.x == 0 && threadIdx.y == 0) {
+            partials[2 * blockIdx.x] = s;
+            partials[2 * blockIdx.x + 1] = v;
+        }
+    }
+}
+
+// final stage of every reduction: ONE block, fixed order => deterministic.
+// nvals interleaved values per partial; op 0 = sum, 1 = max (of non-negatives), 2 = signed max.
+__global__ __launch_bounds__(256) void k_reduce_final(const double* __restrict__ partials, int nparts,
+                                                      int nvals, int op, double* __restrict__ out)
+{
+    for (int v = 0; v < nvals; ++v) {
+        double acc = (op == 2) ? -1.7976931348623157e308 : 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 256) {
+            const double x = partials[(long long)i * nvals + v];
+            acc = op ? fmax(acc, x) : acc + x;
+        }
+        acc = op ? block_reduce<true>(acc) : block_reduce<false>(acc);
+        if (threadIdx.x == 0) out[v] = acc;
+    }
+}
+
+// field[all] -= sums[0]/sums[1]  (whole allocation incl. ghosts: a_phiThisLevel[dit] -= avgPhi,
+// ProlongationStrategy.cpp:160-163)
+__global__ void k_sub_mean(double* __restrict__ f, long long n, const double* __restrict__ sums)
+{
+    const double avg = sums[0] / sums[1];
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        f[i] -= avg;
+}
+
+// ------------------------------------------------------------------------------------
+// coarse metrics (setup): harmonic cell average and arithmetic face average
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_avg_harmonic(const Tile* __restrict__ ctiles,
+                                                      const PatchDesc* __restrict__ cpatches,
+                                                      const PatchDesc* __restrict__ fpatches,
+                                                      double* __restrict__ crse,
+                                                      const double* __restrict__ fine, int r0, int r1, int r2)
+{
+    const Tile t = ctiles[blockIdx.x];
+    const PatchDesc cp = cpatches[t.patch];
+    const PatchDesc fp = fpatches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= cp.n[1]) return;
+    const double refScale = 1.0 / (double)(r0 * r1 * r2);
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int li = li0 + q;
+            if (li >= cp.n[0]) continue;
+            const int lk = t.k0 + kk;
+            double s = 0.0;
+            for (int ii2 = 0; ii2 < r2; ++ii2)
+                for (int ii1 = 0; ii1 < r1; ++ii1)
+                    for (int ii0 = 0; ii0 < r0; ++ii0)
+                        s = s + 1.0 / fine[cidx(fp, li * r0 + ii0, lj * r1 + ii1, lk * r2 + ii2)];
+            crse[cidx(cp, li, lj, lk)] = 1.0 / (s * refScale);
+        }
+}
+
+// Face average in direction dir over the coarse face box (n[dir]+1 faces): one thread per
+// coarse face.  Plain 3-D launch; setup-time only.
+__global__ void k_avg_face(const PatchDesc* __restrict__ cpatches, const PatchDesc* __restrict__ fpatches,
+                           int patch, double* __restrict__ crse, const double* __restrict__ fine, int dir,
+                           int r0, int r1, int r2)
+{
+    const PatchDesc cp = cpatches[patch];
+    const PatchDesc fp = fpatches[patch];
+    const int li = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lj = blockIdx.y * blockDim.y + threadIdx.y;
+    const int lk = blockIdx.z;
+    const int ni = cp.n[0] + (dir == 0), nj = cp.n[1] + (dir == 1), nk = cp.n[2] + (dir == 2);
+    if (li >= ni || lj >= nj || lk >= nk) return;
+    const int rr[3] = {r0, r1, r2};
+    const double refScale = (double)rr[dir] / (double)(r0 * r1 * r2);
+    const int b0 = dir == 0 ? 1 : r0, b1 = dir == 1 ? 1 : r1, b2 = dir == 2 ? 1 : r2;
+    double s = 0.0;
+    for (int ii2 = 0; ii2 < b2; ++ii2)
+        for (int ii1 = 0; ii1 < b1; ++ii1)
+            for (int ii0 = 0; ii0 < b0; ++ii0)
+                s = s + fine[cidx(fp, li * r0 + ii0, lj * r1 + ii1, lk * r2 + ii2)];
+    crse[cidx(cp, li, lj, lk)] = refScale * s;
+}
+
+// ------------------------------------------------------------------------------------
+// ghost exchange inside one GPU: list of box-to-box copies (Chombo Copier motion items)
+// grid.x = item, grid.y = chunk of (j,k) rows
+// ------------------------------------------------------------------------------------
+__global__ void k_copy_items(const CopyItem* __restrict__ items, const PatchDesc* __restrict__ patches,
+                             double* __restrict__ f)
+{
+    const CopyItem it = items[blockIdx.x];
+    const PatchDesc sp = patches[it.src_patch];
+    const PatchDesc dp = patches[it.dst_patch];
+    const int rows = it.n[1] * it.n[2];
+    for (int row = blockIdx.y * blockDim.y + threadIdx.y; row < rows; row += gridDim.y * blockDim.y) {
+        const int j = row % it.n[1], k = row / it.n[1];
+        const long long s = cidx(sp, it.src_lo[0], it.src_lo[1] + j, it.src_lo[2] + k);
+        const long long d = cidx(dp, it.dst_lo[0], it.dst_lo[1] + j, it.dst_lo[2] + k);
+        for (int i = threadIdx.x; i < it.n[0]; i += blockDim.x) f[d + i] = f[s + i];
+    }
+}
+
+// pack / unpack of halo regions into contiguous send/recv buffers (multi-GPU path).
+// items[].dst_lo[0] carries the offset (in elements) inside the buffer.
+template <bool PACK>
+__global__ void k_pack_items(const CopyItem* __restrict__ items, const PatchDesc* __restrict__ patches,
+                             double* __restrict__ f, double* __restrict__ buf, const long long* __restrict__ bufoff)
+{
+    const CopyItem it = items[blockIdx.x];
+    const PatchDesc pp = patches[PACK ? it.src_patch : it.dst_patch];
+    const int* lo = PACK ? it.src_lo : it.dst_lo;
+    const long long b0 = bufoff[blockIdx.x];
+    const int rows = it.n[1] * it.n[2];
+    for (int row = blockIdx.y * blockDim.y + threadIdx.y; row < rows; row += gridDim.y * blockDim.y) {
+        const int j = row % it.n[1], k = row / it.n[1];
+        const long long a = cidx(pp, lo[0], lo[1] + j, lo[2] + k);
+        const long long b = b0 + (long long)row * it.n[0];
+        for (int i = threadIdx.x; i < it.n[0]; i += blockDim.x) {
+            if (PACK) buf[b + i] = f[a + i];
+            else      f[a + i] = buf[b + i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// flat BLAS-1 over whole allocations (LevelDataOps semantics: whole FAB incl. ghosts)
+// ------------------------------------------------------------------------------------
+__global__ void k_set(double* __restrict__ a, long long n, double v)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        a[i] = v;
+}
+__global__ void k_copy(double* __restrict__ d, const double* __restrict__ s, long long n)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        d[i] = s[i];
+}
+// y += a*x
+__global__ void k_incr(double* __restrict__ y, const double* __restrict__ x, double a, long long n)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = y[i] + a * x[i];
+}
+__global__ void k_scale(double* __restrict__ y, double a, long long n)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = y[i] * a;
+}
+// z = a*x + b*y
+__global__ void k_axby(double* __restrict__ z, const double* __restrict__ x, const double* __restrict__ y,
+                       double a, double b, long long n)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        z[i] = a * x[i] + b * y[i];
+}
+
+// valid-cell reductions.  MODE 0: sum a*b   1: max |a|   2: sum |a|   3: signed max a
+template <int MODE>
+__global__ __launch_bounds__(256) void k_reduce_valid(const Tile* __restrict__ tiles,
+                                                      const PatchDesc* __restrict__ patches,
+                                                      const double* __restrict__ a,
+                                                      const double* __restrict__ b,
+                                                      double* __restrict__ partials)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    double acc = (MODE == 3) ? -1.7976931348623157e308 : 0.0;
+    if (lj < p.n[1]) {
+        for (int kk = 0; kk < t.nk; ++kk)
+            for (int q = 0; q < 2; ++q) {
+                const int li = li0 + q;
+                if (li >= p.n[0]) continue;
+                const long long c = cidx(p, li, lj, t.k0 + kk);
+                if (MODE == 0) acc = acc + a[c] * b[c];
+                else if (MODE == 1) acc = fmax(acc, fabs(a[c]));
+                else if (MODE == 2) acc = acc + fabs(a[c]);
+                else acc = fmax(acc, a[c]);
+            }
+    }
+    acc = (MODE == 1 || MODE == 3) ? block_reduce<true>(acc) : block_reduce<false>(acc);
+    if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x] = acc;
+}
+
+// splitmix64(cell index, seed) -> uniform(-1,1): same integer recipe as
+// oracle/somar_oracle.py::hash_uniform; used by bench/tests for device-side synthetic fills.
+__global__ __launch_bounds__(256) void k_fill_hash(const Tile* __restrict__ tiles,
+                                                   const PatchDesc* __restrict__ patches,
+                                                   double* __restrict__ f, StencilParams P,
+                                                   unsigned long long seed)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1]) return;
+    const unsigned long long n0 = P.dom_hi[0] - P.dom_lo[0] + 1, n1 = P.dom_hi[1] - P.dom_lo[1] + 1;
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int li = li0 + q;
+            if (li >= p.n[0]) continue;
+            const int lk = t.k0 + kk;
+            const unsigned long long I = p.lo[0] + li - P.dom_lo[0], J = p.lo[1] + lj - P.dom_lo[1],
+                                     K = p.lo[2] + lk - P.dom_lo[2];
+            unsigned long long z = (I + n0 * (J + n1 * K)) + seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z = z ^ (z >> 31);
+            f[cidx(p, li, lj, lk)] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+        }
+}
+
+// ------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------
+static inline dim3 tile_block() { return dim3(64, TILE_J, 1); }
+static inline int flat_grid(long long n)
+{
+    long long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color)
+{
+    if (L.ntiles == 0) return;
+    hipLaunchKernelGGL(k_gsrb_ortho, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, phi, rhs,
+                       L.jg[0], L.jg[1], L.jg[2], L.jinv, L.lapdiag, L.P, color);
+}
+void launch_op_ortho(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* rhs, int mode)
+{
+    if (L.ntiles == 0) return;
+    if (mode == 0)
+        hipLaunchKernelGGL(k_op_ortho<0>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, out, phi,
+                           rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+    else
+        hipLaunchKernelGGL(k_op_ortho<1>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, out, phi,
+                           rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+}
+void launch_lapdiag(hipStream_t st, const LevelDev& L)
+{
+    if (L.ntiles == 0) return;
+    hipLaunchKernelGGL(k_lapdiag, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, L.lapdiag, L.jg[0],
+                       L.jg[1], L.jg[2], L.jinv, L.P);
+}
+void launch_diag(hipStream_t st, const LevelDev& L, double* phi, const double* r, int mode)
+{
+    if (L.ntiles == 0) return;
+    if (mode == 0)
+        hipLaunchKernelGGL(k_diag<0>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, phi, r, L.lapdiag,
+                           L.P.alpha, L.P.beta);
+    else
+        hipLaunchKernelGGL(k_diag<1>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, phi, r, L.lapdiag,
+                           L.P.alpha, L.P.beta);
+}
+void launch_restrict(hipStream_t st, const LevelDev& C, const LevelDev& F, double* crse, const double* fine,
+                     const int r[3])
+{
+    if (C.ntiles == 0) return;
+    hipLaunchKernelGGL(k_restrict, dim3(C.ntiles), tile_block(), 0, st, C.tiles, C.patches, F.patches, crse, fine,
+                       F.jinv, r[0], r[1], r[2]);
+}
+void launch_prolong(hipStream_t st, const LevelDev& F, const LevelDev& C, double* fine, const double* crse,
+                    const int r[3], bool zeroAvg, double dxProduct, double* partials, double* sums,
+                    long long fieldElems)
+{
+    if (F.ntiles == 0) return;
+    if (!zeroAvg) {
+        hipLaunchKernelGGL(k_prolong<false>, dim3(F.ntiles), tile_block(), 0, st, F.tiles, F.patches, C.patches,
+                           fine, crse, F.jinv, r[0], r[1], r[2], dxProduct, partials);
+    } else {
+        hipLaunchKernelGGL(k_prolong<true>, dim3(F.ntiles), tile_block(), 0, st, F.tiles, F.patches, C.patches,
+                           fine, crse, F.jinv, r[0], r[1], r[2], dxProduct, partials);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, F.ntiles, 2, 0, sums);
+    }
+    (void)fieldElems;
+}
+void launch_sub_mean(hipStream_t st, double* f, long long n, const double* sums)
+{
+    hipLaunchKernelGGL(k_sub_mean, dim3(flat_grid(n)), dim3(256), 0, st, f, n, sums);
+}
+void launch_avg_harmonic(hipStream_t st, const LevelDev& C, const LevelDev& F, double* crse, const double* fine,
+                         const int r[3])
+{
+    if (C.ntiles == 0) return;
+    hipLaunchKernelGGL(k_avg_harmonic, dim3(C.ntiles), tile_block(), 0, st, C.tiles, C.patches, F.patches, crse,
+                       fine, r[0], r[1], r[2]);
+}
+void launch_avg_face(hipStream_t st, const LevelDev& C, const LevelDev& F, int patch, const int cn[3], double* crse,
+                     const double* fine, int dir, const int r[3])
+{
+    const int ni = cn[0] + (dir == 0), nj = cn[1] + (dir == 1), nk = cn[2] + (dir == 2);
+    dim3 b(64, 4, 1), g((ni + 63) / 64, (nj + 3) / 4, nk);
+    hipLaunchKernelGGL(k_avg_face, g, b, 0, st, C.patches, F.patches, patch, crse, fine, dir, r[0], r[1], r[2]);
+}
+void launch_copy_items(hipStream_t st, const LevelDev& L, const CopyItem* items, int nitems, double* f)
+{
+    if (nitems == 0) return;
+    hipLaunchKernelGGL(k_copy_items, dim3(nitems, 8), dim3(64, 4), 0, st, items, L.patches, f);
+}
+void launch_pack(hipStream_t st, const LevelDev& L, const CopyItem* items, const long long* bufoff, int nitems,
+                 double* f, double* buf, bool pack)
+{
+    if (nitems == 0) return;
+    if (pack)
+        hipLaunchKernelGGL(k_pack_items<true>, dim3(nitems, 8), dim3(64, 4), 0, st, items, L.patches, f, buf, bufoff);
+    else
+        hipLaunchKernelGGL(k_pack_items<false>, dim3(nitems, 8), dim3(64, 4), 0, st, items, L.patches, f, buf, bufoff);
+}
+void launch_set(hipStream_t st, double* a, long long n, double v)
+{
+    hipLaunchKernelGGL(k_set, dim3(flat_grid(n)), dim3(256), 0, st, a, n, v);
+}
+void launch_copy(hipStream_t st, double* d, const double* s, long long n)
+{
+    hipLaunchKernelGGL(k_copy, dim3(flat_grid(n)), dim3(256), 0, st, d, s, n);
+}
+void launch_incr(hipStream_t st, double* y, const double* x, double a, long long n)
+{
+    hipLaunchKernelGGL(k_incr, dim3(flat_grid(n)), dim3(256), 0, st, y, x, a, n);
+}
+void launch_scale(hipStream_t st, double* y, double a, long long n)
+{
+    hipLaunchKernelGGL(k_scale, dim3(flat_grid(n)), dim3(256), 0, st, y, a, n);
+}
+void launch_axby(hipStream_t st, double* z, const double* x, const double* y, double a, double b, long long n)
+{
+    hipLaunchKernelGGL(k_axby, dim3(flat_grid(n)), dim3(256), 0, st, z, x, y, a, b, n);
+}
+void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const double* b, int mode, double* partials,
+                   double* out)
+{
+    if (L.ntiles == 0) {
+        hipLaunchKernelGGL(k_set, dim3(1), dim3(64), 0, st, out, 1, 0.0);
+        return;
+    }
+    if (mode == 0)
+        hipLaunchKernelGGL(k_reduce_valid<0>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, a, b, partials);
+    else if (mode == 1)
+        hipLaunchKernelGGL(k_reduce_valid<1>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, a, b, partials);
+    else if (mode == 2)
+        hipLaunchKernelGGL(k_reduce_valid<2>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, a, b, partials);
+    else
+        hipLaunchKernelGGL(k_reduce_valid<3>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, a, b, partials);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, L.ntiles, 1,
+                       mode == 1 ? 1 : (mode == 3 ? 2 : 0), out);
+}
+void launch_fill_hash(hipStream_t st, const LevelDev& L, double* f, unsigned long long seed)
+{
+    if (L.ntiles == 0) return;
+    hipLaunchKernelGGL(k_fill_hash, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, f, L.P, seed);
+}
+
+}  // namespace somar

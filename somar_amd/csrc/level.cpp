@@ -1,0 +1,288 @@
+// somar_amd/csrc/level.cpp -- layout tables, HBM allocation, ghost-exchange plan.
+#include "level.h"
+
+#include <algorithm>
+#include <array>
+#include <cstring>
+
+namespace somar {
+
+bool coarsenable(const std::vector<IBox>& boxes, const int* r)
+{
+    // Chombo: refine(coarsen(b, r), r) == b for every box
+    for (const IBox& b : boxes)
+        if (!(b.coarsen(r).refine(r) == b)) return false;
+    return true;
+}
+
+template <class T>
+static T* to_device(const std::vector<T>& v)
+{
+    if (v.empty()) return nullptr;
+    T* d = nullptr;
+    SOMAR_HIP(hipMalloc(&d, v.size() * sizeof(T)));
+    SOMAR_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+Level::~Level()
+{
+    hipFree(d_patches);
+    hipFree(d_tiles);
+    hipFree(d_local_items);
+    hipFree(d_send_items);
+    hipFree(d_recv_items);
+    hipFree(d_send_off);
+    hipFree(d_recv_off);
+    hipFree(d_sendbuf);
+    hipFree(d_recvbuf);
+    for (int d = 0; d < 3; ++d) hipFree(dev.jg[d]);
+    hipFree(dev.jinv);
+    hipFree(dev.lapdiag);
+}
+
+void Level::define(const IBox& dom, const bool per[3], const double dx_[3], const int bct[3][2],
+                   const std::vector<IBox>& bx, const std::vector<int>& own, Comm* c)
+{
+    domain = dom;
+    comm = c;
+    const int myrank = c ? c->rank : 0;
+    for (int d = 0; d < 3; ++d) {
+        periodic[d] = per[d];
+        dx[d] = dx_[d];
+        bc_type[d][0] = bct[d][0];
+        bc_type[d][1] = bct[d][1];
+    }
+    boxes = bx;
+    owner = own;
+    if (owner.empty()) owner.assign(boxes.size(), 0);
+    SOMAR_CHECK(owner.size() == boxes.size(), "owner/box count mismatch");
+
+    // ---- patches -------------------------------------------------------------------
+    local.clear();
+    hpatches.clear();
+    long long cursor = 0;
+    valid_cells_global = 0;
+    for (size_t b = 0; b < boxes.size(); ++b) {
+        SOMAR_CHECK(!boxes[b].empty(), "empty box in layout");
+        valid_cells_global += boxes[b].numPts();
+        if (owner[b] != myrank) continue;
+        PatchDesc p;
+        std::memset(&p, 0, sizeof(p));
+        for (int d = 0; d < 3; ++d) { p.lo[d] = boxes[b].lo[d]; p.n[d] = boxes[b].size(d); }
+        p.pj = ((p.n[0] + 2 * FRAME + 1) / 2) * 2;
+        p.pk = (long long)p.pj * (p.n[1] + 2 * FRAME);
+        const long long elems = p.pk * (p.n[2] + 2 * FRAME);
+        p.off = cursor + FRAME * p.pk + (long long)FRAME * p.pj + FRAME;
+        cursor += ((elems + 31) / 32) * 32;  // 256-byte aligned patch starts
+        hpatches.push_back(p);
+        local.push_back((int)b);
+    }
+    field_elems = cursor;
+
+    // ---- tiles, XCD-contiguous: block b runs on XCD (b % 8) under round-robin dispatch, so
+    // give each XCD one contiguous slab of the natural (patch,k,j,i) tile order: neighbouring
+    // tiles then share their j/k halo rows through the same 4 MiB L2. ------------------
+    std::vector<Tile> nat;
+    for (int pi = 0; pi < (int)hpatches.size(); ++pi) {
+        const PatchDesc& p = hpatches[pi];
+        for (int k0 = 0; k0 < p.n[2]; k0 += TILE_K)
+            for (int j0 = 0; j0 < p.n[1]; j0 += TILE_J)
+                for (int i0 = 0; i0 < p.n[0]; i0 += TILE_I) {
+                    Tile t;
+                    std::memset(&t, 0, sizeof(t));
+                    t.patch = pi; t.i0 = i0; t.j0 = j0; t.k0 = k0;
+                    t.nk = std::min(TILE_K, p.n[2] - k0);
+                    nat.push_back(t);
+                }
+    }
+    const int N = (int)nat.size();
+    htiles.assign(N, Tile());
+    {
+        const int NX = 8;
+        int start[NX + 1];
+        start[0] = 0;
+        for (int x = 0; x < NX; ++x) start[x + 1] = start[x] + (N - x + NX - 1) / NX;  // #b with b%8==x
+        for (int b = 0; b < N; ++b) htiles[b] = nat[start[b % NX] + b / NX];
+    }
+
+    // ---- exchange plan ----------------------------------------------------------------
+    plan = ExchangePlan();
+    int ghost[3];
+    for (int d = 0; d < 3; ++d) ghost[d] = active[d] ? 1 : 0;
+    std::vector<std::array<int, 3>> shifts;
+    for (int a = -1; a <= 1; ++a)
+        for (int b = -1; b <= 1; ++b)
+            for (int cc = -1; cc <= 1; ++cc) {
+                if ((a && !periodic[0]) || (b && !periodic[1]) || (cc && !periodic[2])) continue;
+                shifts.push_back({a * domain.size(0), b * domain.size(1), cc * domain.size(2)});
+            }
+    std::vector<int> patch_of(boxes.size(), -1);
+    for (int pi = 0; pi < (int)local.size(); ++pi) patch_of[local[pi]] = pi;
+
+    struct Remote { int peer; CopyItem it; };
+    std::vector<Remote> sends, recvs;
+    for (size_t di = 0; di < boxes.size(); ++di) {
+        const IBox gbox = boxes[di].grow(ghost);
+        for (size_t si = 0; si < boxes.size(); ++si) {
+            const bool dl = owner[di] == myrank, sl = owner[si] == myrank;
+            if (!dl && !sl) continue;
+            for (const auto& sh : shifts) {
+                if (si == di && sh[0] == 0 && sh[1] == 0 && sh[2] == 0) continue;
+                const IBox img = boxes[si].shift(sh.data());
+                const IBox r = gbox & img;
+                if (r.empty()) continue;
+                CopyItem it;
+                std::memset(&it, 0, sizeof(it));
+                it.src_patch = sl ? patch_of[si] : -1;
+                it.dst_patch = dl ? patch_of[di] : -1;
+                for (int d = 0; d < 3; ++d) {
+                    it.n[d] = r.size(d);
+                    it.dst_lo[d] = r.lo[d] - boxes[di].lo[d];
+                    it.src_lo[d] = r.lo[d] - sh[d] - boxes[si].lo[d];
+                }
+                if (dl && sl) plan.local.push_back(it);
+                else if (sl) sends.push_back({owner[di], it});
+                else recvs.push_back({owner[si], it});
+            }
+        }
+    }
+    // group remote items by peer (stable => identical canonical order on both sides)
+    for (auto& r : sends) plan.peers.push_back(r.peer);
+    for (auto& r : recvs) plan.peers.push_back(r.peer);
+    std::sort(plan.peers.begin(), plan.peers.end());
+    plan.peers.erase(std::unique(plan.peers.begin(), plan.peers.end()), plan.peers.end());
+    for (int q : plan.peers) {
+        plan.soff.push_back(plan.send_total);
+        for (auto& r : sends)
+            if (r.peer == q) {
+                plan.send_items.push_back(r.it);
+                plan.send_itemoff.push_back(plan.send_total);
+                plan.send_total += (long long)r.it.n[0] * r.it.n[1] * r.it.n[2];
+            }
+        plan.scount.push_back(plan.send_total - plan.soff.back());
+        plan.roff.push_back(plan.recv_total);
+        for (auto& r : recvs)
+            if (r.peer == q) {
+                plan.recv_items.push_back(r.it);
+                plan.recv_itemoff.push_back(plan.recv_total);
+                plan.recv_total += (long long)r.it.n[0] * r.it.n[1] * r.it.n[2];
+            }
+        plan.rcount.push_back(plan.recv_total - plan.roff.back());
+    }
+
+    // ---- device tables ----------------------------------------------------------------
+    d_patches = to_device(hpatches);
+    d_tiles = to_device(htiles);
+    d_local_items = to_device(plan.local);
+    d_send_items = to_device(plan.send_items);
+    d_recv_items = to_device(plan.recv_items);
+    d_send_off = to_device(plan.send_itemoff);
+    d_recv_off = to_device(plan.recv_itemoff);
+    if (plan.send_total) SOMAR_HIP(hipMalloc(&d_sendbuf, plan.send_total * sizeof(double)));
+    if (plan.recv_total) SOMAR_HIP(hipMalloc(&d_recvbuf, plan.recv_total * sizeof(double)));
+
+    dev.tiles = d_tiles;
+    dev.ntiles = N;
+    dev.patches = d_patches;
+    dev.npatches = (int)hpatches.size();
+    refresh_params();
+}
+
+void Level::refresh_params()
+{
+    StencilParams& P = dev.P;
+    for (int d = 0; d < 3; ++d) {
+        P.dom_lo[d] = domain.lo[d];
+        P.dom_hi[d] = domain.hi[d];
+        P.active[d] = active[d];
+        P.dx[d] = dx[d];
+        for (int s = 0; s < 2; ++s) P.neum[d][s] = (!periodic[d] && bc_type[d][s] == BC_NEUM) ? 1 : 0;
+    }
+    P.alpha = alpha;
+    P.beta = beta;
+    dxProduct = dx[0] * dx[1] * dx[2];
+}
+
+double* Level::alloc_field() const
+{
+    double* f = nullptr;
+    const long long n = field_elems > 0 ? field_elems : 1;
+    SOMAR_HIP(hipMalloc(&f, n * sizeof(double)));
+    SOMAR_HIP(hipMemset(f, 0, n * sizeof(double)));
+    return f;
+}
+void Level::free_field(double* f) { hipFree(f); }
+
+void Level::alloc_metric()
+{
+    for (int d = 0; d < 3; ++d)
+        if (!dev.jg[d]) dev.jg[d] = alloc_field();
+    if (!dev.jinv) dev.jinv = alloc_field();
+    if (!dev.lapdiag) dev.lapdiag = alloc_field();
+}
+
+void Level::exchange(double* f, hipStream_t st) const
+{
+    // remote first so the wire time overlaps the local copies
+    const bool remote = !plan.peers.empty();
+    if (remote) {
+        launch_pack(st, dev, d_send_items, d_send_off, (int)plan.send_items.size(), f, d_sendbuf, true);
+        comm->neighbor_exchange(d_sendbuf, d_recvbuf, plan.peers, plan.soff, plan.scount, plan.roff, plan.rcount, st);
+    }
+    launch_copy_items(st, dev, d_local_items, (int)plan.local.size(), f);
+    if (remote)
+        launch_pack(st, dev, d_recv_items, d_recv_off, (int)plan.recv_items.size(), f, d_recvbuf, false);
+}
+
+static void copy3d(void* dst, size_t dpitchB, size_t dheight, int dx0, int dy0, int dz0, const void* src,
+                   size_t spitchB, size_t sheight, int sx0, int sy0, int sz0, const int n[3], hipMemcpyKind kind,
+                   hipStream_t st)
+{
+    hipMemcpy3DParms p;
+    std::memset(&p, 0, sizeof(p));
+    p.srcPtr = make_hipPitchedPtr(const_cast<void*>(src), spitchB, spitchB / sizeof(double), sheight);
+    p.dstPtr = make_hipPitchedPtr(dst, dpitchB, dpitchB / sizeof(double), dheight);
+    p.srcPos = make_hipPos((size_t)sx0 * sizeof(double), sy0, sz0);
+    p.dstPos = make_hipPos((size_t)dx0 * sizeof(double), dy0, dz0);
+    p.extent = make_hipExtent((size_t)n[0] * sizeof(double), n[1], n[2]);
+    p.kind = kind;
+    SOMAR_HIP(hipMemcpy3DAsync(&p, st));
+}
+
+void Level::upload(double* field, int patch, const double* host, const IBox& hostbox, const IBox& region,
+                   hipStream_t st) const
+{
+    if (region.empty()) return;
+    const PatchDesc& p = hpatches[patch];
+    // device "volume": origin at the frame corner of the patch
+    double* base = field + (p.off - FRAME * p.pk - (long long)FRAME * p.pj - FRAME);
+    int n[3] = {region.size(0), region.size(1), region.size(2)};
+    for (int d = 0; d < 3; ++d)
+        SOMAR_CHECK(region.lo[d] - p.lo[d] >= -FRAME && region.hi[d] - p.lo[d] < p.n[d] + FRAME &&
+                        region.lo[d] >= hostbox.lo[d] && region.hi[d] <= hostbox.hi[d],
+                    "upload region outside patch frame or host box");
+    copy3d(base, (size_t)p.pj * 8, (size_t)(p.pk / p.pj), region.lo[0] - p.lo[0] + FRAME,
+           region.lo[1] - p.lo[1] + FRAME, region.lo[2] - p.lo[2] + FRAME, host, (size_t)hostbox.size(0) * 8,
+           (size_t)hostbox.size(1), region.lo[0] - hostbox.lo[0], region.lo[1] - hostbox.lo[1],
+           region.lo[2] - hostbox.lo[2], n, hipMemcpyHostToDevice, st);
+}
+
+void Level::download(const double* field, int patch, double* host, const IBox& hostbox, const IBox& region,
+                     hipStream_t st) const
+{
+    if (region.empty()) return;
+    const PatchDesc& p = hpatches[patch];
+    const double* base = field + (p.off - FRAME * p.pk - (long long)FRAME * p.pj - FRAME);
+    int n[3] = {region.size(0), region.size(1), region.size(2)};
+    for (int d = 0; d < 3; ++d)
+        SOMAR_CHECK(region.lo[d] - p.lo[d] >= -FRAME && region.hi[d] - p.lo[d] < p.n[d] + FRAME &&
+                        region.lo[d] >= hostbox.lo[d] && region.hi[d] <= hostbox.hi[d],
+                    "download region outside patch frame or host box");
+    copy3d(host, (size_t)hostbox.size(0) * 8, (size_t)hostbox.size(1), region.lo[0] - hostbox.lo[0],
+           region.lo[1] - hostbox.lo[1], region.lo[2] - hostbox.lo[2], base, (size_t)p.pj * 8,
+           (size_t)(p.pk / p.pj), region.lo[0] - p.lo[0] + FRAME, region.lo[1] - p.lo[1] + FRAME,
+           region.lo[2] - p.lo[2] + FRAME, n, hipMemcpyDeviceToHost, st);
+}
+
+}  // namespace somar

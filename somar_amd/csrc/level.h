@@ -1,0 +1,140 @@
+// somar_amd/csrc/level.h -- device-resident level data: the MI355X counterpart of
+// Chombo's DisjointBoxLayout + LevelData<FArrayBox> + Copier for ONE (AMR level, MG depth).
+//
+// Design (not a port): the caller's box layout is honoured semantically (it decides the MG
+// depth exactly like the reference's coarsenable() tests) but physically every field of a
+// level is ONE HBM allocation holding all local patches back to back, every field shares
+// the same patch table, and ghost exchange is one kernel launch over a precomputed list of
+// box-to-box copies (plus one packed message per neighbouring rank when the layout is
+// sharded over GPUs).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace somar {
+
+struct IBox {
+    int lo[3], hi[3];
+    IBox() : lo{0, 0, 0}, hi{-1, -1, -1} {}
+    IBox(const int* l, const int* h) { for (int d = 0; d < 3; ++d) { lo[d] = l[d]; hi[d] = h[d]; } }
+    bool empty() const { return hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2]; }
+    int size(int d) const { return hi[d] - lo[d] + 1; }
+    long long numPts() const { return empty() ? 0 : (long long)size(0) * size(1) * size(2); }
+    IBox grow(const int* g) const { IBox b = *this; for (int d = 0; d < 3; ++d) { b.lo[d] -= g[d]; b.hi[d] += g[d]; } return b; }
+    IBox shift(const int* s) const { IBox b = *this; for (int d = 0; d < 3; ++d) { b.lo[d] += s[d]; b.hi[d] += s[d]; } return b; }
+    IBox operator&(const IBox& o) const {
+        IBox b;
+        for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d] > o.lo[d] ? lo[d] : o.lo[d]; b.hi[d] = hi[d] < o.hi[d] ? hi[d] : o.hi[d]; }
+        return b;
+    }
+    bool operator==(const IBox& o) const {
+        for (int d = 0; d < 3; ++d) if (lo[d] != o.lo[d] || hi[d] != o.hi[d]) return false;
+        return true;
+    }
+    // Chombo coarsen(): floor division
+    static int fdiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+    IBox coarsen(const int* r) const { IBox b; for (int d = 0; d < 3; ++d) { b.lo[d] = fdiv(lo[d], r[d]); b.hi[d] = fdiv(hi[d], r[d]); } return b; }
+    IBox refine(const int* r) const { IBox b; for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d] * r[d]; b.hi[d] = (hi[d] + 1) * r[d] - 1; } return b; }
+};
+
+bool coarsenable(const std::vector<IBox>& boxes, const int* r);
+
+// Inter-GPU transport used by a sharded level (one process per GPU).  The default is the
+// single-rank no-op; comm_rccl.cpp provides the RCCL/xGMI implementation.
+struct Comm {
+    int rank = 0, size = 1;
+    virtual ~Comm() {}
+    // in-place on DEVICE memory, enqueued on st.  op: 0 sum, 1 max
+    virtual void allreduce(double* dbuf, int n, int op, hipStream_t st) { (void)dbuf; (void)n; (void)op; (void)st; }
+    // grouped neighbour exchange: for every peer q: send sendbuf+soff[q] (scount[q] doubles) and
+    // receive into recvbuf+roff[q] (rcount[q] doubles), enqueued on st.
+    virtual void neighbor_exchange(const double* sendbuf, double* recvbuf, const std::vector<int>& peers,
+                                   const std::vector<long long>& soff, const std::vector<long long>& scount,
+                                   const std::vector<long long>& roff, const std::vector<long long>& rcount,
+                                   hipStream_t st)
+    {
+        (void)sendbuf; (void)recvbuf; (void)peers; (void)soff; (void)scount; (void)roff; (void)rcount; (void)st;
+    }
+};
+
+// Host-side plan of the ghost exchange of one level ("Copier(grids,grids,domain,ghost,true)").
+struct ExchangePlan {
+    std::vector<CopyItem> local;      // both boxes on this rank
+    // remote part, grouped by peer rank in ascending order
+    std::vector<int> peers;
+    std::vector<CopyItem> send_items, recv_items;           // concatenated per peer
+    std::vector<long long> send_itemoff, recv_itemoff;      // buffer offset of each item
+    std::vector<long long> soff, scount, roff, rcount;      // per peer (doubles)
+    long long send_total = 0, recv_total = 0;
+};
+
+class Level {
+public:
+    // layout
+    IBox domain;
+    bool periodic[3] = {false, false, false};
+    double dx[3] = {1, 1, 1};
+    int active[3] = {1, 1, 1};
+    int bc_type[3][2];
+    std::vector<IBox> boxes;   // the whole DisjointBoxLayout, in the caller's order
+    std::vector<int> owner;    // rank of each box
+    std::vector<int> local;    // global box index of each local patch
+    std::vector<PatchDesc> hpatches;
+    std::vector<Tile> htiles;
+    long long field_elems = 0;
+    long long valid_cells_global = 0;
+    ExchangePlan plan;
+    Comm* comm = nullptr;
+
+    // device tables
+    PatchDesc* d_patches = nullptr;
+    Tile* d_tiles = nullptr;
+    CopyItem* d_local_items = nullptr;
+    CopyItem* d_send_items = nullptr;
+    CopyItem* d_recv_items = nullptr;
+    long long* d_send_off = nullptr;
+    long long* d_recv_off = nullptr;
+    double* d_sendbuf = nullptr;
+    double* d_recvbuf = nullptr;
+    LevelDev dev;  // kernel view (tables + metric planes)
+
+    // operator state
+    double alpha = 0.0, beta = 1.0;
+    int mgCrseRefRatio[3] = {1, 1, 1};
+    bool hasCoarser = false;
+    bool zeroAvg = false;
+    double dxProduct = 1.0;
+
+    Level() {}
+    ~Level();
+    Level(const Level&) = delete;
+    Level& operator=(const Level&) = delete;
+
+    // Build tables for a layout.  bc_type codes: BC_NEUM / BC_DIRI per non-periodic side.
+    void define(const IBox& dom, const bool per[3], const double dx_[3], const int bct[3][2],
+                const std::vector<IBox>& bx, const std::vector<int>& own, Comm* c);
+    // allocate coefficient planes (zero-filled) and fill dev view
+    void alloc_metric();
+    void refresh_params();
+
+    double* alloc_field() const;        // zero-initialised, field_elems doubles
+    static void free_field(double* f);
+
+    // ghost exchange of one field (faces, edges and corners, 1 cell deep in active dirs)
+    void exchange(double* f, hipStream_t st) const;
+
+    // host<->device transfer of one patch in Chombo FRA layout.  `hostbox` is the box the host
+    // array is defined on (valid grown by the caller's ghosts, or a face box); `region` is
+    // what to move.  comp selects a component of a multi-comp host FAB.
+    void upload(double* field, int patch, const double* host, const IBox& hostbox, const IBox& region,
+                hipStream_t st) const;
+    void download(const double* field, int patch, double* host, const IBox& hostbox, const IBox& region,
+                  hipStream_t st) const;
+
+    int npatches() const { return (int)hpatches.size(); }
+};
+
+}  // namespace somar

@@ -1,0 +1,540 @@
+// somar_amd/csrc/solver.cpp -- see solver.h for the reference map.
+#include "solver.h"
+
+#include <array>
+#include <cmath>
+#include <cstring>
+
+namespace somar {
+
+static const int S_MAX_COARSE = 4;  // MappedAMRPoissonOp::s_maxCoarse, MappedAMRPoissonOp.cpp:55
+enum { SLOT_TMP = 0, SLOT_SUMS = 8, NSLOTS = 16 };
+
+PressureSolver::PressureSolver(Comm* comm) : comm_(comm ? comm : &self_)
+{
+    SOMAR_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    SOMAR_HIP(hipMalloc(&d_scalars, NSLOTS * sizeof(double)));
+    SOMAR_HIP(hipMemset(d_scalars, 0, NSLOTS * sizeof(double)));
+    SOMAR_HIP(hipHostMalloc(&h_scalars, NSLOTS * sizeof(double)));
+}
+
+PressureSolver::~PressureSolver()
+{
+    if (st_) hipStreamSynchronize(st_);
+    for (double* f : f_res) hipFree(f);
+    for (double* f : f_corr) hipFree(f);
+    for (double* f : f_scratch) hipFree(f);
+    hipFree(f_phi); hipFree(f_rhs); hipFree(f_uberRes); hipFree(f_uberCorr); hipFree(f_best);
+    for (double* f : bicg) hipFree(f);
+    hipFree(d_partials);
+    hipFree(d_scalars);
+    if (h_scalars) hipHostFree(h_scalars);
+    lev.clear();
+    if (st_) hipStreamDestroy(st_);
+}
+
+void PressureSolver::sync() { SOMAR_HIP(hipStreamSynchronize(st_)); }
+
+double PressureSolver::fetch_scalar(int slot)
+{
+    SOMAR_HIP(hipMemcpyAsync(h_scalars + slot, d_scalars + slot, sizeof(double), hipMemcpyDeviceToHost, st_));
+    SOMAR_HIP(hipStreamSynchronize(st_));
+    return h_scalars[slot];
+}
+
+double* PressureSolver::work(int which)
+{
+    return which == 0 ? f_uberRes : (which == 1 ? f_uberCorr : f_best);
+}
+
+double* PressureSolver::field(int depth, int which)
+{
+    if (depth < 0 || depth >= (int)lev.size() || !finalized) return nullptr;
+    switch (which) {
+        case 0: return depth == 0 ? f_phi : nullptr;
+        case 1: return depth == 0 ? f_rhs : nullptr;
+        case 2: return depth == 0 ? f_uberRes : f_res[depth];
+        case 3: return depth == 0 ? f_uberCorr : f_corr[depth];
+        case 4: return depth == 0 ? f_best : nullptr;
+        case 5: return f_scratch[depth];
+        default: return nullptr;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// definition
+// ------------------------------------------------------------------------------------
+void PressureSolver::define(const IBox& domain, const bool periodic[3], const double dx[3],
+                            const int bc_type[3][2], const std::vector<IBox>& boxes,
+                            const std::vector<int>& owner, double alpha, double beta, const SolverParams& p)
+{
+    SOMAR_CHECK(lev.empty(), "solver already defined");
+    prm = p;
+    SOMAR_CHECK(prm.relaxMode == RELAX_LEVEL_GSRB || prm.relaxMode == RELAX_JACOBI,
+                "only LevelGSRB (relax_mode 1) and Jacobi (0) are implemented");
+    SOMAR_CHECK(prm.precondMode == PRECOND_DIAG_RELAX || prm.precondMode == PRECOND_NONE,
+                "only DiagRelax / None preconditioners are implemented");
+    for (int d = 0; d < 3; ++d)
+        for (int s = 0; s < 2; ++s)
+            SOMAR_CHECK(periodic[d] || bc_type[d][s] == BC_NEUM,
+                        "only homogeneous-Neumann (pressure) physical BCs are implemented");
+    std::unique_ptr<Level> L(new Level);
+    L->alpha = alpha;
+    L->beta = beta;
+    L->define(domain, periodic, dx, bc_type, boxes, owner, comm_);
+    L->alloc_metric();
+    lev.push_back(std::move(L));
+}
+
+void PressureSolver::set_metric_ortho(int patch, const double* jg0, const double* jg1, const double* jg2,
+                                      const double* jinv)
+{
+    SOMAR_CHECK(!lev.empty() && !finalized, "set_metric before define / after finalize");
+    Level& L = *lev[0];
+    SOMAR_CHECK(patch >= 0 && patch < L.npatches(), "bad patch index");
+    const IBox valid = L.boxes[L.local[patch]];
+    const double* jg[3] = {jg0, jg1, jg2};
+    for (int d = 0; d < 3; ++d) {
+        IBox fb = valid;
+        fb.hi[d] += 1;
+        L.upload(L.dev.jg[d], patch, jg[d], fb, fb, st_);
+    }
+    L.upload(L.dev.jinv, patch, jinv, valid, valid, st_);
+    sync();
+}
+
+// Semicoarsening rule + fallback, MappedAMRPoissonOpFactory.cpp:476-550
+bool PressureSolver::build_coarser(int depth)
+{
+    if (prm.maxDepth >= 0 && depth > prm.maxDepth) return false;
+    Level& F = *lev[depth - 1];
+    int prev[3] = {1, 1, 1};
+    for (auto& r : mgRefRatios)
+        for (int d = 0; d < 3; ++d) prev[d] *= r[d];
+    const int mmc[3] = {S_MAX_COARSE, S_MAX_COARSE, S_MAX_COARSE};
+    int r[3] = {1, 1, 1};
+    double maxDx = 0.0;
+    for (int d = 0; d < 3; ++d) maxDx = std::max(maxDx, F.dx[d]);
+    for (int d = 0; d < 3; ++d)
+        if (F.dx[d] <= maxDx / 2.0) r[d] = 2;
+    if (r[0] * r[1] * r[2] == 1) r[0] = r[1] = r[2] = 2;
+    int tot[3];
+    for (int d = 0; d < 3; ++d) tot[d] = prev[d] * r[d] * mmc[d];
+    const std::vector<IBox>& base = lev[0]->boxes;
+    if (!coarsenable(base, tot)) {
+        int q[3] = {1, 1, 1};
+        for (int d = 0; d < 3; ++d) {
+            q[d] = 2;
+            int t2[3];
+            for (int e = 0; e < 3; ++e) t2[e] = prev[e] * mmc[e] * q[e];
+            if (!coarsenable(base, t2)) q[d] = 1;
+        }
+        if (q[0] * q[1] * q[2] == 1) return false;
+        int refDir = 0;
+        while (refDir < 3 && q[refDir] != 1) ++refDir;
+        SOMAR_CHECK(refDir < 3, "semicoarsening fallback: no stuck direction");
+        for (int d = 0; d < 3; ++d)
+            if (q[d] > 1 && F.dx[d] / F.dx[refDir] > 0.5) q[d] = 1;
+        if (q[0] * q[1] * q[2] == 1) return false;
+        for (int d = 0; d < 3; ++d) { r[d] = q[d]; tot[d] = prev[d] * r[d] * mmc[d]; }
+        if (!coarsenable(base, tot)) return false;
+    }
+    mgRefRatios.push_back({r[0], r[1], r[2]});
+    for (int d = 0; d < 3; ++d) F.mgCrseRefRatio[d] = r[d];
+    F.hasCoarser = true;
+
+    std::unique_ptr<Level> C(new Level);
+    C->alpha = F.alpha;
+    C->beta = F.beta;
+    std::vector<IBox> cb;
+    for (const IBox& b : F.boxes) cb.push_back(b.coarsen(r));
+    double cdx[3];
+    for (int d = 0; d < 3; ++d) cdx[d] = F.dx[d] * (double)r[d];
+    C->define(F.domain.coarsen(r), F.periodic, cdx, F.bc_type, cb, F.owner, comm_);
+    C->alloc_metric();
+    // coarse metrics: fill_MGfields, MappedAMRPoissonOpFactory.cpp:1164-1234
+    for (int pi = 0; pi < C->npatches(); ++pi)
+        for (int d = 0; d < 3; ++d)
+            launch_avg_face(st_, C->dev, F.dev, pi, C->hpatches[pi].n, C->dev.jg[d], F.dev.jg[d], d, r);
+    launch_avg_harmonic(st_, C->dev, F.dev, C->dev.jinv, F.dev.jinv, r);
+    launch_lapdiag(st_, C->dev);
+    lev.push_back(std::move(C));
+    return true;
+}
+
+// null-space probe, MappedAMRPoissonOpFactory.cpp:659-693
+void PressureSolver::probe_null_space(int d)
+{
+    Level& L = *lev[d];
+    double* phi = L.alloc_field();
+    double* rhs0 = L.alloc_field();
+    double* res = L.alloc_field();
+    launch_set(st_, phi, L.field_elems, 0.0);
+    apply_op(d, rhs0, phi);
+    launch_set(st_, phi, L.field_elems, 1.0);
+    residual(d, res, phi, rhs0);
+    launch_reduce(st_, L.dev, res, nullptr, 3, d_partials, d_scalars + SLOT_TMP);
+    comm_->allreduce(d_scalars + SLOT_TMP, 1, 1, st_);
+    const double maxNorm = std::fabs(fetch_scalar(SLOT_TMP));
+    L.zeroAvg = maxNorm < 0.01 * prm.eps;
+    Level::free_field(phi);
+    Level::free_field(rhs0);
+    Level::free_field(res);
+}
+
+void PressureSolver::finalize()
+{
+    SOMAR_CHECK(!lev.empty() && !finalized, "finalize before define / twice");
+    launch_lapdiag(st_, lev[0]->dev);
+    int depth = 1;
+    while (build_coarser(depth)) ++depth;
+    int maxTiles = 1;
+    for (auto& L : lev) maxTiles = std::max(maxTiles, L->dev.ntiles);
+    SOMAR_HIP(hipMalloc(&d_partials, (size_t)maxTiles * 2 * sizeof(double)));
+    const int D = (int)lev.size();
+    f_res.assign(D, nullptr);
+    f_corr.assign(D, nullptr);
+    f_scratch.assign(D, nullptr);
+    for (int d = 0; d < D; ++d) {
+        if (d > 0) { f_res[d] = lev[d]->alloc_field(); f_corr[d] = lev[d]->alloc_field(); }
+        f_scratch[d] = lev[d]->alloc_field();
+    }
+    Level& L0 = *lev[0];
+    f_phi = L0.alloc_field();
+    f_rhs = L0.alloc_field();
+    f_uberRes = L0.alloc_field();
+    f_uberCorr = L0.alloc_field();
+    f_best = L0.alloc_field();
+    for (int i = 0; i < 8; ++i) bicg[i] = lev[D - 1]->alloc_field();
+    for (int d = 0; d < D; ++d) probe_null_space(d);
+    sync();
+    finalized = true;
+}
+
+// ------------------------------------------------------------------------------------
+// boundary transfers
+// ------------------------------------------------------------------------------------
+void PressureSolver::upload_phi(int patch, const double* host, const int ghost[3])
+{
+    Level& L = *lev[0];
+    const IBox valid = L.boxes[L.local[patch]];
+    L.upload(f_phi, patch, host, valid.grow(ghost), valid, st_);
+}
+void PressureSolver::upload_rhs(int patch, const double* host, const int ghost[3])
+{
+    Level& L = *lev[0];
+    const IBox valid = L.boxes[L.local[patch]];
+    L.upload(f_rhs, patch, host, valid.grow(ghost), valid, st_);
+}
+void PressureSolver::download_phi(int patch, double* host, const int ghost[3])
+{
+    download_field(f_phi, 0, patch, host, ghost);
+}
+void PressureSolver::download_field(const double* field, int depth, int patch, double* host, const int ghost[3])
+{
+    Level& L = *lev[depth];
+    const IBox valid = L.boxes[L.local[patch]];
+    int g[3];
+    for (int d = 0; d < 3; ++d) {
+        SOMAR_CHECK(ghost[d] >= 0 && ghost[d] <= FRAME, "host ghost wider than the device frame");
+        g[d] = ghost[d];
+    }
+    const IBox hb = valid.grow(g);
+    L.download(field, patch, host, hb, hb, st_);
+    sync();
+}
+
+// ------------------------------------------------------------------------------------
+// level operator
+// ------------------------------------------------------------------------------------
+void PressureSolver::relax(int d, double* e, const double* res, int iters)
+{
+    Level& L = *lev[d];
+    for (int it = 0; it < iters; ++it) {
+        if (prm.relaxMode == RELAX_LEVEL_GSRB) {
+            // LevelGSRB::relax, GSRB.cpp:58-98.  The Neumann ghost fill of
+            // fillGhostsAndExtrapolate is dead code for a diagonal metric (the boundary
+            // stencil never reads a Neumann ghost), so only the exchange remains.
+            for (int pass = 0; pass < 2; ++pass) {
+                L.exchange(e, st_);
+                launch_gsrb_ortho(st_, L.dev, e, res, pass);
+            }
+        } else {
+            // Jacobi::relax, Jacobi.cpp:54-90
+            residual(d, f_scratch[d], e, res);
+            launch_diag(st_, L.dev, e, f_scratch[d], 1);
+        }
+    }
+}
+
+void PressureSolver::residual(int d, double* out, double* phi, const double* rhs)
+{
+    Level& L = *lev[d];
+    L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
+    launch_op_ortho(st_, L.dev, out, phi, rhs, 0);
+}
+
+void PressureSolver::apply_op(int d, double* out, double* phi)
+{
+    Level& L = *lev[d];
+    L.exchange(phi, st_);
+    launch_op_ortho(st_, L.dev, out, phi, nullptr, 1);
+}
+
+void PressureSolver::restrict_residual(int d, double* resCoarse, double* phiFine, const double* rhsFine)
+{
+    // restrictResidual, MappedAMRPoissonOp.cpp:1281-1304
+    residual(d, f_scratch[d], phiFine, rhsFine);
+    launch_restrict(st_, lev[d + 1]->dev, lev[d]->dev, resCoarse, f_scratch[d], lev[d]->mgCrseRefRatio);
+}
+
+void PressureSolver::prolong_increment(int d, double* phiFine, const double* corrCoarse)
+{
+    // ConstInterpPS / ZeroAvgConstInterpPS, ProlongationStrategy.cpp:49-164.  The two scalar
+    // MPI_Allreduce calls of the reference become one 2-element device-side reduction.
+    Level& F = *lev[d];
+    launch_prolong(st_, F.dev, lev[d + 1]->dev, phiFine, corrCoarse, F.mgCrseRefRatio, F.zeroAvg, F.dxProduct,
+                   d_partials, d_scalars + SLOT_SUMS, F.field_elems);
+    if (F.zeroAvg) {
+        comm_->allreduce(d_scalars + SLOT_SUMS, 2, 0, st_);
+        launch_sub_mean(st_, phiFine, F.field_elems, d_scalars + SLOT_SUMS);
+    }
+}
+
+void PressureSolver::pre_cond(int d, double* phi, const double* rhs)
+{
+    // preCond, MappedAMRPoissonOp.cpp:684-734
+    Level& L = *lev[d];
+    if (prm.num_smooth_precond == 0 || prm.precondMode == PRECOND_NONE) {
+        launch_copy(st_, phi, rhs, L.field_elems);
+        return;
+    }
+    launch_diag(st_, L.dev, phi, rhs, 0);
+    relax(d, phi, rhs, prm.num_smooth_precond);
+}
+
+double PressureSolver::norm(int d, const double* a, int ord)
+{
+    Level& L = *lev[d];
+    if (ord == 0) {
+        launch_reduce(st_, L.dev, a, nullptr, 1, d_partials, d_scalars + SLOT_TMP);
+        comm_->allreduce(d_scalars + SLOT_TMP, 1, 1, st_);
+        return fetch_scalar(SLOT_TMP);
+    }
+    if (ord == 1) {
+        launch_reduce(st_, L.dev, a, nullptr, 2, d_partials, d_scalars + SLOT_TMP);
+        comm_->allreduce(d_scalars + SLOT_TMP, 1, 0, st_);
+        return fetch_scalar(SLOT_TMP);
+    }
+    SOMAR_CHECK(ord == 2, "norm order must be 0, 1 or 2");
+    launch_reduce(st_, L.dev, a, a, 0, d_partials, d_scalars + SLOT_TMP);
+    comm_->allreduce(d_scalars + SLOT_TMP, 1, 0, st_);
+    return std::sqrt(fetch_scalar(SLOT_TMP));
+}
+
+double PressureSolver::dot(int d, const double* a, const double* b)
+{
+    launch_reduce(st_, lev[d]->dev, a, b, 0, d_partials, d_scalars + SLOT_TMP);
+    comm_->allreduce(d_scalars + SLOT_TMP, 1, 0, st_);
+    return fetch_scalar(SLOT_TMP);
+}
+
+void PressureSolver::fill_hash(int d, double* f, unsigned long long seed)
+{
+    launch_fill_hash(st_, lev[d]->dev, f, seed);
+}
+
+// ------------------------------------------------------------------------------------
+// MappedMultiGrid::cycle, MappedMultiGrid.H:555-653 (V/W cycles; F-cycle not offered)
+// ------------------------------------------------------------------------------------
+void PressureSolver::vcycle(double* e, const double* res) { cycle(0, e, res); }
+
+void PressureSolver::cycle(int d, double* corr, const double* res)
+{
+    const int D = (int)lev.size();
+    if (d == D - 1) {
+        if (lev[d]->domain.numPts() == 1) {
+            relax(d, corr, res, 1);
+        } else {
+            relax(d, corr, res, prm.num_smooth_bottom);
+            bottom_solve(corr, res);
+        }
+        return;
+    }
+    SOMAR_CHECK(prm.numMG > 0, "F-cycles (numMG < 0) are not implemented");
+    relax(d, corr, res, prm.num_smooth_down);
+    restrict_residual(d, f_res[d + 1], corr, res);
+    launch_set(st_, f_corr[d + 1], lev[d + 1]->field_elems, 0.0);
+    for (int img = 0; img < prm.numMG; ++img) cycle(d + 1, f_corr[d + 1], f_res[d + 1]);
+    prolong_increment(d, corr, f_corr[d + 1]);
+    relax(d, corr, res, prm.num_smooth_up);
+}
+
+// ------------------------------------------------------------------------------------
+// Chombo 3.1 BiCGStabSolver<T>::solve (EXTERNAL to the reference; restated from the published
+// algorithm, same variable names).  Runs on the coarsest MG depth.
+// ------------------------------------------------------------------------------------
+void PressureSolver::bottom_solve(double* phi, const double* rhs)
+{
+    const int d = (int)lev.size() - 1;
+    const long long n = lev[d]->field_elems;
+    double *r = bicg[0], *r_tilde = bicg[1], *e = bicg[2], *p = bicg[3], *p_tilde = bicg[4], *s_tilde = bicg[5],
+           *t = bicg[6], *v = bicg[7];
+    const int nt = prm.bottom_normType;
+    int recount = 0;
+    residual(d, r, phi, rhs);
+    launch_copy(st_, r_tilde, r, n);
+    launch_set(st_, e, n, 0.0);
+    launch_set(st_, p_tilde, n, 0.0);
+    launch_set(st_, s_tilde, n, 0.0);
+    int i = 0;
+    double rho[4] = {0, 0, 0, 0};
+    double nrm[2];
+    nrm[0] = norm(d, r, nt);
+    double initial_norm = nrm[0];
+    const double initial_rnorm = nrm[0];
+    nrm[1] = nrm[0];
+    double alpha[2] = {0, 0}, beta[2] = {0, 0}, omega[2] = {0, 0};
+    bool init = true;
+    int restarts = 0;
+    if (bottom_metric > 0) initial_norm = bottom_metric;
+    const double eps = bottom_eps_eff;
+    bottom_exit = -1;
+    while ((i < prm.bottom_imax && nrm[0] > eps * nrm[1]) && (nrm[1] > 0)) {
+        ++i;
+        nrm[1] = nrm[0];
+        alpha[1] = alpha[0]; beta[1] = beta[0]; omega[1] = omega[0];
+        rho[3] = rho[2]; rho[2] = rho[1];
+        rho[1] = dot(d, r_tilde, r);
+        if (rho[1] == 0.0) {
+            launch_incr(st_, phi, e, 1.0, n);
+            bottom_exit = 2;
+            bottom_iters = i;
+            return;
+        }
+        if (init) {
+            launch_copy(st_, p, r, n);
+            init = false;
+        } else {
+            beta[1] = (rho[1] / rho[2]) * (alpha[1] / omega[1]);
+            launch_scale(st_, p, beta[1], n);
+            launch_incr(st_, p, v, -beta[1] * omega[1], n);
+            launch_incr(st_, p, r, 1.0, n);
+        }
+        pre_cond(d, p_tilde, p);
+        apply_op(d, v, p_tilde);
+        const double m = dot(d, r_tilde, v);
+        alpha[0] = rho[1] / m;
+        if (std::fabs(m) > prm.bottom_small * std::fabs(rho[1])) {
+            launch_incr(st_, r, v, -alpha[0], n);
+            nrm[0] = norm(d, r, nt);
+            launch_incr(st_, e, p_tilde, alpha[0], n);
+        } else {
+            launch_set(st_, r, n, 0.0);
+            nrm[0] = 0.0;
+        }
+        if (nrm[0] > eps * initial_norm && nrm[0] > prm.bottom_reps * initial_rnorm) {
+            pre_cond(d, s_tilde, r);
+            apply_op(d, t, s_tilde);
+            const double tr = dot(d, t, r);
+            const double tt = dot(d, t, t);
+            omega[0] = tr / tt;
+            launch_incr(st_, e, s_tilde, omega[0], n);
+            launch_incr(st_, r, t, -omega[0], n);
+            nrm[0] = norm(d, r, nt);
+        }
+        if (nrm[0] <= eps * initial_norm || nrm[0] <= prm.bottom_reps * initial_rnorm) {
+            bottom_exit = 1;
+            break;
+        }
+        if (omega[0] == 0.0 || nrm[0] > (1 - prm.bottom_hang) * nrm[1]) {
+            if (recount == 0) {
+                recount = 1;
+            } else {
+                recount = 0;
+                launch_incr(st_, phi, e, 1.0, n);
+                if (restarts == prm.bottom_numRestarts) {
+                    bottom_exit = 3;
+                    bottom_iters = i;
+                    return;
+                }
+                residual(d, r, phi, rhs);
+                nrm[0] = norm(d, r, nt);
+                rho[0] = rho[1] = rho[2] = rho[3] = 0.0;
+                alpha[0] = beta[0] = omega[0] = 0.0;
+                launch_copy(st_, r_tilde, r, n);
+                launch_set(st_, e, n, 0.0);
+                ++restarts;
+                init = true;
+            }
+        }
+    }
+    launch_incr(st_, phi, e, 1.0, n);
+    bottom_iters = i;
+}
+
+// ------------------------------------------------------------------------------------
+// MappedAMRMultiGrid::solveNoInitResid for l_base == l_max == 0, MappedAMRMultiGrid.H:979-1183
+// ------------------------------------------------------------------------------------
+void PressureSolver::solve(bool zeroPhi, bool forceHomogeneous, SolveStats& s)
+{
+    (void)forceHomogeneous;  // zero-Neumann data: homogeneous and inhomogeneous BCs coincide
+    SOMAR_CHECK(finalized, "solve before finalize");
+    Level& L = *lev[0];
+    const long long n = L.field_elems;
+    launch_set(st_, f_uberRes, n, 0.0);
+    launch_set(st_, f_uberCorr, n, 0.0);
+    if (zeroPhi) launch_set(st_, f_phi, n, 0.0);
+    launch_copy(st_, f_best, f_phi, n);
+    residual(0, f_uberRes, f_phi, f_rhs);
+    double initial_rnorm = norm(0, f_uberRes, 0);
+    double rnorm = initial_rnorm, norm_last = 2 * initial_rnorm, best_rnorm = rnorm;
+    bool useBestPhi = false, somethingConverged = false;
+    bottom_metric = initial_rnorm;          // setConvergenceMetrics(initial_rnorm, cushion*eps), :1047
+    bottom_eps_eff = 1.0 * prm.eps;
+    int iter = 0;
+    s = SolveStats();
+    s.history.push_back(rnorm);
+    bool goNorm = rnorm > prm.normThresh;
+    bool goRedu = rnorm > prm.eps * initial_rnorm;
+    bool goIter = iter < prm.imax;
+    bool goHang = iter < prm.imin || rnorm < (1 - prm.hang) * norm_last;
+    while (goIter && goRedu && goHang && goNorm) {
+        norm_last = rnorm;
+        vcycle(f_uberCorr, f_uberRes);
+        launch_incr(st_, f_phi, f_uberCorr, 1.0, n);   // postVCycleOps, :1189-1215
+        launch_set(st_, f_uberCorr, n, 0.0);
+        residual(0, f_uberRes, f_phi, f_rhs);
+        rnorm = norm(0, f_uberRes, 0);
+        ++iter;
+        s.history.push_back(rnorm);
+        if (rnorm <= best_rnorm) {
+            best_rnorm = rnorm;
+            launch_copy(st_, f_best, f_phi, n);
+            useBestPhi = false;
+            somethingConverged = true;
+        } else {
+            useBestPhi = true;
+        }
+        goNorm = rnorm > prm.normThresh;
+        goRedu = rnorm > prm.eps * initial_rnorm;
+        goIter = iter < prm.imax;
+        goHang = iter < prm.imin || rnorm < (1 - prm.hang) * norm_last;
+    }
+    if (useBestPhi) {
+        rnorm = best_rnorm;
+        launch_copy(st_, f_phi, f_best, n);
+    }
+    s.status = 0;
+    if (rnorm > 10. * initial_rnorm && rnorm > 10. * prm.eps) s.status = 1;                        // "kaboom" :1134
+    else if (!somethingConverged && rnorm >= initial_rnorm && rnorm >= prm.eps) s.status = 2;      // :1141
+    s.exitStatus = int(!goRedu) + int(!goIter) * 2 + int(!goHang) * 4 + int(!goNorm) * 8;
+    s.iters = iter;
+    s.initial_rnorm = initial_rnorm;
+    s.final_rnorm = rnorm;
+    s.bottom_iters_last = bottom_iters;
+    s.bottom_exit_last = bottom_exit;
+    sync();
+}
+
+}  // namespace somar

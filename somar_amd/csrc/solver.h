@@ -1,0 +1,110 @@
+// somar_amd/csrc/solver.h -- host-side multigrid driver (C++), the MI355X counterpart of
+//   MappedAMRPoissonOpFactory::MGnewOp      calculus/AMRElliptic/MappedAMRPoissonOpFactory.cpp:363-702
+//   MappedMultiGrid<T>::define/init/cycle   calculus/AMRElliptic/MappedMultiGrid.H:328-434, 555-653
+//   MappedAMRMultiGrid<T>::solveNoInitResid calculus/AMRElliptic/MappedAMRMultiGrid.H:979-1183
+//   MappedAMRPoissonOp (level operator)     calculus/AMRElliptic/MappedAMRPoissonOp.cpp
+//   LevelGSRB / Jacobi                      calculus/AMRElliptic/RelaxationMethods/GSRB.cpp:58-98, Jacobi.cpp:54-90
+//   Chombo 3.1 BiCGStabSolver (EXTERNAL)    restated from its published algorithm
+// All level data stay resident in HBM for the life of the solver; the host only sequences
+// kernel launches on one HIP stream and reads back the few scalars the stopping tests need.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "level.h"
+
+namespace somar {
+
+enum { RELAX_JACOBI = 0, RELAX_LEVEL_GSRB = 1, RELAX_LOOSE_GSRB = 2, RELAX_LINE_GSRB = 3 };  // ProblemContext.H:322-340
+enum { PRECOND_NONE = -1, PRECOND_DIAG_RELAX = 0, PRECOND_DIAG_LINE_RELAX = 1 };
+
+// AMRPressureSolver::setAMRMGParameters / setBottomParameters (projection/AMRPressureSolver.H:53-77);
+// defaults utils/ProblemContext.cpp:1147-1236
+struct SolverParams {
+    int imin = 5, imax = 20;
+    double eps = 1e-6, hang = 1e-15, normThresh = 1e-30;
+    int num_smooth_down = 2, num_smooth_up = 2, num_smooth_bottom = 2, num_smooth_precond = 2;
+    int numMG = 1, maxDepth = -1, precondMode = PRECOND_DIAG_RELAX, relaxMode = RELAX_LEVEL_GSRB;
+    int verbosity = 0;
+    int bottom_imax = 80, bottom_numRestarts = 5, bottom_normType = 2, bottom_verbosity = 0;
+    double bottom_eps = 1e-6, bottom_reps = 1e-12, bottom_hang = 1e-15, bottom_small = 1e-30;
+};
+
+struct SolveStats {
+    int iters = 0;
+    int exitStatus = 0;         // !goRedu + 2*!goIter + 4*!goHang + 8*!goNorm (MappedAMRMultiGrid.H:1148)
+    int status = 0;             // 0 ok, 1 "kaboom", 2 "solver blew up"
+    double initial_rnorm = 0, final_rnorm = 0;
+    std::vector<double> history;  // max-norm residual after each V-cycle (history[0] = initial)
+    int bottom_iters_last = 0, bottom_exit_last = 0;
+};
+
+class PressureSolver {
+public:
+    explicit PressureSolver(Comm* comm = nullptr);
+    ~PressureSolver();
+
+    // ---- definition (MappedAMRPoissonOpFactory::define + MappedAMRMultiGrid::define) -----
+    void define(const IBox& domain, const bool periodic[3], const double dx[3], const int bc_type[3][2],
+                const std::vector<IBox>& boxes, const std::vector<int>& owner, double alpha, double beta,
+                const SolverParams& prm);
+    // Diagonal metric of one LOCAL patch in Chombo FRA layout: Jg_aa on faces(valid,a), Jinv on valid.
+    void set_metric_ortho(int patch, const double* jg0, const double* jg1, const double* jg2, const double* jinv);
+    void finalize();  // builds the semicoarsened hierarchy, coarse metrics, lapDiag, null-space probes
+
+    // ---- data movement across the boundary (host FABs, caller-owned) ---------------------
+    void upload_phi(int patch, const double* host, const int ghost[3]);
+    void upload_rhs(int patch, const double* host, const int ghost[3]);
+    void download_phi(int patch, double* host, const int ghost[3]);
+    void download_field(const double* field, int depth, int patch, double* host, const int ghost[3]);
+
+    // ---- AMREllipticSolver::solve on the resident phi/rhs (AMREllipticSolver.H:33-48) -----
+    void solve(bool zeroPhi, bool forceHomogeneous, SolveStats& st);
+
+    // ---- pieces, exposed for benchmarks and kernel-level parity tests -----------------------
+    int depth() const { return (int)lev.size(); }
+    Level& level(int d) { return *lev[d]; }
+    double* phi() { return f_phi; }
+    double* rhs() { return f_rhs; }
+    double* work(int which);  // 0 uberResidual 1 uberCorrection 2 bestPhi
+    double* field(int depth, int which);  // SOMAR_F_* handle -> device pointer (nullptr if absent)
+    void relax(int d, double* e, const double* res, int iters);
+    void residual(int d, double* out, double* phi, const double* rhs);
+    void apply_op(int d, double* out, double* phi);
+    void restrict_residual(int d, double* resCoarse, double* phiFine, const double* rhsFine);
+    void prolong_increment(int d, double* phiFine, const double* corrCoarse);
+    void pre_cond(int d, double* phi, const double* rhs);
+    void vcycle(double* e, const double* res);  // MappedMultiGrid::oneCycle
+    void bottom_solve(double* phi, const double* rhs);
+    double norm(int d, const double* a, int ord);
+    double dot(int d, const double* a, const double* b);
+    void fill_hash(int d, double* f, unsigned long long seed);
+    void sync();
+    hipStream_t stream() const { return st_; }
+
+    SolverParams prm;
+    // bottom-solver state shared with MappedAMRMultiGrid (setConvergenceMetrics)
+    double bottom_metric = -1.0, bottom_eps_eff = 1e-6;
+    int bottom_iters = 0, bottom_exit = 0;
+    std::vector<std::array<int, 3>> mgRefRatios;
+
+private:
+    void cycle(int d, double* corr, const double* res);
+    double fetch_scalar(int slot);
+    bool build_coarser(int depth);
+    void probe_null_space(int d);
+
+    Comm* comm_;
+    Comm self_;
+    hipStream_t st_ = nullptr;
+    std::vector<std::unique_ptr<Level>> lev;
+    std::vector<double*> f_res, f_corr, f_scratch;  // per depth
+    double *f_phi = nullptr, *f_rhs = nullptr, *f_uberRes = nullptr, *f_uberCorr = nullptr, *f_best = nullptr;
+    double* bicg[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* d_partials = nullptr;
+    double* d_scalars = nullptr;  // device scalar slots
+    double* h_scalars = nullptr;  // pinned
+    bool finalized = false;
+};
+
+}  // namespace somar

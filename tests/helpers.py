@@ -1,0 +1,62 @@
+"""Shared set-up for the parity tests: the SAME synthetic inputs go to the oracle (CPU restatement of
+the reference) and, through the C ABI, to the HIP library."""
+import numpy as np
+
+
+def make_problem(so, n, boxsz, variant="stretched", periodic=(False, False, False), L=(1.0, 1.0, 1.0)):
+    n = so._iv(n)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), periodic)
+    grids = so.split_domain(dom.box, boxsz)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_diagonal_metric(grids, dx, L, 3, variant)
+    return dom, grids, dx, Jgup, Jinv
+
+
+def make_oracle_solver(so, dom, grids, dx, Jgup, Jinv, alpha=0.0, beta=1.0, pre=2, post=2, bottom=2, **kw):
+    fac = so.Factory(dom, grids, dx, so.BCHolder(), Jgup, Jinv, alpha=alpha, beta=beta, **kw)
+    amr = so.AMRMultiGrid(fac, so.BiCGStab())
+    amr.pre, amr.post, amr.bottom = pre, post, bottom
+    amr.mg.pre, amr.mg.post, amr.mg.bottom = pre, post, bottom
+    return amr
+
+
+def make_gpu_solver(dom, grids, dx, Jgup, Jinv, alpha=0.0, beta=1.0, pre=2, post=2, bottom=2, maxDepth=-1,
+                    relaxMode=1, owner=None, comm=None):
+    from somar_amd import AMRPressureSolver
+    s = AMRPressureSolver()
+    p = s._p
+    s.setAMRMGParameters(p.imin, p.imax, p.eps, maxDepth, p.num_smooth_precond, pre, post, bottom, p.precond_mode,
+                         relaxMode, p.num_mg, p.hang, p.norm_thresh, 0)
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids], owner=owner, alpha=alpha,
+             beta=beta, comm=comm)
+    for p_ in range(s.num_local_patches):
+        _, _, gi = s.patch_box(p_)
+        jg = [np.asfortranarray(Jgup[gi][d].a[..., d]) for d in range(3)]
+        s.setMetricOrtho(p_, jg[0], jg[1], jg[2], np.asfortranarray(Jinv[gi].a[..., 0]))
+    s.finalize()
+    return s
+
+
+def upload(s, field, ld, depth=0):
+    for p in range(s.num_local_patches):
+        _, _, gi = s.patch_box(p, depth)
+        s.upload(field, p, np.asfortranarray(ld[gi].a[..., 0]), ld.ghost)
+
+
+def download_valid(s, field, grids, depth=0):
+    """-> list (per global box) of valid-region arrays"""
+    out = [None] * len(grids)
+    for p in range(s.num_local_patches):
+        _, _, gi = s.patch_box(p, depth)
+        out[gi] = s.download(field, p, (0, 0, 0), depth)
+    return out
+
+
+def valid_of(ld):
+    return [f.view(g)[..., 0] for g, f in zip(ld.grids, ld.fabs)]
+
+
+def max_rel_diff(a_list, b_list):
+    num = max(float(np.max(np.abs(a - b))) for a, b in zip(a_list, b_list))
+    den = max(float(np.max(np.abs(b))) for b in b_list)
+    return num / den if den > 0 else num
