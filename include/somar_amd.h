@@ -117,6 +117,9 @@ int somar_field_upload(somar_solver_t* s, int field, int patch, const double* ho
 int somar_field_download(somar_solver_t* s, int field, int patch, double* host, const int* ghost);
 int somar_field_set(somar_solver_t* s, int field, double value);
 int somar_field_fill_hash(somar_solver_t* s, int field, unsigned long long seed);
+/* f -= sum(f J)/sum(J) over the level: makes an all-Neumann/periodic rhs solvable
+ * (computeMappedSum / setZeroAvg, MappedChombo/computeMappedSum.cpp) */
+int somar_field_remove_mean(somar_solver_t* s, int field);
 int somar_field_norm(somar_solver_t* s, int field, int ord, double* out);
 int somar_field_dot(somar_solver_t* s, int field_a, int field_b, double* out);
 
@@ -141,6 +144,9 @@ int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* ite
 int somar_sync(somar_solver_t* s);
 int somar_timer_start(somar_solver_t* s);
 int somar_timer_stop(somar_solver_t* s, double* milliseconds);
+/* per-launch HIP events around the depth-0 hot kernels: kernel 0 = GSRB colour pass, 1 = residual */
+int somar_profile_enable(somar_solver_t* s, int on);
+int somar_profile_get(somar_solver_t* s, int kernel, int* launches, double* total_ms);
 
 /* one-process-per-GPU transport (RCCL over xGMI).  The unique id is created on rank 0 and
  * distributed by the launcher (torch.distributed store / MPI / file). */

@@ -67,6 +67,7 @@ _SIGS = {
     "somar_field_download": [_H, C.c_int, C.c_int, _PD, _PI],
     "somar_field_set": [_H, C.c_int, C.c_double],
     "somar_field_fill_hash": [_H, C.c_int, C.c_ulonglong],
+    "somar_field_remove_mean": [_H, C.c_int],
     "somar_field_norm": [_H, C.c_int, C.c_int, _PD],
     "somar_field_dot": [_H, C.c_int, C.c_int, _PD],
     "somar_solver_solve": [_H, C.c_int, C.c_int, C.POINTER(Stats)],
@@ -83,6 +84,8 @@ _SIGS = {
     "somar_sync": [_H],
     "somar_timer_start": [_H],
     "somar_timer_stop": [_H, _PD],
+    "somar_profile_enable": [_H, C.c_int],
+    "somar_profile_get": [_H, C.c_int, _PI, _PD],
     "somar_comm_unique_id": [C.POINTER(C.c_ubyte)],
     "somar_comm_create": [C.POINTER(_H), C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int],
     "somar_comm_destroy": [_H],
@@ -243,6 +246,9 @@ class AMRPressureSolver:
     def fillHash(self, field, seed):
         _ck(lib().somar_field_fill_hash(self._h, field, int(seed)))
 
+    def removeMean(self, field):
+        _ck(lib().somar_field_remove_mean(self._h, field))
+
     def norm(self, field, order):
         v = C.c_double()
         _ck(lib().somar_field_norm(self._h, field, order, C.byref(v)))
@@ -313,6 +319,14 @@ class AMRPressureSolver:
 
     def sync(self):
         _ck(lib().somar_sync(self._h))
+
+    def profileEnable(self, on=True):
+        _ck(lib().somar_profile_enable(self._h, int(on)))
+
+    def profileGet(self, kernel):
+        n, ms = C.c_int(), C.c_double()
+        _ck(lib().somar_profile_get(self._h, kernel, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
 
     def timerStart(self):
         _ck(lib().somar_timer_start(self._h))

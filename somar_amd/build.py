@@ -16,7 +16,7 @@ SOURCES = ["kernels.hip", "level.cpp", "solver.cpp", "comm_rccl.cpp", "capi.cpp"
 HEADERS = ["common.h", "kernels.h", "level.h", "solver.h", os.path.join("..", "..", "include", "somar_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-result", "-I/opt/rocm/include"]
+         "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-I/opt/rocm/include"]
 
 
 def _stale():

@@ -257,6 +257,15 @@ int somar_field_fill_hash(somar_solver_t* s, int field, unsigned long long seed)
     API_END
 }
 
+int somar_field_remove_mean(somar_solver_t* s, int field)
+{
+    API_BEGIN
+    int depth;
+    double* f = field_ptr(s, field, &depth);
+    s->ps->remove_mean(depth, f);
+    API_END
+}
+
 int somar_field_norm(somar_solver_t* s, int field, int ord, double* out)
 {
     API_BEGIN
@@ -435,6 +444,20 @@ int somar_timer_stop(somar_solver_t* s, double* milliseconds)
     float ms = 0.f;
     SOMAR_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     *milliseconds = ms;
+    API_END
+}
+
+int somar_profile_enable(somar_solver_t* s, int on)
+{
+    API_BEGIN
+    s->ps->profile_enable(on != 0);
+    API_END
+}
+
+int somar_profile_get(somar_solver_t* s, int kernel, int* launches, double* total_ms)
+{
+    API_BEGIN
+    s->ps->profile_get(kernel, launches, total_ms);
     API_END
 }
 

@@ -59,8 +59,8 @@ struct Tile {
     int pad_[3];
 };
 constexpr int TILE_I = 128;  // cells in i per block (64 lanes x double2)
-constexpr int TILE_J = 4;
-constexpr int TILE_K = 8;
+constexpr int TILE_J_MAX = 8;   // rows per block (blockDim.y), chosen per level
+constexpr int TILE_K_MAX = 32;  // planes marched by one block, chosen per level
 
 // One box-to-box ghost copy ("motion item" of a Chombo Copier).
 struct CopyItem {

@@ -8,6 +8,7 @@ namespace somar {
 struct LevelDev {
     const Tile* tiles = nullptr;        // XCD-contiguous order
     int ntiles = 0;
+    int tile_j = 4;                     // blockDim.y of every tile kernel on this level
     const PatchDesc* patches = nullptr;
     int npatches = 0;
     double* jg[3] = {nullptr, nullptr, nullptr};  // J g^{aa} on a-faces

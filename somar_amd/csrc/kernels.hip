@@ -75,7 +75,7 @@ __device__ __forceinline__ double block_reduce(double v)
 // become a per-lane branch that only diverges on the shell.
 // Thread = one i-pair; exactly one cell of the pair has this colour.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gsrb_ortho(const Tile* __restrict__ tiles,
+__global__ __launch_bounds__(512) void k_gsrb_ortho(const Tile* __restrict__ tiles,
                                                     const PatchDesc* __restrict__ patches,
                                                     double* __restrict__ phi,
                                                     const double* __restrict__ rhs,
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_gsrb_ortho(const Tile* __restrict__ til
 // Thread = one i-pair (both cells), k-loop over the tile.
 // ------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256) void k_op_ortho(const Tile* __restrict__ tiles,
+__global__ __launch_bounds__(512) void k_op_ortho(const Tile* __restrict__ tiles,
                                                   const PatchDesc* __restrict__ patches,
                                                   double* __restrict__ out,
                                                   const double* __restrict__ phi,
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_op_ortho(const Tile* __restrict__ tiles
 // ------------------------------------------------------------------------------------
 // lapDiag fill (setup).  FILLMAPPEDLAPDIAG3D
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lapdiag(const Tile* __restrict__ tiles,
+__global__ __launch_bounds__(512) void k_lapdiag(const Tile* __restrict__ tiles,
                                                  const PatchDesc* __restrict__ patches,
                                                  double* __restrict__ lap,
                                                  const double* __restrict__ jgx,
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_lapdiag(const Tile* __restrict__ tiles,
 // pointwise: DIAGPRECOND  phi = rhs/(alpha+beta*lapDiag);  JACOBIITER phi += 0.5*res/(..)
 // ------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256) void k_diag(const Tile* __restrict__ tiles,
+__global__ __launch_bounds__(512) void k_diag(const Tile* __restrict__ tiles,
                                               const PatchDesc* __restrict__ patches,
                                               double* __restrict__ phi, const double* __restrict__ r,
                                               const double* __restrict__ lapd, double alpha, double beta)
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_diag(const Tile* __restrict__ tiles,
 // Restriction (tiles run over the COARSE level; patch index is shared fine<->coarse
 // because the coarse layout is coarsen(fine layout)).  MAPPEDAVERAGE2, loop ii2,ii1,ii0.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_restrict(const Tile* __restrict__ ctiles,
+__global__ __launch_bounds__(512) void k_restrict(const Tile* __restrict__ ctiles,
                                                   const PatchDesc* __restrict__ cpatches,
                                                   const PatchDesc* __restrict__ fpatches,
                                                   double* __restrict__ crse,
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_restrict(const Tile* __restrict__ ctile
 // from the reference's sequential sum in the last bits -- the one non-bit-exact step.)
 // ------------------------------------------------------------------------------------
 template <bool AVG>
-__global__ __launch_bounds__(256) void k_prolong(const Tile* __restrict__ ftiles,
+__global__ __launch_bounds__(512) void k_prolong(const Tile* __restrict__ ftiles,
                                                  const PatchDesc* __restrict__ fpatches,
                                                  const PatchDesc* __restrict__ cpatches,
                                                  double* __restrict__ fine,
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_prolong(const Tile* __restrict__ ftiles
 
 // final stage of every reduction: ONE block, fixed order => deterministic.
 // nvals interleaved values per partial; op 0 = sum, 1 = max (of non-negatives), 2 = signed max.
-__global__ __launch_bounds__(256) void k_reduce_final(const double* __restrict__ partials, int nparts,
+__global__ __launch_bounds__(512) void k_reduce_final(const double* __restrict__ partials, int nparts,
                                                       int nvals, int op, double* __restrict__ out)
 {
     for (int v = 0; v < nvals; ++v) {
@@ -360,7 +360,7 @@ __global__ void k_sub_mean(double* __restrict__ f, long long n, const double* __
 // ------------------------------------------------------------------------------------
 // coarse metrics (setup): harmonic cell average and arithmetic face average
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_avg_harmonic(const Tile* __restrict__ ctiles,
+__global__ __launch_bounds__(512) void k_avg_harmonic(const Tile* __restrict__ ctiles,
                                                       const PatchDesc* __restrict__ cpatches,
                                                       const PatchDesc* __restrict__ fpatches,
                                                       double* __restrict__ crse,
@@ -486,7 +486,7 @@ __global__ void k_axby(double* __restrict__ z, const double* __restrict__ x, con
 
 // valid-cell reductions.  MODE 0: sum a*b   1: max |a|   2: sum |a|   3: signed max a
 template <int MODE>
-__global__ __launch_bounds__(256) void k_reduce_valid(const Tile* __restrict__ tiles,
+__global__ __launch_bounds__(512) void k_reduce_valid(const Tile* __restrict__ tiles,
                                                       const PatchDesc* __restrict__ patches,
                                                       const double* __restrict__ a,
                                                       const double* __restrict__ b,
@@ -506,7 +506,9 @@ __global__ __launch_bounds__(256) void k_reduce_valid(const Tile* __restrict__ t
                 if (MODE == 0) acc = acc + a[c] * b[c];
                 else if (MODE == 1) acc = fmax(acc, fabs(a[c]));
                 else if (MODE == 2) acc = acc + fabs(a[c]);
-                else acc = fmax(acc, a[c]);
+                else if (MODE == 3) acc = fmax(acc, a[c]);
+                else if (MODE == 4) acc = acc + a[c] / b[c];   // sum of a*J  (b = Jinv)
+                else acc = acc + 1.0 / b[c];                   // sum of J
             }
     }
     acc = (MODE == 1 || MODE == 3) ? block_reduce<true>(acc) : block_reduce<false>(acc);
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(256) void k_reduce_valid(const Tile* __restrict__ t
 
 // splitmix64(cell index, seed) -> uniform(-1,1): same integer recipe as
 // oracle/somar_oracle.py::hash_uniform; used by bench/tests for device-side synthetic fills.
-__global__ __launch_bounds__(256) void k_fill_hash(const Tile* __restrict__ tiles,
+__global__ __launch_bounds__(512) void k_fill_hash(const Tile* __restrict__ tiles,
                                                    const PatchDesc* __restrict__ patches,
                                                    double* __restrict__ f, StencilParams P,
                                                    unsigned long long seed)
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(256) void k_fill_hash(const Tile* __restrict__ tile
 // ------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------
-static inline dim3 tile_block() { return dim3(64, TILE_J, 1); }
+static inline dim3 tile_block(const LevelDev& L) { return dim3(64, L.tile_j, 1); }
 static inline int flat_grid(long long n)
 {
     long long g = (n + 255) / 256;
@@ -554,40 +556,40 @@ static inline int flat_grid(long long n)
 void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color)
 {
     if (L.ntiles == 0) return;
-    hipLaunchKernelGGL(k_gsrb_ortho, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, phi, rhs,
+    hipLaunchKernelGGL(k_gsrb_ortho, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, phi, rhs,
                        L.jg[0], L.jg[1], L.jg[2], L.jinv, L.lapdiag, L.P, color);
 }
 void launch_op_ortho(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* rhs, int mode)
 {
     if (L.ntiles == 0) return;
     if (mode == 0)
-        hipLaunchKernelGGL(k_op_ortho<0>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, out, phi,
+        hipLaunchKernelGGL(k_op_ortho<0>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, out, phi,
                            rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
     else
-        hipLaunchKernelGGL(k_op_ortho<1>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, out, phi,
+        hipLaunchKernelGGL(k_op_ortho<1>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, out, phi,
                            rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
 }
 void launch_lapdiag(hipStream_t st, const LevelDev& L)
 {
     if (L.ntiles == 0) return;
-    hipLaunchKernelGGL(k_lapdiag, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, L.lapdiag, L.jg[0],
+    hipLaunchKernelGGL(k_lapdiag, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, L.lapdiag, L.jg[0],
                        L.jg[1], L.jg[2], L.jinv, L.P);
 }
 void launch_diag(hipStream_t st, const LevelDev& L, double* phi, const double* r, int mode)
 {
     if (L.ntiles == 0) return;
     if (mode == 0)
-        hipLaunchKernelGGL(k_diag<0>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, phi, r, L.lapdiag,
+        hipLaunchKernelGGL(k_diag<0>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, phi, r, L.lapdiag,
                            L.P.alpha, L.P.beta);
     else
-        hipLaunchKernelGGL(k_diag<1>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, phi, r, L.lapdiag,
+        hipLaunchKernelGGL(k_diag<1>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, phi, r, L.lapdiag,
                            L.P.alpha, L.P.beta);
 }
 void launch_restrict(hipStream_t st, const LevelDev& C, const LevelDev& F, double* crse, const double* fine,
                      const int r[3])
 {
     if (C.ntiles == 0) return;
-    hipLaunchKernelGGL(k_restrict, dim3(C.ntiles), tile_block(), 0, st, C.tiles, C.patches, F.patches, crse, fine,
+    hipLaunchKernelGGL(k_restrict, dim3(C.ntiles), tile_block(C), 0, st, C.tiles, C.patches, F.patches, crse, fine,
                        F.jinv, r[0], r[1], r[2]);
 }
 void launch_prolong(hipStream_t st, const LevelDev& F, const LevelDev& C, double* fine, const double* crse,
@@ -596,10 +598,10 @@ void launch_prolong(hipStream_t st, const LevelDev& F, const LevelDev& C, double
 {
     if (F.ntiles == 0) return;
     if (!zeroAvg) {
-        hipLaunchKernelGGL(k_prolong<false>, dim3(F.ntiles), tile_block(), 0, st, F.tiles, F.patches, C.patches,
+        hipLaunchKernelGGL(k_prolong<false>, dim3(F.ntiles), tile_block(F), 0, st, F.tiles, F.patches, C.patches,
                            fine, crse, F.jinv, r[0], r[1], r[2], dxProduct, partials);
     } else {
-        hipLaunchKernelGGL(k_prolong<true>, dim3(F.ntiles), tile_block(), 0, st, F.tiles, F.patches, C.patches,
+        hipLaunchKernelGGL(k_prolong<true>, dim3(F.ntiles), tile_block(F), 0, st, F.tiles, F.patches, C.patches,
                            fine, crse, F.jinv, r[0], r[1], r[2], dxProduct, partials);
         hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, F.ntiles, 2, 0, sums);
     }
@@ -613,7 +615,7 @@ void launch_avg_harmonic(hipStream_t st, const LevelDev& C, const LevelDev& F, d
                          const int r[3])
 {
     if (C.ntiles == 0) return;
-    hipLaunchKernelGGL(k_avg_harmonic, dim3(C.ntiles), tile_block(), 0, st, C.tiles, C.patches, F.patches, crse,
+    hipLaunchKernelGGL(k_avg_harmonic, dim3(C.ntiles), tile_block(C), 0, st, C.tiles, C.patches, F.patches, crse,
                        fine, r[0], r[1], r[2]);
 }
 void launch_avg_face(hipStream_t st, const LevelDev& C, const LevelDev& F, int patch, const int cn[3], double* crse,
@@ -665,20 +667,24 @@ void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const dou
         return;
     }
     if (mode == 0)
-        hipLaunchKernelGGL(k_reduce_valid<0>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, a, b, partials);
+        hipLaunchKernelGGL(k_reduce_valid<0>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_reduce_valid<1>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, a, b, partials);
+        hipLaunchKernelGGL(k_reduce_valid<1>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
     else if (mode == 2)
-        hipLaunchKernelGGL(k_reduce_valid<2>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, a, b, partials);
+        hipLaunchKernelGGL(k_reduce_valid<2>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
+    else if (mode == 3)
+        hipLaunchKernelGGL(k_reduce_valid<3>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
+    else if (mode == 4)
+        hipLaunchKernelGGL(k_reduce_valid<4>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
     else
-        hipLaunchKernelGGL(k_reduce_valid<3>, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, a, b, partials);
+        hipLaunchKernelGGL(k_reduce_valid<5>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, L.ntiles, 1,
                        mode == 1 ? 1 : (mode == 3 ? 2 : 0), out);
 }
 void launch_fill_hash(hipStream_t st, const LevelDev& L, double* f, unsigned long long seed)
 {
     if (L.ntiles == 0) return;
-    hipLaunchKernelGGL(k_fill_hash, dim3(L.ntiles), tile_block(), 0, st, L.tiles, L.patches, f, L.P, seed);
+    hipLaunchKernelGGL(k_fill_hash, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, f, L.P, seed);
 }
 
 }  // namespace somar

@@ -83,16 +83,29 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     // ---- tiles, XCD-contiguous: block b runs on XCD (b % 8) under round-robin dispatch, so
     // give each XCD one contiguous slab of the natural (patch,k,j,i) tile order: neighbouring
     // tiles then share their j/k halo rows through the same 4 MiB L2. ------------------
+    // Tile shape per level: big bricks (8 rows x 32 planes) keep the j/k halo re-reads of a
+    // stencil sweep at (8+2)/8 * (32+2)/32 of the ideal; shrink k then j until the level still
+    // yields >= 1024 workgroups (4 per CU) so coarse levels keep the chip busy.
+    int tj = TILE_J_MAX, tk = TILE_K_MAX;
+    auto count_tiles = [&](int tj_, int tk_) {
+        long long c = 0;
+        for (const PatchDesc& p : hpatches)
+            c += (long long)((p.n[0] + TILE_I - 1) / TILE_I) * ((p.n[1] + tj_ - 1) / tj_) * ((p.n[2] + tk_ - 1) / tk_);
+        return c;
+    };
+    while (count_tiles(tj, tk) < 1024 && tk > 1) tk /= 2;
+    while (count_tiles(tj, tk) < 1024 && tj > 1) tj /= 2;
+    dev.tile_j = tj;
     std::vector<Tile> nat;
     for (int pi = 0; pi < (int)hpatches.size(); ++pi) {
         const PatchDesc& p = hpatches[pi];
-        for (int k0 = 0; k0 < p.n[2]; k0 += TILE_K)
-            for (int j0 = 0; j0 < p.n[1]; j0 += TILE_J)
+        for (int k0 = 0; k0 < p.n[2]; k0 += tk)
+            for (int j0 = 0; j0 < p.n[1]; j0 += tj)
                 for (int i0 = 0; i0 < p.n[0]; i0 += TILE_I) {
                     Tile t;
                     std::memset(&t, 0, sizeof(t));
                     t.patch = pi; t.i0 = i0; t.j0 = j0; t.k0 = k0;
-                    t.nk = std::min(TILE_K, p.n[2] - k0);
+                    t.nk = std::min(tk, p.n[2] - k0);
                     nat.push_back(t);
                 }
     }

@@ -28,12 +28,58 @@ PressureSolver::~PressureSolver()
     for (double* f : bicg) hipFree(f);
     hipFree(d_partials);
     hipFree(d_scalars);
+    for (Prof& p : prof_) {
+        for (hipEvent_t e : p.a) hipEventDestroy(e);
+        for (hipEvent_t e : p.b) hipEventDestroy(e);
+    }
     if (h_scalars) hipHostFree(h_scalars);
     lev.clear();
     if (st_) hipStreamDestroy(st_);
 }
 
 void PressureSolver::sync() { SOMAR_HIP(hipStreamSynchronize(st_)); }
+
+void PressureSolver::profile_enable(bool on)
+{
+    const int POOL = 4096;
+    if (on)
+        for (Prof& p : prof_) {
+            while ((int)p.a.size() < POOL) {
+                hipEvent_t e0, e1;
+                SOMAR_HIP(hipEventCreate(&e0));
+                SOMAR_HIP(hipEventCreate(&e1));
+                p.a.push_back(e0);
+                p.b.push_back(e1);
+            }
+            p.used = 0;
+        }
+    profiling_ = on;
+}
+void PressureSolver::prof_begin(int k)
+{
+    Prof& p = prof_[k];
+    if (p.used < (int)p.a.size()) SOMAR_HIP(hipEventRecord(p.a[p.used], st_));
+}
+void PressureSolver::prof_end(int k)
+{
+    Prof& p = prof_[k];
+    if (p.used < (int)p.a.size()) { SOMAR_HIP(hipEventRecord(p.b[p.used], st_)); ++p.used; }
+}
+void PressureSolver::profile_get(int kernel, int* count, double* total_ms)
+{
+    SOMAR_CHECK(kernel == 0 || kernel == 1, "profile kernel id must be 0 or 1");
+    sync();
+    Prof& p = prof_[kernel];
+    double tot = 0.0;
+    for (int i = 0; i < p.used; ++i) {
+        float ms = 0.f;
+        SOMAR_HIP(hipEventElapsedTime(&ms, p.a[i], p.b[i]));
+        tot += ms;
+    }
+    *count = p.used;
+    *total_ms = tot;
+    p.used = 0;
+}
 
 double PressureSolver::fetch_scalar(int slot)
 {
@@ -257,7 +303,9 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters)
             // stencil never reads a Neumann ghost), so only the exchange remains.
             for (int pass = 0; pass < 2; ++pass) {
                 L.exchange(e, st_);
+                if (profiling_ && d == 0) prof_begin(0);
                 launch_gsrb_ortho(st_, L.dev, e, res, pass);
+                if (profiling_ && d == 0) prof_end(0);
             }
         } else {
             // Jacobi::relax, Jacobi.cpp:54-90
@@ -271,7 +319,9 @@ void PressureSolver::residual(int d, double* out, double* phi, const double* rhs
 {
     Level& L = *lev[d];
     L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
+    if (profiling_ && d == 0) prof_begin(1);
     launch_op_ortho(st_, L.dev, out, phi, rhs, 0);
+    if (profiling_ && d == 0) prof_end(1);
 }
 
 void PressureSolver::apply_op(int d, double* out, double* phi)
@@ -337,6 +387,17 @@ double PressureSolver::dot(int d, const double* a, const double* b)
     launch_reduce(st_, lev[d]->dev, a, b, 0, d_partials, d_scalars + SLOT_TMP);
     comm_->allreduce(d_scalars + SLOT_TMP, 1, 0, st_);
     return fetch_scalar(SLOT_TMP);
+}
+
+// f -= sum(f*J)/sum(J): the J-weighted mean removal the callers apply to make an all-Neumann/periodic
+// right-hand side solvable (computeMappedSum + setZeroAvg, MappedChombo/computeMappedSum.cpp)
+void PressureSolver::remove_mean(int d, double* f)
+{
+    Level& L = *lev[d];
+    launch_reduce(st_, L.dev, f, L.dev.jinv, 4, d_partials, d_scalars + SLOT_SUMS);
+    launch_reduce(st_, L.dev, f, L.dev.jinv, 5, d_partials, d_scalars + SLOT_SUMS + 1);
+    comm_->allreduce(d_scalars + SLOT_SUMS, 2, 0, st_);
+    launch_sub_mean(st_, f, L.field_elems, d_scalars + SLOT_SUMS);
 }
 
 void PressureSolver::fill_hash(int d, double* f, unsigned long long seed)

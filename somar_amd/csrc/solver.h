@@ -79,7 +79,11 @@ public:
     double norm(int d, const double* a, int ord);
     double dot(int d, const double* a, const double* b);
     void fill_hash(int d, double* f, unsigned long long seed);
+    void remove_mean(int d, double* f);
     void sync();
+    // per-kernel HIP-event timing of the depth-0 launches (0 = GSRB colour pass, 1 = operator/residual)
+    void profile_enable(bool on);
+    void profile_get(int kernel, int* count, double* total_ms);
     hipStream_t stream() const { return st_; }
 
     SolverParams prm;
@@ -105,6 +109,11 @@ private:
     double* d_scalars = nullptr;  // device scalar slots
     double* h_scalars = nullptr;  // pinned
     bool finalized = false;
+    struct Prof { std::vector<hipEvent_t> a, b; int used = 0; };
+    Prof prof_[2];
+    bool profiling_ = false;
+    void prof_begin(int k);
+    void prof_end(int k);
 };
 
 }  // namespace somar
