@@ -180,14 +180,20 @@ def main():
 
     ms_per_step = 1e3 * dt / args.steps
     value = args.steps / dt
-    t_gsrb = ms_gsrb / max(n_gsrb, 1) * 1e-3      # s per colour-pass launch (depth 0)
+    # depth 0 runs the fused red+black sweep (one launch = one sweep = 64 B/cell algorithmic) unless the
+    # level is below SOMAR_FUSED_MIN_CELLS, in which case one launch = one colour pass = 32 B/cell
+    fused = cells_total >= int(os.environ.get("SOMAR_FUSED_MIN_CELLS", "262144"))
+    kname = "k_gsrb_fused (red+black sweep, depth 0)" if fused else "k_gsrb_ortho (one colour pass, depth 0)"
+    b_launch = (2.0 if fused else 1.0) * B_GSRB_COLOR
+    t_gsrb = ms_gsrb / max(n_gsrb, 1) * 1e-3      # s per GSRB launch (depth 0)
     t_op = ms_op / max(n_op, 1) * 1e-3
-    achieved = B_GSRB_COLOR * cells_local / t_gsrb / 1e9
+    achieved = b_launch * cells_local / t_gsrb / 1e9
+    t_sweep = t_gsrb if fused else 2 * t_gsrb
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf) and n == N_FINE and world == 1:
-        traffic = json.load(open(tf)).get("k_gsrb_ortho_bytes_per_launch")
-    unit_t = 2 * t_gsrb + t_op                    # one red+black sweep + one residual (north-star unit)
+        traffic = json.load(open(tf)).get("k_gsrb_fused_bytes_per_launch" if fused else "k_gsrb_ortho_bytes_per_launch")
+    unit_t = t_sweep + t_op                       # one red+black sweep + one residual (north-star unit)
     out = {
         "metric": "pressure-Poisson V-cycles/sec", "value": value, "unit": "V-cycles/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -197,11 +203,11 @@ def main():
                                % (n, world, "x".join(str(h - l + 1) for l, h in zip(*boxes[0]))),
                    "mg_depth": depth, "mg_ref_ratios": [list(r) for r in gpu.mgRefRatios()],
                    "cells": cells_total, "define_seconds": t_def},
-        "roofline": {"bound": "hbm", "kernel": "k_gsrb_ortho (one colour pass, depth 0)", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": B_GSRB_COLOR * cells_local, "launches": n_gsrb,
+                     "algorithmic_bytes_per_launch": b_launch * cells_local, "launches": n_gsrb,
                      "avg_launch_ms": t_gsrb * 1e3},
-        "gsrb_cell_updates_per_s": cells_local / (2 * t_gsrb) * world,
+        "gsrb_cell_updates_per_s": cells_local / t_sweep * world,
         "residual_kernel": {"avg_launch_ms": t_op * 1e3, "achieved_GBs": B_RESIDUAL * cells_local / t_op / 1e9,
                             "frac": B_RESIDUAL * cells_local / t_op / 1e9 / HBM_PEAK_GBS},
         "residual_plus_smooth_unit": {"ms": unit_t * 1e3, "algorithmic_GBs": 120.0 * cells_local / unit_t / 1e9,

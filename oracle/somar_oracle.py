@@ -1200,10 +1200,12 @@ def stretch_factor(a, x, L):
     return 1.0 + 0.3 * np.sin(2.0 * np.pi * x / L + a)
 
 
-def make_diagonal_metric(grids, dx, L, ndim=3, variant="stretched"):
+def make_diagonal_metric(grids, dx, L, ndim=3, variant="stretched", domain=None):
     """C2 metric variants: 'cartesian' (all ones, CartesianMap.cpp:261-280) or the
     separable stretch s_a = 1 + 0.3 sin(2 pi x_a/L_a + a): Jg^{aa} = s_b s_c / s_a at
-    a-faces, Jinv = 1/(s_0 s_1 s_2) at cell centres.  Off-diagonal comps are 0."""
+    a-faces, Jinv = 1/(s_0 s_1 s_2) at cell centres.  Off-diagonal comps are 0.
+    With `domain`, indices are wrapped in periodic directions before the map is evaluated,
+    so the two stored copies of a periodic face (index 0 and index n) are bitwise equal."""
     Jgup = FluxData(grids, 3 if ndim == 3 else 2, ndim)
     Jinv = LevelData(grids, 1, (0, 0, 0), 1.0)
     for i, g in enumerate(grids):
@@ -1216,6 +1218,9 @@ def make_diagonal_metric(grids, dx, L, ndim=3, variant="stretched"):
             xs = []
             for d in range(3):
                 idx = np.arange(box.lo[d], box.hi[d] + 1, dtype=np.float64)
+                if domain is not None and domain.periodic[d]:
+                    nd = domain.box.size()[d]
+                    idx = np.mod(idx - domain.box.lo[d], nd) + domain.box.lo[d]
                 xs.append((idx if d == faceDir else idx + 0.5) * dx[d])
             return xs
 

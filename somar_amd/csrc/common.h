@@ -76,6 +76,7 @@ struct StencilParams {
     int dom_lo[3], dom_hi[3];  // domain box at this depth
     int neum[3][2];            // 1 = homogeneous-Neumann physical face (no ghost, no flux)
     int active[3];             // activeDirs
+    int periodic[3];
     double dx[3];
     double alpha, beta;
 };

@@ -1,0 +1,238 @@
+// somar_amd/csrc/gsrb_fused.hip -- one launch = one full red+black GSRB sweep (diagonal metric).
+//
+// Why: the two-pass form of LevelGSRB (GSRB.cpp:58-98) streams every coefficient line twice per
+// sweep (each colour touches half of every 128-B line) and, measured with rocprofv3 PMC on
+// MI355X, re-fetches phi 3x and Jg^zz 2x per pass because the k+-1 reuse distance (a whole
+// j-slab of every resident workgroup) does not fit the 4 MiB per-XCD L2: 78 B/cell/pass against
+// 32 B/cell algorithmic.  This kernel reads every array ONCE per sweep:
+//
+//   * a workgroup owns a (124 x 12) column of cells and MARCHES in k; per plane it stages phi in
+//     LDS (3 rotating planes of 128 x 16 doubles, one wavefront per row, one double2 per lane) and
+//     keeps the k-neighbours and the k-face coefficients in registers;
+//   * red and black are pipelined one plane apart: step k computes red(k) from OLD black, then
+//     black(k-1) from the NEW red of planes k-2, k-1, k -- exactly the values LevelGSRB produces,
+//     because a red update only reads black cells and vice versa; one barrier per plane;
+//   * the 1-cell ring of red cells around the tile is recomputed redundantly (from a 2-deep phi halo
+//     and 1-deep coefficient/rhs halos) instead of being exchanged between the colours, so a level
+//     needs ONE ghost exchange per sweep instead of two -- on a sharded level that also halves the
+//     number of xGMI round trips;
+//   * lapDiag is not loaded: it is recomputed from Jg/Jinv with FILLMAPPEDLAPDIAG3D's own expression
+//     (MappedAMRPoissonOpF.ChF:266-271), which yields the identical bits and saves 8 B/cell;
+//   * results go to a second array (ping-pong): neighbouring workgroups read each other's halo from
+//     the untouched input.
+//
+// Traffic per cell and sweep: phi 8 in + 8 out, rhs 8, Jg 24, Jinv 8 = 56 B + halo overhead
+// (phi x 128*16/(124*12), ring coefficients) ~ 63 B, versus 128-156 B for the two-pass form.
+//
+// Arithmetic: identical operation order to GSRBITER3DORTHO / GSRBBOUNDARYITER3DORTHO
+// (GSRBF.ChF:545-701, 1362-1505) => bit-identical to the two-pass kernel and to the CPU oracle.
+#include "common.h"
+#include "kernels.h"
+
+namespace somar {
+
+constexpr int FR_I = 128;  // region width  (64 lanes x double2) = tile + 4
+constexpr int FR_J = 16;   // region height (one wavefront per row)  = tile + 4
+
+__device__ __forceinline__ double pick(const double2& v, int s) { return s ? v.y : v.x; }
+
+// load a[idx], a[idx+1] with per-element predicates (idx is 16-byte aligned by construction)
+__device__ __forceinline__ double2 ld2(const double* __restrict__ a, long long idx, bool ok0, bool ok1)
+{
+    double2 v = make_double2(0.0, 0.0);
+    if (ok0 && ok1) v = *reinterpret_cast<const double2*>(a + idx);
+    else if (ok0) v.x = a[idx];
+    else if (ok1) v.y = a[idx + 1];
+    return v;
+}
+
+// One GSRB point update of cell (gi,gj,gk): interior form = GSRBITER3DORTHO, cells touching a domain
+// face = GSRBBOUNDARYITER3DORTHO (a Neumann face contributes neither flux nor diagonal).
+__device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS, double yyS, double zzS, int gi,
+                                             int gj, int gk, double pxl, double pxh, double pyl, double pyh,
+                                             double pzl, double pzh, double gxl, double gxh, double gyl, double gyh,
+                                             double gzl, double gzh, double Ji, double rhs)
+{
+    // a ring cell may be the periodic image of a cell on the far side: classify the REAL cell
+    if (P.periodic[0]) { const int n = P.dom_hi[0] - P.dom_lo[0] + 1; gi = gi < P.dom_lo[0] ? gi + n : (gi > P.dom_hi[0] ? gi - n : gi); }
+    if (P.periodic[1]) { const int n = P.dom_hi[1] - P.dom_lo[1] + 1; gj = gj < P.dom_lo[1] ? gj + n : (gj > P.dom_hi[1] ? gj - n : gj); }
+    if (P.periodic[2]) { const int n = P.dom_hi[2] - P.dom_lo[2] + 1; gk = gk < P.dom_lo[2] ? gk + n : (gk > P.dom_hi[2] ? gk - n : gk); }
+    const bool onb = (gi == P.dom_lo[0]) || (gi == P.dom_hi[0]) || (gj == P.dom_lo[1]) || (gj == P.dom_hi[1]) ||
+                     (gk == P.dom_lo[2]) || (gk == P.dom_hi[2]);
+    if (!onb) {
+        const double JDxx = xxS * (gxh * pxh + gxl * pxl);
+        const double JDyy = yyS * (gyh * pyh + gyl * pyl);
+        const double JDzz = zzS * (gzh * pzh + gzl * pzl);
+        const double lphi = P.beta * Ji * (JDxx + JDyy + JDzz);
+        // lapDiag: FILLMAPPEDLAPDIAG3D's expression, bitwise the stored array's value
+        const double lapd = -Ji * ((gxh + gxl) * xxS + (gyh + gyl) * yyS + (gzh + gzl) * zzS);
+        return (rhs - lphi) / (P.alpha + P.beta * lapd);
+    }
+    const bool nxl = (gi == P.dom_lo[0]) && P.neum[0][0];
+    const bool nxh = (gi == P.dom_hi[0]) && P.neum[0][1];
+    const bool nyl = (gj == P.dom_lo[1]) && P.neum[1][0];
+    const bool nyh = (gj == P.dom_hi[1]) && P.neum[1][1];
+    const bool nzl = (gk == P.dom_lo[2]) && P.neum[2][0];
+    const bool nzh = (gk == P.dom_hi[2]) && P.neum[2][1];
+    double JDloX = 0, JDhiX = 0, JDloY = 0, JDhiY = 0, JDloZ = 0, JDhiZ = 0, ld = 0.0;
+    if (!nxl) { JDloX = gxl * pxl; ld = ld - xxS * gxl; }
+    if (!nyl) { JDloY = gyl * pyl; ld = ld - yyS * gyl; }
+    if (!nzl) { JDloZ = gzl * pzl; ld = ld - zzS * gzl; }
+    if (!nxh) { JDhiX = gxh * pxh; ld = ld - xxS * gxh; }
+    if (!nyh) { JDhiY = gyh * pyh; ld = ld - yyS * gyh; }
+    if (!nzh) { JDhiZ = gzh * pzh; ld = ld - zzS * gzh; }
+    ld = ld * Ji;
+    const double lphi = P.beta * Ji * ((JDloX + JDhiX) * xxS + (JDloY + JDhiY) * yyS + (JDloZ + JDhiZ) * zzS);
+    return (rhs - lphi) / (P.alpha + P.beta * ld);
+}
+
+// blockDim = (64, 16): lane = i-pair of the region, threadIdx.y = region row (one wavefront each).
+__global__ __launch_bounds__(1024) void k_gsrb_fused(const Tile* __restrict__ tiles,
+                                                     const PatchDesc* __restrict__ patches,
+                                                     double* __restrict__ phi_out,
+                                                     const double* __restrict__ phi_in,
+                                                     const double* __restrict__ rhs,
+                                                     const double* __restrict__ jgx,
+                                                     const double* __restrict__ jgy,
+                                                     const double* __restrict__ jgz,
+                                                     const double* __restrict__ jinv, StencilParams P)
+{
+    __shared__ __attribute__((aligned(16))) double S[3][FR_J][FR_I];
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lane = threadIdx.x, row = threadIdx.y;
+    const int ri = 2 * lane;       // region column of the pair's first cell
+    const int li = t.i0 - 2 + ri;  // local i of the pair's first cell (even: rows are 16-byte aligned)
+    const int lj = t.j0 - 2 + row;
+    const int gj = p.lo[1] + lj;
+    const double xxS = 1.0 / (P.dx[0] * P.dx[0]);
+    const double yyS = 1.0 / (P.dx[1] * P.dx[1]);
+    const double zzS = 1.0 / (P.dx[2] * P.dx[2]);
+
+    // memory predicates: a cell may be touched only inside the patch's 2-cell frame
+    const bool fj = (lj >= -FRAME) && (lj < p.n[1] + FRAME);
+    const bool fjh = (lj + 1 >= -FRAME) && (lj + 1 < p.n[1] + FRAME);
+    const bool f0 = fj && (li >= -FRAME) && (li < p.n[0] + FRAME);
+    const bool f1 = fj && (li + 1 >= -FRAME) && (li + 1 < p.n[0] + FRAME);
+    // the outermost region rows only supply phi to the red ring: they need no coefficients
+    const bool cf = (row >= 1) && (row <= FR_J - 2);
+    const bool c0 = f0 && cf, c1 = f1 && cf;
+    // red is computed on the tile grown by one cell, restricted to cells that exist: a cell beyond a
+    // non-periodic (Neumann) domain face does not; a periodic image or a neighbour box's cell does
+    // (its phi was exchanged two deep, its coefficients one deep).  out_* = cells this tile owns.
+    bool comp_ij[2], out_ij[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int l = li + s, g = p.lo[0] + l, r = ri + s;
+        bool cmp = (l >= -1) && (l <= p.n[0]) && (r >= 1) && (r <= FR_I - 2) && (lj >= -1) && (lj <= p.n[1]) &&
+                   (row >= 1) && (row <= FR_J - 2);
+        if ((g < P.dom_lo[0] && P.neum[0][0]) || (g > P.dom_hi[0] && P.neum[0][1])) cmp = false;
+        if ((gj < P.dom_lo[1] && P.neum[1][0]) || (gj > P.dom_hi[1] && P.neum[1][1])) cmp = false;
+        comp_ij[s] = cmp;
+        out_ij[s] = (l >= 0) && (l < p.n[0]) && (lj >= 0) && (lj < p.n[1]) && (r >= 2) && (r < FR_I - 2) &&
+                    (row >= 2) && (row < FR_J - 2);
+    }
+    const long long sj = p.pj, sk = p.pk;
+    const long long base = p.off + li + sj * lj;
+
+    // ---- prologue: planes k0-2 and k0-1 ------------------------------------------------------------
+    int k = t.k0 - 1;  // first red plane (the ring below the tile)
+    bool fk = (k - 1 >= -FRAME) && (k - 1 < p.n[2] + FRAME);
+    double2 Pm = ld2(phi_in, base + sk * (k - 1), f0 && fk, f1 && fk);
+    fk = (k >= -FRAME) && (k < p.n[2] + FRAME);
+    double2 Pc = ld2(phi_in, base + sk * k, f0 && fk, f1 && fk);
+    double2 Gzc = ld2(jgz, base + sk * k, c0 && fk, c1 && fk);  // Jg^zz on the LOW face of plane k
+    // coefficients of the black cell of plane k-1 (column c), captured one step earlier
+    double b_rhs = 0, b_ji = 1, b_gxl = 0, b_gxh = 0, b_gyl = 0, b_gyh = 0, b_gzl = 0;
+    double redPrev1 = 0.0, redPrev2 = 0.0;
+
+    const int kend = t.k0 + t.nk;  // last red plane (the ring above the tile)
+    for (; k <= kend; ++k) {
+        const int gk = p.lo[2] + k;
+        fk = (k >= -FRAME) && (k < p.n[2] + FRAME);
+        const bool fkp = (k + 1 >= -FRAME) && (k + 1 < p.n[2] + FRAME);
+        // ---- this step's loads: phi and Jg^zz of plane k+1, cell coefficients of plane k --------
+        const double2 Pp = ld2(phi_in, base + sk * (k + 1), f0 && fkp, f1 && fkp);
+        const double2 Gzp = ld2(jgz, base + sk * (k + 1), c0 && fkp, c1 && fkp);
+        const double2 Rh = ld2(rhs, base + sk * k, c0 && fk, c1 && fk);
+        const double2 Ji = ld2(jinv, base + sk * k, c0 && fk, c1 && fk);
+        const double2 Gx = ld2(jgx, base + sk * k, c0 && fk, c1 && fk);
+        const double2 Gy = ld2(jgy, base + sk * k, c0 && fk, c1 && fk);
+        const double2 Gyh = ld2(jgy, base + sk * k + sj, c0 && fk && fjh, c1 && fk && fjh);
+        // Jg^xx on the face right of the pair = first component of the next lane's pair
+        const double gx_next = __shfl_down(Gx.x, 1, 64);
+
+        // ---- stage plane k (old values) in LDS; ONE barrier per plane -----------------------------
+        //   slot k%3 was last read two steps ago (black of plane k-3); every wave has passed the
+        //   previous barrier since, so overwriting it is safe.
+        const int slot = ((k % 3) + 3) % 3;
+        *reinterpret_cast<double2*>(&S[slot][row][ri]) = Pc;
+        __syncthreads();
+
+        // ---- red(k) at column c: reads only black cells of the plane, writes only red ones ---------
+        const int c = (p.lo[0] + li + gj + gk) & 1;  // red = pass 0 = even i+j+k (GSRBF.ChF:381-387)
+        const int rc = ri + c;
+        double red = pick(Pc, c);  // cells not computed here keep their old value
+        {
+            bool comp = comp_ij[c] && (k >= -1) && (k <= p.n[2]);
+            if ((gk < P.dom_lo[2] && P.neum[2][0]) || (gk > P.dom_hi[2] && P.neum[2][1])) comp = false;
+            if (comp) {
+                const double pxl = S[slot][row][rc - 1], pxh = S[slot][row][rc + 1];
+                const double pyl = S[slot][row - 1][rc], pyh = S[slot][row + 1][rc];
+                red = gsrb_point(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, gk, pxl, pxh, pyl, pyh, pick(Pm, c),
+                                 pick(Pp, c), c ? Gx.y : Gx.x, c ? gx_next : Gx.y, pick(Gy, c), pick(Gyh, c),
+                                 pick(Gzc, c), pick(Gzp, c), pick(Ji, c), pick(Rh, c));
+                S[slot][row][rc] = red;  // visible to the black phase of the NEXT step (after its barrier)
+            }
+        }
+
+        // ---- black(k-1) at the same column c: in-plane neighbours = new red of plane k-1 (LDS),
+        //      below = red(c,k-2) and above = red(c,k), both computed by this very lane -------------
+        {
+            const int kb = k - 1;
+            if ((kb >= t.k0) && (kb < t.k0 + t.nk) && (out_ij[0] || out_ij[1])) {
+                const int sb = ((kb % 3) + 3) % 3;
+                double black = 0.0;
+                if (out_ij[c]) {
+                    const double pxl = S[sb][row][rc - 1], pxh = S[sb][row][rc + 1];
+                    const double pyl = S[sb][row - 1][rc], pyh = S[sb][row + 1][rc];
+                    black = gsrb_point(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, p.lo[2] + kb, pxl, pxh, pyl, pyh,
+                                       redPrev2, red, b_gxl, b_gxh, b_gyl, b_gyh, b_gzl, pick(Gzc, c), b_ji, b_rhs);
+                }
+                // plane k-1: column c is the new black, column c^1 is red(k-1) (= redPrev1)
+                double* dst = phi_out + base + sk * kb;
+                const double ox = c ? redPrev1 : black, oy = c ? black : redPrev1;
+                if (out_ij[0] && out_ij[1]) *reinterpret_cast<double2*>(dst) = make_double2(ox, oy);
+                else if (out_ij[0]) dst[0] = ox;
+                else dst[1] = oy;
+            }
+        }
+
+        // ---- rotate: the next black cell is column c^1 of plane k ------------------------------------
+        {
+            const int cb = c ^ 1;
+            b_rhs = pick(Rh, cb);
+            b_ji = pick(Ji, cb);
+            b_gxl = cb ? Gx.y : Gx.x;
+            b_gxh = cb ? gx_next : Gx.y;
+            b_gyl = pick(Gy, cb);
+            b_gyh = pick(Gyh, cb);
+            b_gzl = pick(Gzc, cb);
+        }
+        redPrev2 = redPrev1;
+        redPrev1 = red;
+        Pm = Pc;
+        Pc = Pp;
+        Gzc = Gzp;
+    }
+}
+
+void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* phi_out,
+                       const double* phi_in, const double* rhs)
+{
+    if (ntiles == 0) return;
+    hipLaunchKernelGGL(k_gsrb_fused, dim3(ntiles), dim3(64, FR_J, 1), 0, st, tiles, L.patches, phi_out, phi_in, rhs,
+                       L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+}
+
+}  // namespace somar

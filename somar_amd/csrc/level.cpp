@@ -29,6 +29,7 @@ Level::~Level()
 {
     hipFree(d_patches);
     hipFree(d_tiles);
+    hipFree(d_ftiles);
     hipFree(d_local_items);
     hipFree(d_send_items);
     hipFree(d_recv_items);
@@ -119,10 +120,56 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
         for (int b = 0; b < N; ++b) htiles[b] = nat[start[b % NX] + b / NX];
     }
 
+    // ---- tiles of the fused red-black sweep: 124 x 12 columns, k split into chunks so that the
+    // launch fills the 256 CUs evenly (one 1024-thread workgroup per CU at a time) ------------
+    {
+        const int FT_I = 124, FT_J = 12;
+        long long cols = 0;
+        int maxn2 = 1;
+        for (const PatchDesc& p : hpatches) {
+            cols += (long long)((p.n[0] + FT_I - 1) / FT_I) * ((p.n[1] + FT_J - 1) / FT_J);
+            maxn2 = std::max(maxn2, p.n[2]);
+        }
+        int best = 1;
+        double best_eff = -1.0;
+        for (int nch = 1; nch <= 16 && (nch == 1 || maxn2 / nch >= 16); ++nch) {
+            const long long blocks = cols * nch;
+            const long long rounds = (blocks + 255) / 256;
+            const double nk = (double)maxn2 / nch;
+            const double eff = (double)blocks / (double)(rounds * 256) * nk / (nk + 3.0);
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = nch; }
+        }
+        std::vector<Tile> fnat;
+        for (int pi = 0; pi < (int)hpatches.size(); ++pi) {
+            const PatchDesc& p = hpatches[pi];
+            const int nk = (p.n[2] + best - 1) / best;
+            for (int k0 = 0; k0 < p.n[2]; k0 += nk)
+                for (int j0 = 0; j0 < p.n[1]; j0 += FT_J)
+                    for (int i0 = 0; i0 < p.n[0]; i0 += FT_I) {
+                        Tile t;
+                        std::memset(&t, 0, sizeof(t));
+                        t.patch = pi; t.i0 = i0; t.j0 = j0; t.k0 = k0;
+                        t.nk = std::min(nk, p.n[2] - k0);
+                        fnat.push_back(t);
+                    }
+        }
+        const int NF = (int)fnat.size();
+        hftiles.assign(NF, Tile());
+        const int NX = 8;
+        int start[NX + 1];
+        start[0] = 0;
+        for (int x = 0; x < NX; ++x) start[x + 1] = start[x] + (NF - x + NX - 1) / NX;
+        for (int b = 0; b < NF; ++b) hftiles[b] = fnat[start[b % NX] + b / NX];
+        d_ftiles = to_device(hftiles);
+        nftiles = NF;
+    }
+
     // ---- exchange plan ----------------------------------------------------------------
     plan = ExchangePlan();
+    // Ghost depth 2 (= FRAME): the fused red-black sweep recomputes the red ring of its neighbours
+    // and therefore needs phi two deep; every other consumer reads at most one layer.
     int ghost[3];
-    for (int d = 0; d < 3; ++d) ghost[d] = active[d] ? 1 : 0;
+    for (int d = 0; d < 3; ++d) ghost[d] = active[d] ? FRAME : 0;
     std::vector<std::array<int, 3>> shifts;
     for (int a = -1; a <= 1; ++a)
         for (int b = -1; b <= 1; ++b)
@@ -209,6 +256,7 @@ void Level::refresh_params()
         P.dom_lo[d] = domain.lo[d];
         P.dom_hi[d] = domain.hi[d];
         P.active[d] = active[d];
+        P.periodic[d] = periodic[d] ? 1 : 0;
         P.dx[d] = dx[d];
         for (int s = 0; s < 2; ++s) P.neum[d][s] = (!periodic[d] && bc_type[d][s] == BC_NEUM) ? 1 : 0;
     }

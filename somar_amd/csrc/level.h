@@ -84,6 +84,9 @@ public:
     std::vector<int> local;    // global box index of each local patch
     std::vector<PatchDesc> hpatches;
     std::vector<Tile> htiles;
+    std::vector<Tile> hftiles;   // tiles of the fused red-black sweep (gsrb_fused.hip)
+    Tile* d_ftiles = nullptr;
+    int nftiles = 0;
     long long field_elems = 0;
     long long valid_cells_global = 0;
     ExchangePlan plan;

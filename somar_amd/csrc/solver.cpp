@@ -16,6 +16,9 @@ PressureSolver::PressureSolver(Comm* comm) : comm_(comm ? comm : &self_)
     SOMAR_HIP(hipMalloc(&d_scalars, NSLOTS * sizeof(double)));
     SOMAR_HIP(hipMemset(d_scalars, 0, NSLOTS * sizeof(double)));
     SOMAR_HIP(hipHostMalloc(&h_scalars, NSLOTS * sizeof(double)));
+    // levels smaller than this use the two-pass colour kernel (launch-latency bound anyway);
+    // SOMAR_FUSED_MIN_CELLS=0 forces the fused sweep everywhere (tests), a huge value disables it.
+    if (const char* e = getenv("SOMAR_FUSED_MIN_CELLS")) fused_min_cells_ = atoll(e);
 }
 
 PressureSolver::~PressureSolver()
@@ -24,6 +27,7 @@ PressureSolver::~PressureSolver()
     for (double* f : f_res) hipFree(f);
     for (double* f : f_corr) hipFree(f);
     for (double* f : f_scratch) hipFree(f);
+    for (double* f : f_pp) hipFree(f);
     hipFree(f_phi); hipFree(f_rhs); hipFree(f_uberRes); hipFree(f_uberCorr); hipFree(f_best);
     for (double* f : bicg) hipFree(f);
     hipFree(d_partials);
@@ -204,8 +208,19 @@ bool PressureSolver::build_coarser(int depth)
             launch_avg_face(st_, C->dev, F.dev, pi, C->hpatches[pi].n, C->dev.jg[d], F.dev.jg[d], d, r);
     launch_avg_harmonic(st_, C->dev, F.dev, C->dev.jinv, F.dev.jinv, r);
     launch_lapdiag(st_, C->dev);
+    fill_metric_ghosts(*C);
     lev.push_back(std::move(C));
     return true;
+}
+
+// The fused sweep recomputes its neighbours' red ring, so Jg and Jinv need ghost values wherever a
+// neighbouring box or a periodic image exists.  NOTE: a face shared by two boxes (or by periodic
+// images) is stored by both; this exchange makes the two copies identical (the low-side owner's
+// value wins).  They already are identical when both come from one evaluation of the map.
+void PressureSolver::fill_metric_ghosts(Level& L)
+{
+    for (int d = 0; d < 3; ++d) L.exchange(L.dev.jg[d], st_);
+    L.exchange(L.dev.jinv, st_);
 }
 
 // null-space probe, MappedAMRPoissonOpFactory.cpp:659-693
@@ -232,6 +247,7 @@ void PressureSolver::finalize()
 {
     SOMAR_CHECK(!lev.empty() && !finalized, "finalize before define / twice");
     launch_lapdiag(st_, lev[0]->dev);
+    fill_metric_ghosts(*lev[0]);
     int depth = 1;
     while (build_coarser(depth)) ++depth;
     int maxTiles = 1;
@@ -241,9 +257,11 @@ void PressureSolver::finalize()
     f_res.assign(D, nullptr);
     f_corr.assign(D, nullptr);
     f_scratch.assign(D, nullptr);
+    f_pp.assign(D, nullptr);
     for (int d = 0; d < D; ++d) {
         if (d > 0) { f_res[d] = lev[d]->alloc_field(); f_corr[d] = lev[d]->alloc_field(); }
         f_scratch[d] = lev[d]->alloc_field();
+        f_pp[d] = lev[d]->alloc_field();
     }
     Level& L0 = *lev[0];
     f_phi = L0.alloc_field();
@@ -296,6 +314,22 @@ void PressureSolver::download_field(const double* field, int depth, int patch, d
 void PressureSolver::relax(int d, double* e, const double* res, int iters)
 {
     Level& L = *lev[d];
+    if (prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0) {
+        // LevelGSRB::relax (GSRB.cpp:58-98) as ONE fused red+black launch per sweep (gsrb_fused.hip):
+        // same values bit for bit, one ghost exchange per sweep instead of two, ping-pong buffers.
+        L.exchange(const_cast<double*>(res), st_);  // rhs ghosts: constant over the sweeps
+        double* cur = e;
+        double* alt = f_pp[d];
+        for (int it = 0; it < iters; ++it) {
+            L.exchange(cur, st_);
+            if (profiling_ && d == 0) prof_begin(0);
+            launch_gsrb_fused(st_, L.d_ftiles, L.nftiles, L.dev, alt, cur, res);
+            if (profiling_ && d == 0) prof_end(0);
+            std::swap(cur, alt);
+        }
+        if (cur != e) launch_copy(st_, e, cur, L.field_elems);
+        return;
+    }
     for (int it = 0; it < iters; ++it) {
         if (prm.relaxMode == RELAX_LEVEL_GSRB) {
             // LevelGSRB::relax, GSRB.cpp:58-98.  The Neumann ghost fill of

@@ -97,6 +97,9 @@ private:
     double fetch_scalar(int slot);
     bool build_coarser(int depth);
     void probe_null_space(int d);
+    void fill_metric_ghosts(Level& L);
+    std::vector<double*> f_pp;  // per-depth ping-pong buffer of the fused sweep
+    long long fused_min_cells_ = 262144;
 
     Comm* comm_;
     Comm self_;

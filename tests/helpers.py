@@ -8,7 +8,7 @@ def make_problem(so, n, boxsz, variant="stretched", periodic=(False, False, Fals
     dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), periodic)
     grids = so.split_domain(dom.box, boxsz)
     dx = tuple(L[d] / n[d] for d in range(3))
-    Jgup, Jinv = so.make_diagonal_metric(grids, dx, L, 3, variant)
+    Jgup, Jinv = so.make_diagonal_metric(grids, dx, L, 3, variant, domain=dom)
     return dom, grids, dx, Jgup, Jinv
 
 

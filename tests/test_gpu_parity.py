@@ -30,6 +30,14 @@ def F():
     return api
 
 
+@pytest.fixture(params=["twopass", "fused"])
+def gsrb_mode(request, monkeypatch):
+    """LevelGSRB runs either as two colour launches (k_gsrb_ortho) or as one fused red+black launch
+    (k_gsrb_fused); SOMAR_FUSED_MIN_CELLS picks per level.  Both must be bit-identical to the oracle."""
+    monkeypatch.setenv("SOMAR_FUSED_MIN_CELLS", "0" if request.param == "fused" else "1000000000000")
+    return request.param
+
+
 def _both(oracle, case, **kw):
     n, boxsz, variant, periodic, L = case
     dom, grids, dx, Jgup, Jinv = make_problem(oracle, n, boxsz, variant, periodic, L)
@@ -52,7 +60,8 @@ def test_hierarchy_matches(oracle, case):
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_gsrb_sweep_bit_exact(oracle, case, F):
+@pytest.mark.parametrize("sweeps", [1, 2, 3])
+def test_gsrb_sweep_bit_exact(oracle, case, sweeps, gsrb_mode, F):
     so = oracle
     dom, grids, amr, gpu = _both(oracle, case)
     op = amr.mg.ops[0]
@@ -60,8 +69,8 @@ def test_gsrb_sweep_bit_exact(oracle, case, F):
     rhs = so.random_field(grids, 42, (0, 0, 0), dom.box)
     upload(gpu, F.F_PHI, phi)
     upload(gpu, F.F_RHS, rhs)
-    op.relax(phi, rhs, 2)
-    gpu.relax(0, F.F_PHI, F.F_RHS, 2)
+    op.relax(phi, rhs, sweeps)
+    gpu.relax(0, F.F_PHI, F.F_RHS, sweeps)
     got = download_valid(gpu, F.F_PHI, grids)
     for g, w in zip(got, valid_of(phi)):
         np.testing.assert_array_equal(g, w)
@@ -92,7 +101,7 @@ def test_residual_and_applyop_bit_exact(oracle, case, alpha_beta, F):
 
 
 @pytest.mark.parametrize("case", CASES[1:4])
-def test_helmholtz_gsrb_bit_exact(oracle, case, F):
+def test_helmholtz_gsrb_bit_exact(oracle, case, gsrb_mode, F):
     """alpha != 0 (the viscous-solve use of the same operator)."""
     so = oracle
     dom, grids, amr, gpu = _both(oracle, case, alpha=1.0, beta=-0.05)
@@ -141,7 +150,7 @@ def test_restrict_and_prolong(oracle, case, F):
 
 
 @pytest.mark.parametrize("case", CASES[1:3])
-def test_coarse_depth_operator_bit_exact(oracle, case, F):
+def test_coarse_depth_operator_bit_exact(oracle, case, gsrb_mode, F):
     """Coarse metrics (face-arithmetic Jgup, harmonic Jinv, regenerated lapDiag) are exercised by
     running GSRB + residual on depth 1."""
     so = oracle
@@ -231,7 +240,7 @@ def test_bottom_solver_and_vcycle(oracle, case, F):
 
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("smooth", [(2, 2, 2), (4, 4, 2)])
-def test_full_solve_history_matches(oracle, case, smooth):
+def test_full_solve_history_matches(oracle, case, smooth, gsrb_mode):
     so = oracle
     pre, post, bottom = smooth
     dom, grids, amr, gpu = _both(oracle, case, pre=pre, post=post, bottom=bottom)
