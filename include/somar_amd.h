@@ -148,6 +148,15 @@ int somar_timer_stop(somar_solver_t* s, double* milliseconds);
 int somar_profile_enable(somar_solver_t* s, int on);
 int somar_profile_get(somar_solver_t* s, int kernel, int* launches, double* total_ms);
 
+/* Pure host planning, no GPU needed: the ghost-exchange plan of `rank` for a sharded layout =
+ * Chombo's Copier(grids, grids, domain, ghost, exchange=true) (MappedAMRPoissonOpFactory.cpp:161-164).
+ * Each item is 12 ints {src_box, dst_box, src_lo[3], dst_lo[3], n[3], peer_rank} (box-local starts).
+ * Send and receive items are grouped per peer in ascending peer order; within a pair both sides use the
+ * same item order.  Exposed so the N>1 data path can be rehearsed on CPUs (tests/test_multirank_cpu.py). */
+int somar_plan_exchange(const int* domain_lo, const int* domain_hi, const int* periodic, int nboxes, const int* boxes,
+                        const int* owner, int rank, int ghost, int max_items, int* n_local, int* local_items,
+                        int* n_send, int* send_items, int* n_recv, int* recv_items);
+
 /* one-process-per-GPU transport (RCCL over xGMI).  The unique id is created on rank 0 and
  * distributed by the launcher (torch.distributed store / MPI / file). */
 #define SOMAR_COMM_ID_BYTES 128

@@ -86,6 +86,7 @@ _SIGS = {
     "somar_timer_stop": [_H, _PD],
     "somar_profile_enable": [_H, C.c_int],
     "somar_profile_get": [_H, C.c_int, _PI, _PD],
+    "somar_plan_exchange": [_PI, _PI, _PI, C.c_int, _PI, _PI, C.c_int, C.c_int, C.c_int, _PI, _PI, _PI, _PI, _PI, _PI],
     "somar_comm_unique_id": [C.POINTER(C.c_ubyte)],
     "somar_comm_create": [C.POINTER(_H), C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int],
     "somar_comm_destroy": [_H],
@@ -335,6 +336,27 @@ class AMRPressureSolver:
         ms = C.c_double()
         _ck(lib().somar_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+
+def plan_exchange(domain_lo, domain_hi, periodic, boxes, owner, rank, ghost=2, max_items=4096):
+    """-> (local, send, recv): lists of dicts {src, dst, src_lo, dst_lo, n, peer} (pure host call, no GPU)."""
+    flat = []
+    for lo, hi in boxes:
+        flat += list(lo) + list(hi)
+    bufs = [(C.c_int * (12 * max_items))() for _ in range(3)]
+    ns = [C.c_int() for _ in range(3)]
+    _ck(lib().somar_plan_exchange(_ia(domain_lo), _ia(domain_hi), _ia([int(bool(p)) for p in periodic]), len(boxes),
+                                  _ia(flat), _ia(owner), rank, ghost, max_items, C.byref(ns[0]), bufs[0],
+                                  C.byref(ns[1]), bufs[1], C.byref(ns[2]), bufs[2]))
+    out = []
+    for n, b in zip(ns, bufs):
+        items = []
+        for i in range(n.value):
+            o = b[12 * i:12 * i + 12]
+            items.append({"src": o[0], "dst": o[1], "src_lo": tuple(o[2:5]), "dst_lo": tuple(o[5:8]), "n": tuple(o[8:11]),
+                          "peer": o[11]})
+        out.append(items)
+    return tuple(out)
 
 
 def device_count():

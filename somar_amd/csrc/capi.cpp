@@ -461,6 +461,43 @@ int somar_profile_get(somar_solver_t* s, int kernel, int* launches, double* tota
     API_END
 }
 
+int somar_plan_exchange(const int* domain_lo, const int* domain_hi, const int* periodic, int nboxes, const int* boxes,
+                        const int* owner, int rank, int ghost, int max_items, int* n_local, int* local_items,
+                        int* n_send, int* send_items, int* n_recv, int* recv_items)
+{
+    API_BEGIN
+    IBox dom(domain_lo, domain_hi);
+    bool per[3] = {periodic[0] != 0, periodic[1] != 0, periodic[2] != 0};
+    int g[3] = {ghost, ghost, ghost};
+    std::vector<IBox> bx;
+    std::vector<int> own;
+    for (int b = 0; b < nboxes; ++b) { bx.push_back(IBox(boxes + 6 * b, boxes + 6 * b + 3)); own.push_back(owner ? owner[b] : 0); }
+    ExchangePlan plan = build_exchange_plan(dom, per, g, bx, own, rank);
+    auto dump = [&](const std::vector<CopyItem>& v, const std::vector<int>* peer_of, int* n, int* out) {
+        SOMAR_CHECK((int)v.size() <= max_items, "max_items too small");
+        *n = (int)v.size();
+        for (size_t i = 0; i < v.size(); ++i) {
+            int* o = out + 12 * i;
+            o[0] = v[i].src_patch; o[1] = v[i].dst_patch;
+            for (int d = 0; d < 3; ++d) { o[2 + d] = v[i].src_lo[d]; o[5 + d] = v[i].dst_lo[d]; o[8 + d] = v[i].n[d]; }
+            o[11] = peer_of ? (*peer_of)[i] : rank;
+        }
+    };
+    // peer of each remote item: items are grouped per peer in plan.peers order
+    std::vector<int> sp, rp;
+    for (size_t q = 0; q < plan.peers.size(); ++q) {
+        long long s_end = plan.soff[q] + plan.scount[q], r_end = plan.roff[q] + plan.rcount[q];
+        for (size_t i = 0; i < plan.send_items.size(); ++i)
+            if (plan.send_itemoff[i] >= plan.soff[q] && plan.send_itemoff[i] < s_end) sp.push_back(plan.peers[q]);
+        for (size_t i = 0; i < plan.recv_items.size(); ++i)
+            if (plan.recv_itemoff[i] >= plan.roff[q] && plan.recv_itemoff[i] < r_end) rp.push_back(plan.peers[q]);
+    }
+    dump(plan.local, nullptr, n_local, local_items);
+    dump(plan.send_items, &sp, n_send, send_items);
+    dump(plan.recv_items, &rp, n_recv, recv_items);
+    API_END
+}
+
 int somar_comm_unique_id(unsigned char* id128)
 {
     API_BEGIN

@@ -32,7 +32,6 @@
 namespace somar {
 
 constexpr int FR_I = 128;  // region width  (64 lanes x double2) = tile + 4
-constexpr int FR_J = 16;   // region height (one wavefront per row)  = tile + 4
 
 __device__ __forceinline__ double pick(const double2& v, int s) { return s ? v.y : v.x; }
 
@@ -86,8 +85,11 @@ __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS,
     return (rhs - lphi) / (P.alpha + P.beta * ld);
 }
 
-// blockDim = (64, 16): lane = i-pair of the region, threadIdx.y = region row (one wavefront each).
-__global__ __launch_bounds__(1024) void k_gsrb_fused(const Tile* __restrict__ tiles,
+// blockDim = (64, FR_J): lane = i-pair of the region, threadIdx.y = region row (one wavefront each).
+// FR_J = 16: 124 x 12 output columns per 1024-thread workgroup (one per CU);
+// FR_J =  8: 124 x 4 per 512-thread workgroup, two resident per CU so one computes while the other waits.
+template <int FR_J>
+__global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict__ tiles,
                                                      const PatchDesc* __restrict__ patches,
                                                      double* __restrict__ phi_out,
                                                      const double* __restrict__ phi_in,
@@ -231,8 +233,23 @@ void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const Leve
                        const double* phi_in, const double* rhs)
 {
     if (ntiles == 0) return;
-    hipLaunchKernelGGL(k_gsrb_fused, dim3(ntiles), dim3(64, FR_J, 1), 0, st, tiles, L.patches, phi_out, phi_in, rhs,
-                       L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+    if (fused_rows() == 8)
+        hipLaunchKernelGGL(k_gsrb_fused<8>, dim3(ntiles), dim3(64, 8, 1), 0, st, tiles, L.patches, phi_out, phi_in, rhs,
+                           L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+    else
+        hipLaunchKernelGGL(k_gsrb_fused<16>, dim3(ntiles), dim3(64, 16, 1), 0, st, tiles, L.patches, phi_out, phi_in,
+                           rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+}
+
+// region rows per workgroup of the fused sweep (tile rows = rows - 4); SOMAR_FUSED_ROWS = 8 | 16
+int fused_rows()
+{
+    static int rows = 0;
+    if (!rows) {
+        const char* e = getenv("SOMAR_FUSED_ROWS");
+        rows = (e && atoi(e) == 8) ? 8 : 16;
+    }
+    return rows;
 }
 
 }  // namespace somar

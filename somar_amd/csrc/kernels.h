@@ -22,6 +22,7 @@ void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const dou
 // rhs / Jg / Jinv ghosts 1 deep wherever a neighbouring box or periodic image exists
 void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* phi_out,
                        const double* phi_in, const double* rhs);
+int fused_rows();
 void launch_op_ortho(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* rhs, int mode);
 void launch_lapdiag(hipStream_t st, const LevelDev& L);
 void launch_diag(hipStream_t st, const LevelDev& L, double* phi, const double* r, int mode);

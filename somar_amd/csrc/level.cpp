@@ -25,6 +25,73 @@ static T* to_device(const std::vector<T>& v)
     return d;
 }
 
+// Pure host logic (no GPU): the ghost-exchange plan of rank `myrank` for the layout -- Chombo's
+// Copier(grids, grids, domain, ghost, exchange=true).  Items carry GLOBAL box indices in
+// src_patch/dst_patch.  Both sides of a rank pair enumerate (dst box, src box, periodic shift) in the
+// same order, so the i-th item of a send message is the i-th item of the matching receive message.
+ExchangePlan build_exchange_plan(const IBox& domain, const bool periodic[3], const int ghost[3],
+                                 const std::vector<IBox>& boxes, const std::vector<int>& owner, int myrank)
+{
+    ExchangePlan plan;
+    std::vector<std::array<int, 3>> shifts;
+    for (int a = -1; a <= 1; ++a)
+        for (int b = -1; b <= 1; ++b)
+            for (int cc = -1; cc <= 1; ++cc) {
+                if ((a && !periodic[0]) || (b && !periodic[1]) || (cc && !periodic[2])) continue;
+                shifts.push_back({a * domain.size(0), b * domain.size(1), cc * domain.size(2)});
+            }
+    struct Remote { int peer; CopyItem it; };
+    std::vector<Remote> sends, recvs;
+    for (size_t di = 0; di < boxes.size(); ++di) {
+        const IBox gbox = boxes[di].grow(ghost);
+        for (size_t si = 0; si < boxes.size(); ++si) {
+            const bool dl = owner[di] == myrank, sl = owner[si] == myrank;
+            if (!dl && !sl) continue;
+            for (const auto& sh : shifts) {
+                if (si == di && sh[0] == 0 && sh[1] == 0 && sh[2] == 0) continue;
+                const IBox img = boxes[si].shift(sh.data());
+                const IBox r = gbox & img;
+                if (r.empty()) continue;
+                CopyItem it;
+                std::memset(&it, 0, sizeof(it));
+                it.src_patch = (int)si;
+                it.dst_patch = (int)di;
+                for (int d = 0; d < 3; ++d) {
+                    it.n[d] = r.size(d);
+                    it.dst_lo[d] = r.lo[d] - boxes[di].lo[d];
+                    it.src_lo[d] = r.lo[d] - sh[d] - boxes[si].lo[d];
+                }
+                if (dl && sl) plan.local.push_back(it);
+                else if (sl) sends.push_back({owner[di], it});
+                else recvs.push_back({owner[si], it});
+            }
+        }
+    }
+    for (auto& r : sends) plan.peers.push_back(r.peer);
+    for (auto& r : recvs) plan.peers.push_back(r.peer);
+    std::sort(plan.peers.begin(), plan.peers.end());
+    plan.peers.erase(std::unique(plan.peers.begin(), plan.peers.end()), plan.peers.end());
+    for (int q : plan.peers) {
+        plan.soff.push_back(plan.send_total);
+        for (auto& r : sends)
+            if (r.peer == q) {
+                plan.send_items.push_back(r.it);
+                plan.send_itemoff.push_back(plan.send_total);
+                plan.send_total += (long long)r.it.n[0] * r.it.n[1] * r.it.n[2];
+            }
+        plan.scount.push_back(plan.send_total - plan.soff.back());
+        plan.roff.push_back(plan.recv_total);
+        for (auto& r : recvs)
+            if (r.peer == q) {
+                plan.recv_items.push_back(r.it);
+                plan.recv_itemoff.push_back(plan.recv_total);
+                plan.recv_total += (long long)r.it.n[0] * r.it.n[1] * r.it.n[2];
+            }
+        plan.rcount.push_back(plan.recv_total - plan.roff.back());
+    }
+    return plan;
+}
+
 Level::~Level()
 {
     hipFree(d_patches);
@@ -123,7 +190,7 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     // ---- tiles of the fused red-black sweep: 124 x 12 columns, k split into chunks so that the
     // launch fills the 256 CUs evenly (one 1024-thread workgroup per CU at a time) ------------
     {
-        const int FT_I = 124, FT_J = 12;
+        const int FT_I = 124, FT_J = fused_rows() - 4;
         long long cols = 0;
         int maxn2 = 1;
         for (const PatchDesc& p : hpatches) {
@@ -165,70 +232,17 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     }
 
     // ---- exchange plan ----------------------------------------------------------------
-    plan = ExchangePlan();
     // Ghost depth 2 (= FRAME): the fused red-black sweep recomputes the red ring of its neighbours
     // and therefore needs phi two deep; every other consumer reads at most one layer.
     int ghost[3];
     for (int d = 0; d < 3; ++d) ghost[d] = active[d] ? FRAME : 0;
-    std::vector<std::array<int, 3>> shifts;
-    for (int a = -1; a <= 1; ++a)
-        for (int b = -1; b <= 1; ++b)
-            for (int cc = -1; cc <= 1; ++cc) {
-                if ((a && !periodic[0]) || (b && !periodic[1]) || (cc && !periodic[2])) continue;
-                shifts.push_back({a * domain.size(0), b * domain.size(1), cc * domain.size(2)});
-            }
-    std::vector<int> patch_of(boxes.size(), -1);
-    for (int pi = 0; pi < (int)local.size(); ++pi) patch_of[local[pi]] = pi;
-
-    struct Remote { int peer; CopyItem it; };
-    std::vector<Remote> sends, recvs;
-    for (size_t di = 0; di < boxes.size(); ++di) {
-        const IBox gbox = boxes[di].grow(ghost);
-        for (size_t si = 0; si < boxes.size(); ++si) {
-            const bool dl = owner[di] == myrank, sl = owner[si] == myrank;
-            if (!dl && !sl) continue;
-            for (const auto& sh : shifts) {
-                if (si == di && sh[0] == 0 && sh[1] == 0 && sh[2] == 0) continue;
-                const IBox img = boxes[si].shift(sh.data());
-                const IBox r = gbox & img;
-                if (r.empty()) continue;
-                CopyItem it;
-                std::memset(&it, 0, sizeof(it));
-                it.src_patch = sl ? patch_of[si] : -1;
-                it.dst_patch = dl ? patch_of[di] : -1;
-                for (int d = 0; d < 3; ++d) {
-                    it.n[d] = r.size(d);
-                    it.dst_lo[d] = r.lo[d] - boxes[di].lo[d];
-                    it.src_lo[d] = r.lo[d] - sh[d] - boxes[si].lo[d];
-                }
-                if (dl && sl) plan.local.push_back(it);
-                else if (sl) sends.push_back({owner[di], it});
-                else recvs.push_back({owner[si], it});
-            }
-        }
-    }
-    // group remote items by peer (stable => identical canonical order on both sides)
-    for (auto& r : sends) plan.peers.push_back(r.peer);
-    for (auto& r : recvs) plan.peers.push_back(r.peer);
-    std::sort(plan.peers.begin(), plan.peers.end());
-    plan.peers.erase(std::unique(plan.peers.begin(), plan.peers.end()), plan.peers.end());
-    for (int q : plan.peers) {
-        plan.soff.push_back(plan.send_total);
-        for (auto& r : sends)
-            if (r.peer == q) {
-                plan.send_items.push_back(r.it);
-                plan.send_itemoff.push_back(plan.send_total);
-                plan.send_total += (long long)r.it.n[0] * r.it.n[1] * r.it.n[2];
-            }
-        plan.scount.push_back(plan.send_total - plan.soff.back());
-        plan.roff.push_back(plan.recv_total);
-        for (auto& r : recvs)
-            if (r.peer == q) {
-                plan.recv_items.push_back(r.it);
-                plan.recv_itemoff.push_back(plan.recv_total);
-                plan.recv_total += (long long)r.it.n[0] * r.it.n[1] * r.it.n[2];
-            }
-        plan.rcount.push_back(plan.recv_total - plan.roff.back());
+    plan = build_exchange_plan(domain, periodic, ghost, boxes, owner, myrank);
+    {
+        std::vector<int> patch_of(boxes.size(), -1);
+        for (int pi = 0; pi < (int)local.size(); ++pi) patch_of[local[pi]] = pi;
+        for (CopyItem& it : plan.local) { it.src_patch = patch_of[it.src_patch]; it.dst_patch = patch_of[it.dst_patch]; }
+        for (CopyItem& it : plan.send_items) it.src_patch = patch_of[it.src_patch];
+        for (CopyItem& it : plan.recv_items) it.dst_patch = patch_of[it.dst_patch];
     }
 
     // ---- device tables ----------------------------------------------------------------

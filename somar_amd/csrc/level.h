@@ -71,6 +71,9 @@ struct ExchangePlan {
     long long send_total = 0, recv_total = 0;
 };
 
+ExchangePlan build_exchange_plan(const IBox& domain, const bool periodic[3], const int ghost[3],
+                                 const std::vector<IBox>& boxes, const std::vector<int>& owner, int myrank);
+
 class Level {
 public:
     // layout
