@@ -140,6 +140,21 @@ int somar_level_precond(somar_solver_t* s, int depth, int phi_field, int rhs_fie
 int somar_vcycle(somar_solver_t* s, int corr_field, int res_field);
 int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* iters, int* exit_code);
 
+/* MAC level projection of a face-centred velocity given in flux form (J u^a on a-faces, one host array per
+ * local patch spanning faces(valid, a)):  rhs = div(U)/dt ; solve ; U -= dt * Jg^{aa} d_a(phi).
+ *   BaseProjector<FluxBox>::project, a_velIsFlux = true      projection/BaseProjectorI.H:176-299
+ *   LevelMACProjector::computeDiv/computeGrad/applyCorrection  projection/LevelMACProjector.cpp:156-241
+ *   Divergence::levelDivergenceMAC                              calculus/DivCurlGrad/Divergence.cpp:44-127
+ *   Gradient::levelGradientMAC (order-2 extrapolated ghosts)    calculus/DivCurlGrad/Gradient.cpp:85-206
+ * Boundary-face velocities are taken as given (the caller's uStarFuncBC has already been applied). */
+int somar_vel_upload(somar_solver_t* s, int dir, int patch, const double* host);
+int somar_vel_download(somar_solver_t* s, int dir, int patch, double* host);
+int somar_level_divergence_mac(somar_solver_t* s, int out_field, double dt);
+int somar_level_mac_correct(somar_solver_t* s, int phi_field, double dt);
+int somar_mac_project(somar_solver_t* s, double dt, int zero_pressure, int force_homogeneous, somar_stats_t* stats);
+int somar_mac_project_host(somar_solver_t* s, double* const* u0, double* const* u1, double* const* u2, double dt,
+                           int zero_pressure, int force_homogeneous, somar_stats_t* stats);
+
 /* stream control + HIP-event timing on the solver's own stream */
 int somar_sync(somar_solver_t* s);
 int somar_timer_start(somar_solver_t* s);

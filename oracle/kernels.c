@@ -820,3 +820,64 @@ void orc_solve_tridiag(const double *a, const double *b, const double *c, const 
     free(cp);
     free(dp);
 }
+
+/* ------------------------------------------------------------------------
+ * K14 MAPPEDMACGRADORTHO   DivCurlGrad/DivCurlGradF.ChF:221-285
+ * normal branch (gradDir == edgeDir): edgeGrad = dxinv * Jga(:,gradDir) * (phi(i) - phi(i - e))
+ * transverse branch: edgeGrad = (0.25/dx) * Jga(:,gradDir) * centred differences of `extrap`
+ * ---------------------------------------------------------------------- */
+void orc_mappedmacgradortho(double *eg_, const int *elo, const int *ehi,
+                            const double *phi_, const int *plo, const int *phi_hi,
+                            const double *ext_, const int *xlo, const int *xhi,
+                            const double *jga_, const int *glo, const int *ghi,
+                            const int *reglo, const int *reghi, double dxDir, int gradDir, int edgeDir)
+{
+    fra_t edgeGrad = mk(eg_, elo, ehi), phi = mk((double *)phi_, plo, phi_hi);
+    fra_t extrap = mk((double *)ext_, xlo, xhi), Jga = mk((double *)jga_, glo, ghi);
+    const int gi = gradDir == 0, gj = gradDir == 1, gk = gradDir == 2;
+    if (gradDir == edgeDir) {
+        const double dxinv = 1.0 / dxDir;
+        for (int k = reglo[2]; k <= reghi[2]; ++k)
+            for (int j = reglo[1]; j <= reghi[1]; ++j)
+                for (int i = reglo[0]; i <= reghi[0]; ++i)
+                    AT(edgeGrad, i, j, k, 0) = dxinv * AT(Jga, i, j, k, gradDir) *
+                                               (AT(phi, i, j, k, 0) - AT(phi, i - gi, j - gj, k - gk, 0));
+    } else {
+        const int ei = edgeDir == 0, ej = edgeDir == 1, ek = edgeDir == 2;
+        const double dxinv = 0.25 / dxDir;
+        for (int k = reglo[2]; k <= reghi[2]; ++k)
+            for (int j = reglo[1]; j <= reghi[1]; ++j)
+                for (int i = reglo[0]; i <= reghi[0]; ++i)
+                    AT(edgeGrad, i, j, k, 0) =
+                        dxinv * AT(Jga, i, j, k, gradDir) *
+                        (AT(extrap, i + gi, j + gj, k + gk, 0) - AT(extrap, i - gi, j - gj, k - gk, 0) +
+                         AT(extrap, i + gi - ei, j + gj - ej, k + gk - ek, 0) -
+                         AT(extrap, i - gi - ei, j - gj - ej, k - gk - ek, 0));
+    }
+}
+
+/* ELLIPTICEXTRAPBCGHOST   BCInterface/EllipticBCUtilsF.ChF:115-205 (orders 0..2).
+ * sidesign = +1: high side (ghost = f(ghost-1, ghost-2, ...)), -1: low side. */
+int orc_ellipticextrapbcghost(double *st_, const int *slo, const int *shi, int ncomp,
+                              const int *reglo, const int *reghi, int dir, int sidesign, int order)
+{
+    fra_t state = mk(st_, slo, shi);
+    int ii0 = dir == 0, ii1 = dir == 1, ii2 = dir == 2;
+    if (sidesign == 1) { ii0 = -ii0; ii1 = -ii1; ii2 = -ii2; }
+    if (order < 0 || order > 2) return -1;
+    for (int n = 0; n < ncomp; ++n)
+        for (int k = reglo[2]; k <= reghi[2]; ++k)
+            for (int j = reglo[1]; j <= reghi[1]; ++j)
+                for (int i = reglo[0]; i <= reghi[0]; ++i) {
+                    if (order == 0)
+                        AT(state, i, j, k, n) = AT(state, i + ii0, j + ii1, k + ii2, n);
+                    else if (order == 1)
+                        AT(state, i, j, k, n) = 2.0 * AT(state, i + ii0, j + ii1, k + ii2, n) -
+                                                AT(state, i + 2 * ii0, j + 2 * ii1, k + 2 * ii2, n);
+                    else
+                        AT(state, i, j, k, n) = 3.0 * (AT(state, i + ii0, j + ii1, k + ii2, n) -
+                                                       AT(state, i + 2 * ii0, j + 2 * ii1, k + 2 * ii2, n)) +
+                                                AT(state, i + 3 * ii0, j + 3 * ii1, k + 3 * ii2, n);
+                }
+    return 0;
+}

@@ -1279,3 +1279,72 @@ def remove_weighted_mean(rhs, Jinv):
     for g, f in zip(rhs.grids, rhs.fabs):
         f.view(g)[...] -= m
     return m
+
+
+# ----------------------------------------------------------------------------
+# MAC level projection (single level, velocity given in flux form J*u):
+#   BaseProjector<FluxBox>::project           projection/BaseProjectorI.H:176-299
+#   LevelMACProjector::computeDiv/computeGrad/applyCorrection   projection/LevelMACProjector.cpp:156-241
+#   Divergence::levelDivergenceMAC            calculus/DivCurlGrad/Divergence.cpp:44-127   (no flux BC object:
+#                                             boundary faces are taken as given)
+#   Gradient::levelGradientMAC + singleBoxMacGrad   calculus/DivCurlGrad/Gradient.cpp:85-206, 946-1101
+#   gradient BC = order-2 extrapolated ghosts  BCutil/PhysBCUtil.cpp:1432-1443
+# ----------------------------------------------------------------------------
+def level_divergence_mac(div, vel, Jinv, grids, dx, ndim=3):
+    for i, g in enumerate(grids):
+        lo, hi = _b(g)
+        if ndim == 3:
+            lib().orc_mappedfluxdivergence3d(*div[i].fra(), *vel[i][0].fran(), *vel[i][1].fran(), *vel[i][2].fran(),
+                                             *Jinv[i].fra1(0), lo, hi, _rv(dx))
+        else:
+            lib().orc_mappedfluxdivergence2d(*div[i].fra(), *vel[i][0].fran(), *vel[i][1].fran(),
+                                             *Jinv[i].fra1(0), lo, hi, _rv(dx))
+
+
+def set_extrap_ghosts(phiF, valid, domain, order, ndim=3):
+    """EllipticExtrapBCGhostClass::operator() -> setSideExtrapBC (cell-centred branch),
+    BCInterface/EllipticBCUtils.cpp:1011-1050, 224-312."""
+    for d in range(ndim):
+        if domain.periodic[d]:
+            continue
+        for side in (0, 1):
+            vend = valid.lo[d] if side == 0 else valid.hi[d]
+            dend = domain.box.lo[d] if side == 0 else domain.box.hi[d]
+            if vend != dend:
+                continue
+            dest = valid.adjCell(d, side, 1) & phiF.box
+            if dest.isEmpty():
+                continue
+            lo, hi = _b(dest)
+            rc = lib().orc_ellipticextrapbcghost(*phiF.fra(), lo, hi, d, 1 if side else -1, order)
+            assert rc == 0
+
+
+def level_gradient_mac(grad, phi, grids, domain, Jgup, dx, ndim=3):
+    """one-component (normal) MAC gradient, diagonal metric"""
+    exchange(phi, domain, phi.ghost)
+    for i, g in enumerate(grids):
+        set_extrap_ghosts(phi[i], g, domain, 2, ndim)
+        for d in range(ndim):
+            eb = g.faces(d)
+            lo, hi = _b(eb)
+            lib().orc_mappedmacgradortho(*grad[i][d].fra1(0), *phi[i].fra1(0), *phi[i].fra1(0), *Jgup[i][d].fran(),
+                                         lo, hi, C.c_double(dx[d]), d, d)
+
+
+def mac_level_project(amr, vel, phi, dt, zeroPhi=True, ndim=3):
+    """vel: FluxData (1 comp) holding J*u on faces; projected in place.  Returns the solve's final rnorm."""
+    op = amr.op
+    rhs = LevelData(op.grids, 1, (0, 0, 0))
+    level_divergence_mac(rhs, vel, op.Jinv, op.grids, op.dx, ndim)
+    if dt != 0.0:
+        for f in rhs.fabs:
+            f.a /= dt
+    amr.solve(phi, rhs, zeroPhi=zeroPhi)
+    corr = FluxData(op.grids, 1, ndim)
+    level_gradient_mac(corr, phi, op.grids, op.domain, op.Jgup, op.dx, ndim)
+    dtScale = -1.0 if dt == 0.0 else -dt
+    for i in range(len(op.grids)):
+        for d in range(ndim):
+            vel[i][d].a += dtScale * corr[i][d].a   # FArrayBox::plus(src, scale)
+    return rhs

@@ -81,6 +81,13 @@ _SIGS = {
     "somar_level_precond": [_H, C.c_int, C.c_int, C.c_int],
     "somar_vcycle": [_H, C.c_int, C.c_int],
     "somar_bottom_solve": [_H, C.c_int, C.c_int, _PI, _PI],
+    "somar_vel_upload": [_H, C.c_int, C.c_int, _PD],
+    "somar_vel_download": [_H, C.c_int, C.c_int, _PD],
+    "somar_level_divergence_mac": [_H, C.c_int, C.c_double],
+    "somar_level_mac_correct": [_H, C.c_int, C.c_double],
+    "somar_mac_project": [_H, C.c_double, C.c_int, C.c_int, C.POINTER(Stats)],
+    "somar_mac_project_host": [_H, C.POINTER(_PD), C.POINTER(_PD), C.POINTER(_PD), C.c_double, C.c_int, C.c_int,
+                               C.POINTER(Stats)],
     "somar_sync": [_H],
     "somar_timer_start": [_H],
     "somar_timer_stop": [_H, _PD],
@@ -317,6 +324,33 @@ class AMRPressureSolver:
         it, ex = C.c_int(), C.c_int()
         _ck(lib().somar_bottom_solve(self._h, phi_field, rhs_field, C.byref(it), C.byref(ex)))
         return it.value, ex.value
+
+    # -- MAC level projection (LevelMACProjector / BaseProjector::project, velocity in flux form) -------
+    def uploadVel(self, d, patch, host):
+        _ck(lib().somar_vel_upload(self._h, d, patch, _dp(host)))
+
+    def downloadVel(self, d, patch):
+        lo, hi, _ = self.patch_box(patch)
+        shape = [h - l + 1 for l, h in zip(lo, hi)]
+        shape[d] += 1
+        out = np.zeros(shape, dtype=np.float64, order="F")
+        _ck(lib().somar_vel_download(self._h, d, patch, _dp(out)))
+        return out
+
+    def divergenceMAC(self, out_field, dt):
+        _ck(lib().somar_level_divergence_mac(self._h, out_field, float(dt)))
+
+    def macCorrect(self, phi_field, dt):
+        _ck(lib().somar_level_mac_correct(self._h, phi_field, float(dt)))
+
+    def levelProject(self, vel, dt, zeroPressure=True, forceHomogeneous=False):
+        """vel: [u0, u1, u2], each a list (per local patch) of F-ordered face arrays; projected in place."""
+        n = self.num_local_patches
+        U = [( _PD * n)(*[_dp(a) for a in vel[d]]) for d in range(3)]
+        st = Stats()
+        _ck(lib().somar_mac_project_host(self._h, U[0], U[1], U[2], float(dt), int(zeroPressure),
+                                         int(forceHomogeneous), C.byref(st)))
+        return self._stats(st)
 
     def sync(self):
         _ck(lib().somar_sync(self._h))

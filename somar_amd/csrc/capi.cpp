@@ -422,6 +422,69 @@ int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* ite
     API_END
 }
 
+int somar_vel_upload(somar_solver_t* s, int dir, int patch, const double* host)
+{
+    API_BEGIN
+    SOMAR_CHECK(host, "null pointer");
+    s->ps->upload_vel(dir, patch, host);
+    API_END
+}
+
+int somar_vel_download(somar_solver_t* s, int dir, int patch, double* host)
+{
+    API_BEGIN
+    SOMAR_CHECK(host, "null pointer");
+    s->ps->download_vel(dir, patch, host);
+    API_END
+}
+
+int somar_level_divergence_mac(somar_solver_t* s, int out_field, double dt)
+{
+    API_BEGIN
+    int d0;
+    double* out = field_ptr(s, out_field, &d0);
+    SOMAR_CHECK(d0 == 0, "the MAC divergence lives on depth 0");
+    s->ps->divergence_mac(out, dt);
+    API_END
+}
+
+int somar_level_mac_correct(somar_solver_t* s, int phi_field, double dt)
+{
+    API_BEGIN
+    int d0;
+    double* phi = field_ptr(s, phi_field, &d0);
+    SOMAR_CHECK(d0 == 0, "the MAC correction lives on depth 0");
+    s->ps->mac_correct(phi, dt);
+    API_END
+}
+
+int somar_mac_project(somar_solver_t* s, double dt, int zero_pressure, int force_homogeneous, somar_stats_t* stats)
+{
+    API_BEGIN
+    SolveStats st;
+    s->ps->mac_project(dt, zero_pressure != 0, force_homogeneous != 0, st);
+    fill_stats(st, stats);
+    API_END
+}
+
+int somar_mac_project_host(somar_solver_t* s, double* const* u0, double* const* u1, double* const* u2, double dt,
+                           int zero_pressure, int force_homogeneous, somar_stats_t* stats)
+{
+    API_BEGIN
+    SOMAR_CHECK(u0 && u1 && u2, "null pointer");
+    PressureSolver& ps = *s->ps;
+    const int np = ps.level(0).npatches();
+    double* const* u[3] = {u0, u1, u2};
+    for (int p = 0; p < np; ++p)
+        for (int d = 0; d < 3; ++d) ps.upload_vel(d, p, u[d][p]);
+    SolveStats st;
+    ps.mac_project(dt, zero_pressure != 0, force_homogeneous != 0, st);
+    for (int p = 0; p < np; ++p)
+        for (int d = 0; d < 3; ++d) ps.download_vel(d, p, u[d][p]);
+    fill_stats(st, stats);
+    API_END
+}
+
 int somar_sync(somar_solver_t* s)
 {
     API_BEGIN

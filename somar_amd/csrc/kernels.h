@@ -47,6 +47,9 @@ void launch_axby(hipStream_t st, double* z, const double* x, const double* y, do
 // mode 0: sum a*b, 1: max|a|, 2: sum|a|, 3: signed max a  -> out[0] (device)
 void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const double* b, int mode, double* partials,
                    double* out);
+void launch_div_mac(hipStream_t st, const LevelDev& L, double* out, const double* u0, const double* u1,
+                    const double* u2, double dt);
+void launch_mac_correct(hipStream_t st, const LevelDev& L, double* const vel[3], const double* phi, double dtScale);
 void launch_fill_hash(hipStream_t st, const LevelDev& L, double* f, unsigned long long seed);
 
 }  // namespace somar

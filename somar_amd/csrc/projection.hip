@@ -1,0 +1,101 @@
+// somar_amd/csrc/projection.hip -- the two stencils either side of the pressure solve in a MAC level
+// projection (diagonal metric), SURVEY.md rows a20-a22:
+//
+//   k_div_mac      rhs = Jinv * sum_a (U^a_{i+e_a} - U^a_i)/dx_a  [ / dt ]
+//                  MAPPEDFLUXDIVERGENCE3D (calculus/DivCurlGrad/DivCurlGradF.ChF:1122-1215) as called by
+//                  Divergence::levelDivergenceMAC (Divergence.cpp:44-127) + "rhs /= dt" (BaseProjectorI.H:250-257)
+//   k_mac_correct  U^a -= dt * Jg^{aa} (phi_i - phi_{i-e_a})/dx_a on every a-face of every box
+//                  MAPPEDMACGRADORTHO normal branch (DivCurlGradF.ChF:221-258) via Gradient::levelGradientMAC /
+//                  singleBoxMacGrad (Gradient.cpp:85-206, 946-1101), physical-boundary ghosts by order-2
+//                  extrapolation (ELLIPTICEXTRAPBCGHOST, EllipticBCUtilsF.ChF:165-173; BC holder
+//                  PhysBCUtil.cpp:1432-1443) and LevelMACProjector::applyCorrection (LevelMACProjector.cpp:222-241)
+//                  fused: the gradient temporary (3 face arrays written + read) never exists.
+// Same operation order as the reference => bit-identical to the oracle.
+#include "common.h"
+#include "kernels.h"
+
+namespace somar {
+
+__device__ __forceinline__ long long pidx(const PatchDesc& p, int i, int j, int k)
+{
+    return p.off + i + (long long)p.pj * j + p.pk * k;
+}
+
+__global__ __launch_bounds__(512) void k_div_mac(const Tile* __restrict__ tiles,
+                                                 const PatchDesc* __restrict__ patches,
+                                                 double* __restrict__ out, const double* __restrict__ u0,
+                                                 const double* __restrict__ u1, const double* __restrict__ u2,
+                                                 const double* __restrict__ jinv, StencilParams P, double dt)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1]) return;
+    const double dxinv0 = 1.0 / P.dx[0], dxinv1 = 1.0 / P.dx[1], dxinv2 = 1.0 / P.dx[2];
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int li = li0 + q;
+            if (li >= p.n[0]) continue;
+            const long long c = pidx(p, li, lj, t.k0 + kk);
+            double d = jinv[c] * ((u0[c + 1] - u0[c]) * dxinv0 + (u1[c + p.pj] - u1[c]) * dxinv1 +
+                                  (u2[c + p.pk] - u2[c]) * dxinv2);
+            if (dt != 0.0) d = d / dt;
+            out[c] = d;
+        }
+}
+
+// One direction per launch.  Thread = cell (i-pair); it owns the LOW face of each of its cells and, for
+// the last cell of the box in direction DIR, also the HIGH face.
+template <int DIR>
+__global__ __launch_bounds__(512) void k_mac_correct(const Tile* __restrict__ tiles,
+                                                     const PatchDesc* __restrict__ patches,
+                                                     double* __restrict__ vel, const double* __restrict__ phi,
+                                                     const double* __restrict__ jg, StencilParams P, double dtScale)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1]) return;
+    const double dxinv = 1.0 / P.dx[DIR];
+    const long long s = DIR == 0 ? 1 : (DIR == 1 ? (long long)p.pj : p.pk);
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int li = li0 + q;
+            if (li >= p.n[0]) continue;
+            const int lk = t.k0 + kk;
+            const int l = DIR == 0 ? li : (DIR == 1 ? lj : lk);
+            const int g = p.lo[DIR] + l;
+            const long long c = pidx(p, li, lj, lk);
+            const double pc = phi[c];
+            // low face: the cell below is a physical ghost only on a non-periodic domain face
+            double pm = phi[c - s];
+            if (g == P.dom_lo[DIR] && !P.periodic[DIR]) pm = 3.0 * (pc - phi[c + s]) + phi[c + 2 * s];
+            vel[c] = vel[c] + dtScale * (dxinv * jg[c] * (pc - pm));
+            if (l == p.n[DIR] - 1) {
+                double pp = phi[c + s];
+                if (g == P.dom_hi[DIR] && !P.periodic[DIR]) pp = 3.0 * (pc - phi[c - s]) + phi[c - 2 * s];
+                vel[c + s] = vel[c + s] + dtScale * (dxinv * jg[c + s] * (pp - pc));
+            }
+        }
+}
+
+void launch_div_mac(hipStream_t st, const LevelDev& L, double* out, const double* u0, const double* u1,
+                    const double* u2, double dt)
+{
+    if (L.ntiles == 0) return;
+    hipLaunchKernelGGL(k_div_mac, dim3(L.ntiles), dim3(64, L.tile_j, 1), 0, st, L.tiles, L.patches, out, u0, u1, u2,
+                       L.jinv, L.P, dt);
+}
+
+void launch_mac_correct(hipStream_t st, const LevelDev& L, double* const vel[3], const double* phi, double dtScale)
+{
+    if (L.ntiles == 0) return;
+    const dim3 g(L.ntiles), b(64, L.tile_j, 1);
+    hipLaunchKernelGGL(k_mac_correct<0>, g, b, 0, st, L.tiles, L.patches, vel[0], phi, L.jg[0], L.P, dtScale);
+    hipLaunchKernelGGL(k_mac_correct<1>, g, b, 0, st, L.tiles, L.patches, vel[1], phi, L.jg[1], L.P, dtScale);
+    hipLaunchKernelGGL(k_mac_correct<2>, g, b, 0, st, L.tiles, L.patches, vel[2], phi, L.jg[2], L.P, dtScale);
+}
+
+}  // namespace somar

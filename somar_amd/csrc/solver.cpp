@@ -28,6 +28,7 @@ PressureSolver::~PressureSolver()
     for (double* f : f_corr) hipFree(f);
     for (double* f : f_scratch) hipFree(f);
     for (double* f : f_pp) hipFree(f);
+    for (double* f : f_vel) hipFree(f);
     hipFree(f_phi); hipFree(f_rhs); hipFree(f_uberRes); hipFree(f_uberCorr); hipFree(f_best);
     for (double* f : bicg) hipFree(f);
     hipFree(d_partials);
@@ -432,6 +433,59 @@ void PressureSolver::remove_mean(int d, double* f)
     launch_reduce(st_, L.dev, f, L.dev.jinv, 5, d_partials, d_scalars + SLOT_SUMS + 1);
     comm_->allreduce(d_scalars + SLOT_SUMS, 2, 0, st_);
     launch_sub_mean(st_, f, L.field_elems, d_scalars + SLOT_SUMS);
+}
+
+// ------------------------------------------------------------------------------------
+// MAC level projection: BaseProjector<FluxBox>::project (projection/BaseProjectorI.H:176-299) with
+// LevelMACProjector::computeDiv/computeGrad/applyCorrection (LevelMACProjector.cpp:156-241), velocity in
+// flux form (a_velIsFlux = true).  Boundary-face values of the velocity are taken as given.
+// ------------------------------------------------------------------------------------
+double* PressureSolver::vel(int dir)
+{
+    SOMAR_CHECK(dir >= 0 && dir < 3 && finalized, "bad velocity direction / solver not finalized");
+    if (!f_vel[dir]) f_vel[dir] = lev[0]->alloc_field();
+    return f_vel[dir];
+}
+
+void PressureSolver::upload_vel(int dir, int patch, const double* host)
+{
+    Level& L = *lev[0];
+    SOMAR_CHECK(patch >= 0 && patch < L.npatches(), "bad patch index");
+    IBox fb = L.boxes[L.local[patch]];
+    fb.hi[dir] += 1;
+    L.upload(vel(dir), patch, host, fb, fb, st_);
+    sync();
+}
+
+void PressureSolver::download_vel(int dir, int patch, double* host)
+{
+    Level& L = *lev[0];
+    SOMAR_CHECK(patch >= 0 && patch < L.npatches(), "bad patch index");
+    IBox fb = L.boxes[L.local[patch]];
+    fb.hi[dir] += 1;
+    L.download(vel(dir), patch, host, fb, fb, st_);
+    sync();
+}
+
+void PressureSolver::divergence_mac(double* out, double dt)
+{
+    launch_div_mac(st_, lev[0]->dev, out, vel(0), vel(1), vel(2), dt);
+}
+
+void PressureSolver::mac_correct(double* phi, double dt)
+{
+    Level& L = *lev[0];
+    L.exchange(phi, st_);  // Copier excp(grids, grids, domain, ghost, true); a_phi.exchange(excp)  (Gradient.cpp:118-121)
+    double* v[3] = {vel(0), vel(1), vel(2)};
+    launch_mac_correct(st_, L.dev, v, phi, dt == 0.0 ? -1.0 : -dt);
+}
+
+void PressureSolver::mac_project(double dt, bool zeroPressure, bool forceHomogeneous, SolveStats& s)
+{
+    divergence_mac(f_rhs, dt);
+    solve(zeroPressure, forceHomogeneous, s);
+    mac_correct(f_phi, dt);
+    sync();
 }
 
 void PressureSolver::fill_hash(int d, double* f, unsigned long long seed)

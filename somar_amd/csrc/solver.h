@@ -79,6 +79,13 @@ public:
     double norm(int d, const double* a, int ord);
     double dot(int d, const double* a, const double* b);
     void fill_hash(int d, double* f, unsigned long long seed);
+    // ---- MAC level projection pieces (LevelMACProjector / BaseProjector::project), depth 0 -------------
+    double* vel(int dir);   // resident face field J*u^dir (allocated on first use)
+    void upload_vel(int dir, int patch, const double* host);     // host FAB over faces(valid, dir)
+    void download_vel(int dir, int patch, double* host);
+    void divergence_mac(double* out, double dt);                 // out = div(vel) [/ dt]
+    void mac_correct(double* phi, double dt);                    // vel -= dt * G(phi)
+    void mac_project(double dt, bool zeroPressure, bool forceHomogeneous, SolveStats& st);
     void remove_mean(int d, double* f);
     void sync();
     // per-kernel HIP-event timing of the depth-0 launches (0 = GSRB colour pass, 1 = operator/residual)
@@ -98,6 +105,7 @@ private:
     bool build_coarser(int depth);
     void probe_null_space(int d);
     void fill_metric_ghosts(Level& L);
+    double* f_vel[3] = {nullptr, nullptr, nullptr};
     std::vector<double*> f_pp;  // per-depth ping-pong buffer of the fused sweep
     long long fused_min_cells_ = 262144;
 
