@@ -53,8 +53,10 @@ extern "C" {
 /* RelaxMode / PrecondMode, utils/ProblemContext.H:322-340 */
 #define SOMAR_RELAX_JACOBI 0
 #define SOMAR_RELAX_LEVEL_GSRB 1
+#define SOMAR_RELAX_LINE_GSRB 3
 #define SOMAR_PRECOND_NONE (-1)
 #define SOMAR_PRECOND_DIAG_RELAX 0
+#define SOMAR_PRECOND_DIAG_LINE_RELAX 1
 
 typedef struct somar_solver somar_solver_t; /* opaque */
 

@@ -881,3 +881,133 @@ int orc_ellipticextrapbcghost(double *st_, const int *slo, const int *shi, int n
                 }
     return 0;
 }
+
+/* ------------------------------------------------------------------------
+ * LAPACK dgtsv (EXTERNAL, reference LAPACK 3.x dgtsv.f, NRHS = 1), restated for the case the path
+ * produces: a diagonally dominant system, for which the partial-pivoting test |d(i)| >= |dl(i)| always
+ * holds and no row interchange happens.  Returns INFO (0 ok, i > 0: zero pivot at i, -1: an interchange
+ * would have been needed -- never seen on this path).  dl, d, du, b are overwritten like LAPACK does.
+ * Call sites: RelaxationMethods/GSRBF.ChF:1709, 2022.
+ * ---------------------------------------------------------------------- */
+int orc_dgtsv_nopivot(int n, double *dl, double *d, double *du, double *b)
+{
+    if (n <= 0) return 0;
+    for (int i = 0; i < n - 1; ++i) {
+        if (fabs(d[i]) >= fabs(dl[i])) {
+            if (d[i] == 0.0) return i + 1;
+            double fact = dl[i] / d[i];
+            d[i + 1] = d[i + 1] - fact * du[i];
+            b[i + 1] = b[i + 1] - fact * b[i];
+            dl[i] = 0.0;
+        } else {
+            return -1;
+        }
+    }
+    if (d[n - 1] == 0.0) return n;
+    b[n - 1] = b[n - 1] / d[n - 1];
+    if (n > 1) b[n - 2] = (b[n - 2] - du[n - 2] * b[n - 1]) / d[n - 2];
+    for (int i = n - 3; i >= 0; --i) b[i] = (b[i] - du[i] * b[i + 1] - dl[i] * b[i + 2]) / d[i];
+    return 0;
+}
+
+/* ------------------------------------------------------------------------
+ * K5  LineGSRBIter3D   RelaxationMethods/GSRBF.ChF:1730-2042
+ * Vertical-line Gauss-Seidel, one colour: per (i,j) column assemble the tridiagonal system (equation
+ * scaled by J: B = -lphi + rhs/Jinv, D = alpha/Jinv + lapDiag, DL_k = DU_k = Jg2^{22}_{k+1} zzScale) with the
+ * horizontal and cross terms lagged, solve with dgtsv, overwrite the column.
+ * DEVIATION from the reference: the 3-D routine reads uninitialised jmin/jmax
+ * (:1764 vs :1831) and compares i with the parity-shifted imin (:1793-1797); as in the 2-D routine
+ * (:1607-1611) the INTENDED test is used here: a cell drops the flux through a face iff it sits on the
+ * region bound in that direction and that side's BC code is Neumann.
+ * bc = {loX,hiX,loY,hiY,loZ,hiZ}.  Jg0/Jg1/Jg2 carry 3 comps.  Returns the worst dgtsv INFO.
+ * ---------------------------------------------------------------------- */
+int orc_linegsrbiter3d(double *phi_, const int *plo, const int *phi_hi,
+                       const double *ext_, const int *elo, const int *ehi,
+                       const double *rhs_, const int *rlo, const int *rhi,
+                       const double *jg0_, const int *xlo, const int *xhi,
+                       const double *jg1_, const int *ylo, const int *yhi,
+                       const double *jg2_, const int *zlo, const int *zhi,
+                       const double *jinv_, const int *jlo, const int *jhi,
+                       const int *reglo, const int *reghi, const double *dx, double dzCrse,
+                       double alpha, double beta, int redBlack, const int *bc)
+{
+    fra_t phi = mk(phi_, plo, phi_hi), extrap = mk((double *)ext_, elo, ehi);
+    fra_t rhs = mk((double *)rhs_, rlo, rhi);
+    fra_t Jg0 = mk((double *)jg0_, xlo, xhi), Jg1 = mk((double *)jg1_, ylo, yhi);
+    fra_t Jg2 = mk((double *)jg2_, zlo, zhi), Jinv = mk((double *)jinv_, jlo, jhi);
+    const int loX = bc[0], hiX = bc[1], loY = bc[2], hiY = bc[3], loZ = bc[4], hiZ = bc[5];
+    const int k0 = reglo[2], kmax = reghi[2], N = kmax - k0 + 1;
+    const double xxScale = beta * 1.0 / (dx[0] * dx[0]);
+    const double yyScale = beta * 1.0 / (dx[1] * dx[1]);
+    const double zzScale = beta * 1.0 / (dx[2] * dx[2]);
+    const double xyScale = beta * 0.25 / (dx[0] * dx[1]);
+    const double yzScale = beta * 0.25 / (dx[1] * dx[2]);
+    const double zxScale = beta * 0.25 / (dx[2] * dx[0]);
+    double *D = (double *)malloc(sizeof(double) * (size_t)N), *B = (double *)malloc(sizeof(double) * (size_t)N);
+    double *DL = (double *)malloc(sizeof(double) * (size_t)N), *DU = (double *)malloc(sizeof(double) * (size_t)N);
+    int worst = 0;
+#define E(a, b, c) AT(extrap, a, b, c, 0)
+    for (int j = reglo[1]; j <= reghi[1]; ++j) {
+        int imin = reglo[0] + abs((reglo[0] + j + redBlack) % 2);
+        for (int i = imin; i <= reghi[0]; i += 2) {
+            for (int k = k0; k <= kmax; ++k) {
+                const int kdx = k - k0;
+                double coeff1, lapDiag;
+                if (k == k0) {
+                    coeff1 = (loZ == BC_NEUM) ? 0.0 : (loZ == 1 /*Diri*/ ? 2.0 : (loZ == 3 /*CF*/ ? 2.0 * dx[2] / (dzCrse + dx[2]) : 0.0));
+                    lapDiag = -zzScale * (AT(Jg2, i, j, k + 1, 2) + coeff1 * AT(Jg2, i, j, k, 2));
+                    if (N == 1) {  /* degenerate single-cell column: both ends */
+                        double c2 = (hiZ == BC_NEUM) ? 0.0 : (hiZ == 1 ? 2.0 : (hiZ == 3 ? 2.0 * dx[2] / (dzCrse + dx[2]) : 0.0));
+                        lapDiag = -zzScale * (c2 * AT(Jg2, i, j, k + 1, 2) + coeff1 * AT(Jg2, i, j, k, 2));
+                    }
+                } else if (k == kmax) {
+                    coeff1 = (hiZ == BC_NEUM) ? 0.0 : (hiZ == 1 ? 2.0 : (hiZ == 3 ? 2.0 * dx[2] / (dzCrse + dx[2]) : 0.0));
+                    lapDiag = -zzScale * (coeff1 * AT(Jg2, i, j, k + 1, 2) + AT(Jg2, i, j, k, 2));
+                } else {
+                    lapDiag = -zzScale * (AT(Jg2, i, j, k, 2) + AT(Jg2, i, j, k + 1, 2));
+                }
+                double JDxx = 0.0, JDyy = 0.0;
+                if ((loX != BC_NEUM) || (i != reglo[0])) {
+                    JDxx = JDxx + AT(Jg0, i, j, k, 0) * AT(phi, i - 1, j, k, 0);
+                    lapDiag = lapDiag - xxScale * AT(Jg0, i, j, k, 0);
+                }
+                if ((hiX != BC_NEUM) || (i != reghi[0])) {
+                    JDxx = JDxx + AT(Jg0, i + 1, j, k, 0) * AT(phi, i + 1, j, k, 0);
+                    lapDiag = lapDiag - xxScale * AT(Jg0, i + 1, j, k, 0);
+                }
+                if ((loY != BC_NEUM) || (j != reglo[1])) {
+                    JDyy = JDyy + AT(Jg1, i, j, k, 1) * AT(phi, i, j - 1, k, 0);
+                    lapDiag = lapDiag - yyScale * AT(Jg1, i, j, k, 1);
+                }
+                if ((hiY != BC_NEUM) || (j != reghi[1])) {
+                    JDyy = JDyy + AT(Jg1, i, j + 1, k, 1) * AT(phi, i, j + 1, k, 0);
+                    lapDiag = lapDiag - yyScale * AT(Jg1, i, j + 1, k, 1);
+                }
+                double JDxy = AT(Jg0, i + 1, j, k, 1) * (E(i + 1, j + 1, k) - E(i + 1, j - 1, k) + E(i, j + 1, k) - E(i, j - 1, k)) -
+                              AT(Jg0, i, j, k, 1) * (E(i, j + 1, k) - E(i, j - 1, k) + E(i - 1, j + 1, k) - E(i - 1, j - 1, k));
+                double JDxz = AT(Jg0, i + 1, j, k, 2) * (E(i + 1, j, k + 1) - E(i + 1, j, k - 1) + E(i, j, k + 1) - E(i, j, k - 1)) -
+                              AT(Jg0, i, j, k, 2) * (E(i, j, k + 1) - E(i, j, k - 1) + E(i - 1, j, k + 1) - E(i - 1, j, k - 1));
+                double JDyx = AT(Jg1, i, j + 1, k, 0) * (E(i + 1, j + 1, k) - E(i - 1, j + 1, k) + E(i + 1, j, k) - E(i - 1, j, k)) -
+                              AT(Jg1, i, j, k, 0) * (E(i + 1, j, k) - E(i - 1, j, k) + E(i + 1, j - 1, k) - E(i - 1, j - 1, k));
+                double JDyz = AT(Jg1, i, j + 1, k, 2) * (E(i, j + 1, k + 1) - E(i, j + 1, k - 1) + E(i, j, k + 1) - E(i, j, k - 1)) -
+                              AT(Jg1, i, j, k, 2) * (E(i, j, k + 1) - E(i, j, k - 1) + E(i, j - 1, k + 1) - E(i, j - 1, k - 1));
+                double JDzx = AT(Jg2, i, j, k + 1, 0) * (E(i + 1, j, k + 1) - E(i - 1, j, k + 1) + E(i + 1, j, k) - E(i - 1, j, k)) -
+                              AT(Jg2, i, j, k, 0) * (E(i + 1, j, k) - E(i - 1, j, k) + E(i + 1, j, k - 1) - E(i - 1, j, k - 1));
+                double JDzy = AT(Jg2, i, j, k + 1, 1) * (E(i, j + 1, k + 1) - E(i, j - 1, k + 1) + E(i, j + 1, k) - E(i, j - 1, k)) -
+                              AT(Jg2, i, j, k, 1) * (E(i, j + 1, k) - E(i, j - 1, k) + E(i, j + 1, k - 1) - E(i, j - 1, k - 1));
+                double lphi = JDxx * xxScale + JDyy * yyScale + (JDyz + JDzy) * yzScale + (JDzx + JDxz) * zxScale +
+                              (JDxy + JDyx) * xyScale;
+                B[kdx] = -lphi + AT(rhs, i, j, k, 0) / AT(Jinv, i, j, k, 0);
+                D[kdx] = alpha / AT(Jinv, i, j, k, 0) + lapDiag;
+                if (k < kmax) DL[kdx] = AT(Jg2, i, j, k + 1, 2) * zzScale;
+            }
+            for (int q = 0; q < N - 1; ++q) DU[q] = DL[q];
+            int info = orc_dgtsv_nopivot(N, DL, D, DU, B);
+            if (info != 0 && info != N) { if (worst == 0) worst = info; }
+            for (int k = k0; k <= kmax; ++k) AT(phi, i, j, k, 0) = B[k - k0];
+        }
+    }
+#undef E
+    free(D); free(B); free(DL); free(DU);
+    return worst;
+}

@@ -604,6 +604,29 @@ class LooseGSRB(LevelGSRB):
         raise NotImplementedError("LooseGSRB needs a snapshot exchange; not used by default (relax_mode 1)")
 
 
+class LineGSRB(Relaxer):
+    """LineGSRB::relax, RelaxationMethods/GSRB.cpp:148-330 (3-D): vertical line relaxation, dgtsv per column.
+    Uses the intended region-bound Neumann test (deviation Q1, see oracle/kernels.c)."""
+
+    def relax(self, phi, rhs):
+        op = self.op
+        assert op.ndim == 3 and op.activeDirs == (1, 1, 1)
+        L = lib()
+        for whichPass in (0, 1):
+            exchange(phi, op.domain, op.activeDirs)
+            self.fill_ghosts_and_extrapolate(phi)
+            for i, valid in enumerate(op.grids):
+                st = [op.bc.stencil(valid, op.domain, d, s) for d in range(3) for s in (0, 1)]
+                ex = self.extrap[i] if not op.isDiagonal else phi[i]   # diagonal metric: Jg^{ab}=0 kills the cross terms
+                lo, hi = _b(valid)
+                Jg = op.Jgup[i]
+                dzCrse = op.dxCrse[2] if op.dxCrse is not None else float("nan")
+                info = L.orc_linegsrbiter3d(*phi[i].fra1(0), *ex.fra1(0), *rhs[i].fra1(0), *Jg[0].fran(), *Jg[1].fran(),
+                                            *Jg[2].fran(), *op.Jinv[i].fra1(0), lo, hi, _rv(op.dx), C.c_double(dzCrse),
+                                            C.c_double(op.alpha), C.c_double(op.beta), whichPass, (C.c_int * 6)(*st))
+                assert info == 0, "dgtsv INFO = %d" % info
+
+
 class Jacobi(Relaxer):
     """Jacobi::relax, RelaxationMethods/Jacobi.cpp:54-90."""
 
@@ -638,6 +661,8 @@ class PoissonOp:
             self.relaxer = Jacobi(self)
         elif relaxMode == RELAX_LEVEL_GSRB:
             self.relaxer = LevelGSRB(self)
+        elif relaxMode == RELAX_LINE_GSRB:
+            self.relaxer = LineGSRB(self)
         else:
             raise NotImplementedError("relaxMode %d" % relaxMode)
         self.zeroAvg = False

@@ -97,6 +97,7 @@ Level::~Level()
     hipFree(d_patches);
     hipFree(d_tiles);
     hipFree(d_ftiles);
+    hipFree(d_ctiles);
     hipFree(d_local_items);
     hipFree(d_send_items);
     hipFree(d_recv_items);
@@ -229,6 +230,22 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
         for (int b = 0; b < NF; ++b) hftiles[b] = fnat[start[b % NX] + b / NX];
         d_ftiles = to_device(hftiles);
         nftiles = NF;
+    }
+
+    // ---- whole-column tiles for line relaxation (one lane per (i-pair, j) column) ---------------
+    {
+        for (int pi = 0; pi < (int)hpatches.size(); ++pi) {
+            const PatchDesc& p = hpatches[pi];
+            for (int j0 = 0; j0 < p.n[1]; j0 += ctile_j)
+                for (int i0 = 0; i0 < p.n[0]; i0 += TILE_I) {
+                    Tile t;
+                    std::memset(&t, 0, sizeof(t));
+                    t.patch = pi; t.i0 = i0; t.j0 = j0; t.k0 = 0; t.nk = p.n[2];
+                    hctiles.push_back(t);
+                }
+        }
+        d_ctiles = to_device(hctiles);
+        nctiles = (int)hctiles.size();
     }
 
     // ---- exchange plan ----------------------------------------------------------------

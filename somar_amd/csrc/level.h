@@ -90,6 +90,9 @@ public:
     std::vector<Tile> hftiles;   // tiles of the fused red-black sweep (gsrb_fused.hip)
     Tile* d_ftiles = nullptr;
     int nftiles = 0;
+    std::vector<Tile> hctiles;   // whole-column tiles (line relaxation): 128 x ctile_j columns, all of k
+    Tile* d_ctiles = nullptr;
+    int nctiles = 0, ctile_j = 2;
     long long field_elems = 0;
     long long valid_cells_global = 0;
     ExchangePlan plan;

@@ -1,0 +1,106 @@
+// somar_amd/csrc/line_gsrb.hip -- vertical-line Gauss-Seidel (relax_mode 3, LineGSRB), diagonal metric.
+//
+// Reference: LineGSRB::relax (RelaxationMethods/GSRB.cpp:148-330) -> LineGSRBIter3D
+// (RelaxationMethods/GSRBF.ChF:1730-2042) -> LAPACK dgtsv per (i,j) column, called one column at a time
+// with freshly allocated workspace FABs.
+//
+// Here: one launch per colour; a lane owns one (i-pair, j) column -- 64 adjacent columns per wavefront,
+// so every load of the k-march is a unit-stride row segment -- and runs dgtsv's elimination in registers
+// while it assembles the system (no D/DL/DU/B workspace: the modified diagonal goes to one scratch field,
+// the modified right-hand side overwrites the column of phi it will replace anyway), then back-substitutes
+// on the way down.  Columns of one colour are independent (their horizontal neighbours are the other
+// colour), so there is no cross-lane dependence and no shuffle is needed; the serial recurrence lives in
+// k, the slow index, exactly where the layout wants it.
+//
+// Arithmetic follows LineGSRBIter3D term by term (cross terms vanish identically for a diagonal metric)
+// and dgtsv's no-interchange path (|d(i)| >= |dl(i)| always holds for these diagonally dominant systems):
+//   fact = dl(i)/d(i); d(i+1) -= fact*du(i); b(i+1) -= fact*b(i);   x(n) = b(n)/d(n); x(i) = (b(i) - du(i)*x(i+1))/d(i)
+// => bit-identical to the oracle (which is pinned against SciPy's LAPACK dgtsv).
+// Deviation Q1: the reference's uninitialised jmin/jmax and parity-shifted imin are
+// replaced by the intended test "cell on the box bound AND that side is Neumann", as in LineGSRBIter2D.
+#include "common.h"
+#include "kernels.h"
+
+namespace somar {
+
+__global__ __launch_bounds__(256) void k_line_gsrb_ortho(const Tile* __restrict__ tiles,
+                                                         const PatchDesc* __restrict__ patches,
+                                                         double* __restrict__ phi,
+                                                         const double* __restrict__ rhs,
+                                                         const double* __restrict__ jgx,
+                                                         const double* __restrict__ jgy,
+                                                         const double* __restrict__ jgz,
+                                                         const double* __restrict__ jinv,
+                                                         double* __restrict__ dmod, StencilParams P, int color)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1] || li0 >= p.n[0]) return;
+    const int gj = p.lo[1] + lj;
+    const int li = li0 + ((p.lo[0] + li0 + gj + color) & 1);  // colour by i+j only: whole columns are solved
+    if (li >= p.n[0]) return;
+    const int gi = p.lo[0] + li;
+    const int N = p.n[2];
+    const long long sj = p.pj, sk = p.pk;
+    const double xxScale = P.beta * 1.0 / (P.dx[0] * P.dx[0]);
+    const double yyScale = P.beta * 1.0 / (P.dx[1] * P.dx[1]);
+    const double zzScale = P.beta * 1.0 / (P.dx[2] * P.dx[2]);
+    // BC codes of the box: Neumann iff it touches a non-periodic domain face; vertical ends: coeff1 = 0 for
+    // Neumann and for "None" alike (GSRBF.ChF:1804-1817), Dirichlet/CF ends are not offered yet
+    const bool nxl = (gi == P.dom_lo[0]) && P.neum[0][0];
+    const bool nxh = (gi == P.dom_hi[0]) && P.neum[0][1];
+    const bool nyl = (gj == P.dom_lo[1]) && P.neum[1][0];
+    const bool nyh = (gj == P.dom_hi[1]) && P.neum[1][1];
+    const double coeff1 = 0.0;
+    long long c = p.off + li + sj * lj;  // k = 0
+    double d_prev = 0.0, b_prev = 0.0, dl_prev = 0.0;
+    for (int k = 0; k < N; ++k, c += sk) {
+        const double gzl = jgz[c], gzh = jgz[c + sk];
+        double lapDiag;
+        if (k == 0) lapDiag = -zzScale * (gzh + coeff1 * gzl);
+        else if (k == N - 1) lapDiag = -zzScale * (coeff1 * gzh + gzl);
+        else lapDiag = -zzScale * (gzl + gzh);
+        if (N == 1) lapDiag = -zzScale * (coeff1 * gzh + coeff1 * gzl);
+        double JDxx = 0.0, JDyy = 0.0;
+        if (!nxl) { JDxx = JDxx + jgx[c] * phi[c - 1];        lapDiag = lapDiag - xxScale * jgx[c]; }
+        if (!nxh) { JDxx = JDxx + jgx[c + 1] * phi[c + 1];    lapDiag = lapDiag - xxScale * jgx[c + 1]; }
+        if (!nyl) { JDyy = JDyy + jgy[c] * phi[c - sj];       lapDiag = lapDiag - yyScale * jgy[c]; }
+        if (!nyh) { JDyy = JDyy + jgy[c + sj] * phi[c + sj];  lapDiag = lapDiag - yyScale * jgy[c + sj]; }
+        const double lphi = JDxx * xxScale + JDyy * yyScale;
+        const double Ji = jinv[c];
+        double B = -lphi + rhs[c] / Ji;
+        double D = P.alpha / Ji + lapDiag;
+        if (k > 0) {  // dgtsv elimination step i = k-1 (no interchange)
+            const double fact = dl_prev / d_prev;
+            D = D - fact * dl_prev;  // du(i) == dl(i): the system is symmetric
+            B = B - fact * b_prev;
+        }
+        dmod[c] = D;
+        phi[c] = B;
+        d_prev = D;
+        b_prev = B;
+        dl_prev = gzh * zzScale;  // DL(k) = DU(k) = Jg2(k+1) * zzScale
+    }
+    // back substitution
+    c -= sk;  // k = N-1
+    double x = b_prev / d_prev;
+    phi[c] = x;
+    for (int k = N - 2; k >= 0; --k) {
+        c -= sk;
+        const double du = jgz[c + sk] * zzScale;
+        x = (phi[c] - du * x) / dmod[c];
+        phi[c] = x;
+    }
+}
+
+void launch_line_gsrb_ortho(hipStream_t st, const Tile* ctiles, int nctiles, int tile_j, const LevelDev& L,
+                            double* phi, const double* rhs, double* dmod, int color)
+{
+    if (nctiles == 0) return;
+    hipLaunchKernelGGL(k_line_gsrb_ortho, dim3(nctiles), dim3(64, tile_j, 1), 0, st, ctiles, L.patches, phi, rhs,
+                       L.jg[0], L.jg[1], L.jg[2], L.jinv, dmod, L.P, color);
+}
+
+}  // namespace somar

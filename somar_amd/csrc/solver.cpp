@@ -121,10 +121,11 @@ void PressureSolver::define(const IBox& domain, const bool periodic[3], const do
 {
     SOMAR_CHECK(lev.empty(), "solver already defined");
     prm = p;
-    SOMAR_CHECK(prm.relaxMode == RELAX_LEVEL_GSRB || prm.relaxMode == RELAX_JACOBI,
-                "only LevelGSRB (relax_mode 1) and Jacobi (0) are implemented");
-    SOMAR_CHECK(prm.precondMode == PRECOND_DIAG_RELAX || prm.precondMode == PRECOND_NONE,
-                "only DiagRelax / None preconditioners are implemented");
+    SOMAR_CHECK(prm.relaxMode == RELAX_LEVEL_GSRB || prm.relaxMode == RELAX_JACOBI || prm.relaxMode == RELAX_LINE_GSRB,
+                "only LevelGSRB (relax_mode 1), LineGSRB (3) and Jacobi (0) are implemented");
+    SOMAR_CHECK(prm.precondMode == PRECOND_DIAG_RELAX || prm.precondMode == PRECOND_NONE ||
+                    prm.precondMode == PRECOND_DIAG_LINE_RELAX,
+                "bad precondMode");
     for (int d = 0; d < 3; ++d)
         for (int s = 0; s < 2; ++s)
             SOMAR_CHECK(periodic[d] || bc_type[d][s] == BC_NEUM,
@@ -342,11 +343,24 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters)
                 launch_gsrb_ortho(st_, L.dev, e, res, pass);
                 if (profiling_ && d == 0) prof_end(0);
             }
+        } else if (prm.relaxMode == RELAX_LINE_GSRB) {
+            line_relax(d, e, res);
         } else {
             // Jacobi::relax, Jacobi.cpp:54-90
             residual(d, f_scratch[d], e, res);
             launch_diag(st_, L.dev, e, f_scratch[d], 1);
         }
+    }
+}
+
+// LineGSRB::relax, GSRB.cpp:148-330: per colour exchange, then every (i,j) column of that colour is solved
+// exactly in z (line_gsrb.hip); f_pp[d] receives dgtsv's modified diagonal.
+void PressureSolver::line_relax(int d, double* e, const double* res)
+{
+    Level& L = *lev[d];
+    for (int pass = 0; pass < 2; ++pass) {
+        L.exchange(e, st_);
+        launch_line_gsrb_ortho(st_, L.d_ctiles, L.nctiles, L.ctile_j, L.dev, e, res, f_pp[d], pass);
     }
 }
 
@@ -395,6 +409,10 @@ void PressureSolver::pre_cond(int d, double* phi, const double* rhs)
         return;
     }
     launch_diag(st_, L.dev, phi, rhs, 0);
+    if (prm.precondMode == PRECOND_DIAG_LINE_RELAX && prm.relaxMode != RELAX_LINE_GSRB) {
+        for (int it = 0; it < prm.num_smooth_precond; ++it) line_relax(d, phi, rhs);  // m_precondRelaxPtr = LineGSRB
+        return;
+    }
     relax(d, phi, rhs, prm.num_smooth_precond);
 }
 

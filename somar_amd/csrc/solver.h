@@ -105,6 +105,7 @@ private:
     bool build_coarser(int depth);
     void probe_null_space(int d);
     void fill_metric_ghosts(Level& L);
+    void line_relax(int d, double* e, const double* res);
     double* f_vel[3] = {nullptr, nullptr, nullptr};
     std::vector<double*> f_pp;  // per-depth ping-pong buffer of the fused sweep
     long long fused_min_cells_ = 262144;
