@@ -60,3 +60,20 @@ def max_rel_diff(a_list, b_list):
     num = max(float(np.max(np.abs(a - b))) for a, b in zip(a_list, b_list))
     den = max(float(np.max(np.abs(b))) for b in b_list)
     return num / den if den > 0 else num
+
+
+def make_amr_levels(so, am, n, L, periodic, ratios, fine_boxes, variant="stretched", cbox=8):
+    """A nested hierarchy: level 0 covers the domain (n cells, boxes of cbox), level l>0 is the list
+    fine_boxes[l-1] given in level-l index space.  The metric is evaluated analytically at every level's own
+    resolution, as the reference's LevelGeometry does."""
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), periodic)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    grids = [so.split_domain(dom.box, cbox)] + [list(b) for b in fine_boxes]
+    levels = []
+    for l, g in enumerate(grids):
+        if l > 0:
+            dom = dom.refine(ratios[l - 1])
+            dx = tuple(a / b for a, b in zip(dx, ratios[l - 1]))
+        Jgup, Jinv = so.make_diagonal_metric(g, dx, L, variant=variant, domain=dom)
+        levels.append(am.AMRLevel(dom, g, dx, Jgup, Jinv))
+    return levels
