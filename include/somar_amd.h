@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SOMAR_AMD_ABI_VERSION 1
+#define SOMAR_AMD_ABI_VERSION 2
 
 /* BCType codes, calculus/BCInterface/BCDescriptor.H:34-39 */
 #define SOMAR_BC_NONE (-1)
@@ -173,6 +173,41 @@ int somar_profile_get(somar_solver_t* s, int kernel, int* launches, double* tota
 int somar_plan_exchange(const int* domain_lo, const int* domain_hi, const int* periodic, int nboxes, const int* boxes,
                         const int* owner, int rank, int ghost, int max_items, int* n_local, int* local_items,
                         int* n_send, int* send_items, int* n_recv, int* recv_items);
+
+/* ------------------------------------------------------------------------------------------------
+ * Several AMR levels (refinement ratios with entries 1 or 2).
+ *   somar_amr_create/_finalize    AMRPressureSolver::define (projection/AMRPressureSolver.cpp:272-491) ->
+ *                                 MappedAMRPoissonOpFactory::define + MappedAMRMultiGrid::define
+ *                                 (calculus/AMRElliptic/MappedAMRMultiGrid.H:1407-1490)
+ *   somar_amr_level               the per-level operator (MappedAMRMultiGrid::levelOp, :784): a BORROWED
+ *                                 somar_solver_t for metric upload, field I/O and the single-level pieces
+ *   somar_amr_solve               MappedAMRMultiGrid::solve(phi, rhs, l_max, l_base, zeroPhi, forceHomogeneous)
+ *                                 (:933-1183) on the levels' resident PHI/RHS; with l_base > 0 the PHI of level
+ *                                 l_base-1 supplies the coarse-fine boundary values (AMRPressureSolver::levelSolve,
+ *                                 projection/AMRPressureSolver.cpp:567-594)
+ *   somar_amr_interp_cf           MappedAMRPoissonOp::interpCFGhosts(phi, &phiCoarse, false)  (:2170-2216) =
+ *                                 MappedQuadCFInterp::coarseFineInterp (MappedChombo/MappedQuadCFInterp.cpp:579-622)
+ *   somar_amr_residual_level      MappedAMRMultiGrid::computeAMRResidualLevel (:884-927) incl. refluxing
+ *                                 (MappedAMRPoissonOp::reflux :1615-1707, MappedLevelFluxRegister)
+ *   somar_amr_zero_covered        MappedAMRLevelOp::zeroCovered
+ *   somar_amr_vcycle              MappedAMRMultiGrid::AMRVCycle (:1498-1597) on every level's CORR / RES
+ * Level l's boxes are given in level-l index space; `boxes`/`owner` list level 0 first. */
+typedef struct somar_amr somar_amr_t; /* opaque */
+#define SOMAR_F_AMR_CORR 6 /* depth 0: m_correction of MappedAMRMultiGrid */
+#define SOMAR_F_AMR_RES 7  /* depth 0: m_residual   of MappedAMRMultiGrid */
+int somar_amr_create(somar_amr_t** out, int nlevels, const int* domain_lo, const int* domain_hi, const int* periodic,
+                     const double* dx0, const int* bc_type, const int* ref_ratios, const int* nboxes,
+                     const int* boxes, const int* owner, double alpha, double beta, const somar_params_t* prm,
+                     void* comm);
+int somar_amr_destroy(somar_amr_t* a);
+int somar_amr_level(somar_amr_t* a, int level, somar_solver_t** out);
+int somar_amr_finalize(somar_amr_t* a);
+int somar_amr_solve(somar_amr_t* a, int l_max, int l_base, int zero_phi, int force_homogeneous, somar_stats_t* stats);
+int somar_amr_interp_cf(somar_amr_t* a, int level, int fine_field, int coarse_field);
+int somar_amr_residual_level(somar_amr_t* a, int l_max, int l_base, int ilev, int res_field, int phi_field,
+                             int rhs_field);
+int somar_amr_zero_covered(somar_amr_t* a, int level, int field);
+int somar_amr_vcycle(somar_amr_t* a, int l_max, int l_base);
 
 /* one-process-per-GPU transport (RCCL over xGMI).  The unique id is created on rank 0 and
  * distributed by the launcher (torch.distributed store / MPI / file). */

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 BC_NONE, BC_NEUM, BC_DIRI = -1, 0, 1
-F_PHI, F_RHS, F_RES, F_CORR, F_BEST, F_SCRATCH = 0, 1, 2, 3, 4, 5
+F_PHI, F_RHS, F_RES, F_CORR, F_BEST, F_SCRATCH, F_AMR_CORR, F_AMR_RES = 0, 1, 2, 3, 4, 5, 6, 7
 MAX_HISTORY = 64
 COMM_ID_BYTES = 128
 
@@ -94,6 +94,16 @@ _SIGS = {
     "somar_profile_enable": [_H, C.c_int],
     "somar_profile_get": [_H, C.c_int, _PI, _PD],
     "somar_plan_exchange": [_PI, _PI, _PI, C.c_int, _PI, _PI, C.c_int, C.c_int, C.c_int, _PI, _PI, _PI, _PI, _PI, _PI],
+    "somar_amr_create": [C.POINTER(_H), C.c_int, _PI, _PI, _PI, _PD, _PI, _PI, _PI, _PI, _PI, C.c_double, C.c_double,
+                         C.POINTER(Params), _H],
+    "somar_amr_destroy": [_H],
+    "somar_amr_level": [_H, C.c_int, C.POINTER(_H)],
+    "somar_amr_finalize": [_H],
+    "somar_amr_solve": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
+    "somar_amr_interp_cf": [_H, C.c_int, C.c_int, C.c_int],
+    "somar_amr_residual_level": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
+    "somar_amr_zero_covered": [_H, C.c_int, C.c_int],
+    "somar_amr_vcycle": [_H, C.c_int, C.c_int],
     "somar_comm_unique_id": [C.POINTER(C.c_ubyte)],
     "somar_comm_create": [C.POINTER(_H), C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int],
     "somar_comm_destroy": [_H],
@@ -184,6 +194,55 @@ class AMRPressureSolver:
         _ck(lib().somar_solver_num_local_patches(h, C.byref(n)))
         self.num_local_patches = n.value
 
+    # -- define on several AMR levels: AMRPressureSolver::define(levGeos, boxes, ...) (AMRPressureSolver.cpp:272-491)
+    def defineAMR(self, domain_lo, domain_hi, periodic, dx0, ref_ratios, boxes_per_level, bc_type=None,
+                  owners_per_level=None, alpha=0.0, beta=1.0, comm=None):
+        """boxes_per_level[l]: (lo, hi) boxes of level l in level-l index space.  After this call self.levels[l]
+        is a per-level view (metric upload, field I/O, single-level pieces); finalize() and solve*() act on the
+        whole hierarchy."""
+        assert self._h is None and getattr(self, "_amr", None) is None, "already defined"
+        bc = bc_type if bc_type is not None else [BC_NEUM] * 6
+        flat, nb, own = [], [], []
+        for l, boxes in enumerate(boxes_per_level):
+            nb.append(len(boxes))
+            for lo, hi in boxes:
+                flat += list(lo) + list(hi)
+            own += list(owners_per_level[l]) if owners_per_level is not None else [0] * len(boxes)
+        rr = [int(x) for r in ref_ratios for x in r] or [1, 1, 1]
+        h = _H()
+        _ck(lib().somar_amr_create(C.byref(h), len(boxes_per_level), _ia(domain_lo), _ia(domain_hi),
+                                   _ia([int(bool(x)) for x in periodic]), _da(dx0), _ia(bc), _ia(rr), _ia(nb), _ia(flat),
+                                   _ia(own), float(alpha), float(beta), C.byref(self._p), comm))
+        self._amr = h
+        self.levels = []
+        for l in range(len(boxes_per_level)):
+            v = AMRPressureSolver()
+            lh = _H()
+            _ck(lib().somar_amr_level(h, l, C.byref(lh)))
+            v._h, v._borrowed = lh, True
+            n = C.c_int()
+            _ck(lib().somar_solver_num_local_patches(lh, C.byref(n)))
+            v.num_local_patches = n.value
+            self.levels.append(v)
+
+    def solveAMR(self, lmax, lbase, zeroPhi=True, forceHomogeneous=False):
+        """MappedAMRMultiGrid::solve on the levels' resident PHI / RHS."""
+        st = Stats()
+        _ck(lib().somar_amr_solve(self._amr, lmax, lbase, int(zeroPhi), int(forceHomogeneous), C.byref(st)))
+        return self._stats(st)
+
+    def interpCF(self, level, fine_field=F_PHI, coarse_field=F_PHI):
+        _ck(lib().somar_amr_interp_cf(self._amr, level, fine_field, coarse_field))
+
+    def residualLevel(self, lmax, lbase, ilev, res_field=F_RES, phi_field=F_PHI, rhs_field=F_RHS):
+        _ck(lib().somar_amr_residual_level(self._amr, lmax, lbase, ilev, res_field, phi_field, rhs_field))
+
+    def zeroCovered(self, level, field):
+        _ck(lib().somar_amr_zero_covered(self._amr, level, field))
+
+    def vcycleAMR(self, lmax, lbase):
+        _ck(lib().somar_amr_vcycle(self._amr, lmax, lbase))
+
     def patch_box(self, patch, depth=0):
         b = (C.c_int * 6)()
         g = C.c_int()
@@ -194,14 +253,23 @@ class AMRPressureSolver:
         _ck(lib().somar_solver_set_metric_ortho(self._h, patch, _dp(jg0), _dp(jg1), _dp(jg2), _dp(jinv)))
 
     def finalize(self):
-        _ck(lib().somar_solver_finalize(self._h))
+        if getattr(self, "_amr", None) is not None:
+            _ck(lib().somar_amr_finalize(self._amr))
+        else:
+            _ck(lib().somar_solver_finalize(self._h))
 
     def isDefined(self):
-        return self._h is not None
+        return self._h is not None or getattr(self, "_amr", None) is not None
 
     def undefine(self):
+        if getattr(self, "_amr", None) is not None:
+            for v in self.levels:
+                v._h = None
+            _ck(lib().somar_amr_destroy(self._amr))
+            self._amr, self.levels = None, []
         if self._h is not None:
-            _ck(lib().somar_solver_destroy(self._h))
+            if not getattr(self, "_borrowed", False):
+                _ck(lib().somar_solver_destroy(self._h))
             self._h = None
 
     def __del__(self):

@@ -1,0 +1,898 @@
+// somar_amd/csrc/amr.cpp -- see amr.h for the reference map.
+#include "amr.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+namespace somar {
+
+template <class T>
+static T* to_device(const std::vector<T>& v)
+{
+    if (v.empty()) return nullptr;
+    T* d = nullptr;
+    SOMAR_HIP(hipMalloc(&d, v.size() * sizeof(T)));
+    SOMAR_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+static IBox adj_cell(const IBox& b, int d, int s)
+{
+    IBox g = b;
+    if (s == 0) { g.lo[d] = b.lo[d] - 1; g.hi[d] = b.lo[d] - 1; }
+    else { g.lo[d] = b.hi[d] + 1; g.hi[d] = b.hi[d] + 1; }
+    return g;
+}
+static bool contains(const IBox& b, const int iv[3])
+{
+    for (int d = 0; d < 3; ++d)
+        if (iv[d] < b.lo[d] || iv[d] > b.hi[d]) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------
+// Copier between two layouts
+// ------------------------------------------------------------------------------------
+// Pure host logic.  Items carry GLOBAL box indices; every rank enumerates (dst box, src box, shift) in the
+// same order, so the i-th item of a send message is the i-th item of the matching receive message.
+ExchangePlan build_copy_plan(const IBox& domain, const bool periodic[3], const std::vector<IBox>& srcBoxes,
+                             const std::vector<int>& srcOwner, const std::vector<IBox>& dstBoxes,
+                             const std::vector<int>& dstOwner, const int ghost[3], int myrank)
+{
+    ExchangePlan plan;
+    const auto shifts = periodic_shifts(domain, periodic);
+    struct Remote { int peer; CopyItem it; };
+    std::vector<Remote> sends, recvs;
+    for (size_t di = 0; di < dstBoxes.size(); ++di) {
+        const IBox gbox = dstBoxes[di].grow(ghost);
+        for (size_t si = 0; si < srcBoxes.size(); ++si) {
+            const bool dl = dstOwner[di] == myrank, sl = srcOwner[si] == myrank;
+            if (!dl && !sl) continue;
+            for (const auto& sh : shifts) {
+                const IBox r = gbox & srcBoxes[si].shift(sh.data());
+                if (r.empty()) continue;
+                CopyItem it;
+                std::memset(&it, 0, sizeof(it));
+                it.src_patch = (int)si;
+                it.dst_patch = (int)di;
+                for (int d = 0; d < 3; ++d) {
+                    it.n[d] = r.size(d);
+                    it.dst_lo[d] = r.lo[d] - dstBoxes[di].lo[d];
+                    it.src_lo[d] = r.lo[d] - sh[d] - srcBoxes[si].lo[d];
+                }
+                if (dl && sl) plan.local.push_back(it);
+                else if (sl) sends.push_back({dstOwner[di], it});
+                else recvs.push_back({srcOwner[si], it});
+            }
+        }
+    }
+    for (auto& r : sends) plan.peers.push_back(r.peer);
+    for (auto& r : recvs) plan.peers.push_back(r.peer);
+    std::sort(plan.peers.begin(), plan.peers.end());
+    plan.peers.erase(std::unique(plan.peers.begin(), plan.peers.end()), plan.peers.end());
+    for (int q : plan.peers) {
+        plan.soff.push_back(plan.send_total);
+        for (auto& r : sends)
+            if (r.peer == q) {
+                plan.send_items.push_back(r.it);
+                plan.send_itemoff.push_back(plan.send_total);
+                plan.send_total += (long long)r.it.n[0] * r.it.n[1] * r.it.n[2];
+            }
+        plan.scount.push_back(plan.send_total - plan.soff.back());
+        plan.roff.push_back(plan.recv_total);
+        for (auto& r : recvs)
+            if (r.peer == q) {
+                plan.recv_items.push_back(r.it);
+                plan.recv_itemoff.push_back(plan.recv_total);
+                plan.recv_total += (long long)r.it.n[0] * r.it.n[1] * r.it.n[2];
+            }
+        plan.rcount.push_back(plan.recv_total - plan.roff.back());
+    }
+    return plan;
+}
+
+Copier::~Copier()
+{
+    hipFree(d_local); hipFree(d_send); hipFree(d_recv); hipFree(d_soff); hipFree(d_roff); hipFree(d_sbuf); hipFree(d_rbuf);
+}
+
+void Copier::define(const IBox& domain, const bool periodic[3], const Level& src, const Level& dst, const int ghost[3],
+                    Comm* comm)
+{
+    src_ = &src;
+    dst_ = &dst;
+    comm_ = comm;
+    for (int d = 0; d < 3; ++d) SOMAR_CHECK(ghost[d] <= FRAME, "copier ghost wider than the device frame");
+    plan = build_copy_plan(domain, periodic, src.boxes, src.owner, dst.boxes, dst.owner, ghost, comm ? comm->rank : 0);
+    std::vector<int> sp(src.boxes.size(), -1), dp(dst.boxes.size(), -1);
+    for (int pi = 0; pi < (int)src.local.size(); ++pi) sp[src.local[pi]] = pi;
+    for (int pi = 0; pi < (int)dst.local.size(); ++pi) dp[dst.local[pi]] = pi;
+    for (CopyItem& it : plan.local) { it.src_patch = sp[it.src_patch]; it.dst_patch = dp[it.dst_patch]; }
+    for (CopyItem& it : plan.send_items) it.src_patch = sp[it.src_patch];
+    for (CopyItem& it : plan.recv_items) it.dst_patch = dp[it.dst_patch];
+    d_local = to_device(plan.local);
+    d_send = to_device(plan.send_items);
+    d_recv = to_device(plan.recv_items);
+    d_soff = to_device(plan.send_itemoff);
+    d_roff = to_device(plan.recv_itemoff);
+    if (plan.send_total) SOMAR_HIP(hipMalloc(&d_sbuf, plan.send_total * sizeof(double)));
+    if (plan.recv_total) SOMAR_HIP(hipMalloc(&d_rbuf, plan.recv_total * sizeof(double)));
+}
+
+void Copier::run(const double* s, double* d, hipStream_t st) const
+{
+    const bool remote = !plan.peers.empty();
+    if (remote) {
+        launch_pack(st, src_->dev, d_send, d_soff, (int)plan.send_items.size(), const_cast<double*>(s), d_sbuf, true);
+        comm_->neighbor_exchange(d_sbuf, d_rbuf, plan.peers, plan.soff, plan.scount, plan.roff, plan.rcount, st);
+    }
+    launch_copy_items2(st, src_->dev.patches, dst_->dev.patches, d_local, (int)plan.local.size(), s, d);
+    if (remote) launch_pack(st, dst_->dev, d_recv, d_roff, (int)plan.recv_items.size(), d, d_rbuf, false);
+}
+
+AMRLink::~AMRLink()
+{
+    Level::free_field(buf);
+    Level::free_field(resC);
+    hipFree(d_cc); hipFree(d_pts); hipFree(d_fc); hipFree(d_der); hipFree(d_cover); hipFree(d_reg); hipFree(d_regvals);
+    hipFree(d_reflux); hipFree(d_A); hipFree(d_B); hipFree(d_sendidx); hipFree(d_sendbuf);
+}
+
+// ------------------------------------------------------------------------------------
+// AMRSolver
+// ------------------------------------------------------------------------------------
+AMRSolver::AMRSolver(Comm* comm) : comm_(comm ? comm : &self_)
+{
+    SOMAR_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+}
+
+AMRSolver::~AMRSolver()
+{
+    if (st_) hipStreamSynchronize(st_);
+    links_.clear();
+    S.clear();
+    if (st_) hipStreamDestroy(st_);
+}
+
+void AMRSolver::define(const IBox& domain0, const bool periodic[3], const double dx0[3], const int bc_type[3][2],
+                       const std::vector<std::array<int, 3>>& ratios, const std::vector<std::vector<IBox>>& boxes,
+                       const std::vector<std::vector<int>>& owners, double alpha, double beta, const SolverParams& p)
+{
+    SOMAR_CHECK(S.empty(), "AMR solver already defined");
+    const int n = (int)boxes.size();
+    SOMAR_CHECK(n >= 1 && (int)ratios.size() >= n - 1 && (int)owners.size() == n, "bad level count");
+    prm = p;
+    ratios_ = ratios;
+    IBox dom = domain0;
+    double dx[3] = {dx0[0], dx0[1], dx0[2]}, dxc[3] = {0, 0, 0};
+    for (int l = 0; l < n; ++l) {
+        if (l > 0) {
+            const int* r = ratios[l - 1].data();
+            for (int d = 0; d < 3; ++d) {
+                SOMAR_CHECK(r[d] == 1 || r[d] == 2,
+                            "refinement ratios > 2 need the mini V-cycle (MappedAMRMultiGrid.H:742-754): not implemented");
+                dxc[d] = dx[d];
+                dx[d] = dx[d] / (double)r[d];
+            }
+            dom = dom.refine(r);
+            // proper nesting as far as the tables need it: every fine box coarsens exactly
+            SOMAR_CHECK(coarsenable(boxes[l], r), "fine boxes must be coarsenable by the refinement ratio");
+            for (const IBox& b : boxes[l])
+                for (int d = 0; d < 3; ++d)
+                    SOMAR_CHECK(b.lo[d] >= dom.lo[d] && b.hi[d] <= dom.hi[d], "fine box outside the domain");
+        }
+        std::unique_ptr<PressureSolver> ps(new PressureSolver(comm_, st_));
+        ps->define(dom, periodic, dx, bc_type, boxes[l], owners[l], alpha, beta, p, l > 0 ? dxc : nullptr);
+        S.push_back(std::move(ps));
+    }
+}
+
+void AMRSolver::finalize()
+{
+    SOMAR_CHECK(!S.empty() && !finalized_, "finalize before define / twice");
+    const int n = nlevels();
+    for (auto& s : S) s->finalize();
+    corr_.assign(n, nullptr);
+    res_.assign(n, nullptr);
+    for (int l = 0; l < n; ++l) {
+        corr_[l] = S[l]->amr_field(0);
+        res_[l] = S[l]->amr_field(1);
+    }
+    links_.resize(n);
+    for (int l = 1; l < n; ++l) build_link(l);
+    sync();
+    finalized_ = true;
+}
+
+void AMRSolver::build_link(int l)
+{
+    std::unique_ptr<AMRLink> K(new AMRLink);
+    Level& F = S[l]->level(0);
+    Level& C = S[l - 1]->level(0);
+    for (int d = 0; d < 3; ++d) K->r[d] = ratios_[l - 1][d];
+    std::vector<IBox> cb;
+    for (const IBox& b : F.boxes) cb.push_back(b.coarsen(K->r));
+    K->cfl.reset(new Level);
+    K->cfl->define(C.domain, C.periodic, C.dx, C.bc_type, cb, F.owner, comm_);
+    K->buf = K->cfl->alloc_field();
+    K->resC = K->cfl->alloc_field();
+    const int g2[3] = {2, 2, 2}, g0[3] = {0, 0, 0};
+    K->gather.define(C.domain, C.periodic, C, *K->cfl, g2, comm_);
+    K->scatter.define(C.domain, C.periodic, *K->cfl, C, g0, comm_);
+    // zeroCovered: the coarse cells under the fine level
+    std::vector<FillItem> cover;
+    for (int pi = 0; pi < C.npatches(); ++pi) {
+        const IBox valid = C.boxes[C.local[pi]];
+        for (const IBox& b : cb) {
+            const IBox reg = b & valid;
+            if (reg.empty()) continue;
+            FillItem it;
+            std::memset(&it, 0, sizeof(it));
+            it.patch = pi;
+            for (int d = 0; d < 3; ++d) { it.lo[d] = reg.lo[d] - valid.lo[d]; it.n[d] = reg.size(d); }
+            cover.push_back(it);
+        }
+    }
+    K->ncover = (int)cover.size();
+    K->d_cover = to_device(cover);
+    links_[l] = std::move(K);
+    build_quad_tables(l);
+    build_reflux_tables(l);
+}
+
+// ------------------------------------------------------------------------------------
+// MappedQuadCFInterp::define + MappedQuadCFStencil::define/buildStencils as flat tables
+// ------------------------------------------------------------------------------------
+namespace {
+struct Mask {
+    IBox b;
+    std::vector<char> m;
+    void define(const IBox& box, char v)
+    {
+        b = box;
+        m.assign((size_t)std::max<long long>(box.numPts(), 0), v);
+    }
+    size_t idx(const int iv[3]) const
+    {
+        return (size_t)(iv[0] - b.lo[0]) + (size_t)b.size(0) * ((size_t)(iv[1] - b.lo[1]) + (size_t)b.size(1) * (size_t)(iv[2] - b.lo[2]));
+    }
+    bool at(const int iv[3]) const { return contains(b, iv) && m[idx(iv)]; }
+    void set_box(const IBox& r0, char v)
+    {
+        const IBox r = r0 & b;
+        if (r.empty()) return;
+        int iv[3];
+        for (iv[2] = r.lo[2]; iv[2] <= r.hi[2]; ++iv[2])
+            for (iv[1] = r.lo[1]; iv[1] <= r.hi[1]; ++iv[1])
+                for (iv[0] = r.lo[0]; iv[0] <= r.hi[0]; ++iv[0]) m[idx(iv)] = v;
+    }
+};
+}  // namespace
+
+void AMRSolver::build_quad_tables(int l)
+{
+    AMRLink& K = *links_[l];
+    Level& F = S[l]->level(0);
+    Level& C = S[l - 1]->level(0);
+    const int* r = K.r;
+    // m_level < 0-equivalent: the fine level covers the whole coarse level -> no CF interpolation
+    long long nf = 0, nc = 0;
+    for (const IBox& b : F.boxes) nf += b.numPts();
+    for (const IBox& b : C.boxes) nc += b.numPts();
+    K.hasCF = (nf / ((long long)r[0] * r[1] * r[2])) != nc;
+    if (!K.hasCF) return;
+
+    const IBox fdom = F.domain, cdom = C.domain;
+    int gp1[3], gp6[3];
+    for (int d = 0; d < 3; ++d) { gp1[d] = F.periodic[d] ? 1 : 0; gp6[d] = F.periodic[d] ? 6 : 0; }
+    const IBox fdomG = fdom.grow(gp1), cdomG1 = cdom.grow(gp1), cdomG6 = cdom.grow(gp6);
+    const auto fshifts = periodic_shifts(fdom, F.periodic);
+    const auto cshifts = periodic_shifts(cdom, C.periodic);
+    // coarsened images of every fine box, images of every coarse box
+    std::vector<IBox> crseImgsOfFine, coarImgs;
+    for (const auto& sh : fshifts)
+        for (const IBox& b : F.boxes) crseImgsOfFine.push_back(b.shift(sh.data()).coarsen(r));
+    for (const auto& sh : cshifts)
+        for (const IBox& b : C.boxes) coarImgs.push_back(b.shift(sh.data()));
+
+    std::vector<QCoarse> ccs;
+    std::vector<QPoint> pts;
+    std::vector<QFine> fcs;
+
+    for (int pi = 0; pi < F.npatches(); ++pi) {
+        const IBox grid = F.boxes[F.local[pi]];
+        const PatchDesc& fp = F.hpatches[pi];
+        const PatchDesc& cp = K.cfl->hpatches[pi];
+        const long long fst[3] = {1, fp.pj, fp.pk};
+        const long long cst[3] = {1, cp.pj, cp.pk};
+        const IBox coarseGrid = grid.coarsen(r);
+        for (int dir = 0; dir < 3; ++dir) {
+            const int t1 = dir == 0 ? 1 : 0, t2 = dir == 2 ? 1 : 2;
+            for (int s = 0; s < 2; ++s) {
+                const IBox edge = adj_cell(grid, dir, s) & fdomG;
+                if (edge.empty()) continue;
+                const std::vector<IBox> fineIVS = uncovered(edge, F.boxes, fdom, F.periodic);
+                if (fineIVS.empty()) continue;
+                long long nunc = 0;
+                for (const IBox& u : fineIVS) nunc += u.numPts();
+                const bool packed = nunc == edge.numPts();
+                // coarse IVS = coarsen(fine IVS) & (coarse domain grown 1 in periodic directions)
+                Mask coar;
+                coar.define(edge.coarsen(r) & cdomG1, 0);
+                if (coar.b.empty()) continue;
+                for (const IBox& u : fineIVS) coar.set_box(u.coarsen(r), 1);
+                // "all good" coarse cells: not under the fine level, covered by the coarse level
+                IBox g2 = adj_cell(coarseGrid, dir, s), g1 = g2;
+                g2.lo[t1] -= 2; g2.hi[t1] += 2; g2.lo[t2] -= 2; g2.hi[t2] += 2;
+                g1.lo[t1] -= 1; g1.hi[t1] += 1; g1.lo[t2] -= 1; g1.hi[t2] += 1;
+                g2 = g2 & cdomG6;
+                g1 = g1 & cdomG6;
+                Mask good;
+                good.define(g2, 0);
+                for (const IBox& b : coarImgs) good.set_box(b, 1);
+                for (const IBox& b : crseImgsOfFine) good.set_box(b, 0);
+                // standard = good within g1, shrunk by one in each tangential direction
+                Mask stdm;
+                stdm.define(g2, 0);
+                {
+                    const IBox r1 = g1 & g2;
+                    int iv[3];
+                    for (iv[2] = r1.lo[2]; iv[2] <= r1.hi[2]; ++iv[2])
+                        for (iv[1] = r1.lo[1]; iv[1] <= r1.hi[1]; ++iv[1])
+                            for (iv[0] = r1.lo[0]; iv[0] <= r1.hi[0]; ++iv[0]) stdm.m[stdm.idx(iv)] = good.m[good.idx(iv)];
+                    for (int t : {t1, t2}) {
+                        Mask nxt = stdm;
+                        for (iv[2] = g2.lo[2]; iv[2] <= g2.hi[2]; ++iv[2])
+                            for (iv[1] = g2.lo[1]; iv[1] <= g2.hi[1]; ++iv[1])
+                                for (iv[0] = g2.lo[0]; iv[0] <= g2.hi[0]; ++iv[0]) {
+                                    int a[3] = {iv[0], iv[1], iv[2]}, b[3] = {iv[0], iv[1], iv[2]};
+                                    a[t] -= 1;
+                                    b[t] += 1;
+                                    nxt.m[nxt.idx(iv)] = stdm.m[stdm.idx(iv)] && stdm.at(a) && stdm.at(b);
+                                }
+                        stdm = nxt;
+                    }
+                }
+                // ---- coarse records ----
+                std::map<long long, int> ccIndex;  // buffer offset -> record
+                int iv[3];
+                for (iv[2] = coar.b.lo[2]; iv[2] <= coar.b.hi[2]; ++iv[2])
+                    for (iv[1] = coar.b.lo[1]; iv[1] <= coar.b.hi[1]; ++iv[1])
+                        for (iv[0] = coar.b.lo[0]; iv[0] <= coar.b.hi[0]; ++iv[0]) {
+                            if (!coar.m[coar.idx(iv)]) continue;
+                            QCoarse q;
+                            std::memset(&q, 0, sizeof(q));
+                            q.boff = cp.off + (iv[0] - cp.lo[0]) + cst[1] * (iv[1] - cp.lo[1]) + cst[2] * (iv[2] - cp.lo[2]);
+                            for (int d = 0; d < 3; ++d)
+                                SOMAR_CHECK(iv[d] - cp.lo[d] >= -1 && iv[d] - cp.lo[d] <= cp.n[d], "coarse CF cell outside the buffer ring");
+                            q.dir = dir;
+                            q.s1 = (int)cst[t1];
+                            q.s2 = (int)cst[t2];
+                            q.p0 = (int)pts.size();
+                            auto G = [&](int a, int b) {
+                                int w[3] = {iv[0], iv[1], iv[2]};
+                                w[t1] += a;
+                                w[t2] += b;
+                                return good.at(w);
+                            };
+                            if (stdm.at(iv)) {
+                                q.flags = 1;
+                            } else {
+                                bool drop = false;
+                                // mixed derivative first (it may set dropOrd), MappedCFStencil.cpp:1010-1075
+                                std::vector<std::pair<std::pair<int, int>, double>> mix;
+                                int nused = 0;
+                                const int quad[4][2] = {{-1, 0}, {0, 0}, {0, -1}, {-1, -1}};
+                                for (int qd = 0; qd < 4; ++qd) {
+                                    const int la = quad[qd][0], lb = quad[qd][1];
+                                    if (!(G(la, lb) && G(la + 1, lb) && G(la, lb + 1) && G(la + 1, lb + 1))) continue;
+                                    ++nused;
+                                    for (int db = 0; db < 2; ++db)
+                                        for (int da = 0; da < 2; ++da) {
+                                            const double w = (da == db) ? -1.0 : 1.0;
+                                            const std::pair<int, int> key(la + da, lb + db);
+                                            bool found = false;
+                                            for (auto& e : mix)
+                                                if (e.first == key) { e.second += w; found = true; break; }
+                                            if (!found) mix.push_back({key, w});
+                                        }
+                                }
+                                if (nused == 0) drop = true;
+                                // first/second derivatives per tangential direction, :1077-1178
+                                std::vector<QPoint> d1[2], d2[2];
+                                for (int ti = 0; ti < 2; ++ti) {
+                                    const long long sst = ti == 0 ? cst[t1] : cst[t2];
+                                    auto g = [&](int k) { return ti == 0 ? G(k, 0) : G(0, k); };
+                                    auto P = [&](std::vector<QPoint>& v, int k, double w) { v.push_back({k * sst, w}); };
+                                    if (drop) continue;  // dropped before this direction: no stencils
+                                    if (g(-1) && g(0) && g(1)) {
+                                        P(d2[ti], -1, 1.0); P(d2[ti], 0, -2.0); P(d2[ti], 1, 1.0);
+                                        P(d1[ti], -1, -0.5); P(d1[ti], 0, 0.0); P(d1[ti], 1, 0.5);
+                                    } else if (g(0) && g(1) && g(2)) {
+                                        P(d2[ti], 0, 1.0); P(d2[ti], 1, -2.0); P(d2[ti], 2, 1.0);
+                                        P(d1[ti], 0, -3.0 / 2.0); P(d1[ti], 1, 4.0 / 2.0); P(d1[ti], 2, -1.0 / 2.0);
+                                    } else if (g(-2) && g(-1) && g(0)) {
+                                        P(d2[ti], -2, 1.0); P(d2[ti], -1, -2.0); P(d2[ti], 0, 1.0);
+                                        P(d1[ti], -2, 1.0 / 2.0); P(d1[ti], -1, -4.0 / 2.0); P(d1[ti], 0, 3.0 / 2.0);
+                                    } else {
+                                        drop = true;  // m_dropOrd(iv) = true
+                                        if (g(1)) { P(d1[ti], 0, -1.0); P(d1[ti], 1, 1.0); }
+                                        else if (g(-1)) { P(d1[ti], -1, -1.0); P(d1[ti], 0, 1.0); }
+                                        else P(d1[ti], 0, 0.0);
+                                    }
+                                }
+                                if (drop) { d2[0].clear(); d2[1].clear(); mix.clear(); }
+                                q.np[0] = (int)d1[0].size(); q.np[1] = (int)d2[0].size();
+                                q.np[2] = (int)d1[1].size(); q.np[3] = (int)d2[1].size();
+                                q.np[4] = (int)mix.size();
+                                for (auto& e : d1[0]) pts.push_back(e);
+                                for (auto& e : d2[0]) pts.push_back(e);
+                                for (auto& e : d1[1]) pts.push_back(e);
+                                for (auto& e : d2[1]) pts.push_back(e);
+                                for (auto& e : mix)
+                                    pts.push_back({e.first.first * cst[t1] + e.first.second * cst[t2], e.second / (double)nused});
+                            }
+                            ccIndex[q.boff] = (int)ccs.size();
+                            ccs.push_back(q);
+                        }
+                // ---- fine records ----
+                for (const IBox& u : fineIVS)
+                    for (iv[2] = u.lo[2]; iv[2] <= u.hi[2]; ++iv[2])
+                        for (iv[1] = u.lo[1]; iv[1] <= u.hi[1]; ++iv[1])
+                            for (iv[0] = u.lo[0]; iv[0] <= u.hi[0]; ++iv[0]) {
+                                int ivc[3];
+                                for (int d = 0; d < 3; ++d) ivc[d] = IBox::fdiv(iv[d], r[d]);
+                                const long long boff = cp.off + (ivc[0] - cp.lo[0]) + cst[1] * (ivc[1] - cp.lo[1]) + cst[2] * (ivc[2] - cp.lo[2]);
+                                auto itc = ccIndex.find(boff);
+                                SOMAR_CHECK(itc != ccIndex.end(), "fine CF ghost cell without a coarse stencil");
+                                QFine f;
+                                std::memset(&f, 0, sizeof(f));
+                                f.foff = fp.off + (iv[0] - fp.lo[0]) + fst[1] * (iv[1] - fp.lo[1]) + fst[2] * (iv[2] - fp.lo[2]);
+                                f.stride = (int)(s ? fst[dir] : -fst[dir]);
+                                f.cc = itc->second;
+                                f.ivf1 = iv[t1]; f.ivf2 = iv[t2];
+                                f.ivc1 = ivc[t1]; f.ivc2 = ivc[t2];
+                                f.dirflags = dir | (packed ? 4 : 0);
+                                fcs.push_back(f);
+                            }
+            }
+        }
+    }
+    K.ncc = (int)ccs.size();
+    K.nfc = (int)fcs.size();
+    K.d_cc = to_device(ccs);
+    K.d_pts = to_device(pts);
+    K.d_fc = to_device(fcs);
+    if (K.ncc) SOMAR_HIP(hipMalloc(&K.d_der, (size_t)K.ncc * 5 * sizeof(double)));
+}
+
+// ------------------------------------------------------------------------------------
+// MappedLevelFluxRegister::define as flat tables
+// ------------------------------------------------------------------------------------
+void AMRSolver::build_reflux_tables(int l)
+{
+    AMRLink& K = *links_[l];
+    Level& F = S[l]->level(0);
+    Level& C = S[l - 1]->level(0);
+    const int* r = K.r;
+    const int me = comm_->rank;
+    long long nc = 0, ncf = 0;
+    for (const IBox& b : C.boxes) nc += b.numPts();
+    for (const IBox& b : K.cfl->boxes) ncf += b.numPts();
+    K.fluxDefined = (nc - ncf) != 0;  // the "temporary flux register optimization", MappedLevelFluxRegister.cpp:97-109
+    if (!K.fluxDefined) return;
+    const std::vector<IBox>& cf = K.cfl->boxes;
+    const auto shifts = periodic_shifts(C.domain, C.periodic);
+    const double beta = C.beta;
+    for (int d = 0; d < 3; ++d) {
+        const double scale = beta / C.dx[d];
+        const double denom = (double)(r[0] * r[1] * r[2] / r[d]);
+        K.sc_fine[d][0] = -1.0 * scale / denom;
+        K.sc_fine[d][1] = 1.0 * scale / denom;
+    }
+    // ---- register cells of the local fine boxes: (patch, dir, side, slab cell in Fortran order) ----
+    std::vector<FRegCell> reg;
+    std::vector<std::array<std::array<int, 2>, 3>> regbase(F.npatches());
+    for (int pi = 0; pi < F.npatches(); ++pi) {
+        const PatchDesc& fp = F.hpatches[pi];
+        const IBox fb = F.boxes[F.local[pi]];
+        const IBox cb = cf[F.local[pi]];
+        const long long st[3] = {1, fp.pj, fp.pk};
+        for (int d = 0; d < 3; ++d)
+            for (int s = 0; s < 2; ++s) {
+                regbase[pi][d][s] = (int)reg.size();
+                const IBox slab = adj_cell(cb, d, s);
+                int c[3];
+                for (c[2] = slab.lo[2]; c[2] <= slab.hi[2]; ++c[2])
+                    for (c[1] = slab.lo[1]; c[1] <= slab.hi[1]; ++c[1])
+                        for (c[0] = slab.lo[0]; c[0] <= slab.hi[0]; ++c[0]) {
+                            int f[3];
+                            for (int a = 0; a < 3; ++a) f[a] = c[a] * r[a];
+                            f[d] = s == 0 ? fb.lo[d] : fb.hi[d] + 1;
+                            FRegCell q;
+                            std::memset(&q, 0, sizeof(q));
+                            q.cell0 = fp.off + (f[0] - fp.lo[0]) + st[1] * (f[1] - fp.lo[1]) + st[2] * (f[2] - fp.lo[2]);
+                            q.patch = pi;
+                            q.dir = d;
+                            q.side = s;
+                            reg.push_back(q);
+                        }
+            }
+    }
+    K.nreg_local = (int)reg.size();
+    std::vector<int> fpatch_of(F.boxes.size(), -1);
+    for (int pi = 0; pi < F.npatches(); ++pi) fpatch_of[F.local[pi]] = pi;
+    auto local_reg_index = [&](int fi, int d, int s, const int c[3]) {
+        const int pi = fpatch_of[fi];
+        const IBox slab = adj_cell(cf[fi], d, s);
+        return regbase[pi][d][s] + (c[0] - slab.lo[0]) + slab.size(0) * ((c[1] - slab.lo[1]) + slab.size(1) * (c[2] - slab.lo[2]));
+    };
+    auto covered = [&](const int c[3]) {
+        for (const IBox& b : cf)
+            if (contains(b, c)) return true;
+        return false;
+    };
+    // ---- per coarse cell records ----
+    struct Tmp { int patch; long long coff; std::vector<RefluxA> A; std::vector<std::pair<int, int>> B; };  // B: (peer or -1, index)
+    std::vector<Tmp> tmp;
+    std::map<std::pair<int, long long>, int> index;
+    std::vector<int> cpatch_of(C.boxes.size(), -1);
+    for (int pi = 0; pi < C.npatches(); ++pi) cpatch_of[C.local[pi]] = pi;
+    auto record = [&](int pi, const int c[3]) -> Tmp& {
+        const PatchDesc& p = C.hpatches[pi];
+        const long long off = p.off + (c[0] - p.lo[0]) + (long long)p.pj * (c[1] - p.lo[1]) + p.pk * (c[2] - p.lo[2]);
+        auto key = std::make_pair(pi, off);
+        auto it = index.find(key);
+        if (it == index.end()) {
+            it = index.insert({key, (int)tmp.size()}).first;
+            Tmp t;
+            t.patch = pi;
+            t.coff = off;
+            tmp.push_back(t);
+        }
+        return tmp[it->second];
+    };
+    // coarse side (incrementCoarse): local coarse boxes only
+    for (int pi = 0; pi < C.npatches(); ++pi) {
+        const IBox cb = C.boxes[C.local[pi]];
+        const PatchDesc& p = C.hpatches[pi];
+        const long long st[3] = {1, p.pj, p.pk};
+        for (int d = 0; d < 3; ++d)
+            for (int s = 0; s < 2; ++s) {
+                const double sc = -(s ? 1.0 : -1.0) * (beta / C.dx[d]);
+                for (const auto& sh : shifts)
+                    for (const IBox& fb : cf) {
+                        const IBox b = adj_cell(fb.shift(sh.data()), d, s) & cb;
+                        if (b.empty()) continue;
+                        int c[3];
+                        for (c[2] = b.lo[2]; c[2] <= b.hi[2]; ++c[2])
+                            for (c[1] = b.lo[1]; c[1] <= b.hi[1]; ++c[1])
+                                for (c[0] = b.lo[0]; c[0] <= b.hi[0]; ++c[0]) {
+                                    if (covered(c)) continue;
+                                    Tmp& t = record(pi, c);
+                                    RefluxA a;
+                                    std::memset(&a, 0, sizeof(a));
+                                    // Lo: the cell sees the interface through its HIGH face = low face of c + e_d
+                                    a.face = t.coff + (s == 0 ? st[d] : 0);
+                                    a.sc = sc;
+                                    a.dir = d;
+                                    t.A.push_back(a);
+                                }
+                    }
+            }
+    }
+    // fine side (the reverse copier): every rank walks (coarse box, shift, fine box, cell) in the same order
+    std::map<int, std::vector<int>> sendTo;   // peer -> local register indices, in walk order
+    std::map<int, int> recvCount;             // peer -> values expected
+    for (size_t ci = 0; ci < C.boxes.size(); ++ci) {
+        const int co = C.owner[ci];
+        const IBox cb = C.boxes[ci];
+        for (const auto& sh : shifts)
+            for (size_t fi = 0; fi < cf.size(); ++fi) {
+                const int fo = F.owner[fi];
+                if (co != me && fo != me) continue;
+                const int g1[3] = {1, 1, 1};
+                const IBox ring = cf[fi].grow(g1).shift(sh.data()) & cb;
+                if (ring.empty()) continue;
+                int c[3];
+                for (c[2] = ring.lo[2]; c[2] <= ring.hi[2]; ++c[2])
+                    for (c[1] = ring.lo[1]; c[1] <= ring.hi[1]; ++c[1])
+                        for (c[0] = ring.lo[0]; c[0] <= ring.hi[0]; ++c[0]) {
+                            int u[3] = {c[0] - sh[0], c[1] - sh[1], c[2] - sh[2]};
+                            int nout = 0, d = -1, s = 0;
+                            for (int a = 0; a < 3; ++a) {
+                                if (u[a] < cf[fi].lo[a]) { ++nout; d = a; s = 0; }
+                                else if (u[a] > cf[fi].hi[a]) { ++nout; d = a; s = 1; }
+                            }
+                            if (nout != 1) continue;   // interior and edge/corner cells of the register hold zeros
+                            if (covered(c)) continue;  // refluxed values under the fine level are never used
+                            if (co == me) {
+                                Tmp& t = record(cpatch_of[ci], c);
+                                if (fo == me) t.B.push_back({-1, local_reg_index((int)fi, d, s, u)});
+                                else t.B.push_back({fo, recvCount[fo]++});
+                            } else {
+                                sendTo[co].push_back(local_reg_index((int)fi, d, s, u));
+                            }
+                        }
+            }
+    }
+    // peers, message layout
+    for (auto& kv : sendTo) K.peers.push_back(kv.first);
+    for (auto& kv : recvCount) K.peers.push_back(kv.first);
+    std::sort(K.peers.begin(), K.peers.end());
+    K.peers.erase(std::unique(K.peers.begin(), K.peers.end()), K.peers.end());
+    std::vector<int> sendidx;
+    std::map<int, long long> recvBase;
+    long long rtot = 0;
+    for (int q : K.peers) {
+        K.soff.push_back((long long)sendidx.size());
+        if (sendTo.count(q)) sendidx.insert(sendidx.end(), sendTo[q].begin(), sendTo[q].end());
+        K.scount.push_back((long long)sendidx.size() - K.soff.back());
+        K.roff.push_back(rtot);
+        recvBase[q] = rtot;
+        rtot += recvCount.count(q) ? recvCount[q] : 0;
+        K.rcount.push_back(rtot - K.roff.back());
+    }
+    K.nsend = (long long)sendidx.size();
+    K.nreg_recv = (int)rtot;
+    K.d_sendidx = to_device(sendidx);
+    if (K.nsend) SOMAR_HIP(hipMalloc(&K.d_sendbuf, K.nsend * sizeof(double)));
+    // flatten
+    std::vector<RefluxCell> cells;
+    std::vector<RefluxA> A;
+    std::vector<int> B;
+    for (const Tmp& t : tmp) {
+        RefluxCell c;
+        std::memset(&c, 0, sizeof(c));
+        c.coff = t.coff;
+        c.patch = t.patch;
+        c.a0 = (int)A.size();
+        c.na = (int)t.A.size();
+        c.b0 = (int)B.size();
+        c.nb = (int)t.B.size();
+        for (const RefluxA& a : t.A) A.push_back(a);
+        for (const auto& b : t.B) B.push_back(b.first < 0 ? b.second : K.nreg_local + (int)recvBase[b.first] + b.second);
+        cells.push_back(c);
+    }
+    K.nreflux = (int)cells.size();
+    K.d_reg = to_device(reg);
+    K.d_reflux = to_device(cells);
+    K.d_A = to_device(A);
+    K.d_B = to_device(B);
+    const size_t nvals = (size_t)std::max(1, K.nreg_local + K.nreg_recv);
+    SOMAR_HIP(hipMalloc(&K.d_regvals, nvals * sizeof(double)));
+    SOMAR_HIP(hipMemset(K.d_regvals, 0, nvals * sizeof(double)));
+}
+
+// ------------------------------------------------------------------------------------
+// MappedAMRPoissonOp AMR* members
+// ------------------------------------------------------------------------------------
+void AMRSolver::interp_cf(int l, double* phiFine, const double* phiCoarse)
+{
+    SOMAR_CHECK(l >= 1 && l < nlevels(), "interp_cf: level has no coarser level");
+    AMRLink& K = *links_[l];
+    if (!K.hasCF) return;
+    Level& F = S[l]->level(0);
+    double dxc[3];
+    for (int d = 0; d < 3; ++d) dxc[d] = F.dx[d] * (double)K.r[d];  // m_dxCrse of MappedQuadCFInterp::define
+    K.gather.run(phiCoarse, K.buf, st_);
+    launch_cf_slopes(st_, K.d_cc, K.ncc, K.d_pts, K.buf, K.d_der, dxc);
+    launch_cf_quad(st_, K.d_fc, K.nfc, K.d_cc, K.d_der, K.buf, phiFine, F.dx, dxc, K.r);
+}
+
+void AMRSolver::amr_operator(int l, double* LofPhi, double* phiFine, double* phi, const double* phiCoarse)
+{
+    if (phiCoarse) interp_cf(l, phi, phiCoarse);
+    S[l]->apply_op_i(0, LofPhi, phi);
+    if (phiFine) reflux(l, phiFine, phi, LofPhi);
+}
+
+void AMRSolver::amr_residual(int l, double* res, double* phiFine, double* phi, const double* phiCoarse,
+                             const double* rhs)
+{
+    amr_operator(l, res, phiFine, phi, phiCoarse);
+    launch_axby(st_, res, res, rhs, -1.0, 1.0, S[l]->level(0).field_elems);  // axby(res, res, rhs, -1, 1)
+}
+
+void AMRSolver::amr_residual_nf(int l, double* res, double* phi, const double* phiCoarse, const double* rhs)
+{
+    if (phiCoarse) interp_cf(l, phi, phiCoarse);
+    S[l]->residual_i(0, res, phi, rhs);
+}
+
+void AMRSolver::reflux(int l, double* phiFine, double* phi, double* LofPhi)
+{
+    SOMAR_CHECK(l >= 0 && l + 1 < nlevels(), "reflux: level has no finer level");
+    AMRLink& K = *links_[l + 1];
+    interp_cf(l + 1, phiFine, phi);
+    if (!K.fluxDefined) return;
+    Level& F = S[l + 1]->level(0);
+    Level& C = S[l]->level(0);
+    launch_fine_register(st_, K.d_reg, K.nreg_local, F.dev.patches, phiFine, F.dev.jg, F.dx, K.sc_fine, K.r, K.d_regvals);
+    if (!K.peers.empty()) {
+        launch_gather(st_, K.d_sendidx, K.nsend, K.d_regvals, K.d_sendbuf);
+        comm_->neighbor_exchange(K.d_sendbuf, K.d_regvals + K.nreg_local, K.peers, K.soff, K.scount, K.roff, K.rcount, st_);
+    }
+    launch_reflux(st_, K.d_reflux, K.nreflux, K.d_A, K.d_B, C.dev.patches, phi, C.dev.jg, C.dev.jinv, C.dx, K.d_regvals,
+                  LofPhi);
+}
+
+void AMRSolver::amr_restrict(int l, double* residual, double* correction, const double* coarseCorrection,
+                             double* scratch)
+{
+    AMRLink& K = *links_[l];
+    amr_residual_nf(l, scratch, correction, coarseCorrection, residual);
+    launch_restrict(st_, K.cfl->dev, S[l]->level(0).dev, K.resC, scratch, K.r);
+}
+
+void AMRSolver::assign_coarse_residual(int l, double* coarseResidual)
+{
+    AMRLink& K = *links_[l];
+    K.scatter.run(K.resC, coarseResidual, st_);
+}
+
+void AMRSolver::amr_prolong(int l, double* correction, const double* coarseCorrection)
+{
+    AMRLink& K = *links_[l];
+    K.gather.run(coarseCorrection, K.buf, st_);
+    S[l]->prolong_from(K.cfl->dev, K.buf, K.r, correction);
+}
+
+void AMRSolver::amr_update_residual(int l, double* residual, double* correction, const double* coarseCorrection)
+{
+    double* old = S[l]->field(0, 5);
+    launch_copy(st_, old, residual, S[l]->level(0).field_elems);
+    amr_residual_nf(l, residual, correction, coarseCorrection, old);
+}
+
+void AMRSolver::zero_covered(int l, double* f)
+{
+    AMRLink& K = *links_[l + 1];
+    launch_fill_items(st_, S[l]->level(0).dev.patches, K.d_cover, K.ncover, f, 0.0);
+}
+
+// ------------------------------------------------------------------------------------
+// MappedAMRMultiGrid
+// ------------------------------------------------------------------------------------
+void AMRSolver::compute_residual_level(double* const* resid, double* const* phi, double* const* rhs, int l_max,
+                                       int l_base, int ilev, bool homogeneous)
+{
+    (void)homogeneous;  // physical BCs are homogeneous Neumann / periodic: nothing to switch
+    if (l_max != l_base) {
+        if (ilev == l_max) amr_residual_nf(l_max, resid[l_max], phi[l_max], phi[l_max - 1], rhs[l_max]);
+        else if (ilev == l_base && l_base == 0) amr_residual(0, resid[0], phi[1], phi[0], nullptr, rhs[0]);
+        else amr_residual(ilev, resid[ilev], phi[ilev + 1], phi[ilev], phi[ilev - 1], rhs[ilev]);
+    } else {
+        if (l_base == 0) S[0]->residual(0, resid[0], phi[0], rhs[0]);
+        else amr_residual_nf(l_max, resid[l_max], phi[l_max], phi[l_max - 1], rhs[l_max]);
+    }
+}
+
+double AMRSolver::compute_residual(double* const* resid, double* const* phi, double* const* rhs, int l_max, int l_base,
+                                   bool homogeneous)
+{
+    double rnorm = 0.0;
+    for (int ilev = l_base; ilev <= l_max; ++ilev) {
+        compute_residual_level(resid, phi, rhs, l_max, l_base, ilev, homogeneous);
+        if (ilev != l_max) zero_covered(ilev, resid[ilev]);
+        rnorm = std::max(S[ilev]->norm(0, resid[ilev], 0), rnorm);
+    }
+    return rnorm;
+}
+
+void AMRSolver::vcycle(double* const* uberCorr, double* const* uberRes, int ilev, int l_max, int l_base)
+{
+    if (ilev == l_max)
+        for (int l = l_base; l <= l_max; ++l) {
+            const long long n = S[l]->level(0).field_elems;
+            launch_copy(st_, res_[l], uberRes[l], n);
+            launch_set(st_, corr_[l], n, 0.0);
+        }
+    const long long n = S[ilev]->level(0).field_elems;
+    if (l_max == l_base) {
+        S[l_base]->vcycle(uberCorr[ilev], uberRes[ilev]);
+    } else if (ilev == l_base) {
+        S[l_base]->vcycle(corr_[ilev], res_[ilev]);
+        launch_incr(st_, uberCorr[ilev], corr_[ilev], 1.0, n);
+    } else {
+        S[ilev]->relax(0, corr_[ilev], res_[ilev], prm.num_smooth_down);
+        launch_incr(st_, uberCorr[ilev], corr_[ilev], 1.0, n);
+        launch_set(st_, corr_[ilev - 1], S[ilev - 1]->level(0).field_elems, 0.0);
+        compute_residual_level(res_.data(), uberCorr, uberRes, l_max, l_base, ilev - 1, true);
+        // the scratch of AMRRestrictS IS uberCorrection[ilev] (MappedAMRMultiGrid.H:1548-1552)
+        amr_restrict(ilev, res_[ilev], corr_[ilev], corr_[ilev - 1], uberCorr[ilev]);
+        assign_coarse_residual(ilev, res_[ilev - 1]);
+        for (int img = 0; img < prm.numMG; ++img) vcycle(uberCorr, uberRes, ilev - 1, l_max, l_base);
+        amr_prolong(ilev, corr_[ilev], corr_[ilev - 1]);
+        amr_update_residual(ilev, res_[ilev], corr_[ilev], corr_[ilev - 1]);
+        double* dCorr = uberCorr[ilev];
+        launch_set(st_, dCorr, n, 0.0);
+        S[ilev]->relax(0, dCorr, res_[ilev], prm.num_smooth_up);
+        launch_incr(st_, corr_[ilev], dCorr, 1.0, n);
+        launch_copy(st_, uberCorr[ilev], corr_[ilev], n);
+    }
+}
+
+void AMRSolver::solve(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous, SolveStats& s)
+{
+    SOMAR_CHECK(finalized_, "solve before finalize");
+    SOMAR_CHECK(0 <= l_base && l_base <= l_max && l_max < nlevels(), "bad level range");
+    const int n = nlevels();
+    std::vector<double*> phi(n), rhs(n), uRes(n), uCorr(n), best(n);
+    for (int l = 0; l < n; ++l) {
+        phi[l] = S[l]->phi();
+        rhs[l] = S[l]->rhs();
+        uRes[l] = S[l]->work(0);
+        uCorr[l] = S[l]->work(1);
+        best[l] = S[l]->work(2);
+    }
+    const int lowlim = l_base > 0 ? l_base - 1 : l_base;
+    for (int l = 0; l < n; ++l) {
+        S[l]->prm.num_smooth_down = prm.num_smooth_down;
+        S[l]->prm.num_smooth_up = prm.num_smooth_up;
+        S[l]->prm.num_smooth_bottom = prm.num_smooth_bottom;
+        S[l]->prm.numMG = prm.numMG;
+    }
+    for (int l = lowlim; l <= l_max; ++l) {
+        const long long ne = S[l]->level(0).field_elems;
+        launch_set(st_, uCorr[l], ne, 0.0);
+        if (l >= l_base) launch_set(st_, uRes[l], ne, 0.0);
+    }
+    if (zeroPhi)
+        for (int l = l_base; l <= l_max; ++l) launch_set(st_, phi[l], S[l]->level(0).field_elems, 0.0);
+    for (int l = lowlim; l <= l_max; ++l) launch_copy(st_, best[l], phi[l], S[l]->level(0).field_elems);
+    double initial_rnorm = compute_residual(uRes.data(), phi.data(), rhs.data(), l_max, l_base, forceHomogeneous);
+    double rnorm = initial_rnorm, norm_last = 2 * initial_rnorm, best_rnorm = rnorm;
+    bool useBestPhi = false, somethingConverged = false;
+    S[l_base]->bottom_metric = initial_rnorm;  // setConvergenceMetrics(initial_rnorm, cushion * eps)
+    S[l_base]->bottom_eps_eff = 1.0 * prm.eps;
+    int iter = 0;
+    s = SolveStats();
+    s.history.push_back(rnorm);
+    bool goNorm = rnorm > prm.normThresh;
+    bool goRedu = rnorm > prm.eps * initial_rnorm;
+    bool goIter = iter < prm.imax;
+    bool goHang = iter < prm.imin || rnorm < (1 - prm.hang) * norm_last;
+    while (goIter && goRedu && goHang && goNorm) {
+        norm_last = rnorm;
+        vcycle(uCorr.data(), uRes.data(), l_max, l_max, l_base);
+        for (int l = l_base; l <= l_max; ++l) {  // postVCycleOps
+            const long long ne = S[l]->level(0).field_elems;
+            launch_incr(st_, phi[l], uCorr[l], 1.0, ne);
+            launch_set(st_, uCorr[l], ne, 0.0);
+        }
+        rnorm = compute_residual(uRes.data(), phi.data(), rhs.data(), l_max, l_base, forceHomogeneous);
+        ++iter;
+        s.history.push_back(rnorm);
+        if (rnorm <= best_rnorm) {
+            best_rnorm = rnorm;
+            for (int l = l_base; l <= l_max; ++l) launch_copy(st_, best[l], phi[l], S[l]->level(0).field_elems);
+            useBestPhi = false;
+            somethingConverged = true;
+        } else {
+            useBestPhi = true;
+        }
+        goNorm = rnorm > prm.normThresh;
+        goRedu = rnorm > prm.eps * initial_rnorm;
+        goIter = iter < prm.imax;
+        goHang = iter < prm.imin || rnorm < (1 - prm.hang) * norm_last;
+    }
+    if (useBestPhi) {
+        rnorm = best_rnorm;
+        for (int l = l_base; l <= l_max; ++l) launch_copy(st_, phi[l], best[l], S[l]->level(0).field_elems);
+    }
+    s.status = 0;
+    if (rnorm > 10. * initial_rnorm && rnorm > 10. * prm.eps) s.status = 1;
+    else if (!somethingConverged && rnorm >= initial_rnorm && rnorm >= prm.eps) s.status = 2;
+    s.exitStatus = int(!goRedu) + int(!goIter) * 2 + int(!goHang) * 4 + int(!goNorm) * 8;
+    s.iters = iter;
+    s.initial_rnorm = initial_rnorm;
+    s.final_rnorm = rnorm;
+    s.bottom_iters_last = S[l_base]->bottom_iters;
+    s.bottom_exit_last = S[l_base]->bottom_exit;
+    sync();
+}
+
+}  // namespace somar

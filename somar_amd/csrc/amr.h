@@ -1,0 +1,200 @@
+// somar_amd/csrc/amr.h -- several AMR levels: the MI355X counterpart of
+//   MappedAMRMultiGrid<T> (multi-level part)  calculus/AMRElliptic/MappedAMRMultiGrid.H:736-927, 933-1215, 1320-1598
+//   MappedAMRPoissonOp AMR* members + reflux  calculus/AMRElliptic/MappedAMRPoissonOp.cpp:1311-1707
+//   MappedQuadCFInterp / MappedQuadCFStencil  MappedChombo/MappedQuadCFInterp.cpp, MappedCFStencil.cpp:831-1232
+//   MappedLevelFluxRegister                   MappedChombo/MappedLevelFluxRegister.cpp
+//
+// Design (not a port): every level keeps its fields resident in HBM (one PressureSolver per level, all on
+// one HIP stream).  Everything that crosses levels is precomputed on the host into flat tables --
+//   * a Copier (box-to-box copy list, packed messages between ranks) coarse level -> "coarsened fine"
+//     buffer layout and back,
+//   * per coarse-fine ghost cell records for the quadratic interpolation (stencil weights included),
+//   * per coarse cell records for refluxing (which coarse faces to subtract, which fine register sums to add)
+// -- so that at solve time an inter-level operation is one or two kernel launches over a table, no host
+// geometry, no atomics (each output cell is owned by exactly one thread, contributions are added in the
+// reference's order => bit-identical results).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "solver.h"
+
+namespace somar {
+
+// ---- device records (amr_kernels.hip) ---------------------------------------------------------------
+struct QPoint {       // one point of a derivative stencil
+    long long off;    // element offset relative to the coarse cell, in the buffer field
+    double w;
+};
+struct QCoarse {      // one coarse cell under the CF ghost layer of (fine box, dir, side)
+    long long boff;   // offset of the cell in the buffer field
+    int flags;        // bit0: standard (centred) stencils
+    int dir;          // normal direction
+    int s1, s2;       // buffer element strides of the two tangential directions (ascending)
+    int p0;           // first QPoint
+    int np[5];        // points of D1_t1, D2_t1, D1_t2, D2_t2, Dmixed
+};
+struct QFine {        // one fine CF ghost cell
+    long long foff;   // its offset in the fine field
+    int stride;       // signed element stride pointing OUT of the box: foff - stride is the first valid cell
+    int cc;           // QCoarse index
+    int ivf1, ivf2, ivc1, ivc2;  // global fine / coarse indices in the two tangential directions
+    int dirflags;     // dir | packed << 2
+    int pad_;
+};
+struct FRegCell {     // one cell of the fine flux register: sum over the fine faces of one coarse face
+    long long cell0;  // offset (fine field) of the cell whose LOW face is the first fine face
+    int patch;        // fine patch
+    int dir, side;
+    int pad_;
+};
+struct RefluxA {      // coarse-side contribution: coar += sc * F_c(face)
+    long long face;   // offset (coarse field) of the cell whose LOW face it is
+    double sc;
+    int dir;
+    int pad_;
+};
+struct RefluxCell {   // one coarse cell next to the fine level
+    long long coff;
+    int patch;
+    int a0, na;       // RefluxA range
+    int b0, nb;       // register-value index range (into the rank's register array)
+    int pad_;
+};
+struct FillItem {     // a region of one patch
+    int patch;
+    int lo[3];        // local start
+    int n[3];
+    int pad_;
+};
+
+void launch_copy_items2(hipStream_t st, const PatchDesc* spatches, const PatchDesc* dpatches, const CopyItem* items,
+                        int nitems, const double* src, double* dst);
+void launch_fill_items(hipStream_t st, const PatchDesc* patches, const FillItem* items, int nitems, double* f, double v);
+void launch_cf_slopes(hipStream_t st, const QCoarse* cc, int ncc, const QPoint* pts, const double* buf, double* der,
+                      const double dxc[3]);
+void launch_cf_quad(hipStream_t st, const QFine* fc, int nfc, const QCoarse* cc, const double* der, const double* buf,
+                    double* fine, const double dxf[3], const double dxc[3], const int r[3]);
+void launch_fine_register(hipStream_t st, const FRegCell* cells, int n, const PatchDesc* fpatches, const double* phi,
+                          double* const jg[3], const double dxf[3], const double sc[3][2], const int r[3], double* out);
+void launch_gather(hipStream_t st, const int* idx, long long n, const double* src, double* dst);
+void launch_reflux(hipStream_t st, const RefluxCell* cells, int n, const RefluxA* A, const int* B,
+                   const PatchDesc* cpatches, const double* phi, double* const jg[3], const double* jinv,
+                   const double dxc[3], const double* freg, double* LofPhi);
+
+// ---- host side -------------------------------------------------------------------------------------
+// Copier between two layouts of one index space: valid cells of `src` boxes (and their periodic images) into
+// the cells of grow(dst box, ghost).
+class Copier {
+public:
+    ~Copier();
+    void define(const IBox& domain, const bool periodic[3], const Level& src, const Level& dst, const int ghost[3],
+                Comm* comm);
+    void run(const double* s, double* d, hipStream_t st) const;
+    ExchangePlan plan;
+
+private:
+    const Level* src_ = nullptr;
+    const Level* dst_ = nullptr;
+    Comm* comm_ = nullptr;
+    CopyItem *d_local = nullptr, *d_send = nullptr, *d_recv = nullptr;
+    long long *d_soff = nullptr, *d_roff = nullptr;
+    double *d_sbuf = nullptr, *d_rbuf = nullptr;
+};
+
+ExchangePlan build_copy_plan(const IBox& domain, const bool periodic[3], const std::vector<IBox>& srcBoxes,
+                             const std::vector<int>& srcOwner, const std::vector<IBox>& dstBoxes,
+                             const std::vector<int>& dstOwner, const int ghost[3], int myrank);
+
+// What ties level l (fine) to level l-1 (coarse).
+struct AMRLink {
+    int r[3] = {1, 1, 1};
+    std::unique_ptr<Level> cfl;  // coarsened fine layout, owned by the fine boxes' ranks
+    double* buf = nullptr;       // coarse values under and around the fine boxes (2 ghosts)
+    double* resC = nullptr;      // restricted fine residual
+    Copier gather;               // coarse level -> buf (valid + 2 ghosts, periodic)
+    Copier scatter;              // resC valid -> coarse level valid
+    // quadratic CF interpolation
+    bool hasCF = false;          // false: the fine level covers the whole domain
+    int ncc = 0, nfc = 0;
+    QCoarse* d_cc = nullptr;
+    QPoint* d_pts = nullptr;
+    QFine* d_fc = nullptr;
+    double* d_der = nullptr;
+    // zeroCovered on the coarse level
+    int ncover = 0;
+    FillItem* d_cover = nullptr;
+    // flux register
+    bool fluxDefined = false;
+    int nreg_local = 0, nreg_recv = 0, nreflux = 0;
+    FRegCell* d_reg = nullptr;
+    double* d_regvals = nullptr;       // [local | received]
+    RefluxCell* d_reflux = nullptr;
+    RefluxA* d_A = nullptr;
+    int* d_B = nullptr;
+    // register values that travel between ranks
+    std::vector<int> peers;
+    std::vector<long long> soff, scount, roff, rcount;
+    int* d_sendidx = nullptr;
+    long long nsend = 0;
+    double* d_sendbuf = nullptr;
+    double sc_fine[3][2];
+    ~AMRLink();
+};
+
+class AMRSolver {
+public:
+    explicit AMRSolver(Comm* comm = nullptr);
+    ~AMRSolver();
+
+    // levels[l]: boxes + owners in level-l index space; domain/dx are level 0's, refined by ratios
+    void define(const IBox& domain0, const bool periodic[3], const double dx0[3], const int bc_type[3][2],
+                const std::vector<std::array<int, 3>>& ratios, const std::vector<std::vector<IBox>>& boxes,
+                const std::vector<std::vector<int>>& owners, double alpha, double beta, const SolverParams& prm);
+    void finalize();  // after every level's metric is set
+    int nlevels() const { return (int)S.size(); }
+    PressureSolver& level(int l) { return *S[l]; }
+
+    // MappedAMRMultiGrid::solve on the resident phi/rhs of levels l_base..l_max (phi of l_base-1 supplies the
+    // CF values when l_base > 0)
+    void solve(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous, SolveStats& st);
+
+    // pieces (parity tests)
+    void interp_cf(int l, double* phiFine, const double* phiCoarse);  // interpCFGhosts(phi, &phiCoarse, false)
+    void amr_operator(int l, double* LofPhi, double* phiFine, double* phi, const double* phiCoarse);
+    void amr_residual(int l, double* res, double* phiFine, double* phi, const double* phiCoarse, const double* rhs);
+    void amr_residual_nf(int l, double* res, double* phi, const double* phiCoarse, const double* rhs);
+    void reflux(int l, double* phiFine, double* phi, double* LofPhi);
+    void amr_restrict(int l, double* residual, double* correction, const double* coarseCorrection, double* scratch);
+    void assign_coarse_residual(int l, double* coarseResidual);  // assignCopier of link l's resC
+    void amr_prolong(int l, double* correction, const double* coarseCorrection);
+    void amr_update_residual(int l, double* residual, double* correction, const double* coarseCorrection);
+    void zero_covered(int l, double* f);
+    void compute_residual_level(double* const* resid, double* const* phi, double* const* rhs, int l_max, int l_base,
+                                int ilev, bool homogeneous);
+    double compute_residual(double* const* resid, double* const* phi, double* const* rhs, int l_max, int l_base,
+                            bool homogeneous);
+    void vcycle(double* const* uberCorr, double* const* uberRes, int ilev, int l_max, int l_base);
+    double* corr(int l) { return corr_[l]; }
+    double* res(int l) { return res_[l]; }
+    AMRLink& link(int l) { return *links_[l]; }
+    hipStream_t stream() const { return st_; }
+    void sync() { SOMAR_HIP(hipStreamSynchronize(st_)); }
+
+    SolverParams prm;
+
+private:
+    void build_link(int l);
+    void build_quad_tables(int l);
+    void build_reflux_tables(int l);
+    Comm* comm_;
+    Comm self_;
+    hipStream_t st_ = nullptr;
+    std::vector<std::unique_ptr<PressureSolver>> S;
+    std::vector<std::unique_ptr<AMRLink>> links_;  // links_[l] ties l to l-1 (links_[0] unused)
+    std::vector<std::array<int, 3>> ratios_;
+    std::vector<double*> corr_, res_;
+    bool finalized_ = false;
+};
+
+}  // namespace somar

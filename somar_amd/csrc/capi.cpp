@@ -3,6 +3,7 @@
 #include <string>
 
 #include "../../include/somar_amd.h"
+#include "amr.h"
 #include "solver.h"
 
 namespace somar {
@@ -15,6 +16,12 @@ using namespace somar;
 struct somar_solver {
     PressureSolver* ps = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool owned = true;  // false: a level of a somar_amr (somar_amr_level)
+};
+
+struct somar_amr {
+    AMRSolver* amr = nullptr;
+    std::vector<somar_solver*> levels;
 };
 
 static thread_local std::string g_err;
@@ -133,6 +140,7 @@ int somar_solver_destroy(somar_solver_t* s)
 {
     API_BEGIN
     if (s) {
+        SOMAR_CHECK(s->owned, "this handle belongs to a somar_amr: destroy that instead");
         if (s->ev0) hipEventDestroy(s->ev0);
         if (s->ev1) hipEventDestroy(s->ev1);
         delete s->ps;
@@ -558,6 +566,154 @@ int somar_plan_exchange(const int* domain_lo, const int* domain_hi, const int* p
     dump(plan.local, nullptr, n_local, local_items);
     dump(plan.send_items, &sp, n_send, send_items);
     dump(plan.recv_items, &rp, n_recv, recv_items);
+    API_END
+}
+
+// ---- several AMR levels ---------------------------------------------------------------------------------
+int somar_amr_create(somar_amr_t** out, int nlevels, const int* domain_lo, const int* domain_hi, const int* periodic,
+                     const double* dx0, const int* bc_type, const int* ref_ratios, const int* nboxes,
+                     const int* boxes, const int* owner, double alpha, double beta, const somar_params_t* prm,
+                     void* comm)
+{
+    API_BEGIN
+    SOMAR_CHECK(out && nlevels >= 1 && domain_lo && domain_hi && periodic && dx0 && bc_type && nboxes && boxes &&
+                    (nlevels == 1 || ref_ratios),
+                "null/empty argument");
+    IBox dom(domain_lo, domain_hi);
+    bool per[3] = {periodic[0] != 0, periodic[1] != 0, periodic[2] != 0};
+    int bct[3][2] = {{bc_type[0], bc_type[1]}, {bc_type[2], bc_type[3]}, {bc_type[4], bc_type[5]}};
+    std::vector<std::array<int, 3>> ratios;
+    for (int l = 0; l + 1 < nlevels; ++l) ratios.push_back({ref_ratios[3 * l], ref_ratios[3 * l + 1], ref_ratios[3 * l + 2]});
+    std::vector<std::vector<IBox>> bx(nlevels);
+    std::vector<std::vector<int>> own(nlevels);
+    int cursor = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        SOMAR_CHECK(nboxes[l] > 0, "level without boxes");
+        for (int b = 0; b < nboxes[l]; ++b, ++cursor) {
+            IBox q(boxes + 6 * cursor, boxes + 6 * cursor + 3);
+            SOMAR_CHECK(!q.empty(), "empty box");
+            bx[l].push_back(q);
+            own[l].push_back(owner ? owner[cursor] : 0);
+        }
+        for (size_t a = 0; a < bx[l].size(); ++a)
+            for (size_t b = a + 1; b < bx[l].size(); ++b) SOMAR_CHECK((bx[l][a] & bx[l][b]).empty(), "boxes overlap");
+    }
+    for (const IBox& b : bx[0])
+        for (int d = 0; d < 3; ++d) SOMAR_CHECK(b.lo[d] >= dom.lo[d] && b.hi[d] <= dom.hi[d], "box outside the domain");
+    somar_amr* a = new somar_amr;
+    try {
+        a->amr = new AMRSolver(static_cast<Comm*>(comm));
+        a->amr->define(dom, per, dx0, bct, ratios, bx, own, alpha, beta, to_params(prm));
+        for (int l = 0; l < nlevels; ++l) {
+            somar_solver* s = new somar_solver;
+            s->ps = &a->amr->level(l);
+            s->owned = false;
+            SOMAR_HIP(hipEventCreate(&s->ev0));
+            SOMAR_HIP(hipEventCreate(&s->ev1));
+            a->levels.push_back(s);
+        }
+    } catch (...) {
+        for (somar_solver* s : a->levels) delete s;
+        delete a->amr;
+        delete a;
+        throw;
+    }
+    *out = a;
+    API_END
+}
+
+int somar_amr_destroy(somar_amr_t* a)
+{
+    API_BEGIN
+    if (a) {
+        for (somar_solver* s : a->levels) {
+            if (s->ev0) hipEventDestroy(s->ev0);
+            if (s->ev1) hipEventDestroy(s->ev1);
+            delete s;
+        }
+        delete a->amr;
+        delete a;
+    }
+    API_END
+}
+
+int somar_amr_level(somar_amr_t* a, int level, somar_solver_t** out)
+{
+    API_BEGIN
+    SOMAR_CHECK(a && out && level >= 0 && level < (int)a->levels.size(), "bad AMR level");
+    *out = a->levels[level];
+    API_END
+}
+
+int somar_amr_finalize(somar_amr_t* a)
+{
+    API_BEGIN
+    a->amr->finalize();
+    API_END
+}
+
+int somar_amr_solve(somar_amr_t* a, int l_max, int l_base, int zero_phi, int force_homogeneous, somar_stats_t* stats)
+{
+    API_BEGIN
+    SolveStats st;
+    a->amr->solve(l_max, l_base, zero_phi != 0, force_homogeneous != 0, st);
+    fill_stats(st, stats);
+    API_END
+}
+
+static double* amr_field(somar_amr* a, int level, int field)
+{
+    SOMAR_CHECK(level >= 0 && level < (int)a->levels.size(), "bad AMR level");
+    SOMAR_CHECK((field >> 8) == 0, "AMR operations act on depth-0 fields");
+    return field_ptr(a->levels[level], field);
+}
+
+int somar_amr_interp_cf(somar_amr_t* a, int level, int fine_field, int coarse_field)
+{
+    API_BEGIN
+    SOMAR_CHECK(level >= 1, "level 0 has no coarser level");
+    a->amr->interp_cf(level, amr_field(a, level, fine_field), amr_field(a, level - 1, coarse_field));
+    a->amr->sync();
+    API_END
+}
+
+int somar_amr_residual_level(somar_amr_t* a, int l_max, int l_base, int ilev, int res_field, int phi_field,
+                             int rhs_field)
+{
+    API_BEGIN
+    const int n = a->amr->nlevels();
+    SOMAR_CHECK(0 <= l_base && l_base <= ilev && ilev <= l_max && l_max < n, "bad level range");
+    std::vector<double*> res(n, nullptr), phi(n, nullptr), rhs(n, nullptr);
+    for (int l = (l_base > 0 ? l_base - 1 : 0); l <= l_max; ++l) {
+        phi[l] = amr_field(a, l, phi_field);
+        if (l >= l_base) { res[l] = amr_field(a, l, res_field); rhs[l] = amr_field(a, l, rhs_field); }
+    }
+    a->amr->compute_residual_level(res.data(), phi.data(), rhs.data(), l_max, l_base, ilev, true);
+    a->amr->sync();
+    API_END
+}
+
+int somar_amr_zero_covered(somar_amr_t* a, int level, int field)
+{
+    API_BEGIN
+    SOMAR_CHECK(level >= 0 && level + 1 < a->amr->nlevels(), "level has no finer level");
+    a->amr->zero_covered(level, amr_field(a, level, field));
+    a->amr->sync();
+    API_END
+}
+
+int somar_amr_vcycle(somar_amr_t* a, int l_max, int l_base)
+{
+    API_BEGIN
+    const int n = a->amr->nlevels();
+    SOMAR_CHECK(0 <= l_base && l_base <= l_max && l_max < n, "bad level range");
+    std::vector<double*> corr(n, nullptr), res(n, nullptr);
+    for (int l = (l_base > 0 ? l_base - 1 : 0); l <= l_max; ++l) {
+        corr[l] = amr_field(a, l, SOMAR_F_CORR);
+        res[l] = amr_field(a, l, SOMAR_F_RES);
+    }
+    a->amr->vcycle(corr.data(), res.data(), l_max, l_max, l_base);
+    a->amr->sync();
     API_END
 }
 

@@ -71,6 +71,13 @@ struct CopyItem {
     int pad_;
 };
 
+// One coarse-fine ghost cell of a level that sits on a coarser one (homogeneous CF interpolation).
+struct CFCell {
+    long long off;  // the ghost cell
+    int stride;     // signed element stride pointing OUT of the box: off - stride is the first valid cell
+    int dir;        // direction | 4 if the box is one cell wide in that direction
+};
+
 // Per-level constants handed to the stencil kernels by value.
 struct StencilParams {
     int dom_lo[3], dom_hi[3];  // domain box at this depth

@@ -33,7 +33,7 @@ void launch_restrict(hipStream_t st, const LevelDev& C, const LevelDev& F, doubl
                      const int r[3]);
 void launch_prolong(hipStream_t st, const LevelDev& F, const LevelDev& C, double* fine, const double* crse,
                     const int r[3], bool zeroAvg, double dxProduct, double* partials, double* sums,
-                    long long fieldElems);
+                    long long fieldElems, bool ordered = false);
 void launch_sub_mean(hipStream_t st, double* f, long long n, const double* sums);
 void launch_avg_harmonic(hipStream_t st, const LevelDev& C, const LevelDev& F, double* crse, const double* fine,
                          const int r[3]);
@@ -48,11 +48,14 @@ void launch_incr(hipStream_t st, double* y, const double* x, double a, long long
 void launch_scale(hipStream_t st, double* y, double a, long long n);
 void launch_axby(hipStream_t st, double* z, const double* x, const double* y, double a, double b, long long n);
 // mode 0: sum a*b, 1: max|a|, 2: sum|a|, 3: signed max a  -> out[0] (device)
+// ordered: reference-ordered serial sum (modes 0 and 2; meant for small levels, see k_reduce_ordered)
 void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const double* b, int mode, double* partials,
-                   double* out);
+                   double* out, bool ordered = false);
 void launch_div_mac(hipStream_t st, const LevelDev& L, double* out, const double* u0, const double* u1,
                     const double* u2, double dt);
 void launch_mac_correct(hipStream_t st, const LevelDev& L, double* const vel[3], const double* phi, double dtScale);
+void launch_cf_homog(hipStream_t st, const CFCell* cells, int n, double* phi, const double c1[3], const double c2[3],
+                     const double fac[3]);
 void launch_fill_hash(hipStream_t st, const LevelDev& L, double* f, unsigned long long seed);
 
 }  // namespace somar

@@ -515,6 +515,55 @@ __global__ __launch_bounds__(512) void k_reduce_valid(const Tile* __restrict__ t
     if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x] = acc;
 }
 
+// Reference-ordered sums for SMALL levels (one wavefront): box after box, cells in Fortran order, one running
+// sum -- the order of FArrayBox::dotProduct / sumPow (Chombo) and of CONSTINTERPWITHAVGPS, so the scalars that
+// steer BiCGStab and the zero-average prolongation come out bit-identical to the reference's serial run.
+// (BiCGStab amplifies a last-bit difference of its dot products by ~1e8 within 20-30 iterations; the bottom
+// level is a few hundred cells, where 64 dependent adds per 64 cells cost microseconds.)
+// MODE 0: out[0] = sum_boxes( seqsum(a*b) )   MODE 2: out[0] = sum_boxes( seqsum(|a|) )
+// MODE 6: running s += (dxProduct / b) * a, v += dxProduct / b over all boxes: out[0] = s, out[1] = v   (b = Jinv)
+template <int MODE>
+__global__ __launch_bounds__(64) void k_reduce_ordered(const PatchDesc* __restrict__ patches, int npatches,
+                                                       const double* __restrict__ a, const double* __restrict__ b,
+                                                       double dxProduct, double* __restrict__ out)
+{
+    const int lane = threadIdx.x;
+    double tot = 0.0, run_s = 0.0, run_v = 0.0;
+    for (int pi = 0; pi < npatches; ++pi) {
+        const PatchDesc p = patches[pi];
+        const long long n = (long long)p.n[0] * p.n[1] * p.n[2];
+        double sbox = 0.0;
+        for (long long base = 0; base < n; base += 64) {
+            const long long idx = base + lane;
+            double x = 0.0, y = 0.0;
+            if (idx < n) {
+                const int i = (int)(idx % p.n[0]);
+                const long long q = idx / p.n[0];
+                const int j = (int)(q % p.n[1]), k = (int)(q / p.n[1]);
+                const long long c = cidx(p, i, j, k);
+                if (MODE == 0) x = a[c] * b[c];
+                else if (MODE == 2) x = fabs(a[c]);
+                else { y = dxProduct / b[c]; x = y * a[c]; }
+            }
+            const int cnt = (int)((n - base) < 64 ? (n - base) : 64);
+            for (int l = 0; l < cnt; ++l) {
+                const double xl = __shfl(x, l);
+                if (MODE == 6) {
+                    run_s = run_s + xl;
+                    run_v = run_v + __shfl(y, l);
+                } else {
+                    sbox = (base == 0 && l == 0) ? xl : sbox + xl;
+                }
+            }
+        }
+        if (MODE != 6) tot = tot + sbox;
+    }
+    if (lane == 0) {
+        if (MODE == 6) { out[0] = run_s; out[1] = run_v; }
+        else out[0] = tot;
+    }
+}
+
 // splitmix64(cell index, seed) -> uniform(-1,1): same integer recipe as
 // oracle/somar_oracle.py::hash_uniform; used by bench/tests for device-side synthetic fills.
 __global__ __launch_bounds__(512) void k_fill_hash(const Tile* __restrict__ tiles,
@@ -594,9 +643,16 @@ void launch_restrict(hipStream_t st, const LevelDev& C, const LevelDev& F, doubl
 }
 void launch_prolong(hipStream_t st, const LevelDev& F, const LevelDev& C, double* fine, const double* crse,
                     const int r[3], bool zeroAvg, double dxProduct, double* partials, double* sums,
-                    long long fieldElems)
+                    long long fieldElems, bool ordered)
 {
     if (F.ntiles == 0) return;
+    if (zeroAvg && ordered) {
+        hipLaunchKernelGGL(k_prolong<false>, dim3(F.ntiles), tile_block(F), 0, st, F.tiles, F.patches, C.patches,
+                           fine, crse, F.jinv, r[0], r[1], r[2], dxProduct, partials);
+        hipLaunchKernelGGL(k_reduce_ordered<6>, dim3(1), dim3(64), 0, st, F.patches, F.npatches, fine, F.jinv, dxProduct,
+                           sums);
+        return;
+    }
     if (!zeroAvg) {
         hipLaunchKernelGGL(k_prolong<false>, dim3(F.ntiles), tile_block(F), 0, st, F.tiles, F.patches, C.patches,
                            fine, crse, F.jinv, r[0], r[1], r[2], dxProduct, partials);
@@ -660,8 +716,15 @@ void launch_axby(hipStream_t st, double* z, const double* x, const double* y, do
     hipLaunchKernelGGL(k_axby, dim3(flat_grid(n)), dim3(256), 0, st, z, x, y, a, b, n);
 }
 void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const double* b, int mode, double* partials,
-                   double* out)
+                   double* out, bool ordered)
 {
+    if (ordered && (mode == 0 || mode == 2) && L.ntiles > 0) {
+        if (mode == 0)
+            hipLaunchKernelGGL(k_reduce_ordered<0>, dim3(1), dim3(64), 0, st, L.patches, L.npatches, a, b, 0.0, out);
+        else
+            hipLaunchKernelGGL(k_reduce_ordered<2>, dim3(1), dim3(64), 0, st, L.patches, L.npatches, a, b, 0.0, out);
+        return;
+    }
     if (L.ntiles == 0) {
         hipLaunchKernelGGL(k_set, dim3(1), dim3(64), 0, st, out, 1, 0.0);
         return;

@@ -92,8 +92,97 @@ ExchangePlan build_exchange_plan(const IBox& domain, const bool periodic[3], con
     return plan;
 }
 
+// a minus b as a list of disjoint boxes (at most 6)
+void box_subtract(const IBox& a, const IBox& b, std::vector<IBox>& out)
+{
+    const IBox c = a & b;
+    if (c.empty()) { out.push_back(a); return; }
+    IBox rest = a;
+    for (int d = 2; d >= 0; --d) {
+        if (rest.lo[d] < c.lo[d]) { IBox p = rest; p.hi[d] = c.lo[d] - 1; out.push_back(p); rest.lo[d] = c.lo[d]; }
+        if (rest.hi[d] > c.hi[d]) { IBox p = rest; p.lo[d] = c.hi[d] + 1; out.push_back(p); rest.hi[d] = c.hi[d]; }
+    }
+}
+
+std::vector<std::array<int, 3>> periodic_shifts(const IBox& domain, const bool periodic[3])
+{
+    // the unshifted image first, then the others in (x, y, z) lexicographic order of (-n, 0, +n)
+    std::vector<std::array<int, 3>> shifts;
+    shifts.push_back({0, 0, 0});
+    for (int a = -1; a <= 1; ++a)
+        for (int b = -1; b <= 1; ++b)
+            for (int cc = -1; cc <= 1; ++cc) {
+                if ((a && !periodic[0]) || (b && !periodic[1]) || (cc && !periodic[2])) continue;
+                if (!a && !b && !cc) continue;
+                shifts.push_back({a * domain.size(0), b * domain.size(1), cc * domain.size(2)});
+            }
+    return shifts;
+}
+
+// `region` minus every box of `boxes` and every periodic image of them
+std::vector<IBox> uncovered(const IBox& region, const std::vector<IBox>& boxes, const IBox& domain,
+                            const bool periodic[3])
+{
+    std::vector<IBox> cur{region};
+    const auto shifts = periodic_shifts(domain, periodic);
+    for (const IBox& b : boxes)
+        for (const auto& sh : shifts) {
+            const IBox img = b.shift(sh.data());
+            if ((img & region).empty()) continue;
+            std::vector<IBox> nxt;
+            for (const IBox& c : cur) box_subtract(c, img, nxt);
+            cur.swap(nxt);
+            if (cur.empty()) return cur;
+        }
+    return cur;
+}
+
+// CFRegion of this level + homogeneousCFInterp weights (HomogeneousCFInterp.cpp:56, 72-73)
+void Level::define_cf(const double dxCrse[3])
+{
+    hcf.clear();
+    int g[3];
+    for (int d = 0; d < 3; ++d) g[d] = periodic[d] ? 1 : 0;
+    const IBox dom = domain.grow(g);
+    for (int pi = 0; pi < npatches(); ++pi) {
+        const PatchDesc& p = hpatches[pi];
+        const IBox valid = boxes[local[pi]];
+        const long long st[3] = {1, p.pj, p.pk};
+        for (int d = 0; d < 3; ++d) {
+            if (!active[d]) continue;
+            for (int s = 0; s < 2; ++s) {
+                IBox gb = valid;
+                if (s == 0) { gb.lo[d] = valid.lo[d] - 1; gb.hi[d] = valid.lo[d] - 1; }
+                else { gb.lo[d] = valid.hi[d] + 1; gb.hi[d] = valid.hi[d] + 1; }
+                gb = gb & dom;
+                if (gb.empty()) continue;
+                for (const IBox& u : uncovered(gb, boxes, domain, periodic))
+                    for (int k = u.lo[2]; k <= u.hi[2]; ++k)
+                        for (int j = u.lo[1]; j <= u.hi[1]; ++j)
+                            for (int i = u.lo[0]; i <= u.hi[0]; ++i) {
+                                CFCell c;
+                                c.off = p.off + (i - p.lo[0]) + st[1] * (j - p.lo[1]) + st[2] * (k - p.lo[2]);
+                                c.stride = (int)(s ? st[d] : -st[d]);
+                                c.dir = d | (p.n[d] == 1 ? 4 : 0);
+                                hcf.push_back(c);
+                            }
+            }
+        }
+    }
+    hipFree(d_cf);
+    d_cf = to_device(hcf);
+    ncf = (int)hcf.size();
+    for (int d = 0; d < 3; ++d) {
+        const double Df = dx[d], Dc = dxCrse[d];
+        cf_c1[d] = 2.0 * (Dc - Df) / (Dc + Df);
+        cf_c2[d] = -(Dc - Df) / (Dc + 3.0 * Df);
+        cf_fac[d] = 1.0 - 2.0 * Df / (Df + Dc);
+    }
+}
+
 Level::~Level()
 {
+    hipFree(d_cf);
     hipFree(d_patches);
     hipFree(d_tiles);
     hipFree(d_ftiles);

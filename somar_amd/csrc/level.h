@@ -8,6 +8,7 @@
 // box-to-box copies (plus one packed message per neighbouring rank when the layout is
 // sharded over GPUs).
 #pragma once
+#include <array>
 #include <memory>
 #include <vector>
 
@@ -41,6 +42,10 @@ struct IBox {
 };
 
 bool coarsenable(const std::vector<IBox>& boxes, const int* r);
+void box_subtract(const IBox& a, const IBox& b, std::vector<IBox>& out);
+std::vector<std::array<int, 3>> periodic_shifts(const IBox& domain, const bool periodic[3]);
+std::vector<IBox> uncovered(const IBox& region, const std::vector<IBox>& boxes, const IBox& domain,
+                            const bool periodic[3]);
 
 // Inter-GPU transport used by a sharded level (one process per GPU).  The default is the
 // single-rank no-op; comm_rccl.cpp provides the RCCL/xGMI implementation.
@@ -116,6 +121,19 @@ public:
     bool hasCoarser = false;
     bool zeroAvg = false;
     double dxProduct = 1.0;
+
+    // coarse-fine ghost cells (only on levels that sit on a coarser AMR level): the cells of the 1-deep
+    // ghost layer that lie inside the (periodically extended) domain and are covered by no box of this level
+    std::vector<CFCell> hcf;
+    CFCell* d_cf = nullptr;
+    int ncf = 0;
+    double cf_c1[3] = {0, 0, 0}, cf_c2[3] = {0, 0, 0}, cf_fac[3] = {0, 0, 0};
+    // builds hcf/d_cf and the interpolation weights for a coarser-level spacing dxCrse
+    void define_cf(const double dxCrse[3]);
+    void cf_homog(double* phi, hipStream_t st) const
+    {
+        launch_cf_homog(st, d_cf, ncf, phi, cf_c1, cf_c2, cf_fac);
+    }
 
     Level() {}
     ~Level();

@@ -10,15 +10,19 @@ namespace somar {
 static const int S_MAX_COARSE = 4;  // MappedAMRPoissonOp::s_maxCoarse, MappedAMRPoissonOp.cpp:55
 enum { SLOT_TMP = 0, SLOT_SUMS = 8, NSLOTS = 16 };
 
-PressureSolver::PressureSolver(Comm* comm) : comm_(comm ? comm : &self_)
+PressureSolver::PressureSolver(Comm* comm, hipStream_t shared) : comm_(comm ? comm : &self_)
 {
-    SOMAR_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    if (shared) { st_ = shared; own_stream_ = false; }
+    else SOMAR_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
     SOMAR_HIP(hipMalloc(&d_scalars, NSLOTS * sizeof(double)));
     SOMAR_HIP(hipMemset(d_scalars, 0, NSLOTS * sizeof(double)));
     SOMAR_HIP(hipHostMalloc(&h_scalars, NSLOTS * sizeof(double)));
     // levels smaller than this use the two-pass colour kernel (launch-latency bound anyway);
     // SOMAR_FUSED_MIN_CELLS=0 forces the fused sweep everywhere (tests), a huge value disables it.
     if (const char* e = getenv("SOMAR_FUSED_MIN_CELLS")) fused_min_cells_ = atoll(e);
+    // levels up to this many cells sum in the reference's serial order (k_reduce_ordered); tests raise it to
+    // make whole solves reproduce the oracle's histories to the last bits
+    if (const char* e = getenv("SOMAR_ORDERED_REDUCE_MAX")) ordered_max_cells_ = atoll(e);
 }
 
 PressureSolver::~PressureSolver()
@@ -29,6 +33,7 @@ PressureSolver::~PressureSolver()
     for (double* f : f_scratch) hipFree(f);
     for (double* f : f_pp) hipFree(f);
     for (double* f : f_vel) hipFree(f);
+    for (double* f : f_amr) hipFree(f);
     hipFree(f_phi); hipFree(f_rhs); hipFree(f_uberRes); hipFree(f_uberCorr); hipFree(f_best);
     for (double* f : bicg) hipFree(f);
     hipFree(d_partials);
@@ -39,7 +44,7 @@ PressureSolver::~PressureSolver()
     }
     if (h_scalars) hipHostFree(h_scalars);
     lev.clear();
-    if (st_) hipStreamDestroy(st_);
+    if (st_ && own_stream_) hipStreamDestroy(st_);
 }
 
 void PressureSolver::sync() { SOMAR_HIP(hipStreamSynchronize(st_)); }
@@ -108,6 +113,8 @@ double* PressureSolver::field(int depth, int which)
         case 3: return depth == 0 ? f_uberCorr : f_corr[depth];
         case 4: return depth == 0 ? f_best : nullptr;
         case 5: return f_scratch[depth];
+        case 6: return depth == 0 ? amr_field(0) : nullptr;
+        case 7: return depth == 0 ? amr_field(1) : nullptr;
         default: return nullptr;
     }
 }
@@ -117,10 +124,17 @@ double* PressureSolver::field(int depth, int which)
 // ------------------------------------------------------------------------------------
 void PressureSolver::define(const IBox& domain, const bool periodic[3], const double dx[3],
                             const int bc_type[3][2], const std::vector<IBox>& boxes,
-                            const std::vector<int>& owner, double alpha, double beta, const SolverParams& p)
+                            const std::vector<int>& owner, double alpha, double beta, const SolverParams& p,
+                            const double* dxCrse)
 {
     SOMAR_CHECK(lev.empty(), "solver already defined");
     prm = p;
+    hasCF_ = dxCrse != nullptr;
+    if (hasCF_) {
+        for (int d = 0; d < 3; ++d) dxCrse_[d] = dxCrse[d];
+        SOMAR_CHECK(prm.relaxMode != RELAX_LINE_GSRB && prm.precondMode != PRECOND_DIAG_LINE_RELAX,
+                    "line relaxation on a level with coarse-fine boundaries is not implemented");
+    }
     SOMAR_CHECK(prm.relaxMode == RELAX_LEVEL_GSRB || prm.relaxMode == RELAX_JACOBI || prm.relaxMode == RELAX_LINE_GSRB,
                 "only LevelGSRB (relax_mode 1), LineGSRB (3) and Jacobi (0) are implemented");
     SOMAR_CHECK(prm.precondMode == PRECOND_DIAG_RELAX || prm.precondMode == PRECOND_NONE ||
@@ -135,6 +149,7 @@ void PressureSolver::define(const IBox& domain, const bool periodic[3], const do
     L->beta = beta;
     L->define(domain, periodic, dx, bc_type, boxes, owner, comm_);
     L->alloc_metric();
+    if (hasCF_) L->define_cf(dxCrse_);
     lev.push_back(std::move(L));
 }
 
@@ -204,6 +219,7 @@ bool PressureSolver::build_coarser(int depth)
     for (int d = 0; d < 3; ++d) cdx[d] = F.dx[d] * (double)r[d];
     C->define(F.domain.coarsen(r), F.periodic, cdx, F.bc_type, cb, F.owner, comm_);
     C->alloc_metric();
+    if (hasCF_) C->define_cf(dxCrse_);  // CFRegion::coarsen + the AMR coarser level's spacing (Factory.cpp:596-600)
     // coarse metrics: fill_MGfields, MappedAMRPoissonOpFactory.cpp:1164-1234
     for (int pi = 0; pi < C->npatches(); ++pi)
         for (int d = 0; d < 3; ++d)
@@ -316,7 +332,8 @@ void PressureSolver::download_field(const double* field, int depth, int patch, d
 void PressureSolver::relax(int d, double* e, const double* res, int iters)
 {
     Level& L = *lev[d];
-    if (prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0) {
+    if (prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0 && L.ncf == 0 &&
+        !hasCF_) {
         // LevelGSRB::relax (GSRB.cpp:58-98) as ONE fused red+black launch per sweep (gsrb_fused.hip):
         // same values bit for bit, one ghost exchange per sweep instead of two, ping-pong buffers.
         L.exchange(const_cast<double*>(res), st_);  // rhs ghosts: constant over the sweeps
@@ -338,6 +355,7 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters)
             // fillGhostsAndExtrapolate is dead code for a diagonal metric (the boundary
             // stencil never reads a Neumann ghost), so only the exchange remains.
             for (int pass = 0; pass < 2; ++pass) {
+                L.cf_homog(e, st_);  // homogeneousCFInterp (Relaxer::fillGhostsAndExtrapolate)
                 L.exchange(e, st_);
                 if (profiling_ && d == 0) prof_begin(0);
                 launch_gsrb_ortho(st_, L.dev, e, res, pass);
@@ -366,6 +384,18 @@ void PressureSolver::line_relax(int d, double* e, const double* res)
 
 void PressureSolver::residual(int d, double* out, double* phi, const double* rhs)
 {
+    lev[d]->cf_homog(phi, st_);  // interpCFGhosts(homogeneous), MappedAMRPoissonOp.cpp:628-640
+    residual_i(d, out, phi, rhs);
+}
+
+void PressureSolver::apply_op(int d, double* out, double* phi)
+{
+    lev[d]->cf_homog(phi, st_);
+    apply_op_i(d, out, phi);
+}
+
+void PressureSolver::residual_i(int d, double* out, double* phi, const double* rhs)
+{
     Level& L = *lev[d];
     L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
     if (profiling_ && d == 0) prof_begin(1);
@@ -373,11 +403,29 @@ void PressureSolver::residual(int d, double* out, double* phi, const double* rhs
     if (profiling_ && d == 0) prof_end(1);
 }
 
-void PressureSolver::apply_op(int d, double* out, double* phi)
+void PressureSolver::apply_op_i(int d, double* out, double* phi)
 {
     Level& L = *lev[d];
     L.exchange(phi, st_);
     launch_op_ortho(st_, L.dev, out, phi, nullptr, 1);
+}
+
+void PressureSolver::prolong_from(const LevelDev& C, const double* crse, const int r[3], double* fine)
+{
+    Level& F = *lev[0];
+    launch_prolong(st_, F.dev, C, fine, crse, r, F.zeroAvg, F.dxProduct, d_partials, d_scalars + SLOT_SUMS,
+                   F.field_elems, ordered(0));
+    if (F.zeroAvg) {
+        comm_->allreduce(d_scalars + SLOT_SUMS, 2, 0, st_);
+        launch_sub_mean(st_, fine, F.field_elems, d_scalars + SLOT_SUMS);
+    }
+}
+
+double* PressureSolver::amr_field(int which)
+{
+    SOMAR_CHECK(which == 0 || which == 1, "bad AMR work field");
+    if (!f_amr[which]) f_amr[which] = lev[0]->alloc_field();
+    return f_amr[which];
 }
 
 void PressureSolver::restrict_residual(int d, double* resCoarse, double* phiFine, const double* rhsFine)
@@ -393,7 +441,7 @@ void PressureSolver::prolong_increment(int d, double* phiFine, const double* cor
     // MPI_Allreduce calls of the reference become one 2-element device-side reduction.
     Level& F = *lev[d];
     launch_prolong(st_, F.dev, lev[d + 1]->dev, phiFine, corrCoarse, F.mgCrseRefRatio, F.zeroAvg, F.dxProduct,
-                   d_partials, d_scalars + SLOT_SUMS, F.field_elems);
+                   d_partials, d_scalars + SLOT_SUMS, F.field_elems, ordered(d));
     if (F.zeroAvg) {
         comm_->allreduce(d_scalars + SLOT_SUMS, 2, 0, st_);
         launch_sub_mean(st_, phiFine, F.field_elems, d_scalars + SLOT_SUMS);
@@ -425,19 +473,19 @@ double PressureSolver::norm(int d, const double* a, int ord)
         return fetch_scalar(SLOT_TMP);
     }
     if (ord == 1) {
-        launch_reduce(st_, L.dev, a, nullptr, 2, d_partials, d_scalars + SLOT_TMP);
+        launch_reduce(st_, L.dev, a, nullptr, 2, d_partials, d_scalars + SLOT_TMP, ordered(d));
         comm_->allreduce(d_scalars + SLOT_TMP, 1, 0, st_);
         return fetch_scalar(SLOT_TMP);
     }
     SOMAR_CHECK(ord == 2, "norm order must be 0, 1 or 2");
-    launch_reduce(st_, L.dev, a, a, 0, d_partials, d_scalars + SLOT_TMP);
+    launch_reduce(st_, L.dev, a, a, 0, d_partials, d_scalars + SLOT_TMP, ordered(d));
     comm_->allreduce(d_scalars + SLOT_TMP, 1, 0, st_);
     return std::sqrt(fetch_scalar(SLOT_TMP));
 }
 
 double PressureSolver::dot(int d, const double* a, const double* b)
 {
-    launch_reduce(st_, lev[d]->dev, a, b, 0, d_partials, d_scalars + SLOT_TMP);
+    launch_reduce(st_, lev[d]->dev, a, b, 0, d_partials, d_scalars + SLOT_TMP, ordered(d));
     comm_->allreduce(d_scalars + SLOT_TMP, 1, 0, st_);
     return fetch_scalar(SLOT_TMP);
 }

@@ -41,13 +41,15 @@ struct SolveStats {
 
 class PressureSolver {
 public:
-    explicit PressureSolver(Comm* comm = nullptr);
+    // shared: run on the caller's stream (the levels of an AMR hierarchy share one) instead of an own one
+    explicit PressureSolver(Comm* comm = nullptr, hipStream_t shared = nullptr);
     ~PressureSolver();
 
     // ---- definition (MappedAMRPoissonOpFactory::define + MappedAMRMultiGrid::define) -----
     void define(const IBox& domain, const bool periodic[3], const double dx[3], const int bc_type[3][2],
                 const std::vector<IBox>& boxes, const std::vector<int>& owner, double alpha, double beta,
-                const SolverParams& prm);
+                const SolverParams& prm, const double* dxCrse = nullptr);
+    bool has_cf() const { return hasCF_; }
     // Diagonal metric of one LOCAL patch in Chombo FRA layout: Jg_aa on faces(valid,a), Jinv on valid.
     void set_metric_ortho(int patch, const double* jg0, const double* jg1, const double* jg2, const double* jinv);
     void finalize();  // builds the semicoarsened hierarchy, coarse metrics, lapDiag, null-space probes
@@ -69,8 +71,13 @@ public:
     double* work(int which);  // 0 uberResidual 1 uberCorrection 2 bestPhi
     double* field(int depth, int which);  // SOMAR_F_* handle -> device pointer (nullptr if absent)
     void relax(int d, double* e, const double* res, int iters);
-    void residual(int d, double* out, double* phi, const double* rhs);
+    void residual(int d, double* out, double* phi, const double* rhs);   // homogeneous CF ghosts, then residual_i
     void apply_op(int d, double* out, double* phi);
+    void residual_i(int d, double* out, double* phi, const double* rhs); // residualI: CF ghosts as they are
+    void apply_op_i(int d, double* out, double* phi);
+    // ConstInterpPS / ZeroAvgConstInterpPS of depth 0 from a coarse field living on layout C (AMRProlong)
+    void prolong_from(const LevelDev& C, const double* crse, const int r[3], double* fine);
+    double* amr_field(int which);  // 0 m_correction, 1 m_residual of MappedAMRMultiGrid (allocated on first use)
     void restrict_residual(int d, double* resCoarse, double* phiFine, const double* rhsFine);
     void prolong_increment(int d, double* phiFine, const double* corrCoarse);
     void pre_cond(int d, double* phi, const double* rhs);
@@ -107,8 +114,14 @@ private:
     void fill_metric_ghosts(Level& L);
     void line_relax(int d, double* e, const double* res);
     double* f_vel[3] = {nullptr, nullptr, nullptr};
+    double* f_amr[2] = {nullptr, nullptr};
+    bool hasCF_ = false;
+    bool own_stream_ = true;
+    double dxCrse_[3] = {0, 0, 0};
     std::vector<double*> f_pp;  // per-depth ping-pong buffer of the fused sweep
     long long fused_min_cells_ = 262144;
+    long long ordered_max_cells_ = 32768;
+    bool ordered(int d) const { return lev[d]->valid_cells_global <= ordered_max_cells_; }
 
     Comm* comm_;
     Comm self_;

@@ -77,3 +77,22 @@ def make_amr_levels(so, am, n, L, periodic, ratios, fine_boxes, variant="stretch
         Jgup, Jinv = so.make_diagonal_metric(g, dx, L, variant=variant, domain=dom)
         levels.append(am.AMRLevel(dom, g, dx, Jgup, Jinv))
     return levels
+
+
+def make_gpu_amr(levels, ratios, alpha=0.0, beta=1.0, pre=2, post=2, bottom=2, maxDepth=-1, relaxMode=1):
+    """The same hierarchy (oracle AMRLevel list) on the GPU through the C ABI."""
+    from somar_amd import AMRPressureSolver
+    s = AMRPressureSolver()
+    p = s._p
+    s.setAMRMGParameters(p.imin, p.imax, p.eps, maxDepth, p.num_smooth_precond, pre, post, bottom, p.precond_mode,
+                         relaxMode, p.num_mg, p.hang, p.norm_thresh, 0)
+    L0 = levels[0]
+    s.defineAMR(L0.domain.box.lo, L0.domain.box.hi, L0.domain.periodic, L0.dx, ratios,
+                [[(g.lo, g.hi) for g in L.grids] for L in levels], alpha=alpha, beta=beta)
+    for L, v in zip(levels, s.levels):
+        for p_ in range(v.num_local_patches):
+            _, _, gi = v.patch_box(p_)
+            jg = [np.asfortranarray(L.Jgup[gi][d].a[..., d]) for d in range(3)]
+            v.setMetricOrtho(p_, jg[0], jg[1], jg[2], np.asfortranarray(L.Jinv[gi].a[..., 0]))
+    s.finalize()
+    return s
