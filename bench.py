@@ -13,11 +13,11 @@ layout sharded over N GPUs (one box per GPU, one process per GPU, halo exchange 
 RCCL/xGMI) => strong scaling.
 
 One JSON line on rank 0.  Besides the contract keys it carries
-  roofline     -- dominant kernel (k_gsrb_ortho, depth 0): algorithmic bytes (32 B/cell per colour pass =
+  roofline     -- dominant kernel (k_gsrb_fused, depth 0; k_gsrb_ortho below the fused threshold): algorithmic bytes (32 B/cell per colour pass =
                   half of the 64 B/cell red+black sweep of SURVEY.md 8d) / HIP-event launch duration measured
                   in the timed region on the solver's stream, against the 8 TB/s HBM3E peak
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference's Fortran+C++ path; the reference itself
-                  cannot be built here) timed on a bounded 128^3 sample of the same workload, 1 core
+                  cannot be built here) timed on a bounded 256^3 sample of the same workload, 1 core
 """
 import argparse
 import json
