@@ -527,33 +527,36 @@ __global__ __launch_bounds__(64) void k_reduce_ordered(const PatchDesc* __restri
                                                        const double* __restrict__ a, const double* __restrict__ b,
                                                        double dxProduct, double* __restrict__ out)
 {
+    // one wavefront: 512 cells are fetched coalesced (8 per lane) into LDS, then every lane walks them in order
+    // (uniform LDS reads are broadcasts), so the dependent chain is 512 adds per chunk, not 512 cross-lane hops
+    constexpr int CH = 512;
+    __shared__ double X[CH], Y[MODE == 6 ? CH : 1];
     const int lane = threadIdx.x;
     double tot = 0.0, run_s = 0.0, run_v = 0.0;
     for (int pi = 0; pi < npatches; ++pi) {
         const PatchDesc p = patches[pi];
         const long long n = (long long)p.n[0] * p.n[1] * p.n[2];
         double sbox = 0.0;
-        for (long long base = 0; base < n; base += 64) {
-            const long long idx = base + lane;
-            double x = 0.0, y = 0.0;
-            if (idx < n) {
+        for (long long base = 0; base < n; base += CH) {
+            const int cnt = (int)((n - base) < CH ? (n - base) : CH);
+            __syncthreads();  // the previous chunk has been consumed
+            for (int q = lane; q < cnt; q += 64) {
+                const long long idx = base + q;
                 const int i = (int)(idx % p.n[0]);
-                const long long q = idx / p.n[0];
-                const int j = (int)(q % p.n[1]), k = (int)(q / p.n[1]);
+                const long long r = idx / p.n[0];
+                const int j = (int)(r % p.n[1]), k = (int)(r / p.n[1]);
                 const long long c = cidx(p, i, j, k);
-                if (MODE == 0) x = a[c] * b[c];
-                else if (MODE == 2) x = fabs(a[c]);
-                else { y = dxProduct / b[c]; x = y * a[c]; }
+                if (MODE == 0) X[q] = a[c] * b[c];
+                else if (MODE == 2) X[q] = fabs(a[c]);
+                else { const double y = dxProduct / b[c]; Y[q] = y; X[q] = y * a[c]; }
             }
-            const int cnt = (int)((n - base) < 64 ? (n - base) : 64);
-            for (int l = 0; l < cnt; ++l) {
-                const double xl = __shfl(x, l);
-                if (MODE == 6) {
-                    run_s = run_s + xl;
-                    run_v = run_v + __shfl(y, l);
-                } else {
-                    sbox = (base == 0 && l == 0) ? xl : sbox + xl;
-                }
+            __syncthreads();
+            if (MODE == 6) {
+                for (int q = 0; q < cnt; ++q) { run_s = run_s + X[q]; run_v = run_v + Y[q]; }
+            } else {
+                int q = 0;
+                if (base == 0) { sbox = X[0]; q = 1; }
+                for (; q < cnt; ++q) sbox = sbox + X[q];
             }
         }
         if (MODE != 6) tot = tot + sbox;

@@ -186,6 +186,7 @@ Level::~Level()
     hipFree(d_patches);
     hipFree(d_tiles);
     hipFree(d_ftiles);
+    hipFree(d_rtiles);
     hipFree(d_ctiles);
     hipFree(d_local_items);
     hipFree(d_send_items);
@@ -277,10 +278,10 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
         for (int b = 0; b < N; ++b) htiles[b] = nat[start[b % NX] + b / NX];
     }
 
-    // ---- tiles of the fused red-black sweep: 124 x 12 columns, k split into chunks so that the
-    // launch fills the 256 CUs evenly (one 1024-thread workgroup per CU at a time) ------------
-    {
-        const int FT_I = 124, FT_J = fused_rows() - 4;
+    // ---- tiles of the k-marching kernels: (FT_I x FT_J) columns, k split into chunks so that the launch
+    // fills the 256 CUs evenly (one 1024-thread workgroup per CU at a time); `halo` = planes a chunk reads
+    // beyond its own (fused red-black sweep: 3, marching residual: 2) ----------------------------------
+    auto march_tiles = [&](int FT_I, int FT_J, double halo) {
         long long cols = 0;
         int maxn2 = 1;
         for (const PatchDesc& p : hpatches) {
@@ -293,7 +294,7 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
             const long long blocks = cols * nch;
             const long long rounds = (blocks + 255) / 256;
             const double nk = (double)maxn2 / nch;
-            const double eff = (double)blocks / (double)(rounds * 256) * nk / (nk + 3.0);
+            const double eff = (double)blocks / (double)(rounds * 256) * nk / (nk + halo);
             if (eff > best_eff + 1e-9) { best_eff = eff; best = nch; }
         }
         std::vector<Tile> fnat;
@@ -311,15 +312,20 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
                     }
         }
         const int NF = (int)fnat.size();
-        hftiles.assign(NF, Tile());
+        std::vector<Tile> perm(NF);
         const int NX = 8;
         int start[NX + 1];
         start[0] = 0;
         for (int x = 0; x < NX; ++x) start[x + 1] = start[x] + (NF - x + NX - 1) / NX;
-        for (int b = 0; b < NF; ++b) hftiles[b] = fnat[start[b % NX] + b / NX];
-        d_ftiles = to_device(hftiles);
-        nftiles = NF;
-    }
+        for (int b = 0; b < NF; ++b) perm[b] = fnat[start[b % NX] + b / NX];
+        return perm;
+    };
+    hftiles = march_tiles(124, fused_rows() - 4, 3.0);
+    d_ftiles = to_device(hftiles);
+    nftiles = (int)hftiles.size();
+    hrtiles = march_tiles(124, 14, 2.0);
+    d_rtiles = to_device(hrtiles);
+    nrtiles = (int)hrtiles.size();
 
     // ---- whole-column tiles for line relaxation (one lane per (i-pair, j) column) ---------------
     {

@@ -95,6 +95,9 @@ public:
     std::vector<Tile> hftiles;   // tiles of the fused red-black sweep (gsrb_fused.hip)
     Tile* d_ftiles = nullptr;
     int nftiles = 0;
+    std::vector<Tile> hrtiles;   // tiles of the k-marching operator/residual (resid_march.hip): 124 x 14 columns
+    Tile* d_rtiles = nullptr;
+    int nrtiles = 0;
     std::vector<Tile> hctiles;   // whole-column tiles (line relaxation): 128 x ctile_j columns, all of k
     Tile* d_ctiles = nullptr;
     int nctiles = 0, ctile_j = 2;

@@ -1,0 +1,158 @@
+// somar_amd/csrc/resid_march.hip -- operator / residual of a large level as a k-marching, LDS-staged kernel.
+//
+// Why: k_op_ortho (kernels.hip) reads phi through L2 and, measured with rocprofv3 PMC at 512^3, moves 136 B
+// per cell over the fabric against 56 algorithmic: the k+-1 (and j+-1) reuse distance of a 7-point stencil
+// does not fit the 4 MiB per-XCD L2 when 256 workgroups stream different slabs.  Here a workgroup owns a
+// (124 x 14) column of cells and marches in k, exactly like the fused GSRB sweep (gsrb_fused.hip):
+//   * phi of plane k is staged in LDS (2 rotating planes of 128 x 16 doubles, one wavefront per row, one
+//     double2 per lane, ONE barrier per plane); the k-neighbours and Jg^zz stay in registers;
+//   * every array is read once: phi 8 (x 128*16/(124*14) halo), rhs 8, Jg 24, Jinv 8, out 8 = ~58 B/cell.
+//
+// Arithmetic: the expression order of k_op_ortho (= MAPPEDGETFLUXORTHO + zero Neumann flux + flux*=beta +
+// MAPPEDFLUXDIVERGENCE3D + AXBYIP + SUBTRACTOP) => bit-identical to it and to the CPU oracle.
+// MODE 0: out = rhs - L[phi]   MODE 1: out = L[phi]
+#include "common.h"
+#include "kernels.h"
+
+namespace somar {
+
+constexpr int RM_I = 128;  // region width (64 lanes x double2) = 124-cell tile + 2 low + 2 high
+constexpr int RM_J = 16;   // region rows = 14-row tile + 1 low + 1 high
+
+__device__ __forceinline__ double2 rm_ld2(const double* __restrict__ a, long long idx, bool ok0, bool ok1)
+{
+    double2 v = make_double2(0.0, 0.0);
+    if (ok0 && ok1) v = *reinterpret_cast<const double2*>(a + idx);
+    else if (ok0) v.x = a[idx];
+    else if (ok1) v.y = a[idx + 1];
+    return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restrict__ tiles,
+                                                           const PatchDesc* __restrict__ patches,
+                                                           double* __restrict__ out,
+                                                           const double* __restrict__ phi,
+                                                           const double* __restrict__ rhs,
+                                                           const double* __restrict__ jgx,
+                                                           const double* __restrict__ jgy,
+                                                           const double* __restrict__ jgz,
+                                                           const double* __restrict__ jinv, StencilParams P)
+{
+    __shared__ __attribute__((aligned(16))) double S[2][RM_J][RM_I];
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lane = threadIdx.x, row = threadIdx.y;
+    const int ri = 2 * lane;
+    const int li = t.i0 - 2 + ri;  // even: rows are 16-byte aligned
+    const int lj = t.j0 - 1 + row;
+    const int gj = p.lo[1] + lj;
+    const double sx = 1.0 / P.dx[0], sy = 1.0 / P.dx[1], sz = 1.0 / P.dx[2];
+
+    // phi may be touched inside the 1-cell ghost layer, coefficients only at the tile's own cells / faces
+    const bool fj = (lj >= -1) && (lj <= p.n[1]);
+    const bool f0 = fj && (li >= -1) && (li <= p.n[0]);
+    const bool f1 = fj && (li + 1 >= -1) && (li + 1 <= p.n[0]);
+    const bool own_j = (lj >= 0) && (lj < p.n[1]) && (row >= 1) && (row <= RM_J - 2) && (lj < t.j0 + (RM_J - 2));
+    bool o[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int l = li + s, r = ri + s;
+        o[s] = own_j && (l >= 0) && (l < p.n[0]) && (r >= 2) && (r < RM_I - 2);
+    }
+    // Jg^xx is also needed on the face right of the pair's second cell (next lane's first component): load the
+    // pair if either of its cells, or the cell left of it, is an output cell
+    // (the shuffle must run with all lanes active: keep it out of the short-circuit)
+    const int left_o1 = __shfl_up((int)o[1], 1, 64);
+    const bool gxo0 = o[0] || (left_o1 != 0);
+    const bool any = o[0] || o[1];
+    const long long sj = p.pj, sk = p.pk;
+    const long long base = p.off + li + sj * lj;
+    const bool zyl = (gj == P.dom_lo[1]) && P.neum[1][0];
+    const bool zyh = (gj == P.dom_hi[1]) && P.neum[1][1];
+    bool zxl[2], zxh[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int gi = p.lo[0] + li + s;
+        zxl[s] = (gi == P.dom_lo[0]) && P.neum[0][0];
+        zxh[s] = (gi == P.dom_hi[0]) && P.neum[0][1];
+    }
+
+    int k = t.k0;
+    double2 Pm = rm_ld2(phi, base + sk * (k - 1), o[0], o[1]);
+    double2 Pc = rm_ld2(phi, base + sk * k, f0, f1);
+    double2 Gzc = rm_ld2(jgz, base + sk * k, o[0], o[1]);
+    const int kend = t.k0 + t.nk;
+    for (; k < kend; ++k) {
+        const int gk = p.lo[2] + k;
+        const bool more = (k + 1 < kend);
+        // ---- this step's loads ----
+        const double2 Pp = rm_ld2(phi, base + sk * (k + 1), more ? f0 : o[0], more ? f1 : o[1]);
+        const double2 Gzp = rm_ld2(jgz, base + sk * (k + 1), o[0], o[1]);
+        double2 Rh = make_double2(0.0, 0.0);
+        if (MODE == 0) Rh = rm_ld2(rhs, base + sk * k, o[0], o[1]);
+        const double2 Ji = rm_ld2(jinv, base + sk * k, o[0], o[1]);
+        const double2 Gx = rm_ld2(jgx, base + sk * k, gxo0, o[0] || o[1]);
+        const double2 Gy = rm_ld2(jgy, base + sk * k, o[0], o[1]);
+        const double2 Gyh = rm_ld2(jgy, base + sk * k + sj, o[0], o[1]);
+        const double gx_next = __shfl_down(Gx.x, 1, 64);
+
+        // ---- stage plane k; slot k&1 was last read two steps ago, one barrier per plane suffices ----
+        const int slot = k & 1;
+        *reinterpret_cast<double2*>(&S[slot][row][ri]) = Pc;
+        __syncthreads();
+
+        if (any) {
+            const bool zzl = (gk == P.dom_lo[2]) && P.neum[2][0];
+            const bool zzh = (gk == P.dom_hi[2]) && P.neum[2][1];
+            double res[2] = {0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (!o[s]) continue;
+                const int rc = ri + s;
+                const double pc = s ? Pc.y : Pc.x;
+                const double pxl = s ? Pc.x : S[slot][row][rc - 1];
+                const double pxh = s ? S[slot][row][rc + 1] : Pc.y;
+                const double pyl = S[slot][row - 1][rc], pyh = S[slot][row + 1][rc];
+                const double gxl = s ? Gx.y : Gx.x, gxh = s ? gx_next : Gx.y;
+                double fxl = gxl * sx * (pc - pxl);
+                double fxh = gxh * sx * (pxh - pc);
+                double fyl = (s ? Gy.y : Gy.x) * sy * (pc - pyl);
+                double fyh = (s ? Gyh.y : Gyh.x) * sy * (pyh - pc);
+                double fzl = (s ? Gzc.y : Gzc.x) * sz * (pc - (s ? Pm.y : Pm.x));
+                double fzh = (s ? Gzp.y : Gzp.x) * sz * ((s ? Pp.y : Pp.x) - pc);
+                if (zxl[s]) fxl = 0.0;
+                if (zxh[s]) fxh = 0.0;
+                if (zyl) fyl = 0.0;
+                if (zyh) fyh = 0.0;
+                if (zzl) fzl = 0.0;
+                if (zzh) fzh = 0.0;
+                fxl *= P.beta; fxh *= P.beta; fyl *= P.beta; fyh *= P.beta; fzl *= P.beta; fzh *= P.beta;
+                double l = (s ? Ji.y : Ji.x) * ((fxh - fxl) * sx + (fyh - fyl) * sy + (fzh - fzl) * sz);
+                if (P.alpha != 0.0) l = P.alpha * pc + 1.0 * l;
+                res[s] = (MODE == 0) ? ((s ? Rh.y : Rh.x) - l) : l;
+            }
+            double* dst = out + base + sk * k;
+            if (o[0] && o[1]) *reinterpret_cast<double2*>(dst) = make_double2(res[0], res[1]);
+            else if (o[0]) dst[0] = res[0];
+            else dst[1] = res[1];
+        }
+        Pm = Pc;
+        Pc = Pp;
+        Gzc = Gzp;
+    }
+}
+
+void launch_resid_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out,
+                        const double* phi, const double* rhs, int mode)
+{
+    if (ntiles == 0) return;
+    if (mode == 0)
+        hipLaunchKernelGGL(k_resid_march<0>, dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, L.patches, out, phi, rhs,
+                           L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+    else
+        hipLaunchKernelGGL(k_resid_march<1>, dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, L.patches, out, phi, rhs,
+                           L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+}
+
+}  // namespace somar

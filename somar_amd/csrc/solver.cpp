@@ -20,6 +20,8 @@ PressureSolver::PressureSolver(Comm* comm, hipStream_t shared) : comm_(comm ? co
     // levels smaller than this use the two-pass colour kernel (launch-latency bound anyway);
     // SOMAR_FUSED_MIN_CELLS=0 forces the fused sweep everywhere (tests), a huge value disables it.
     if (const char* e = getenv("SOMAR_FUSED_MIN_CELLS")) fused_min_cells_ = atoll(e);
+    march_min_cells_ = fused_min_cells_;
+    if (const char* e = getenv("SOMAR_MARCH_MIN_CELLS")) march_min_cells_ = atoll(e);
     // levels up to this many cells sum in the reference's serial order (k_reduce_ordered); tests raise it to
     // make whole solves reproduce the oracle's histories to the last bits
     if (const char* e = getenv("SOMAR_ORDERED_REDUCE_MAX")) ordered_max_cells_ = atoll(e);
@@ -399,7 +401,8 @@ void PressureSolver::residual_i(int d, double* out, double* phi, const double* r
     Level& L = *lev[d];
     L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
     if (profiling_ && d == 0) prof_begin(1);
-    launch_op_ortho(st_, L.dev, out, phi, rhs, 0);
+    if (L.valid_cells_global >= march_min_cells_) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, rhs, 0);
+    else launch_op_ortho(st_, L.dev, out, phi, rhs, 0);
     if (profiling_ && d == 0) prof_end(1);
 }
 
@@ -407,7 +410,8 @@ void PressureSolver::apply_op_i(int d, double* out, double* phi)
 {
     Level& L = *lev[d];
     L.exchange(phi, st_);
-    launch_op_ortho(st_, L.dev, out, phi, nullptr, 1);
+    if (L.valid_cells_global >= march_min_cells_) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, nullptr, 1);
+    else launch_op_ortho(st_, L.dev, out, phi, nullptr, 1);
 }
 
 void PressureSolver::prolong_from(const LevelDev& C, const double* crse, const int r[3], double* fine)

@@ -120,7 +120,8 @@ private:
     double dxCrse_[3] = {0, 0, 0};
     std::vector<double*> f_pp;  // per-depth ping-pong buffer of the fused sweep
     long long fused_min_cells_ = 262144;
-    long long ordered_max_cells_ = 32768;
+    long long march_min_cells_ = 262144;  // levels at least this big use the k-marching operator/residual
+    long long ordered_max_cells_ = 4096;
     bool ordered(int d) const { return lev[d]->valid_cells_global <= ordered_max_cells_; }
 
     Comm* comm_;

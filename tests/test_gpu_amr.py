@@ -101,7 +101,7 @@ VCYCLES = [(LAYOUTS[0], 1, 0), (LAYOUTS[1], 1, 0), (LAYOUTS[3], 2, 0), (LAYOUTS[
 
 @pytest.mark.parametrize("case", VCYCLES)
 def test_amr_vcycle_bit_exact(oracle, am, case):
-    """One AMRVCycle from identical inputs.  Every level here is small enough (<= 32768 cells) for the library
+    """One AMRVCycle from identical inputs.  Every level here is small enough (<= 4096 cells) for the library
     to sum BiCGStab's scalars and the zero-average mean in the reference's serial order (k_reduce_ordered), so
     the whole cycle -- smoothing, CF interpolation, refluxed residual, restriction, bottom solve,
     prolongation -- reproduces the oracle bit for bit."""
