@@ -36,13 +36,14 @@ constexpr int FR_I = 128;  // region width  (64 lanes x double2) = tile + 4
 __device__ __forceinline__ double pick(const double2& v, int s) { return s ? v.y : v.x; }
 
 // load a[idx], a[idx+1] with per-element predicates (idx is 16-byte aligned by construction)
-__device__ __forceinline__ double2 ld2(const double* __restrict__ a, long long idx, bool ok0, bool ok1)
+__device__ __forceinline__ double2 ld2(const double* __restrict__ a, long long idx, bool ok0, bool ok1,
+                                          long long safe)
 {
-    double2 v = make_double2(0.0, 0.0);
-    if (ok0 && ok1) v = *reinterpret_cast<const double2*>(a + idx);
-    else if (ok0) v.x = a[idx];
-    else if (ok1) v.y = a[idx + 1];
-    return v;
+    // branch-free: always one aligned 16-byte load (from `safe`, any valid aligned element of the patch, when
+    // neither element may be touched), then selects.  Straight-line loads let the compiler count outstanding
+    // loads exactly (s_waitcnt vmcnt(N)) instead of draining everything at every predicated branch.
+    const double2 v = *reinterpret_cast<const double2*>(a + ((ok0 || ok1) ? idx : safe));
+    return make_double2(ok0 ? v.x : 0.0, ok1 ? v.y : 0.0);
 }
 
 // One GSRB point update of cell (gi,gj,gk): interior form = GSRBITER3DORTHO, cells touching a domain
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
     // ---- prologue: planes k0-2 and k0-1 ------------------------------------------------------------
     int k = t.k0 - 1;  // first red plane (the ring below the tile)
     bool fk = (k - 1 >= -FRAME) && (k - 1 < p.n[2] + FRAME);
-    double2 Pm = ld2(phi_in, base + sk * (k - 1), f0 && fk, f1 && fk);
+    double2 Pm = ld2(phi_in, base + sk * (k - 1), f0 && fk, f1 && fk, p.off);
     fk = (k >= -FRAME) && (k < p.n[2] + FRAME);
-    double2 Pc = ld2(phi_in, base + sk * k, f0 && fk, f1 && fk);
-    double2 Gzc = ld2(jgz, base + sk * k, c0 && fk, c1 && fk);  // Jg^zz on the LOW face of plane k
+    double2 Pc = ld2(phi_in, base + sk * k, f0 && fk, f1 && fk, p.off);
+    double2 Gzc = ld2(jgz, base + sk * k, c0 && fk, c1 && fk, p.off);  // Jg^zz on the LOW face of plane k
     // coefficients of the black cell of plane k-1 (column c), captured one step earlier
     double b_rhs = 0, b_ji = 1, b_gxl = 0, b_gxh = 0, b_gyl = 0, b_gyh = 0, b_gzl = 0;
     double redPrev1 = 0.0, redPrev2 = 0.0;
@@ -154,13 +155,13 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         fk = (k >= -FRAME) && (k < p.n[2] + FRAME);
         const bool fkp = (k + 1 >= -FRAME) && (k + 1 < p.n[2] + FRAME);
         // ---- this step's loads: phi and Jg^zz of plane k+1, cell coefficients of plane k --------
-        const double2 Pp = ld2(phi_in, base + sk * (k + 1), f0 && fkp, f1 && fkp);
-        const double2 Gzp = ld2(jgz, base + sk * (k + 1), c0 && fkp, c1 && fkp);
-        const double2 Rh = ld2(rhs, base + sk * k, c0 && fk, c1 && fk);
-        const double2 Ji = ld2(jinv, base + sk * k, c0 && fk, c1 && fk);
-        const double2 Gx = ld2(jgx, base + sk * k, c0 && fk, c1 && fk);
-        const double2 Gy = ld2(jgy, base + sk * k, c0 && fk, c1 && fk);
-        const double2 Gyh = ld2(jgy, base + sk * k + sj, c0 && fk && fjh, c1 && fk && fjh);
+        const double2 Pp = ld2(phi_in, base + sk * (k + 1), f0 && fkp, f1 && fkp, p.off);
+        const double2 Gzp = ld2(jgz, base + sk * (k + 1), c0 && fkp, c1 && fkp, p.off);
+        const double2 Rh = ld2(rhs, base + sk * k, c0 && fk, c1 && fk, p.off);
+        const double2 Ji = ld2(jinv, base + sk * k, c0 && fk, c1 && fk, p.off);
+        const double2 Gx = ld2(jgx, base + sk * k, c0 && fk, c1 && fk, p.off);
+        const double2 Gy = ld2(jgy, base + sk * k, c0 && fk, c1 && fk, p.off);
+        const double2 Gyh = ld2(jgy, base + sk * k + sj, c0 && fk && fjh, c1 && fk && fjh, p.off);
         // Jg^xx on the face right of the pair = first component of the next lane's pair
         const double gx_next = __shfl_down(Gx.x, 1, 64);
 

@@ -19,13 +19,14 @@ namespace somar {
 constexpr int RM_I = 128;  // region width (64 lanes x double2) = 124-cell tile + 2 low + 2 high
 constexpr int RM_J = 16;   // region rows = 14-row tile + 1 low + 1 high
 
-__device__ __forceinline__ double2 rm_ld2(const double* __restrict__ a, long long idx, bool ok0, bool ok1)
+__device__ __forceinline__ double2 rm_ld2(const double* __restrict__ a, long long idx, bool ok0, bool ok1,
+                                          long long safe)
 {
-    double2 v = make_double2(0.0, 0.0);
-    if (ok0 && ok1) v = *reinterpret_cast<const double2*>(a + idx);
-    else if (ok0) v.x = a[idx];
-    else if (ok1) v.y = a[idx + 1];
-    return v;
+    // branch-free: always one aligned 16-byte load (from `safe`, any valid aligned element of the patch, when
+    // neither element may be touched), then selects.  Straight-line loads let the compiler count outstanding
+    // loads exactly (s_waitcnt vmcnt(N)) instead of draining everything at every predicated branch.
+    const double2 v = *reinterpret_cast<const double2*>(a + ((ok0 || ok1) ? idx : safe));
+    return make_double2(ok0 ? v.x : 0.0, ok1 ? v.y : 0.0);
 }
 
 template <int MODE>
@@ -79,22 +80,22 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
     }
 
     int k = t.k0;
-    double2 Pm = rm_ld2(phi, base + sk * (k - 1), o[0], o[1]);
-    double2 Pc = rm_ld2(phi, base + sk * k, f0, f1);
-    double2 Gzc = rm_ld2(jgz, base + sk * k, o[0], o[1]);
+    double2 Pm = rm_ld2(phi, base + sk * (k - 1), o[0], o[1], p.off);
+    double2 Pc = rm_ld2(phi, base + sk * k, f0, f1, p.off);
+    double2 Gzc = rm_ld2(jgz, base + sk * k, o[0], o[1], p.off);
     const int kend = t.k0 + t.nk;
     for (; k < kend; ++k) {
         const int gk = p.lo[2] + k;
         const bool more = (k + 1 < kend);
         // ---- this step's loads ----
-        const double2 Pp = rm_ld2(phi, base + sk * (k + 1), more ? f0 : o[0], more ? f1 : o[1]);
-        const double2 Gzp = rm_ld2(jgz, base + sk * (k + 1), o[0], o[1]);
+        const double2 Pp = rm_ld2(phi, base + sk * (k + 1), more ? f0 : o[0], more ? f1 : o[1], p.off);
+        const double2 Gzp = rm_ld2(jgz, base + sk * (k + 1), o[0], o[1], p.off);
         double2 Rh = make_double2(0.0, 0.0);
-        if (MODE == 0) Rh = rm_ld2(rhs, base + sk * k, o[0], o[1]);
-        const double2 Ji = rm_ld2(jinv, base + sk * k, o[0], o[1]);
-        const double2 Gx = rm_ld2(jgx, base + sk * k, gxo0, o[0] || o[1]);
-        const double2 Gy = rm_ld2(jgy, base + sk * k, o[0], o[1]);
-        const double2 Gyh = rm_ld2(jgy, base + sk * k + sj, o[0], o[1]);
+        if (MODE == 0) Rh = rm_ld2(rhs, base + sk * k, o[0], o[1], p.off);
+        const double2 Ji = rm_ld2(jinv, base + sk * k, o[0], o[1], p.off);
+        const double2 Gx = rm_ld2(jgx, base + sk * k, gxo0, o[0] || o[1], p.off);
+        const double2 Gy = rm_ld2(jgy, base + sk * k, o[0], o[1], p.off);
+        const double2 Gyh = rm_ld2(jgy, base + sk * k + sj, o[0], o[1], p.off);
         const double gx_next = __shfl_down(Gx.x, 1, 64);
 
         // ---- stage plane k; slot k&1 was last read two steps ago, one barrier per plane suffices ----

@@ -75,7 +75,7 @@ def pmc(fd, wd, out, cells):
     inc_f, inc_w = biggest(fetch, "k_sub_mean"), biggest(write, "k_sub_mean")
     res["k_sub_mean_raw_fetch"], res["k_sub_mean_raw_write"] = inc_f, inc_w
     res["raw"] = {}
-    for key in ("k_gsrb_ortho", "k_gsrb_fused", "k_op_ortho<0>", "k_restrict", "k_prolong"):
+    for key in ("k_gsrb_ortho", "k_gsrb_fused", "k_op_ortho<0>", "k_resid_march<0>", "k_restrict", "k_prolong"):
         f, w = biggest(fetch, key), biggest(write, key)
         if f and w:
             res["raw"][key] = {"fetch_bytes_raw": f[0], "write_bytes": w[0], "launches": f[1]}
