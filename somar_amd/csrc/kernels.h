@@ -26,6 +26,8 @@ int fused_rows();
 // k-marching operator/residual of a large level (resid_march.hip); mode 0: out = rhs - L[phi], 1: out = L[phi]
 void launch_resid_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out,
                         const double* phi, const double* rhs, int mode);
+void launch_resid_restrict(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& F, const LevelDev& C,
+                           double* crse, const double* phi, const double* rhs, const int r[3]);
 // one colour of vertical-line GSRB (line_gsrb.hip); ctiles = whole-column tiles (k0 = 0, nk = n2)
 void launch_line_gsrb_ortho(hipStream_t st, const Tile* ctiles, int nctiles, int tile_j, const LevelDev& L,
                             double* phi, const double* rhs, double* dmod, int color);

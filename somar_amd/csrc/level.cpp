@@ -300,7 +300,8 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
         std::vector<Tile> fnat;
         for (int pi = 0; pi < (int)hpatches.size(); ++pi) {
             const PatchDesc& p = hpatches[pi];
-            const int nk = (p.n[2] + best - 1) / best;
+            int nk = (p.n[2] + best - 1) / best;
+            nk += nk & 1;  // even chunks: a chunk never splits the two planes of a coarse cell (fused restriction)
             for (int k0 = 0; k0 < p.n[2]; k0 += nk)
                 for (int j0 = 0; j0 < p.n[1]; j0 += FT_J)
                     for (int i0 = 0; i0 < p.n[0]; i0 += FT_I) {

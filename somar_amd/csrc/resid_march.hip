@@ -38,9 +38,13 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
                                                            const double* __restrict__ jgx,
                                                            const double* __restrict__ jgy,
                                                            const double* __restrict__ jgz,
-                                                           const double* __restrict__ jinv, StencilParams P)
+                                                           const double* __restrict__ jinv, StencilParams P,
+                                                           const PatchDesc* __restrict__ cpatches, int r0, int r1,
+                                                           int r2)
 {
     __shared__ __attribute__((aligned(16))) double S[2][RM_J][RM_I];
+    // MODE 2: (res/J, 1/J) of both cells of every pair, handed from the odd row of a coarse cell to the even one
+    __shared__ __attribute__((aligned(16))) double T[MODE == 2 ? 2 : 1][MODE == 2 ? RM_J : 1][MODE == 2 ? 64 : 1][4];
     const Tile t = tiles[blockIdx.x];
     const PatchDesc p = patches[t.patch];
     const int lane = threadIdx.x, row = threadIdx.y;
@@ -79,6 +83,47 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
         zxh[s] = (gi == P.dom_hi[0]) && P.neum[0][1];
     }
 
+    // MODE 2 state: this pair's (res/J, 1/J) of the previous plane, running sums of up to two coarse cells
+    double pv[4] = {0.0, 0.0, 0.0, 0.0}, cs[2] = {0.0, 0.0}, cjs[2] = {0.0, 0.0};
+    const bool leader = (MODE == 2) && any && (r1 == 1 || ((lj & 1) == 0));
+    auto accumulate = [&](int kp) {
+        // MAPPEDAVERAGE2's loop order: ii2 (planes), ii1 (rows), ii0 (cells of the pair)
+        if (!leader) return;
+        const bool first = (r2 == 1) || ((kp & 1) == 0);
+        const bool last = (r2 == 1) || ((kp & 1) == 1);
+        if (first) { cs[0] = cs[1] = 0.0; cjs[0] = cjs[1] = 0.0; }
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+        if (r1 == 2) {
+            const double* src = T[kp & 1][row + 1][lane];
+            q[0] = src[0]; q[1] = src[1]; q[2] = src[2]; q[3] = src[3];
+        }
+        if (r0 == 2) {
+            cs[0] = cs[0] + pv[0]; cjs[0] = cjs[0] + pv[2];
+            cs[0] = cs[0] + pv[1]; cjs[0] = cjs[0] + pv[3];
+            if (r1 == 2) {
+                cs[0] = cs[0] + q[0]; cjs[0] = cjs[0] + q[2];
+                cs[0] = cs[0] + q[1]; cjs[0] = cjs[0] + q[3];
+            }
+        } else {
+            cs[0] = cs[0] + pv[0]; cjs[0] = cjs[0] + pv[2];
+            cs[1] = cs[1] + pv[1]; cjs[1] = cjs[1] + pv[3];
+            if (r1 == 2) {
+                cs[0] = cs[0] + q[0]; cjs[0] = cjs[0] + q[2];
+                cs[1] = cs[1] + q[1]; cjs[1] = cjs[1] + q[3];
+            }
+        }
+        if (last) {
+            const PatchDesc cp = cpatches[t.patch];
+            const long long c = cp.off + (li / r0) + (long long)cp.pj * (lj / r1) + cp.pk * (kp / r2);
+            if (r0 == 2) {
+                out[c] = cs[0] / cjs[0];
+            } else {
+                if (o[0]) out[c] = cs[0] / cjs[0];
+                if (o[1]) out[c + 1] = cs[1] / cjs[1];
+            }
+        }
+    };
+
     int k = t.k0;
     double2 Pm = rm_ld2(phi, base + sk * (k - 1), o[0], o[1], p.off);
     double2 Pc = rm_ld2(phi, base + sk * k, f0, f1, p.off);
@@ -91,7 +136,7 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
         const double2 Pp = rm_ld2(phi, base + sk * (k + 1), more ? f0 : o[0], more ? f1 : o[1], p.off);
         const double2 Gzp = rm_ld2(jgz, base + sk * (k + 1), o[0], o[1], p.off);
         double2 Rh = make_double2(0.0, 0.0);
-        if (MODE == 0) Rh = rm_ld2(rhs, base + sk * k, o[0], o[1], p.off);
+        if (MODE != 1) Rh = rm_ld2(rhs, base + sk * k, o[0], o[1], p.off);
         const double2 Ji = rm_ld2(jinv, base + sk * k, o[0], o[1], p.off);
         const double2 Gx = rm_ld2(jgx, base + sk * k, gxo0, o[0] || o[1], p.off);
         const double2 Gy = rm_ld2(jgy, base + sk * k, o[0], o[1], p.off);
@@ -102,6 +147,7 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
         const int slot = k & 1;
         *reinterpret_cast<double2*>(&S[slot][row][ri]) = Pc;
         __syncthreads();
+        if (MODE == 2 && k > t.k0) accumulate(k - 1);
 
         if (any) {
             const bool zzl = (gk == P.dom_lo[2]) && P.neum[2][0];
@@ -131,16 +177,33 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
                 fxl *= P.beta; fxh *= P.beta; fyl *= P.beta; fyh *= P.beta; fzl *= P.beta; fzh *= P.beta;
                 double l = (s ? Ji.y : Ji.x) * ((fxh - fxl) * sx + (fyh - fyl) * sy + (fzh - fzl) * sz);
                 if (P.alpha != 0.0) l = P.alpha * pc + 1.0 * l;
-                res[s] = (MODE == 0) ? ((s ? Rh.y : Rh.x) - l) : l;
+                res[s] = (MODE != 1) ? ((s ? Rh.y : Rh.x) - l) : l;
             }
-            double* dst = out + base + sk * k;
-            if (o[0] && o[1]) *reinterpret_cast<double2*>(dst) = make_double2(res[0], res[1]);
-            else if (o[0]) dst[0] = res[0];
-            else dst[1] = res[1];
+            if (MODE == 2) {
+                // coarseSum + fine/J, coarseCCJSum + 1.0/J  (MAPPEDAVERAGE2)
+                pv[0] = o[0] ? res[0] / Ji.x : 0.0;
+                pv[1] = o[1] ? res[1] / Ji.y : 0.0;
+                pv[2] = o[0] ? 1.0 / Ji.x : 0.0;
+                pv[3] = o[1] ? 1.0 / Ji.y : 0.0;
+                if (r1 == 2) {
+                    double* dstT = T[k & 1][row][lane];
+                    *reinterpret_cast<double2*>(dstT) = make_double2(pv[0], pv[1]);
+                    *reinterpret_cast<double2*>(dstT + 2) = make_double2(pv[2], pv[3]);
+                }
+            } else {
+                double* dst = out + base + sk * k;
+                if (o[0] && o[1]) *reinterpret_cast<double2*>(dst) = make_double2(res[0], res[1]);
+                else if (o[0]) dst[0] = res[0];
+                else dst[1] = res[1];
+            }
         }
         Pm = Pc;
         Pc = Pp;
         Gzc = Gzp;
+    }
+    if (MODE == 2) {
+        __syncthreads();
+        accumulate(kend - 1);
     }
 }
 
@@ -150,10 +213,20 @@ void launch_resid_march(hipStream_t st, const Tile* tiles, int ntiles, const Lev
     if (ntiles == 0) return;
     if (mode == 0)
         hipLaunchKernelGGL(k_resid_march<0>, dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, L.patches, out, phi, rhs,
-                           L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+                           L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, nullptr, 1, 1, 1);
     else
         hipLaunchKernelGGL(k_resid_march<1>, dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, L.patches, out, phi, rhs,
-                           L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+                           L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, nullptr, 1, 1, 1);
+}
+
+// restrictResidual in one pass: crse = J-weighted average (MAPPEDAVERAGE2) of rhs - L[phi]; the fine residual is
+// never written.  Needs tiles whose k-extent is even (Level::hrtiles are) and a coarsenable layout.
+void launch_resid_restrict(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& F, const LevelDev& C,
+                           double* crse, const double* phi, const double* rhs, const int r[3])
+{
+    if (ntiles == 0) return;
+    hipLaunchKernelGGL(k_resid_march<2>, dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, F.patches, crse, phi, rhs,
+                       F.jg[0], F.jg[1], F.jg[2], F.jinv, F.P, C.patches, r[0], r[1], r[2]);
 }
 
 }  // namespace somar

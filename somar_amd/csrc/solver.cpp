@@ -435,6 +435,17 @@ double* PressureSolver::amr_field(int which)
 void PressureSolver::restrict_residual(int d, double* resCoarse, double* phiFine, const double* rhsFine)
 {
     // restrictResidual, MappedAMRPoissonOp.cpp:1281-1304
+    Level& F = *lev[d];
+    if (F.valid_cells_global >= march_min_cells_) {
+        // large level: residual and J-weighted average in one marching pass, the fine residual is never stored
+        F.cf_homog(phiFine, st_);
+        F.exchange(phiFine, st_);
+        if (profiling_ && d == 0) prof_begin(1);
+        launch_resid_restrict(st_, F.d_rtiles, F.nrtiles, F.dev, lev[d + 1]->dev, resCoarse, phiFine, rhsFine,
+                              F.mgCrseRefRatio);
+        if (profiling_ && d == 0) prof_end(1);
+        return;
+    }
     residual(d, f_scratch[d], phiFine, rhsFine);
     launch_restrict(st_, lev[d + 1]->dev, lev[d]->dev, resCoarse, f_scratch[d], lev[d]->mgCrseRefRatio);
 }
