@@ -140,6 +140,10 @@ int somar_level_restrict_residual(somar_solver_t* s, int depth, int coarse_res_f
 int somar_level_prolong_increment(somar_solver_t* s, int depth, int phi_field, int coarse_corr_field);
 int somar_level_precond(somar_solver_t* s, int depth, int phi_field, int rhs_field);
 int somar_vcycle(somar_solver_t* s, int corr_field, int res_field);
+/* the same cycle started from a ZERO correction, as MappedAMRMultiGrid::solveNoInitResid does every iteration
+ * (uberCorrection is setToZero'ed in postVCycleOps, MappedAMRMultiGrid.H:1203): the contents of corr_field are
+ * ignored and overwritten, which saves the memset and the first sweep's read */
+int somar_vcycle_from_zero(somar_solver_t* s, int corr_field, int res_field);
 int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* iters, int* exit_code);
 
 /* MAC level projection of a face-centred velocity given in flux form (J u^a on a-faces, one host array per

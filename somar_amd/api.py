@@ -80,6 +80,7 @@ _SIGS = {
     "somar_level_prolong_increment": [_H, C.c_int, C.c_int, C.c_int],
     "somar_level_precond": [_H, C.c_int, C.c_int, C.c_int],
     "somar_vcycle": [_H, C.c_int, C.c_int],
+    "somar_vcycle_from_zero": [_H, C.c_int, C.c_int],
     "somar_bottom_solve": [_H, C.c_int, C.c_int, _PI, _PI],
     "somar_vel_upload": [_H, C.c_int, C.c_int, _PD],
     "somar_vel_download": [_H, C.c_int, C.c_int, _PD],
@@ -387,6 +388,10 @@ class AMRPressureSolver:
 
     def vcycle(self, corr_field=F_CORR, res_field=F_RES):
         _ck(lib().somar_vcycle(self._h, corr_field, res_field))
+
+    def vcycleFromZero(self, corr_field=F_CORR, res_field=F_RES):
+        """oneCycle on a correction taken to be zero (contents of corr_field are ignored and overwritten)"""
+        _ck(lib().somar_vcycle_from_zero(self._h, corr_field, res_field))
 
     def bottomSolve(self, phi_field, rhs_field):
         it, ex = C.c_int(), C.c_int()

@@ -794,7 +794,7 @@ void AMRSolver::vcycle(double* const* uberCorr, double* const* uberRes, int ilev
     if (l_max == l_base) {
         S[l_base]->vcycle(uberCorr[ilev], uberRes[ilev]);
     } else if (ilev == l_base) {
-        S[l_base]->vcycle(corr_[ilev], res_[ilev]);
+        S[l_base]->vcycle(corr_[ilev], res_[ilev], true);  // m_correction was set to zero above
         launch_incr(st_, uberCorr[ilev], corr_[ilev], 1.0, n);
     } else {
         S[ilev]->relax(0, corr_[ilev], res_[ilev], prm.num_smooth_down);

@@ -417,6 +417,17 @@ int somar_vcycle(somar_solver_t* s, int corr_field, int res_field)
     API_END
 }
 
+int somar_vcycle_from_zero(somar_solver_t* s, int corr_field, int res_field)
+{
+    API_BEGIN
+    int d1, d2;
+    double* c = field_ptr(s, corr_field, &d1);
+    double* r = field_ptr(s, res_field, &d2);
+    SOMAR_CHECK(d1 == 0 && d2 == 0, "V-cycles start at depth 0");
+    s->ps->vcycle(c, r, true);
+    API_END
+}
+
 int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* iters, int* exit_code)
 {
     API_BEGIN

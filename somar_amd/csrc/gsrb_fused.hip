@@ -89,7 +89,8 @@ __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS,
 // blockDim = (64, FR_J): lane = i-pair of the region, threadIdx.y = region row (one wavefront each).
 // FR_J = 16: 124 x 12 output columns per 1024-thread workgroup (one per CU);
 // FR_J =  8: 124 x 4 per 512-thread workgroup, two resident per CU so one computes while the other waits.
-template <int FR_J>
+// ZIN: phi_in is taken to be zero everywhere and is not read (first sweep on a zero correction)
+template <int FR_J, bool ZIN>
 __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict__ tiles,
                                                      const PatchDesc* __restrict__ patches,
                                                      double* __restrict__ phi_out,
@@ -141,9 +142,9 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
     // ---- prologue: planes k0-2 and k0-1 ------------------------------------------------------------
     int k = t.k0 - 1;  // first red plane (the ring below the tile)
     bool fk = (k - 1 >= -FRAME) && (k - 1 < p.n[2] + FRAME);
-    double2 Pm = ld2(phi_in, base + sk * (k - 1), f0 && fk, f1 && fk, p.off);
+    double2 Pm = ZIN ? make_double2(0.0, 0.0) : ld2(phi_in, base + sk * (k - 1), f0 && fk, f1 && fk, p.off);
     fk = (k >= -FRAME) && (k < p.n[2] + FRAME);
-    double2 Pc = ld2(phi_in, base + sk * k, f0 && fk, f1 && fk, p.off);
+    double2 Pc = ZIN ? make_double2(0.0, 0.0) : ld2(phi_in, base + sk * k, f0 && fk, f1 && fk, p.off);
     double2 Gzc = ld2(jgz, base + sk * k, c0 && fk, c1 && fk, p.off);  // Jg^zz on the LOW face of plane k
     // coefficients of the black cell of plane k-1 (column c), captured one step earlier
     double b_rhs = 0, b_ji = 1, b_gxl = 0, b_gxh = 0, b_gyl = 0, b_gyh = 0, b_gzl = 0;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         fk = (k >= -FRAME) && (k < p.n[2] + FRAME);
         const bool fkp = (k + 1 >= -FRAME) && (k + 1 < p.n[2] + FRAME);
         // ---- this step's loads: phi and Jg^zz of plane k+1, cell coefficients of plane k --------
-        const double2 Pp = ld2(phi_in, base + sk * (k + 1), f0 && fkp, f1 && fkp, p.off);
+        const double2 Pp = ZIN ? make_double2(0.0, 0.0) : ld2(phi_in, base + sk * (k + 1), f0 && fkp, f1 && fkp, p.off);
         const double2 Gzp = ld2(jgz, base + sk * (k + 1), c0 && fkp, c1 && fkp, p.off);
         const double2 Rh = ld2(rhs, base + sk * k, c0 && fk, c1 && fk, p.off);
         const double2 Ji = ld2(jinv, base + sk * k, c0 && fk, c1 && fk, p.off);
@@ -231,15 +232,20 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
 }
 
 void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* phi_out,
-                       const double* phi_in, const double* rhs)
+                       const double* phi_in, const double* rhs, bool zero_in)
 {
     if (ntiles == 0) return;
-    if (fused_rows() == 8)
-        hipLaunchKernelGGL(k_gsrb_fused<8>, dim3(ntiles), dim3(64, 8, 1), 0, st, tiles, L.patches, phi_out, phi_in, rhs,
-                           L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
-    else
-        hipLaunchKernelGGL(k_gsrb_fused<16>, dim3(ntiles), dim3(64, 16, 1), 0, st, tiles, L.patches, phi_out, phi_in,
-                           rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+#define SOMAR_LAUNCH_FUSED(ROWS, Z)                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gsrb_fused<ROWS, Z>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
+                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P)
+    if (fused_rows() == 8) {
+        if (zero_in) SOMAR_LAUNCH_FUSED(8, true);
+        else SOMAR_LAUNCH_FUSED(8, false);
+    } else {
+        if (zero_in) SOMAR_LAUNCH_FUSED(16, true);
+        else SOMAR_LAUNCH_FUSED(16, false);
+    }
+#undef SOMAR_LAUNCH_FUSED
 }
 
 // region rows per workgroup of the fused sweep (tile rows = rows - 4); SOMAR_FUSED_ROWS = 8 | 16

@@ -20,8 +20,9 @@ struct LevelDev {
 void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color);
 // one full red+black sweep, phi_in -> phi_out (gsrb_fused.hip); needs phi_in ghosts 2 deep and
 // rhs / Jg / Jinv ghosts 1 deep wherever a neighbouring box or periodic image exists
+// zero_in: phi_in is taken to be all zeros and is not read
 void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* phi_out,
-                       const double* phi_in, const double* rhs);
+                       const double* phi_in, const double* rhs, bool zero_in = false);
 int fused_rows();
 // k-marching operator/residual of a large level (resid_march.hip); mode 0: out = rhs - L[phi], 1: out = L[phi]
 void launch_resid_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out,

@@ -331,20 +331,27 @@ void PressureSolver::download_field(const double* field, int depth, int patch, d
 // ------------------------------------------------------------------------------------
 // level operator
 // ------------------------------------------------------------------------------------
-void PressureSolver::relax(int d, double* e, const double* res, int iters)
+void PressureSolver::relax(int d, double* e, const double* res, int iters, bool e_zero)
 {
     Level& L = *lev[d];
-    if (prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0 && L.ncf == 0 &&
-        !hasCF_) {
+    const bool fused_path = prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0 &&
+                            L.ncf == 0 && !hasCF_;
+    static const bool no_zero_start = getenv("SOMAR_NO_ZERO_START") != nullptr;  // A/B switch
+    if (e_zero && (!fused_path || no_zero_start)) {
+        launch_set(st_, e, L.field_elems, 0.0);
+        e_zero = false;
+    }
+    if (fused_path) {
         // LevelGSRB::relax (GSRB.cpp:58-98) as ONE fused red+black launch per sweep (gsrb_fused.hip):
         // same values bit for bit, one ghost exchange per sweep instead of two, ping-pong buffers.
         L.exchange(const_cast<double*>(res), st_);  // rhs ghosts: constant over the sweeps
         double* cur = e;
         double* alt = f_pp[d];
         for (int it = 0; it < iters; ++it) {
-            L.exchange(cur, st_);
+            const bool zin = e_zero && it == 0;  // zeros need neither an exchange nor a read
+            if (!zin) L.exchange(cur, st_);
             if (profiling_ && d == 0) prof_begin(0);
-            launch_gsrb_fused(st_, L.d_ftiles, L.nftiles, L.dev, alt, cur, res);
+            launch_gsrb_fused(st_, L.d_ftiles, L.nftiles, L.dev, alt, cur, res, zin);
             if (profiling_ && d == 0) prof_end(0);
             std::swap(cur, alt);
         }
@@ -577,25 +584,29 @@ void PressureSolver::fill_hash(int d, double* f, unsigned long long seed)
 // ------------------------------------------------------------------------------------
 // MappedMultiGrid::cycle, MappedMultiGrid.H:555-653 (V/W cycles; F-cycle not offered)
 // ------------------------------------------------------------------------------------
-void PressureSolver::vcycle(double* e, const double* res) { cycle(0, e, res); }
+void PressureSolver::vcycle(double* e, const double* res, bool e_zero) { cycle(0, e, res, e_zero); }
 
-void PressureSolver::cycle(int d, double* corr, const double* res)
+// corr_zero: the correction is to be taken as zero whatever the array holds (the reference zeroes it with
+// setToZero right before: MappedMultiGrid.H:589, MappedAMRMultiGrid.H:1203); a smoother that knows this skips the
+// memset and the read.  Only honoured when at least one smoothing sweep will overwrite the whole array.
+void PressureSolver::cycle(int d, double* corr, const double* res, bool corr_zero)
 {
     const int D = (int)lev.size();
     if (d == D - 1) {
         if (lev[d]->domain.numPts() == 1) {
-            relax(d, corr, res, 1);
+            relax(d, corr, res, 1, corr_zero);
         } else {
-            relax(d, corr, res, prm.num_smooth_bottom);
+            if (corr_zero && prm.num_smooth_bottom == 0) launch_set(st_, corr, lev[d]->field_elems, 0.0);
+            relax(d, corr, res, prm.num_smooth_bottom, corr_zero && prm.num_smooth_bottom > 0);
             bottom_solve(corr, res);
         }
         return;
     }
     SOMAR_CHECK(prm.numMG > 0, "F-cycles (numMG < 0) are not implemented");
-    relax(d, corr, res, prm.num_smooth_down);
+    if (corr_zero && prm.num_smooth_down == 0) launch_set(st_, corr, lev[d]->field_elems, 0.0);
+    relax(d, corr, res, prm.num_smooth_down, corr_zero && prm.num_smooth_down > 0);
     restrict_residual(d, f_res[d + 1], corr, res);
-    launch_set(st_, f_corr[d + 1], lev[d + 1]->field_elems, 0.0);
-    for (int img = 0; img < prm.numMG; ++img) cycle(d + 1, f_corr[d + 1], f_res[d + 1]);
+    for (int img = 0; img < prm.numMG; ++img) cycle(d + 1, f_corr[d + 1], f_res[d + 1], img == 0);
     prolong_increment(d, corr, f_corr[d + 1]);
     relax(d, corr, res, prm.num_smooth_up);
 }
@@ -731,9 +742,8 @@ void PressureSolver::solve(bool zeroPhi, bool forceHomogeneous, SolveStats& s)
     bool goHang = iter < prm.imin || rnorm < (1 - prm.hang) * norm_last;
     while (goIter && goRedu && goHang && goNorm) {
         norm_last = rnorm;
-        vcycle(f_uberCorr, f_uberRes);
+        vcycle(f_uberCorr, f_uberRes, true);          // uberCorrection is zero here (setToZero, :1203)
         launch_incr(st_, f_phi, f_uberCorr, 1.0, n);   // postVCycleOps, :1189-1215
-        launch_set(st_, f_uberCorr, n, 0.0);
         residual(0, f_uberRes, f_phi, f_rhs);
         rnorm = norm(0, f_uberRes, 0);
         ++iter;

@@ -70,7 +70,8 @@ public:
     double* rhs() { return f_rhs; }
     double* work(int which);  // 0 uberResidual 1 uberCorrection 2 bestPhi
     double* field(int depth, int which);  // SOMAR_F_* handle -> device pointer (nullptr if absent)
-    void relax(int d, double* e, const double* res, int iters);
+    // e_zero: e is to be taken as all zeros, whatever it holds (saves the memset and the first sweep's read)
+    void relax(int d, double* e, const double* res, int iters, bool e_zero = false);
     void residual(int d, double* out, double* phi, const double* rhs);   // homogeneous CF ghosts, then residual_i
     void apply_op(int d, double* out, double* phi);
     void residual_i(int d, double* out, double* phi, const double* rhs); // residualI: CF ghosts as they are
@@ -81,7 +82,7 @@ public:
     void restrict_residual(int d, double* resCoarse, double* phiFine, const double* rhsFine);
     void prolong_increment(int d, double* phiFine, const double* corrCoarse);
     void pre_cond(int d, double* phi, const double* rhs);
-    void vcycle(double* e, const double* res);  // MappedMultiGrid::oneCycle
+    void vcycle(double* e, const double* res, bool e_zero = false);  // MappedMultiGrid::oneCycle
     void bottom_solve(double* phi, const double* rhs);
     double norm(int d, const double* a, int ord);
     double dot(int d, const double* a, const double* b);
@@ -107,7 +108,7 @@ public:
     std::vector<std::array<int, 3>> mgRefRatios;
 
 private:
-    void cycle(int d, double* corr, const double* res);
+    void cycle(int d, double* corr, const double* res, bool corr_zero = false);
     double fetch_scalar(int slot);
     bool build_coarser(int depth);
     void probe_null_space(int d);
