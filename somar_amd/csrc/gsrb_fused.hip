@@ -89,8 +89,11 @@ __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS,
 // blockDim = (64, FR_J): lane = i-pair of the region, threadIdx.y = region row (one wavefront each).
 // FR_J = 16: 124 x 12 output columns per 1024-thread workgroup (one per CU);
 // FR_J =  8: 124 x 4 per 512-thread workgroup, two resident per CU so one computes while the other waits.
-// ZIN: phi_in is taken to be zero everywhere and is not read (first sweep on a zero correction)
-template <int FR_J, bool ZIN>
+// INMODE 0: plain.  1: phi_in is taken to be zero everywhere and is not read (first sweep on a zero correction).
+// 2: every value of phi_in is read as (value - sums[0]/sums[1]): the mean removal of ZeroAvgConstInterpPS
+//    (a_phiThisLevel[dit] -= avgPhi over the whole FAB, ProlongationStrategy.cpp:160-163) folded into the first
+//    post-smoothing sweep instead of a separate 16 B/cell pass.
+template <int FR_J, int INMODE>
 __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict__ tiles,
                                                      const PatchDesc* __restrict__ patches,
                                                      double* __restrict__ phi_out,
@@ -99,11 +102,19 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
                                                      const double* __restrict__ jgx,
                                                      const double* __restrict__ jgy,
                                                      const double* __restrict__ jgz,
-                                                     const double* __restrict__ jinv, StencilParams P)
+                                                     const double* __restrict__ jinv, StencilParams P,
+                                                     const double* __restrict__ sums)
 {
     __shared__ __attribute__((aligned(16))) double S[3][FR_J][FR_I];
     const Tile t = tiles[blockIdx.x];
     const PatchDesc p = patches[t.patch];
+    const double avg = (INMODE == 2) ? sums[0] / sums[1] : 0.0;
+    auto ldphi = [&](long long idx, bool ok0, bool ok1) {
+        if (INMODE == 1) return make_double2(0.0, 0.0);
+        double2 v = ld2(phi_in, idx, ok0, ok1, p.off);
+        if (INMODE == 2) { v.x = v.x - avg; v.y = v.y - avg; }
+        return v;
+    };
     const int lane = threadIdx.x, row = threadIdx.y;
     const int ri = 2 * lane;       // region column of the pair's first cell
     const int li = t.i0 - 2 + ri;  // local i of the pair's first cell (even: rows are 16-byte aligned)
@@ -142,9 +153,9 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
     // ---- prologue: planes k0-2 and k0-1 ------------------------------------------------------------
     int k = t.k0 - 1;  // first red plane (the ring below the tile)
     bool fk = (k - 1 >= -FRAME) && (k - 1 < p.n[2] + FRAME);
-    double2 Pm = ZIN ? make_double2(0.0, 0.0) : ld2(phi_in, base + sk * (k - 1), f0 && fk, f1 && fk, p.off);
+    double2 Pm = ldphi(base + sk * (k - 1), f0 && fk, f1 && fk);
     fk = (k >= -FRAME) && (k < p.n[2] + FRAME);
-    double2 Pc = ZIN ? make_double2(0.0, 0.0) : ld2(phi_in, base + sk * k, f0 && fk, f1 && fk, p.off);
+    double2 Pc = ldphi(base + sk * k, f0 && fk, f1 && fk);
     double2 Gzc = ld2(jgz, base + sk * k, c0 && fk, c1 && fk, p.off);  // Jg^zz on the LOW face of plane k
     // coefficients of the black cell of plane k-1 (column c), captured one step earlier
     double b_rhs = 0, b_ji = 1, b_gxl = 0, b_gxh = 0, b_gyl = 0, b_gyh = 0, b_gzl = 0;
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         fk = (k >= -FRAME) && (k < p.n[2] + FRAME);
         const bool fkp = (k + 1 >= -FRAME) && (k + 1 < p.n[2] + FRAME);
         // ---- this step's loads: phi and Jg^zz of plane k+1, cell coefficients of plane k --------
-        const double2 Pp = ZIN ? make_double2(0.0, 0.0) : ld2(phi_in, base + sk * (k + 1), f0 && fkp, f1 && fkp, p.off);
+        const double2 Pp = ldphi(base + sk * (k + 1), f0 && fkp, f1 && fkp);
         const double2 Gzp = ld2(jgz, base + sk * (k + 1), c0 && fkp, c1 && fkp, p.off);
         const double2 Rh = ld2(rhs, base + sk * k, c0 && fk, c1 && fk, p.off);
         const double2 Ji = ld2(jinv, base + sk * k, c0 && fk, c1 && fk, p.off);
@@ -232,18 +243,20 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
 }
 
 void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* phi_out,
-                       const double* phi_in, const double* rhs, bool zero_in)
+                       const double* phi_in, const double* rhs, int in_mode, const double* sums)
 {
     if (ntiles == 0) return;
-#define SOMAR_LAUNCH_FUSED(ROWS, Z)                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gsrb_fused<ROWS, Z>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
-                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P)
+#define SOMAR_LAUNCH_FUSED(ROWS, M)                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gsrb_fused<ROWS, M>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
+                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums)
     if (fused_rows() == 8) {
-        if (zero_in) SOMAR_LAUNCH_FUSED(8, true);
-        else SOMAR_LAUNCH_FUSED(8, false);
+        if (in_mode == 1) SOMAR_LAUNCH_FUSED(8, 1);
+        else if (in_mode == 2) SOMAR_LAUNCH_FUSED(8, 2);
+        else SOMAR_LAUNCH_FUSED(8, 0);
     } else {
-        if (zero_in) SOMAR_LAUNCH_FUSED(16, true);
-        else SOMAR_LAUNCH_FUSED(16, false);
+        if (in_mode == 1) SOMAR_LAUNCH_FUSED(16, 1);
+        else if (in_mode == 2) SOMAR_LAUNCH_FUSED(16, 2);
+        else SOMAR_LAUNCH_FUSED(16, 0);
     }
 #undef SOMAR_LAUNCH_FUSED
 }

@@ -20,9 +20,10 @@ struct LevelDev {
 void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color);
 // one full red+black sweep, phi_in -> phi_out (gsrb_fused.hip); needs phi_in ghosts 2 deep and
 // rhs / Jg / Jinv ghosts 1 deep wherever a neighbouring box or periodic image exists
-// zero_in: phi_in is taken to be all zeros and is not read
+// in_mode 0: plain; 1: phi_in is taken to be all zeros and is not read; 2: phi_in is read as
+// (value - sums[0]/sums[1]) (deferred mean removal of the zero-average prolongation)
 void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* phi_out,
-                       const double* phi_in, const double* rhs, bool zero_in = false);
+                       const double* phi_in, const double* rhs, int in_mode = 0, const double* sums = nullptr);
 int fused_rows();
 // k-marching operator/residual of a large level (resid_march.hip); mode 0: out = rhs - L[phi], 1: out = L[phi]
 void launch_resid_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out,

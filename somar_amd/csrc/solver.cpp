@@ -331,11 +331,18 @@ void PressureSolver::download_field(const double* field, int depth, int patch, d
 // ------------------------------------------------------------------------------------
 // level operator
 // ------------------------------------------------------------------------------------
-void PressureSolver::relax(int d, double* e, const double* res, int iters, bool e_zero)
+bool PressureSolver::fused_relax(int d, int iters) const
+{
+    const Level& L = *lev[d];
+    return prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0 && L.ncf == 0 &&
+           !hasCF_;
+}
+
+void PressureSolver::relax(int d, double* e, const double* res, int iters, bool e_zero, const double* e_shift)
 {
     Level& L = *lev[d];
-    const bool fused_path = prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0 &&
-                            L.ncf == 0 && !hasCF_;
+    const bool fused_path = fused_relax(d, iters);
+    SOMAR_CHECK(!e_shift || fused_path, "deferred mean removal needs the fused sweep");
     static const bool no_zero_start = getenv("SOMAR_NO_ZERO_START") != nullptr;  // A/B switch
     if (e_zero && (!fused_path || no_zero_start)) {
         launch_set(st_, e, L.field_elems, 0.0);
@@ -351,7 +358,8 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
             const bool zin = e_zero && it == 0;  // zeros need neither an exchange nor a read
             if (!zin) L.exchange(cur, st_);
             if (profiling_ && d == 0) prof_begin(0);
-            launch_gsrb_fused(st_, L.d_ftiles, L.nftiles, L.dev, alt, cur, res, zin);
+            launch_gsrb_fused(st_, L.d_ftiles, L.nftiles, L.dev, alt, cur, res,
+                              zin ? 1 : ((e_shift && it == 0) ? 2 : 0), e_shift);
             if (profiling_ && d == 0) prof_end(0);
             std::swap(cur, alt);
         }
@@ -457,7 +465,7 @@ void PressureSolver::restrict_residual(int d, double* resCoarse, double* phiFine
     launch_restrict(st_, lev[d + 1]->dev, lev[d]->dev, resCoarse, f_scratch[d], lev[d]->mgCrseRefRatio);
 }
 
-void PressureSolver::prolong_increment(int d, double* phiFine, const double* corrCoarse)
+const double* PressureSolver::prolong_increment(int d, double* phiFine, const double* corrCoarse, bool defer_mean)
 {
     // ConstInterpPS / ZeroAvgConstInterpPS, ProlongationStrategy.cpp:49-164.  The two scalar
     // MPI_Allreduce calls of the reference become one 2-element device-side reduction.
@@ -466,8 +474,10 @@ void PressureSolver::prolong_increment(int d, double* phiFine, const double* cor
                    d_partials, d_scalars + SLOT_SUMS, F.field_elems, ordered(d));
     if (F.zeroAvg) {
         comm_->allreduce(d_scalars + SLOT_SUMS, 2, 0, st_);
+        if (defer_mean) return d_scalars + SLOT_SUMS;
         launch_sub_mean(st_, phiFine, F.field_elems, d_scalars + SLOT_SUMS);
     }
+    return nullptr;
 }
 
 void PressureSolver::pre_cond(int d, double* phi, const double* rhs)
@@ -607,8 +617,9 @@ void PressureSolver::cycle(int d, double* corr, const double* res, bool corr_zer
     relax(d, corr, res, prm.num_smooth_down, corr_zero && prm.num_smooth_down > 0);
     restrict_residual(d, f_res[d + 1], corr, res);
     for (int img = 0; img < prm.numMG; ++img) cycle(d + 1, f_corr[d + 1], f_res[d + 1], img == 0);
-    prolong_increment(d, corr, f_corr[d + 1]);
-    relax(d, corr, res, prm.num_smooth_up);
+    // the zero-average mean is folded into the first post-smoothing sweep when that sweep is the fused kernel
+    const double* shift = prolong_increment(d, corr, f_corr[d + 1], fused_relax(d, prm.num_smooth_up));
+    relax(d, corr, res, prm.num_smooth_up, false, shift);
 }
 
 // ------------------------------------------------------------------------------------

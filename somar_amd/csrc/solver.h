@@ -71,7 +71,10 @@ public:
     double* work(int which);  // 0 uberResidual 1 uberCorrection 2 bestPhi
     double* field(int depth, int which);  // SOMAR_F_* handle -> device pointer (nullptr if absent)
     // e_zero: e is to be taken as all zeros, whatever it holds (saves the memset and the first sweep's read)
-    void relax(int d, double* e, const double* res, int iters, bool e_zero = false);
+    // e_shift: device pointer to (sum, volume): e is to be read as e - sum/volume (deferred mean removal); only
+    //          legal when fused_relax(d, iters) holds
+    void relax(int d, double* e, const double* res, int iters, bool e_zero = false, const double* e_shift = nullptr);
+    bool fused_relax(int d, int iters) const;
     void residual(int d, double* out, double* phi, const double* rhs);   // homogeneous CF ghosts, then residual_i
     void apply_op(int d, double* out, double* phi);
     void residual_i(int d, double* out, double* phi, const double* rhs); // residualI: CF ghosts as they are
@@ -80,7 +83,9 @@ public:
     void prolong_from(const LevelDev& C, const double* crse, const int r[3], double* fine);
     double* amr_field(int which);  // 0 m_correction, 1 m_residual of MappedAMRMultiGrid (allocated on first use)
     void restrict_residual(int d, double* resCoarse, double* phiFine, const double* rhsFine);
-    void prolong_increment(int d, double* phiFine, const double* corrCoarse);
+    // defer_mean: leave the zero-average mean (if any) to the caller; returns the device (sum, volume) pair to
+    //             subtract, or nullptr if nothing is pending
+    const double* prolong_increment(int d, double* phiFine, const double* corrCoarse, bool defer_mean = false);
     void pre_cond(int d, double* phi, const double* rhs);
     void vcycle(double* e, const double* res, bool e_zero = false);  // MappedMultiGrid::oneCycle
     void bottom_solve(double* phi, const double* rhs);
