@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SOMAR_AMD_ABI_VERSION 2
+#define SOMAR_AMD_ABI_VERSION 3
 
 /* BCType codes, calculus/BCInterface/BCDescriptor.H:34-39 */
 #define SOMAR_BC_NONE (-1)
@@ -69,6 +69,9 @@ typedef struct somar_params {
     /* bottom.* (utils/ProblemContext.cpp:1207-1231) */
     int bottom_imax, bottom_num_restarts, bottom_norm_type, bottom_verbosity;
     double bottom_eps, bottom_reps, bottom_hang, bottom_small;
+    /* CH_SPACEDIM of the build being replaced: 3, or 2 (domain and boxes one cell thick in z, z inactive;
+     * the 2-D Fortran kernels GSRBITER2DORTHO / MAPPEDFLUXDIVERGENCE2D / FILLMAPPEDLAPDIAG2D are reproduced) */
+    int space_dim;
 } somar_params_t;
 
 #define SOMAR_MAX_HISTORY 64

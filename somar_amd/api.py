@@ -32,7 +32,7 @@ class Params(C.Structure):
                 ("max_depth", C.c_int), ("precond_mode", C.c_int), ("relax_mode", C.c_int), ("verbosity", C.c_int),
                 ("bottom_imax", C.c_int), ("bottom_num_restarts", C.c_int), ("bottom_norm_type", C.c_int),
                 ("bottom_verbosity", C.c_int), ("bottom_eps", C.c_double), ("bottom_reps", C.c_double),
-                ("bottom_hang", C.c_double), ("bottom_small", C.c_double)]
+                ("bottom_hang", C.c_double), ("bottom_small", C.c_double), ("space_dim", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -171,6 +171,11 @@ class AMRPressureSolver:
         p.num_smooth_bottom, p.precond_mode, p.relax_mode, p.num_mg = num_smooth_bottom, precondMode, relaxMode, numMG
         p.hang, p.norm_thresh, p.verbosity = hang, norm_thresh, verbosity
 
+    def setSpaceDim(self, n):
+        """CH_SPACEDIM of the reference build this solver stands in for (3, or 2 with boxes one cell thick in z)"""
+        assert self._h is None and n in (2, 3)
+        self._p.space_dim = n
+
     def setBottomParameters(self, imax, numRestarts, eps, reps, hang, small, normType, verbosity):
         assert self._h is None, "setBottomParameters can only be called before define"
         p = self._p
@@ -251,7 +256,8 @@ class AMRPressureSolver:
         return tuple(b[0:3]), tuple(b[3:6]), g.value
 
     def setMetricOrtho(self, patch, jg0, jg1, jg2, jinv):
-        _ck(lib().somar_solver_set_metric_ortho(self._h, patch, _dp(jg0), _dp(jg1), _dp(jg2), _dp(jinv)))
+        _ck(lib().somar_solver_set_metric_ortho(self._h, patch, _dp(jg0), _dp(jg1), _dp(jg2) if jg2 is not None else None,
+                                                _dp(jinv)))
 
     def finalize(self):
         if getattr(self, "_amr", None) is not None:

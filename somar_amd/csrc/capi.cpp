@@ -79,6 +79,7 @@ int somar_params_default(somar_params_t* p)
     p->bottom_norm_type = d.bottom_normType; p->bottom_verbosity = d.bottom_verbosity;
     p->bottom_eps = d.bottom_eps; p->bottom_reps = d.bottom_reps; p->bottom_hang = d.bottom_hang;
     p->bottom_small = d.bottom_small;
+    p->space_dim = d.spaceDim;
     API_END
 }
 
@@ -95,6 +96,7 @@ static SolverParams to_params(const somar_params_t* p)
     d.bottom_normType = p->bottom_norm_type; d.bottom_verbosity = p->bottom_verbosity;
     d.bottom_eps = p->bottom_eps; d.bottom_reps = p->bottom_reps; d.bottom_hang = p->bottom_hang;
     d.bottom_small = p->bottom_small;
+    d.spaceDim = p->space_dim;
     return d;
 }
 
@@ -172,7 +174,7 @@ int somar_solver_set_metric_ortho(somar_solver_t* s, int patch, const double* jg
                                   const double* jg2, const double* jinv)
 {
     API_BEGIN
-    SOMAR_CHECK(jg0 && jg1 && jg2 && jinv, "null metric pointer");
+    SOMAR_CHECK(jg0 && jg1 && jinv && (jg2 || s->ps->prm.spaceDim == 2), "null metric pointer");
     s->ps->set_metric_ortho(patch, jg0, jg1, jg2, jinv);
     API_END
 }

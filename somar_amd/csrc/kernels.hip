@@ -108,7 +108,30 @@ __global__ __launch_bounds__(512) void k_gsrb_ortho(const Tile* __restrict__ til
                          (gi == P.dom_hi[0]);
         const double Ji = jinv[c];
         double out;
-        if (!onb) {
+        if (!P.active[2]) {
+            // SpaceDim == 2 build of the reference: GSRBITER2DORTHO / GSRBBOUNDARYITER2DORTHO
+            // (GSRBF.ChF:440-540, 1254-1356) -- note the different association of beta, Jinv and the side order
+            const bool onb2 = bj || (gi == P.dom_lo[0]) || (gi == P.dom_hi[0]);
+            if (!onb2) {
+                const double JDxx = xxScale * (jgx[c + 1] * phi[c + 1] + jgx[c] * phi[c - 1]);
+                const double JDyy = yyScale * (jgy[c + sj] * phi[c + sj] + jgy[c] * phi[c - sj]);
+                const double lphi = P.beta * (JDxx + JDyy) * Ji;
+                out = (rhs[c] - lphi) / (P.alpha + P.beta * lapd[c]);
+            } else {
+                const bool nxl = (gi == P.dom_lo[0]) && P.neum[0][0];
+                const bool nxh = (gi == P.dom_hi[0]) && P.neum[0][1];
+                const bool nyl = (gj == P.dom_lo[1]) && P.neum[1][0];
+                const bool nyh = (gj == P.dom_hi[1]) && P.neum[1][1];
+                double JDloX = 0, JDhiX = 0, JDloY = 0, JDhiY = 0, ld = 0.0;
+                if (!nxl) { JDloX = jgx[c] * phi[c - 1];        ld = ld - xxScale * jgx[c]; }
+                if (!nxh) { JDhiX = jgx[c + 1] * phi[c + 1];    ld = ld - xxScale * jgx[c + 1]; }
+                if (!nyl) { JDloY = jgy[c] * phi[c - sj];       ld = ld - yyScale * jgy[c]; }
+                if (!nyh) { JDhiY = jgy[c + sj] * phi[c + sj];  ld = ld - yyScale * jgy[c + sj]; }
+                ld = ld * Ji;
+                const double lphi = P.beta * Ji * ((JDloX + JDhiX) * xxScale + (JDloY + JDhiY) * yyScale);
+                out = (rhs[c] - lphi) / (P.alpha + P.beta * ld);
+            }
+        } else if (!onb) {
             const double JDxx = xxScale * (jgx[c + 1] * phi[c + 1] + jgx[c] * phi[c - 1]);
             const double JDyy = yyScale * (jgy[c + sj] * phi[c + sj] + jgy[c] * phi[c - sj]);
             const double JDzz = zzScale * (jgz[c + sk] * phi[c + sk] + jgz[c] * phi[c - sk]);
@@ -181,8 +204,11 @@ __global__ __launch_bounds__(512) void k_op_ortho(const Tile* __restrict__ tiles
             double fxh = jgx[c + 1] * sx * (phi[c + 1] - pc);
             double fyl = jgy[c] * sy * (pc - phi[c - sj]);
             double fyh = jgy[c + sj] * sy * (phi[c + sj] - pc);
-            double fzl = jgz[c] * sz * (pc - phi[c - sk]);
-            double fzh = jgz[c + sk] * sz * (phi[c + sk] - pc);
+            double fzl = 0.0, fzh = 0.0;
+            if (P.active[2]) {
+                fzl = jgz[c] * sz * (pc - phi[c - sk]);
+                fzh = jgz[c + sk] * sz * (phi[c + sk] - pc);
+            }
             if ((gi == P.dom_lo[0]) && P.neum[0][0]) fxl = 0.0;
             if ((gi == P.dom_hi[0]) && P.neum[0][1]) fxh = 0.0;
             if (zyl) fyl = 0.0;
@@ -190,7 +216,8 @@ __global__ __launch_bounds__(512) void k_op_ortho(const Tile* __restrict__ tiles
             if (zzl) fzl = 0.0;
             if (zzh) fzh = 0.0;
             fxl *= P.beta; fxh *= P.beta; fyl *= P.beta; fyh *= P.beta; fzl *= P.beta; fzh *= P.beta;
-            double l = jinv[c] * ((fxh - fxl) * sx + (fyh - fyl) * sy + (fzh - fzl) * sz);
+            double l = P.active[2] ? jinv[c] * ((fxh - fxl) * sx + (fyh - fyl) * sy + (fzh - fzl) * sz)
+                                   : jinv[c] * ((fxh - fxl) * sx + (fyh - fyl) * sy);  // MAPPEDFLUXDIVERGENCE2D
             if (P.alpha != 0.0) l = P.alpha * pc + 1.0 * l;
             out[c] = (MODE == 0) ? (rhs[c] - l) : l;
         }
@@ -220,8 +247,11 @@ __global__ __launch_bounds__(512) void k_lapdiag(const Tile* __restrict__ tiles,
             const int li = li0 + q;
             if (li >= p.n[0]) continue;
             const long long c = cidx(p, li, lj, t.k0 + kk);
-            lap[c] = -jinv[c] * ((jgx[c + 1] + jgx[c]) * s0 + (jgy[c + p.pj] + jgy[c]) * s1 +
-                                 (jgz[c + p.pk] + jgz[c]) * s2);
+            if (P.active[2])
+                lap[c] = -jinv[c] * ((jgx[c + 1] + jgx[c]) * s0 + (jgy[c + p.pj] + jgy[c]) * s1 +
+                                     (jgz[c + p.pk] + jgz[c]) * s2);
+            else  // FILLMAPPEDLAPDIAG2D
+                lap[c] = -jinv[c] * ((jgx[c + 1] + jgx[c]) * s0 + (jgy[c + p.pj] + jgy[c]) * s1);
         }
 }
 

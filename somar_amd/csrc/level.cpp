@@ -389,7 +389,7 @@ void Level::refresh_params()
     }
     P.alpha = alpha;
     P.beta = beta;
-    dxProduct = dx[0] * dx[1] * dx[2];
+    dxProduct = active[2] ? dx[0] * dx[1] * dx[2] : dx[0] * dx[1];
 }
 
 double* Level::alloc_field() const

@@ -142,11 +142,18 @@ void PressureSolver::define(const IBox& domain, const bool periodic[3], const do
     SOMAR_CHECK(prm.precondMode == PRECOND_DIAG_RELAX || prm.precondMode == PRECOND_NONE ||
                     prm.precondMode == PRECOND_DIAG_LINE_RELAX,
                 "bad precondMode");
-    for (int d = 0; d < 3; ++d)
+    for (int d = 0; d < p.spaceDim; ++d)
         for (int s = 0; s < 2; ++s)
             SOMAR_CHECK(periodic[d] || bc_type[d][s] == BC_NEUM,
                         "only homogeneous-Neumann (pressure) physical BCs are implemented");
+    SOMAR_CHECK(prm.spaceDim == 2 || prm.spaceDim == 3, "space_dim must be 2 or 3");
     std::unique_ptr<Level> L(new Level);
+    if (prm.spaceDim == 2) {
+        SOMAR_CHECK(domain.size(2) == 1, "space_dim 2 wants a domain (and boxes) one cell thick in z");
+        SOMAR_CHECK(prm.relaxMode != RELAX_LINE_GSRB && prm.precondMode != PRECOND_DIAG_LINE_RELAX,
+                    "line relaxation is implemented for space_dim 3 only");
+        L->active[2] = 0;
+    }
     L->alpha = alpha;
     L->beta = beta;
     L->define(domain, periodic, dx, bc_type, boxes, owner, comm_);
@@ -163,7 +170,8 @@ void PressureSolver::set_metric_ortho(int patch, const double* jg0, const double
     SOMAR_CHECK(patch >= 0 && patch < L.npatches(), "bad patch index");
     const IBox valid = L.boxes[L.local[patch]];
     const double* jg[3] = {jg0, jg1, jg2};
-    for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < prm.spaceDim; ++d) {
+        SOMAR_CHECK(jg[d] != nullptr, "null metric array");
         IBox fb = valid;
         fb.hi[d] += 1;
         L.upload(L.dev.jg[d], patch, jg[d], fb, fb, st_);
@@ -180,19 +188,20 @@ bool PressureSolver::build_coarser(int depth)
     int prev[3] = {1, 1, 1};
     for (auto& r : mgRefRatios)
         for (int d = 0; d < 3; ++d) prev[d] *= r[d];
-    const int mmc[3] = {S_MAX_COARSE, S_MAX_COARSE, S_MAX_COARSE};
+    const int nd = prm.spaceDim;
+    const int mmc[3] = {S_MAX_COARSE, S_MAX_COARSE, nd == 3 ? S_MAX_COARSE : 1};
     int r[3] = {1, 1, 1};
     double maxDx = 0.0;
-    for (int d = 0; d < 3; ++d) maxDx = std::max(maxDx, F.dx[d]);
-    for (int d = 0; d < 3; ++d)
+    for (int d = 0; d < nd; ++d) maxDx = std::max(maxDx, F.dx[d]);
+    for (int d = 0; d < nd; ++d)
         if (F.dx[d] <= maxDx / 2.0) r[d] = 2;
-    if (r[0] * r[1] * r[2] == 1) r[0] = r[1] = r[2] = 2;
+    if (r[0] * r[1] * r[2] == 1) { r[0] = r[1] = 2; r[2] = nd == 3 ? 2 : 1; }
     int tot[3];
     for (int d = 0; d < 3; ++d) tot[d] = prev[d] * r[d] * mmc[d];
     const std::vector<IBox>& base = lev[0]->boxes;
     if (!coarsenable(base, tot)) {
         int q[3] = {1, 1, 1};
-        for (int d = 0; d < 3; ++d) {
+        for (int d = 0; d < nd; ++d) {
             q[d] = 2;
             int t2[3];
             for (int e = 0; e < 3; ++e) t2[e] = prev[e] * mmc[e] * q[e];
@@ -200,9 +209,9 @@ bool PressureSolver::build_coarser(int depth)
         }
         if (q[0] * q[1] * q[2] == 1) return false;
         int refDir = 0;
-        while (refDir < 3 && q[refDir] != 1) ++refDir;
-        SOMAR_CHECK(refDir < 3, "semicoarsening fallback: no stuck direction");
-        for (int d = 0; d < 3; ++d)
+        while (refDir < nd && q[refDir] != 1) ++refDir;
+        SOMAR_CHECK(refDir < nd, "semicoarsening fallback: no stuck direction");
+        for (int d = 0; d < nd; ++d)
             if (q[d] > 1 && F.dx[d] / F.dx[refDir] > 0.5) q[d] = 1;
         if (q[0] * q[1] * q[2] == 1) return false;
         for (int d = 0; d < 3; ++d) { r[d] = q[d]; tot[d] = prev[d] * r[d] * mmc[d]; }
@@ -213,6 +222,7 @@ bool PressureSolver::build_coarser(int depth)
     F.hasCoarser = true;
 
     std::unique_ptr<Level> C(new Level);
+    C->active[2] = F.active[2];
     C->alpha = F.alpha;
     C->beta = F.beta;
     std::vector<IBox> cb;
@@ -224,7 +234,7 @@ bool PressureSolver::build_coarser(int depth)
     if (hasCF_) C->define_cf(dxCrse_);  // CFRegion::coarsen + the AMR coarser level's spacing (Factory.cpp:596-600)
     // coarse metrics: fill_MGfields, MappedAMRPoissonOpFactory.cpp:1164-1234
     for (int pi = 0; pi < C->npatches(); ++pi)
-        for (int d = 0; d < 3; ++d)
+        for (int d = 0; d < nd; ++d)
             launch_avg_face(st_, C->dev, F.dev, pi, C->hpatches[pi].n, C->dev.jg[d], F.dev.jg[d], d, r);
     launch_avg_harmonic(st_, C->dev, F.dev, C->dev.jinv, F.dev.jinv, r);
     launch_lapdiag(st_, C->dev);
@@ -335,7 +345,7 @@ bool PressureSolver::fused_relax(int d, int iters) const
 {
     const Level& L = *lev[d];
     return prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0 && L.ncf == 0 &&
-           !hasCF_;
+           !hasCF_ && L.active[2];
 }
 
 void PressureSolver::relax(int d, double* e, const double* res, int iters, bool e_zero, const double* e_shift)
@@ -416,7 +426,7 @@ void PressureSolver::residual_i(int d, double* out, double* phi, const double* r
     Level& L = *lev[d];
     L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
     if (profiling_ && d == 0) prof_begin(1);
-    if (L.valid_cells_global >= march_min_cells_) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, rhs, 0);
+    if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, rhs, 0);
     else launch_op_ortho(st_, L.dev, out, phi, rhs, 0);
     if (profiling_ && d == 0) prof_end(1);
 }
@@ -425,7 +435,7 @@ void PressureSolver::apply_op_i(int d, double* out, double* phi)
 {
     Level& L = *lev[d];
     L.exchange(phi, st_);
-    if (L.valid_cells_global >= march_min_cells_) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, nullptr, 1);
+    if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, nullptr, 1);
     else launch_op_ortho(st_, L.dev, out, phi, nullptr, 1);
 }
 
@@ -451,7 +461,7 @@ void PressureSolver::restrict_residual(int d, double* resCoarse, double* phiFine
 {
     // restrictResidual, MappedAMRPoissonOp.cpp:1281-1304
     Level& F = *lev[d];
-    if (F.valid_cells_global >= march_min_cells_) {
+    if (F.valid_cells_global >= march_min_cells_ && F.active[2]) {
         // large level: residual and J-weighted average in one marching pass, the fine residual is never stored
         F.cf_homog(phiFine, st_);
         F.exchange(phiFine, st_);

@@ -26,6 +26,7 @@ struct SolverParams {
     int num_smooth_down = 2, num_smooth_up = 2, num_smooth_bottom = 2, num_smooth_precond = 2;
     int numMG = 1, maxDepth = -1, precondMode = PRECOND_DIAG_RELAX, relaxMode = RELAX_LEVEL_GSRB;
     int verbosity = 0;
+    int spaceDim = 3;  // 2: the reference built with CH_SPACEDIM = 2 (boxes one cell thick in z, which is inactive)
     int bottom_imax = 80, bottom_numRestarts = 5, bottom_normType = 2, bottom_verbosity = 0;
     double bottom_eps = 1e-6, bottom_reps = 1e-12, bottom_hang = 1e-15, bottom_small = 1e-30;
 };

