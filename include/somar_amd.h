@@ -221,6 +221,10 @@ int somar_amr_vcycle(somar_amr_t* a, int l_max, int l_base);
 #define SOMAR_COMM_ID_BYTES 128
 int somar_comm_unique_id(unsigned char* id128);
 int somar_comm_create(void** comm, const unsigned char* id128, int rank, int nranks, int device);
+/* host-staged transport over a POSIX shared-memory segment `name` (single node; every rank passes the same name,
+ * rank 0 creates it): a way to run the sharded path where RCCL cannot be used -- several ranks on ONE GPU of a
+ * development box -- with the same message plans.  Synchronous; not for production. */
+int somar_comm_create_shm(void** comm, const char* name, int rank, int nranks, long long outbox_bytes);
 int somar_comm_destroy(void* comm);
 
 #ifdef __cplusplus

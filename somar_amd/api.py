@@ -107,6 +107,7 @@ _SIGS = {
     "somar_amr_vcycle": [_H, C.c_int, C.c_int],
     "somar_comm_unique_id": [C.POINTER(C.c_ubyte)],
     "somar_comm_create": [C.POINTER(_H), C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int],
+    "somar_comm_create_shm": [C.POINTER(_H), C.c_char_p, C.c_int, C.c_int, C.c_longlong],
     "somar_comm_destroy": [_H],
 }
 EXPORTS = sorted(list(_SIGS) + ["somar_last_error"])
@@ -488,6 +489,12 @@ def comm_create(id_bytes, rank, nranks, device):
     h = _H()
     buf = (C.c_ubyte * COMM_ID_BYTES)(*id_bytes)
     _ck(lib().somar_comm_create(C.byref(h), buf, rank, nranks, device))
+    return h
+
+
+def comm_create_shm(name, rank, nranks, outbox_bytes=64 << 20):
+    h = _H()
+    _ck(lib().somar_comm_create_shm(C.byref(h), name.encode(), rank, nranks, outbox_bytes))
     return h
 
 

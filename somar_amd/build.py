@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsomar_amd.so")
-SOURCES = ["kernels.hip", "gsrb_fused.hip", "resid_march.hip", "projection.hip", "line_gsrb.hip", "amr_kernels.hip", "level.cpp", "solver.cpp", "amr.cpp", "comm_rccl.cpp", "capi.cpp"]
+SOURCES = ["kernels.hip", "gsrb_fused.hip", "resid_march.hip", "projection.hip", "line_gsrb.hip", "amr_kernels.hip", "level.cpp", "solver.cpp", "amr.cpp", "comm_rccl.cpp", "comm_shm.cpp", "capi.cpp"]
 HEADERS = ["common.h", "kernels.h", "level.h", "solver.h", "amr.h", os.path.join("..", "..", "include", "somar_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -38,7 +38,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl", "-lrt"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -202,7 +202,7 @@ void AMRSolver::finalize()
     }
     links_.resize(n);
     for (int l = 1; l < n; ++l) build_link(l);
-    sync();
+    SOMAR_HIP(hipDeviceSynchronize());  // tables were uploaded with plain hipMemcpy (null stream)
     finalized_ = true;
 }
 

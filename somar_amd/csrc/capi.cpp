@@ -9,6 +9,7 @@
 namespace somar {
 void rccl_unique_id(unsigned char* id128);
 Comm* rccl_create(const unsigned char* id128, int rank, int nranks, int device);
+Comm* shm_create(const char* name, int rank, int nranks, size_t outbox_bytes);
 }  // namespace somar
 
 using namespace somar;
@@ -741,6 +742,14 @@ int somar_comm_create(void** comm, const unsigned char* id128, int rank, int nra
 {
     API_BEGIN
     *comm = rccl_create(id128, rank, nranks, device);
+    API_END
+}
+
+int somar_comm_create_shm(void** comm, const char* name, int rank, int nranks, long long outbox_bytes)
+{
+    API_BEGIN
+    SOMAR_CHECK(comm && name && outbox_bytes > 0, "null/empty argument");
+    *comm = shm_create(name, rank, nranks, (size_t)outbox_bytes);
     API_END
 }
 

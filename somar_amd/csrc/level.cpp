@@ -171,6 +171,7 @@ void Level::define_cf(const double dxCrse[3])
     }
     hipFree(d_cf);
     d_cf = to_device(hcf);
+    SOMAR_HIP(hipDeviceSynchronize());
     ncf = (int)hcf.size();
     for (int d = 0; d < 3; ++d) {
         const double Df = dx[d], Dc = dxCrse[d];
@@ -374,6 +375,9 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     dev.patches = d_patches;
     dev.npatches = (int)hpatches.size();
     refresh_params();
+    // the tables above went up with plain hipMemcpy (null stream); the solver's stream is non-blocking and
+    // would not wait for them
+    SOMAR_HIP(hipDeviceSynchronize());
 }
 
 void Level::refresh_params()
@@ -398,6 +402,7 @@ double* Level::alloc_field() const
     const long long n = field_elems > 0 ? field_elems : 1;
     SOMAR_HIP(hipMalloc(&f, n * sizeof(double)));
     SOMAR_HIP(hipMemset(f, 0, n * sizeof(double)));
+    SOMAR_HIP(hipDeviceSynchronize());  // null-stream memset vs the solver's non-blocking stream
     return f;
 }
 void Level::free_field(double* f) { hipFree(f); }

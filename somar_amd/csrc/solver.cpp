@@ -16,6 +16,7 @@ PressureSolver::PressureSolver(Comm* comm, hipStream_t shared) : comm_(comm ? co
     else SOMAR_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
     SOMAR_HIP(hipMalloc(&d_scalars, NSLOTS * sizeof(double)));
     SOMAR_HIP(hipMemset(d_scalars, 0, NSLOTS * sizeof(double)));
+    SOMAR_HIP(hipDeviceSynchronize());
     SOMAR_HIP(hipHostMalloc(&h_scalars, NSLOTS * sizeof(double)));
     // levels smaller than this use the two-pass colour kernel (launch-latency bound anyway);
     // SOMAR_FUSED_MIN_CELLS=0 forces the fused sweep everywhere (tests), a huge value disables it.
