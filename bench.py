@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=N_FINE, help="fine grid size per direction (512 = BASELINE C2)")
+    ap.add_argument("--n", "--size", dest="n", type=int, default=N_FINE, help="fine grid size per direction (512 = BASELINE C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -98,16 +98,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    # SOMAR_BENCH_COMM=shm: rehearsal of the N > 1 path on a box with ONE GPU (all ranks on device 0, host-staged
+    # shared-memory transport, csrc/comm_shm.cpp).  Not a performance mode; the driver's runs use RCCL.
+    use_shm = os.environ.get("SOMAR_BENCH_COMM") == "shm"
+    torch.cuda.set_device(0 if use_shm else local_rank)
     comm = None
     dist = None
     if world > 1:
         import torch.distributed as dist
         # control plane only (id broadcast, barrier, max over ranks); the data path is RCCL inside the library
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        ids = [api.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        comm = api.comm_create(ids[0], rank, world, local_rank)
+        if use_shm:
+            names = ["/somar_bench_%d" % os.getpid() if rank == 0 else None]
+            dist.broadcast_object_list(names, src=0)
+            comm = api.comm_create_shm(names[0], rank, world, 256 << 20)
+        else:
+            ids = [api.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = api.comm_create(ids[0], rank, world, local_rank)
 
     n = args.n
     L = (1.0, 1.0, 1.0)
