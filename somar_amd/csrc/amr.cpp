@@ -32,106 +32,6 @@ static bool contains(const IBox& b, const int iv[3])
     return true;
 }
 
-// ------------------------------------------------------------------------------------
-// Copier between two layouts
-// ------------------------------------------------------------------------------------
-// Pure host logic.  Items carry GLOBAL box indices; every rank enumerates (dst box, src box, shift) in the
-// same order, so the i-th item of a send message is the i-th item of the matching receive message.
-ExchangePlan build_copy_plan(const IBox& domain, const bool periodic[3], const std::vector<IBox>& srcBoxes,
-                             const std::vector<int>& srcOwner, const std::vector<IBox>& dstBoxes,
-                             const std::vector<int>& dstOwner, const int ghost[3], int myrank)
-{
-    ExchangePlan plan;
-    const auto shifts = periodic_shifts(domain, periodic);
-    struct Remote { int peer; CopyItem it; };
-    std::vector<Remote> sends, recvs;
-    for (size_t di = 0; di < dstBoxes.size(); ++di) {
-        const IBox gbox = dstBoxes[di].grow(ghost);
-        for (size_t si = 0; si < srcBoxes.size(); ++si) {
-            const bool dl = dstOwner[di] == myrank, sl = srcOwner[si] == myrank;
-            if (!dl && !sl) continue;
-            for (const auto& sh : shifts) {
-                const IBox r = gbox & srcBoxes[si].shift(sh.data());
-                if (r.empty()) continue;
-                CopyItem it;
-                std::memset(&it, 0, sizeof(it));
-                it.src_patch = (int)si;
-                it.dst_patch = (int)di;
-                for (int d = 0; d < 3; ++d) {
-                    it.n[d] = r.size(d);
-                    it.dst_lo[d] = r.lo[d] - dstBoxes[di].lo[d];
-                    it.src_lo[d] = r.lo[d] - sh[d] - srcBoxes[si].lo[d];
-                }
-                if (dl && sl) plan.local.push_back(it);
-                else if (sl) sends.push_back({dstOwner[di], it});
-                else recvs.push_back({srcOwner[si], it});
-            }
-        }
-    }
-    for (auto& r : sends) plan.peers.push_back(r.peer);
-    for (auto& r : recvs) plan.peers.push_back(r.peer);
-    std::sort(plan.peers.begin(), plan.peers.end());
-    plan.peers.erase(std::unique(plan.peers.begin(), plan.peers.end()), plan.peers.end());
-    for (int q : plan.peers) {
-        plan.soff.push_back(plan.send_total);
-        for (auto& r : sends)
-            if (r.peer == q) {
-                plan.send_items.push_back(r.it);
-                plan.send_itemoff.push_back(plan.send_total);
-                plan.send_total += (long long)r.it.n[0] * r.it.n[1] * r.it.n[2];
-            }
-        plan.scount.push_back(plan.send_total - plan.soff.back());
-        plan.roff.push_back(plan.recv_total);
-        for (auto& r : recvs)
-            if (r.peer == q) {
-                plan.recv_items.push_back(r.it);
-                plan.recv_itemoff.push_back(plan.recv_total);
-                plan.recv_total += (long long)r.it.n[0] * r.it.n[1] * r.it.n[2];
-            }
-        plan.rcount.push_back(plan.recv_total - plan.roff.back());
-    }
-    return plan;
-}
-
-Copier::~Copier()
-{
-    hipFree(d_local); hipFree(d_send); hipFree(d_recv); hipFree(d_soff); hipFree(d_roff); hipFree(d_sbuf); hipFree(d_rbuf);
-}
-
-void Copier::define(const IBox& domain, const bool periodic[3], const Level& src, const Level& dst, const int ghost[3],
-                    Comm* comm)
-{
-    src_ = &src;
-    dst_ = &dst;
-    comm_ = comm;
-    for (int d = 0; d < 3; ++d) SOMAR_CHECK(ghost[d] <= FRAME, "copier ghost wider than the device frame");
-    plan = build_copy_plan(domain, periodic, src.boxes, src.owner, dst.boxes, dst.owner, ghost, comm ? comm->rank : 0);
-    std::vector<int> sp(src.boxes.size(), -1), dp(dst.boxes.size(), -1);
-    for (int pi = 0; pi < (int)src.local.size(); ++pi) sp[src.local[pi]] = pi;
-    for (int pi = 0; pi < (int)dst.local.size(); ++pi) dp[dst.local[pi]] = pi;
-    for (CopyItem& it : plan.local) { it.src_patch = sp[it.src_patch]; it.dst_patch = dp[it.dst_patch]; }
-    for (CopyItem& it : plan.send_items) it.src_patch = sp[it.src_patch];
-    for (CopyItem& it : plan.recv_items) it.dst_patch = dp[it.dst_patch];
-    d_local = to_device(plan.local);
-    d_send = to_device(plan.send_items);
-    d_recv = to_device(plan.recv_items);
-    d_soff = to_device(plan.send_itemoff);
-    d_roff = to_device(plan.recv_itemoff);
-    if (plan.send_total) SOMAR_HIP(hipMalloc(&d_sbuf, plan.send_total * sizeof(double)));
-    if (plan.recv_total) SOMAR_HIP(hipMalloc(&d_rbuf, plan.recv_total * sizeof(double)));
-}
-
-void Copier::run(const double* s, double* d, hipStream_t st) const
-{
-    const bool remote = !plan.peers.empty();
-    if (remote) {
-        launch_pack(st, src_->dev, d_send, d_soff, (int)plan.send_items.size(), const_cast<double*>(s), d_sbuf, true);
-        comm_->neighbor_exchange(d_sbuf, d_rbuf, plan.peers, plan.soff, plan.scount, plan.roff, plan.rcount, st);
-    }
-    launch_copy_items2(st, src_->dev.patches, dst_->dev.patches, d_local, (int)plan.local.size(), s, d);
-    if (remote) launch_pack(st, dst_->dev, d_recv, d_roff, (int)plan.recv_items.size(), d, d_rbuf, false);
-}
-
 AMRLink::~AMRLink()
 {
     Level::free_field(buf);

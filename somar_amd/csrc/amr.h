@@ -68,8 +68,6 @@ struct FillItem {     // a region of one patch
     int pad_;
 };
 
-void launch_copy_items2(hipStream_t st, const PatchDesc* spatches, const PatchDesc* dpatches, const CopyItem* items,
-                        int nitems, const double* src, double* dst);
 void launch_fill_items(hipStream_t st, const PatchDesc* patches, const FillItem* items, int nitems, double* f, double v);
 void launch_cf_slopes(hipStream_t st, const QCoarse* cc, int ncc, const QPoint* pts, const double* buf, double* der,
                       const double dxc[3]);
@@ -83,29 +81,6 @@ void launch_reflux(hipStream_t st, const RefluxCell* cells, int n, const RefluxA
                    const double dxc[3], const double* freg, double* LofPhi);
 
 // ---- host side -------------------------------------------------------------------------------------
-// Copier between two layouts of one index space: valid cells of `src` boxes (and their periodic images) into
-// the cells of grow(dst box, ghost).
-class Copier {
-public:
-    ~Copier();
-    void define(const IBox& domain, const bool periodic[3], const Level& src, const Level& dst, const int ghost[3],
-                Comm* comm);
-    void run(const double* s, double* d, hipStream_t st) const;
-    ExchangePlan plan;
-
-private:
-    const Level* src_ = nullptr;
-    const Level* dst_ = nullptr;
-    Comm* comm_ = nullptr;
-    CopyItem *d_local = nullptr, *d_send = nullptr, *d_recv = nullptr;
-    long long *d_soff = nullptr, *d_roff = nullptr;
-    double *d_sbuf = nullptr, *d_rbuf = nullptr;
-};
-
-ExchangePlan build_copy_plan(const IBox& domain, const bool periodic[3], const std::vector<IBox>& srcBoxes,
-                             const std::vector<int>& srcOwner, const std::vector<IBox>& dstBoxes,
-                             const std::vector<int>& dstOwner, const int ghost[3], int myrank);
-
 // What ties level l (fine) to level l-1 (coarse).
 struct AMRLink {
     int r[3] = {1, 1, 1};

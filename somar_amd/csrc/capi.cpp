@@ -197,8 +197,9 @@ int somar_solver_depth(somar_solver_t* s, int* depth)
 int somar_solver_mg_ref_ratio(somar_solver_t* s, int depth, int* r3)
 {
     API_BEGIN
-    SOMAR_CHECK(depth >= 0 && depth < (int)s->ps->mgRefRatios.size(), "no coarser depth");
-    for (int d = 0; d < 3; ++d) r3[d] = s->ps->mgRefRatios[depth][d];
+    SOMAR_CHECK(depth >= 0 && depth + 1 < s->ps->depth(), "no coarser depth");
+    const std::array<int, 3> r = s->ps->ref_ratio(depth);
+    for (int d = 0; d < 3; ++d) r3[d] = r[d];
     API_END
 }
 

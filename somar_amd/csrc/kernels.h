@@ -63,6 +63,8 @@ void launch_div_mac(hipStream_t st, const LevelDev& L, double* out, const double
 void launch_mac_correct(hipStream_t st, const LevelDev& L, double* const vel[3], const double* phi, double dtScale);
 void launch_cf_homog(hipStream_t st, const CFCell* cells, int n, double* phi, const double c1[3], const double c2[3],
                      const double fac[3]);
+void launch_copy_items2(hipStream_t st, const PatchDesc* spatches, const PatchDesc* dpatches, const CopyItem* items,
+                        int nitems, const double* src, double* dst);
 void launch_fill_hash(hipStream_t st, const LevelDev& L, double* f, unsigned long long seed);
 
 }  // namespace somar

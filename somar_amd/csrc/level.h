@@ -167,4 +167,33 @@ public:
     int npatches() const { return (int)hpatches.size(); }
 };
 
+// Copier between two layouts of one index space: valid cells of `src` boxes (and their periodic images) into
+// the cells of grow(dst box, ghost).  define_allgather: every rank receives EVERY box of `src` (grown by `grow`
+// cells) into a replicated layout `dst` that holds all boxes locally (coarse-level agglomeration).
+class Copier {
+public:
+    ~Copier();
+    void define(const IBox& domain, const bool periodic[3], const Level& src, const Level& dst, const int ghost[3],
+                Comm* comm);
+    void define_allgather(const Level& src, const Level& dst, int grow, Comm* comm);
+    void run(const double* s, double* d, hipStream_t st) const;
+    ExchangePlan plan;
+
+private:
+    void upload_tables();
+    const Level* src_ = nullptr;
+    const Level* dst_ = nullptr;
+    Comm* comm_ = nullptr;
+    CopyItem *d_local = nullptr, *d_send = nullptr, *d_recv = nullptr;
+    long long *d_soff = nullptr, *d_roff = nullptr;
+    double *d_sbuf = nullptr, *d_rbuf = nullptr;
+};
+
+ExchangePlan build_copy_plan(const IBox& domain, const bool periodic[3], const std::vector<IBox>& srcBoxes,
+                             const std::vector<int>& srcOwner, const std::vector<IBox>& dstBoxes,
+                             const std::vector<int>& dstOwner, const int ghost[3], int myrank);
+// every rank gets every box (grown): items carry GLOBAL box indices on both sides
+ExchangePlan build_allgather_plan(const std::vector<IBox>& boxes, const std::vector<int>& owner, int grow, int myrank,
+                                  int nranks);
+
 }  // namespace somar

@@ -26,6 +26,7 @@ PressureSolver::PressureSolver(Comm* comm, hipStream_t shared) : comm_(comm ? co
     // levels up to this many cells sum in the reference's serial order (k_reduce_ordered); tests raise it to
     // make whole solves reproduce the oracle's histories to the last bits
     if (const char* e = getenv("SOMAR_ORDERED_REDUCE_MAX")) ordered_max_cells_ = atoll(e);
+    if (const char* e = getenv("SOMAR_AGGLOM_CELLS")) agglom_cells_ = atoll(e);
 }
 
 PressureSolver::~PressureSolver()
@@ -46,6 +47,8 @@ PressureSolver::~PressureSolver()
         for (hipEvent_t e : p.b) hipEventDestroy(e);
     }
     if (h_scalars) hipHostFree(h_scalars);
+    hipFree(d_agglom_back_);
+    coarse_.reset();
     lev.clear();
     if (st_ && own_stream_) hipStreamDestroy(st_);
 }
@@ -280,7 +283,13 @@ void PressureSolver::finalize()
     launch_lapdiag(st_, lev[0]->dev);
     fill_metric_ghosts(*lev[0]);
     int depth = 1;
-    while (build_coarser(depth)) ++depth;
+    while (build_coarser(depth)) {
+        if (comm_->size > 1 && lev[depth]->valid_cells_global <= agglom_cells_) {
+            build_agglomerated_tail(depth);
+            break;
+        }
+        ++depth;
+    }
     int maxTiles = 1;
     for (auto& L : lev) maxTiles = std::max(maxTiles, L->dev.ntiles);
     SOMAR_HIP(hipMalloc(&d_partials, (size_t)maxTiles * 2 * sizeof(double)));
@@ -304,6 +313,65 @@ void PressureSolver::finalize()
     for (int d = 0; d < D; ++d) probe_null_space(d);
     sync();
     finalized = true;
+}
+
+// The hierarchy from `depth` on, replicated on every rank (see solver.h).  lev[depth] stays as the sharded
+// landing layout of the restriction; its data are allgathered into depth 0 of a communicator-less solver that
+// owns every box and builds the remaining depths itself with the same rules.
+void PressureSolver::build_agglomerated_tail(int depth)
+{
+    Level& T = *lev[depth];
+    SolverParams cp = prm;
+    if (cp.maxDepth >= 0) cp.maxDepth = std::max(0, cp.maxDepth - depth);
+    coarse_.reset(new PressureSolver(nullptr, st_));
+    std::vector<int> own(T.boxes.size(), 0);
+    coarse_->define(T.domain, T.periodic, T.dx, T.bc_type, T.boxes, own, T.alpha, T.beta, cp,
+                    hasCF_ ? dxCrse_ : nullptr);
+    Level& R = *coarse_->lev[0];
+    // metric: faces of a box live at indices 0..n, so take one layer beyond the valid cells
+    Copier metric;
+    metric.define_allgather(T, R, 1, comm_);
+    for (int d = 0; d < prm.spaceDim; ++d) metric.run(T.dev.jg[d], R.dev.jg[d], st_);
+    metric.run(T.dev.jinv, R.dev.jinv, st_);
+    sync();
+    coarse_->finalize();
+    agglom_depth_ = depth;
+    agglom_gather_.define_allgather(T, R, 0, comm_);
+    std::vector<CopyItem> back;
+    for (int pi = 0; pi < T.npatches(); ++pi) {
+        CopyItem it;
+        std::memset(&it, 0, sizeof(it));
+        it.src_patch = T.local[pi];  // replicated layout: patch index = global box index
+        it.dst_patch = pi;
+        for (int d = 0; d < 3; ++d) it.n[d] = T.hpatches[pi].n[d];
+        back.push_back(it);
+    }
+    n_agglom_back_ = (int)back.size();
+    if (n_agglom_back_) {
+        SOMAR_HIP(hipMalloc(&d_agglom_back_, back.size() * sizeof(CopyItem)));
+        SOMAR_HIP(hipMemcpy(d_agglom_back_, back.data(), back.size() * sizeof(CopyItem), hipMemcpyHostToDevice));
+        SOMAR_HIP(hipDeviceSynchronize());
+    }
+}
+
+void PressureSolver::agglom_cycle(double* corr, const double* res, bool corr_zero)
+{
+    Level& T = *lev[agglom_depth_];
+    PressureSolver& C = *coarse_;
+    double* rC = C.work(0);
+    double* cC = C.work(1);
+    agglom_gather_.run(res, rC, st_);
+    if (!corr_zero) agglom_gather_.run(corr, cC, st_);
+    C.bottom_metric = bottom_metric;
+    C.bottom_eps_eff = bottom_eps_eff;
+    C.prm.num_smooth_down = prm.num_smooth_down;
+    C.prm.num_smooth_up = prm.num_smooth_up;
+    C.prm.num_smooth_bottom = prm.num_smooth_bottom;
+    C.prm.numMG = prm.numMG;
+    C.cycle(0, cC, rC, corr_zero);
+    bottom_iters = C.bottom_iters;
+    bottom_exit = C.bottom_exit;
+    launch_copy_items2(st_, C.lev[0]->dev.patches, T.dev.patches, d_agglom_back_, n_agglom_back_, cC, corr);
 }
 
 // ------------------------------------------------------------------------------------
@@ -612,6 +680,10 @@ void PressureSolver::vcycle(double* e, const double* res, bool e_zero) { cycle(0
 // memset and the read.  Only honoured when at least one smoothing sweep will overwrite the whole array.
 void PressureSolver::cycle(int d, double* corr, const double* res, bool corr_zero)
 {
+    if (coarse_ && d == agglom_depth_) {
+        agglom_cycle(corr, res, corr_zero);
+        return;
+    }
     const int D = (int)lev.size();
     if (d == D - 1) {
         if (lev[d]->domain.numPts() == 1) {

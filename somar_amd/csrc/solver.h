@@ -65,8 +65,22 @@ public:
     void solve(bool zeroPhi, bool forceHomogeneous, SolveStats& st);
 
     // ---- pieces, exposed for benchmarks and kernel-level parity tests -----------------------
-    int depth() const { return (int)lev.size(); }
-    Level& level(int d) { return *lev[d]; }
+    // MG depths of the whole hierarchy (the agglomerated tail included)
+    int depth() const { return coarse_ ? agglom_depth_ + coarse_->depth() : (int)lev.size(); }
+    // Coarse-level agglomeration (sharded runs only): from the first depth with at most SOMAR_AGGLOM_CELLS cells
+    // on, EVERY rank holds all boxes and runs the rest of the cycle redundantly -- no halo exchange, no
+    // allreduce and no host round trip per BiCGStab scalar where the work is microseconds and the wire is not.
+    // One allgather of the restricted residual goes down; nothing comes back (every rank already has the
+    // correction).  Same arithmetic, same order (in fact the serial order), so results do not change.
+    int agglom_depth() const { return coarse_ ? agglom_depth_ : -1; }
+    PressureSolver* coarse_solver() { return coarse_.get(); }
+    // depth d of the whole hierarchy; depths inside the agglomerated tail (d > agglom_depth()) are the replicated
+    // solver's, depth == agglom_depth() is the sharded landing layout
+    Level& level(int d) { return (coarse_ && d > agglom_depth_) ? coarse_->level(d - agglom_depth_) : *lev[d]; }
+    std::array<int, 3> ref_ratio(int d) const
+    {
+        return (coarse_ && d >= agglom_depth_) ? coarse_->ref_ratio(d - agglom_depth_) : mgRefRatios.at(d);
+    }
     double* phi() { return f_phi; }
     double* rhs() { return f_rhs; }
     double* work(int which);  // 0 uberResidual 1 uberCorrection 2 bestPhi
@@ -142,6 +156,14 @@ private:
     double* d_scalars = nullptr;  // device scalar slots
     double* h_scalars = nullptr;  // pinned
     bool finalized = false;
+    std::unique_ptr<PressureSolver> coarse_;   // replicated tail of the hierarchy (agglomeration)
+    int agglom_depth_ = -1;
+    long long agglom_cells_ = 262144;
+    Copier agglom_gather_;                      // sharded depth agglom_depth_ -> replicated depth 0 of coarse_
+    CopyItem* d_agglom_back_ = nullptr;         // my boxes of the replicated correction -> sharded layout
+    int n_agglom_back_ = 0;
+    void build_agglomerated_tail(int depth);
+    void agglom_cycle(double* corr, const double* res, bool corr_zero);
     struct Prof { std::vector<hipEvent_t> a, b; int used = 0; };
     Prof prof_[2];
     bool profiling_ = false;

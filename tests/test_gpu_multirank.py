@@ -20,6 +20,10 @@ pytestmark = pytest.mark.gpu
 def _worker(rank, nranks, name, mode, q):
     try:
         os.environ["SOMAR_FUSED_MIN_CELLS"] = "0" if mode == "fused" else "1000000000000"
+        # "fused": coarse depths agglomerated (replicated on both ranks, the default for small levels);
+        # "twopass": every depth stays sharded (halo exchange and allreduce down to the bottom solver)
+        if mode == "twopass":
+            os.environ["SOMAR_AGGLOM_CELLS"] = "0"
         import sys
         here = os.path.dirname(os.path.abspath(__file__))
         sys.path.insert(0, here)
@@ -56,6 +60,7 @@ def _worker(rank, nranks, name, mode, q):
 
         gpu = make_gpu_solver(dom, grids, dx, Mine(Jgup), Mine(Jinv), owner=owner, comm=comm)
         assert gpu.num_local_patches == len(grids) // nranks
+        assert gpu.depth() == amr.mg.depth and gpu.mgRefRatios() == [tuple(r) for r in amr.mg.mgRefRatios]
         phi = so.random_field(grids, 3, (1, 1, 1), dom.box)
         rhs = so.random_field(grids, 4, (0, 0, 0), dom.box)
         upload(gpu, F.F_PHI, phi)
