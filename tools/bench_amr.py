@@ -30,24 +30,18 @@ def boxes_of(lo, hi, bs):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="c3")
-    ap.add_argument("--scale", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--box", type=int, default=128, help="box edge in x,y (z is never split)")
-    args = ap.parse_args()
+def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2):
+    """-> (AMRPressureSolver (finalized), levels' boxes, cells per level, define seconds)"""
     from somar_amd import api as F
-    s = args.scale
-    if args.config == "c3":
+    s = scale
+    if config == "c3":
         n0, nlev = (512 // s, 512 // s, 64 // s), 2
     else:
         n0, nlev = (1024 // s, 1024 // s, 128 // s), 3
     L = (15.0, 3.0, 2.0)
     ratios = [(2, 2, 1)] * (nlev - 1)
     dx0 = tuple(L[d] / n0[d] for d in range(3))
-    bs = (max(args.box // s, 8), max(args.box // s, 8), n0[2])
+    bs = (max(box // s, 8), max(box // s, 8), n0[2])
     levels = [boxes_of((0, 0, 0), tuple(a - 1 for a in n0), bs)]
     n = list(n0)
     frac = 2
@@ -55,13 +49,13 @@ def main():
         n = [n[0] * 2, n[1] * 2, n[2]]
         w = n[0] // frac          # central half, then central quarter (of the refined index space)
         lo_x = (n[0] - w) // 2
-        lo_x -= lo_x % (2 * bs[0]) if lo_x % (2 * bs[0]) else 0
+        lo_x -= lo_x % (2 * bs[0])
         levels.append(boxes_of((lo_x, 0, 0), (lo_x + w - 1, n[1] - 1, n[2] - 1), bs))
         frac *= 2
     gpu = F.AMRPressureSolver()
     p = gpu._p
-    gpu.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 4, 4, 2, p.precond_mode, 1, p.num_mg, p.hang,
-                           p.norm_thresh, 0)
+    gpu.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, pre, post, bottom, p.precond_mode, 1, p.num_mg,
+                           p.hang, p.norm_thresh, 0)
     t0 = time.perf_counter()
     gpu.defineAMR((0, 0, 0), tuple(a - 1 for a in n0), (False, True, False), dx0, ratios, levels)
     cells = []
@@ -75,7 +69,21 @@ def main():
             v.setMetricOrtho(q, ones[0], ones[1], ones[2], np.ones(shp, order="F"))   # Cartesian: J = 1, Jg^aa = 1
         cells.append(tot)
     gpu.finalize()
-    t_def = time.perf_counter() - t0
+    return gpu, levels, cells, time.perf_counter() - t0, dx0, ratios
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c3")
+    ap.add_argument("--scale", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--box", type=int, default=128, help="box edge in x,y (z is never split)")
+    args = ap.parse_args()
+    from somar_amd import api as F
+    s = args.scale
+    gpu, levels, cells, t_def, dx0, ratios = build_hierarchy(args.config, s, args.box)
+    nlev = len(levels)
     for l, v in enumerate(gpu.levels):
         v.fillHash(F.F_RES, 12345 + l)
     for l in range(nlev - 1):
@@ -94,12 +102,6 @@ def main():
         step()
     gpu.levels[0].sync()
     dt = (time.perf_counter() - t0) / args.steps
-    # one full solve from the same rhs: convergence as a size-independent check
-    for v in gpu.levels:
-        v.setVal(F.F_RHS, 0.0)
-    for l, v in enumerate(gpu.levels):
-        v.fillHash(F.F_RHS, 777 + l)
-    st = gpu.solveAMR(nlev - 1, 0) if False else None
     print(json.dumps({"config": args.config, "scale": s, "levels": nlev, "cells_per_level": cells,
                       "boxes_per_level": [len(b) for b in levels], "define_seconds": t_def, "ms_per_amr_vcycle": dt * 1e3,
                       "amr_vcycles_per_s": 1.0 / dt, "mg_depth_per_level": [v.depth() for v in gpu.levels],
