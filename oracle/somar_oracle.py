@@ -588,20 +588,20 @@ class LevelGSRB(Relaxer):
 
 
 class LooseGSRB(LevelGSRB):
-    """LooseGSRB::relax, GSRB.cpp:104-141 (one exchange per sweep; quirk Q8: the
-    extrap copy is taken before the exchange lands -- in the serial oracle the
-    exchange is completed at exchangeEnd, i.e. after the interior sweeps)."""
+    """LooseGSRB::relax, GSRB.cpp:104-141: one exchange per sweep.  exchangeBegin posts the ghost copies before
+    the interior phase and exchangeEnd lands them after it; the copies only carry cells of the box shells
+    (ghost depth 1), which the interior phase does not touch, so landing them up front gives the same data."""
 
     def relax(self, phi, rhs):
         op = self.op
+        exchange(phi, op.domain, op.activeDirs)
         self.fill_ghosts_and_extrapolate(phi)
         for i, g in enumerate(op.grids):
             interior = g.grow([-a for a in op.activeDirs])
             self.full_stencil_gsrb(phi[i], rhs[i], interior, i, 0)
             self.full_stencil_gsrb(phi[i], rhs[i], interior, i, 1)
-        # exchangeBegin posted the sends BEFORE the interior sweeps (GSRB.cpp:123):
-        # the ghost data that arrives is the pre-sweep boundary data.
-        raise NotImplementedError("LooseGSRB needs a snapshot exchange; not used by default (relax_mode 1)")
+        self.boundary_gsrb(phi, rhs, 0, True)
+        self.boundary_gsrb(phi, rhs, 1, True)
 
 
 class LineGSRB(Relaxer):
@@ -661,6 +661,8 @@ class PoissonOp:
             self.relaxer = Jacobi(self)
         elif relaxMode == RELAX_LEVEL_GSRB:
             self.relaxer = LevelGSRB(self)
+        elif relaxMode == RELAX_LOOSE_GSRB:
+            self.relaxer = LooseGSRB(self)
         elif relaxMode == RELAX_LINE_GSRB:
             self.relaxer = LineGSRB(self)
         else:

@@ -17,7 +17,8 @@ struct LevelDev {
     StencilParams P;
 };
 
-void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color);
+// loose: 0 LevelGSRB pass; 1 / 2: interior / box-shell phase of LooseGSRB (see k_gsrb_ortho)
+void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color, int loose = 0);
 // one full red+black sweep, phi_in -> phi_out (gsrb_fused.hip); needs phi_in ghosts 2 deep and
 // rhs / Jg / Jinv ghosts 1 deep wherever a neighbouring box or periodic image exists
 // in_mode 0: plain; 1: phi_in is taken to be all zeros and is not read; 2: phi_in is read as

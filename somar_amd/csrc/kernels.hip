@@ -84,8 +84,11 @@ __global__ __launch_bounds__(512) void k_gsrb_ortho(const Tile* __restrict__ til
                                                     const double* __restrict__ jgz,
                                                     const double* __restrict__ jinv,
                                                     const double* __restrict__ lapd,
-                                                    StencilParams P, int color)
+                                                    StencilParams P, int color, int loose)
 {
+    // loose 0: LevelGSRB -- every cell of the colour; boundary form where the cell touches a DOMAIN face.
+    // loose 1: LooseGSRB's interior phase -- cells at least one cell inside their BOX, interior form.
+    // loose 2: LooseGSRB's boundaryGSRB(doAll) -- the one-cell shell of every box, boundary form (GSRB.cpp:104-141)
     const Tile t = tiles[blockIdx.x];
     const PatchDesc p = patches[t.patch];
     const int lj = t.j0 + threadIdx.y;
@@ -104,15 +107,21 @@ __global__ __launch_bounds__(512) void k_gsrb_ortho(const Tile* __restrict__ til
         if (li >= p.n[0]) continue;
         const int gi = p.lo[0] + li;
         const long long c = cidx(p, li, lj, lk);
-        const bool onb = bj || (gk == P.dom_lo[2]) || (gk == P.dom_hi[2]) || (gi == P.dom_lo[0]) ||
-                         (gi == P.dom_hi[0]);
+        bool onb = bj || (gk == P.dom_lo[2]) || (gk == P.dom_hi[2]) || (gi == P.dom_lo[0]) || (gi == P.dom_hi[0]);
+        bool onb2d = bj || (gi == P.dom_lo[0]) || (gi == P.dom_hi[0]);
+        if (loose) {
+            const bool shell2 = (li == 0) || (li == p.n[0] - 1) || (lj == 0) || (lj == p.n[1] - 1);
+            const bool shell = shell2 || (P.active[2] && ((lk == 0) || (lk == p.n[2] - 1)));
+            if ((loose == 1) == shell) continue;  // phase 1 skips the shell, phase 2 skips the interior
+            onb = shell;
+            onb2d = shell2;
+        }
         const double Ji = jinv[c];
         double out;
         if (!P.active[2]) {
             // SpaceDim == 2 build of the reference: GSRBITER2DORTHO / GSRBBOUNDARYITER2DORTHO
             // (GSRBF.ChF:440-540, 1254-1356) -- note the different association of beta, Jinv and the side order
-            const bool onb2 = bj || (gi == P.dom_lo[0]) || (gi == P.dom_hi[0]);
-            if (!onb2) {
+            if (!onb2d) {
                 const double JDxx = xxScale * (jgx[c + 1] * phi[c + 1] + jgx[c] * phi[c - 1]);
                 const double JDyy = yyScale * (jgy[c + sj] * phi[c + sj] + jgy[c] * phi[c - sj]);
                 const double lphi = P.beta * (JDxx + JDyy) * Ji;
@@ -635,11 +644,11 @@ static inline int flat_grid(long long n)
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
-void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color)
+void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color, int loose)
 {
     if (L.ntiles == 0) return;
     hipLaunchKernelGGL(k_gsrb_ortho, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, phi, rhs,
-                       L.jg[0], L.jg[1], L.jg[2], L.jinv, L.lapdiag, L.P, color);
+                       L.jg[0], L.jg[1], L.jg[2], L.jinv, L.lapdiag, L.P, color, loose);
 }
 void launch_op_ortho(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* rhs, int mode)
 {

@@ -141,8 +141,9 @@ void PressureSolver::define(const IBox& domain, const bool periodic[3], const do
         SOMAR_CHECK(prm.relaxMode != RELAX_LINE_GSRB && prm.precondMode != PRECOND_DIAG_LINE_RELAX,
                     "line relaxation on a level with coarse-fine boundaries is not implemented");
     }
-    SOMAR_CHECK(prm.relaxMode == RELAX_LEVEL_GSRB || prm.relaxMode == RELAX_JACOBI || prm.relaxMode == RELAX_LINE_GSRB,
-                "only LevelGSRB (relax_mode 1), LineGSRB (3) and Jacobi (0) are implemented");
+    SOMAR_CHECK(prm.relaxMode == RELAX_LEVEL_GSRB || prm.relaxMode == RELAX_JACOBI || prm.relaxMode == RELAX_LINE_GSRB ||
+                    prm.relaxMode == RELAX_LOOSE_GSRB,
+                "relax_mode must be 0 (Jacobi), 1 (LevelGSRB), 2 (LooseGSRB) or 3 (LineGSRB)");
     SOMAR_CHECK(prm.precondMode == PRECOND_DIAG_RELAX || prm.precondMode == PRECOND_NONE ||
                     prm.precondMode == PRECOND_DIAG_LINE_RELAX,
                 "bad precondMode");
@@ -457,6 +458,16 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
                 launch_gsrb_ortho(st_, L.dev, e, res, pass);
                 if (profiling_ && d == 0) prof_end(0);
             }
+        } else if (prm.relaxMode == RELAX_LOOSE_GSRB) {
+            // LooseGSRB::relax, GSRB.cpp:104-141: ONE exchange per sweep; red+black on the cells strictly inside
+            // each box, then red+black on the box shells.  (The exchange "begun" before the interior phase only
+            // carries shell cells, which that phase does not touch: completing it first changes nothing.)
+            L.cf_homog(e, st_);
+            L.exchange(e, st_);
+            launch_gsrb_ortho(st_, L.dev, e, res, 0, 1);
+            launch_gsrb_ortho(st_, L.dev, e, res, 1, 1);
+            launch_gsrb_ortho(st_, L.dev, e, res, 0, 2);
+            launch_gsrb_ortho(st_, L.dev, e, res, 1, 2);
         } else if (prm.relaxMode == RELAX_LINE_GSRB) {
             line_relax(d, e, res);
         } else {
