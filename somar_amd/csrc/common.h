@@ -46,7 +46,7 @@ struct PatchDesc {
     int lo[3];  // global index of the valid low corner
     int n[3];   // valid cells per direction
     int pj;     // j pitch (elements), even => 16-byte aligned rows
-    int pad_;
+    int cf;     // bit (2*dir + side): that whole face of the box is a coarse-fine boundary (levels on a coarser one)
     long long pk;   // k pitch
     long long off;  // offset of local cell (0,0,0)
 };
@@ -86,6 +86,7 @@ struct StencilParams {
     int periodic[3];
     double dx[3];
     double alpha, beta;
+    double cf_c1[3], cf_c2[3];  // homogeneous CF interpolation: ghost = c1 * first valid + c2 * second valid
 };
 
 }  // namespace somar

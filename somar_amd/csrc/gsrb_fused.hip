@@ -143,6 +143,10 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
                    (row >= 1) && (row <= FR_J - 2);
         if ((g < P.dom_lo[0] && P.neum[0][0]) || (g > P.dom_hi[0] && P.neum[0][1])) cmp = false;
         if ((gj < P.dom_lo[1] && P.neum[1][0]) || (gj > P.dom_hi[1] && P.neum[1][1])) cmp = false;
+        // beyond a coarse-fine face of this box there is no cell of this level either: the ghost there is an
+        // interpolated value (filled before the sweep for the red phase, recomputed below for the black one)
+        if ((l < 0 && (p.cf & 1)) || (l >= p.n[0] && (p.cf & 2))) cmp = false;
+        if ((lj < 0 && (p.cf & 4)) || (lj >= p.n[1] && (p.cf & 8))) cmp = false;
         comp_ij[s] = cmp;
         out_ij[s] = (l >= 0) && (l < p.n[0]) && (lj >= 0) && (lj < p.n[1]) && (r >= 2) && (r < FR_I - 2) &&
                     (row >= 2) && (row < FR_J - 2);
@@ -191,6 +195,7 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         {
             bool comp = comp_ij[c] && (k >= -1) && (k <= p.n[2]);
             if ((gk < P.dom_lo[2] && P.neum[2][0]) || (gk > P.dom_hi[2] && P.neum[2][1])) comp = false;
+            if ((k < 0 && (p.cf & 16)) || (k >= p.n[2] && (p.cf & 32))) comp = false;
             if (comp) {
                 const double pxl = S[slot][row][rc - 1], pxh = S[slot][row][rc + 1];
                 const double pyl = S[slot][row - 1][rc], pyh = S[slot][row + 1][rc];
@@ -209,10 +214,25 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
                 const int sb = ((kb % 3) + 3) % 3;
                 double black = 0.0;
                 if (out_ij[c]) {
-                    const double pxl = S[sb][row][rc - 1], pxh = S[sb][row][rc + 1];
-                    const double pyl = S[sb][row - 1][rc], pyh = S[sb][row + 1][rc];
+                    double pxl = S[sb][row][rc - 1], pxh = S[sb][row][rc + 1];
+                    double pyl = S[sb][row - 1][rc], pyh = S[sb][row + 1][rc];
+                    double pzl = redPrev2, pzh = red;
+                    if (p.cf) {
+                        // homogeneousCFInterp between the colours (LevelGSRB refills the CF ghosts before the
+                        // black pass): ghost = c1 * first valid cell (this black cell, old value) + c2 * second
+                        // valid cell (its opposite neighbour, a NEW red value)
+                        const double own = S[sb][row][rc];
+                        const int l = li + c;
+                        const double xl = pxl, xh = pxh, yl = pyl, yh = pyh, zl = pzl, zh = pzh;
+                        if ((p.cf & 1) && l == 0) pxl = P.cf_c1[0] * own + P.cf_c2[0] * xh;
+                        if ((p.cf & 2) && l == p.n[0] - 1) pxh = P.cf_c1[0] * own + P.cf_c2[0] * xl;
+                        if ((p.cf & 4) && lj == 0) pyl = P.cf_c1[1] * own + P.cf_c2[1] * yh;
+                        if ((p.cf & 8) && lj == p.n[1] - 1) pyh = P.cf_c1[1] * own + P.cf_c2[1] * yl;
+                        if ((p.cf & 16) && kb == 0) pzl = P.cf_c1[2] * own + P.cf_c2[2] * zh;
+                        if ((p.cf & 32) && kb == p.n[2] - 1) pzh = P.cf_c1[2] * own + P.cf_c2[2] * zl;
+                    }
                     black = gsrb_point(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, p.lo[2] + kb, pxl, pxh, pyl, pyh,
-                                       redPrev2, red, b_gxl, b_gxh, b_gyl, b_gyh, b_gzl, pick(Gzc, c), b_ji, b_rhs);
+                                       pzl, pzh, b_gxl, b_gxh, b_gyl, b_gyh, b_gzl, pick(Gzc, c), b_ji, b_rhs);
                 }
                 // plane k-1: column c is the new black, column c^1 is red(k-1) (= redPrev1)
                 double* dst = phi_out + base + sk * kb;

@@ -137,6 +137,13 @@ std::vector<IBox> uncovered(const IBox& region, const std::vector<IBox>& boxes, 
     return cur;
 }
 
+static bool contains_cell(const IBox& b, const int c[3])
+{
+    for (int d = 0; d < 3; ++d)
+        if (c[d] < b.lo[d] || c[d] > b.hi[d]) return false;
+    return true;
+}
+
 // CFRegion of this level + homogeneousCFInterp weights (HomogeneousCFInterp.cpp:56, 72-73)
 void Level::define_cf(const double dxCrse[3])
 {
@@ -171,7 +178,6 @@ void Level::define_cf(const double dxCrse[3])
     }
     hipFree(d_cf);
     d_cf = to_device(hcf);
-    SOMAR_HIP(hipDeviceSynchronize());
     ncf = (int)hcf.size();
     for (int d = 0; d < 3; ++d) {
         const double Df = dx[d], Dc = dxCrse[d];
@@ -179,6 +185,103 @@ void Level::define_cf(const double dxCrse[3])
         cf_c2[d] = -(Dc - Df) / (Dc + 3.0 * Df);
         cf_fac[d] = 1.0 - 2.0 * Df / (Df + Dc);
     }
+
+    // ---- what the fused sweep needs (see level.h) ----------------------------------------------------
+    cf_fusable = true;
+    hcfx = hcf;
+    const auto shifts = periodic_shifts(domain, periodic);
+    std::vector<IBox> near;  // box images around the patch at hand
+    auto covered1 = [&](const int c[3]) {
+        for (const IBox& b : near)
+            if (contains_cell(b, c)) return true;
+        return false;
+    };
+    for (int pi = 0; pi < npatches(); ++pi) {
+        PatchDesc& p = hpatches[pi];
+        const IBox valid = boxes[local[pi]];
+        const long long st[3] = {1, p.pj, p.pk};
+        p.cf = 0;
+        near.clear();
+        {
+            const int g2[3] = {2, 2, 2};
+            const IBox around = valid.grow(g2);
+            for (const IBox& b : boxes)
+                for (const auto& sh : shifts) {
+                    const IBox img = b.shift(sh.data());
+                    if (!(img & around).empty()) near.push_back(img);
+                }
+        }
+        for (int d = 0; d < 3; ++d) {
+            if (!active[d]) continue;
+            for (int s = 0; s < 2; ++s) {
+                IBox gb = valid;
+                if (s == 0) { gb.lo[d] = gb.hi[d] = valid.lo[d] - 1; }
+                else { gb.lo[d] = gb.hi[d] = valid.hi[d] + 1; }
+                gb = gb & dom;
+                if (gb.empty()) continue;
+                long long nunc = 0;
+                for (const IBox& u : uncovered(gb, boxes, domain, periodic)) nunc += u.numPts();
+                if (nunc == gb.numPts()) p.cf |= 1 << (2 * d + s);
+                else if (nunc != 0) cf_fusable = false;  // a face that is only partly coarse-fine
+                if (nunc != 0 && p.n[d] < 2) cf_fusable = false;
+            }
+        }
+        // edge ghosts: two coordinates one cell outside the box
+        for (int d1 = 0; d1 < 3 && cf_fusable; ++d1)
+            for (int d2 = d1 + 1; d2 < 3 && cf_fusable; ++d2) {
+                if (!active[d1] || !active[d2]) continue;
+                const int d3 = 3 - d1 - d2;
+                for (int s1 = 0; s1 < 2; ++s1)
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        for (int t = valid.lo[d3]; t <= valid.hi[d3] && cf_fusable; ++t) {
+                            int g[3];
+                            g[d1] = s1 ? valid.hi[d1] + 1 : valid.lo[d1] - 1;
+                            g[d2] = s2 ? valid.hi[d2] + 1 : valid.lo[d2] - 1;
+                            g[d3] = t;
+                            if (!contains_cell(dom, g) || covered1(g)) continue;
+                            // candidates: directions along which the cell next to g (towards the box) is a real
+                            // cell of a neighbouring box, which then owns g as one of ITS face ghosts
+                            int ncand = 0, cd = -1, cs = 0;
+                            const int dd[2] = {d1, d2}, ss[2] = {s1, s2};
+                            for (int q = 0; q < 2; ++q) {
+                                int h[3] = {g[0], g[1], g[2]};
+                                h[dd[q]] += ss[q] ? -1 : 1;
+                                if (!covered1(h)) continue;
+                                int h2[3] = {h[0], h[1], h[2]};
+                                h2[dd[q]] += ss[q] ? -1 : 1;
+                                if (!covered1(h2)) { cf_fusable = false; break; }  // neighbour box one cell wide
+                                ++ncand;
+                                cd = dd[q];
+                                cs = ss[q];
+                            }
+                            if (ncand == 2) cf_fusable = false;  // re-entrant corner of the refined region
+                            if (ncand != 1 || !cf_fusable) continue;
+                            CFCell c;
+                            c.off = p.off + (g[0] - p.lo[0]) + st[1] * (g[1] - p.lo[1]) + st[2] * (g[2] - p.lo[2]);
+                            c.stride = (int)(cs ? st[cd] : -st[cd]);
+                            c.dir = cd;
+                            hcfx.push_back(c);
+                        }
+            }
+    }
+    if (!cf_fusable) hcfx = hcf;
+    for (int d = 0; d < 3; ++d) {
+        cf_faces[d].reset();
+        if (cf_fusable && ncf > 0 && active[d]) {
+            int gh[3];
+            for (int e = 0; e < 3; ++e) gh[e] = active[e] ? FRAME : 0;
+            cf_faces[d].reset(new Copier);
+            cf_faces[d]->define_faces(domain, periodic, *this, d, gh, comm);
+        }
+    }
+    hipFree(d_cfx);
+    d_cfx = to_device(hcfx);
+    ncfx = (int)hcfx.size();
+    hipFree(d_patches);
+    d_patches = to_device(hpatches);  // the flag bits
+    dev.patches = d_patches;
+    refresh_params();
+    SOMAR_HIP(hipDeviceSynchronize());
 }
 
 // ------------------------------------------------------------------------------------
@@ -261,6 +364,34 @@ void Copier::define(const IBox& domain, const bool periodic[3], const Level& src
     for (CopyItem& it : plan.local) { it.src_patch = sp[it.src_patch]; it.dst_patch = dp[it.dst_patch]; }
     for (CopyItem& it : plan.send_items) it.src_patch = sp[it.src_patch];
     for (CopyItem& it : plan.recv_items) it.dst_patch = dp[it.dst_patch];
+    upload_tables();
+}
+
+// Face-centred data of direction `dir`: the source of box b is faces(b, dir) -- the valid cells plus the layer
+// that holds the box's HIGH face -- so a neighbour's frame also receives the coefficient of a face that no box
+// owns as a low face (a box face on a coarse-fine boundary).  Run it BEFORE the ordinary exchange: where a real
+// low-face owner exists its value then overwrites this one.
+void Copier::define_faces(const IBox& domain, const bool periodic[3], const Level& L, int dir, const int ghost[3],
+                          Comm* comm)
+{
+    src_ = &L;
+    dst_ = &L;
+    comm_ = comm;
+    std::vector<IBox> fb = L.boxes;
+    for (IBox& b : fb) b.hi[dir] += 1;
+    plan = build_copy_plan(domain, periodic, fb, L.owner, L.boxes, L.owner, ghost, comm ? comm->rank : 0);
+    std::vector<int> lp(L.boxes.size(), -1);
+    for (int pi = 0; pi < (int)L.local.size(); ++pi) lp[L.local[pi]] = pi;
+    for (CopyItem& it : plan.local) { it.src_patch = lp[it.src_patch]; it.dst_patch = lp[it.dst_patch]; }
+    for (CopyItem& it : plan.send_items) it.src_patch = lp[it.src_patch];
+    for (CopyItem& it : plan.recv_items) it.dst_patch = lp[it.dst_patch];
+    // drop the copies of a box onto itself (same cells)
+    std::vector<CopyItem> keep;
+    for (const CopyItem& it : plan.local)
+        if (!(it.src_patch == it.dst_patch && it.src_lo[0] == it.dst_lo[0] && it.src_lo[1] == it.dst_lo[1] &&
+              it.src_lo[2] == it.dst_lo[2]))
+            keep.push_back(it);
+    plan.local.swap(keep);
     upload_tables();
 }
 
@@ -351,6 +482,7 @@ void Copier::run(const double* s, double* d, hipStream_t st) const
 Level::~Level()
 {
     hipFree(d_cf);
+    hipFree(d_cfx);
     hipFree(d_patches);
     hipFree(d_tiles);
     hipFree(d_ftiles);
@@ -560,6 +692,7 @@ void Level::refresh_params()
     }
     P.alpha = alpha;
     P.beta = beta;
+    for (int d = 0; d < 3; ++d) { P.cf_c1[d] = cf_c1[d]; P.cf_c2[d] = cf_c2[d]; }
     dxProduct = active[2] ? dx[0] * dx[1] * dx[2] : dx[0] * dx[1];
 }
 

@@ -131,6 +131,19 @@ public:
     CFCell* d_cf = nullptr;
     int ncf = 0;
     double cf_c1[3] = {0, 0, 0}, cf_c2[3] = {0, 0, 0}, cf_fac[3] = {0, 0, 0};
+    // The fused red-black sweep on a level with CF boundaries needs (a) every box face to be CF either entirely
+    // or not at all (flag bits in PatchDesc.cf), boxes at least two cells wide, and (b) the pre-sweep CF values
+    // also in the EDGE ghosts that the recomputed red ring of a neighbouring box reads -- hcfx = hcf + those.  A
+    // re-entrant corner of the refined region (one edge ghost wanted with two different values) rules it out.
+    std::vector<CFCell> hcfx;
+    CFCell* d_cfx = nullptr;
+    int ncfx = 0;
+    bool cf_fusable = true;
+    std::unique_ptr<class Copier> cf_faces[3];  // high-face coefficients of neighbouring boxes (Copier::define_faces)
+    void cf_homog_ext(double* phi, hipStream_t st) const
+    {
+        launch_cf_homog(st, d_cfx, ncfx, phi, cf_c1, cf_c2, cf_fac);
+    }
     // builds hcf/d_cf and the interpolation weights for a coarser-level spacing dxCrse
     void define_cf(const double dxCrse[3]);
     void cf_homog(double* phi, hipStream_t st) const
@@ -176,6 +189,8 @@ public:
     void define(const IBox& domain, const bool periodic[3], const Level& src, const Level& dst, const int ghost[3],
                 Comm* comm);
     void define_allgather(const Level& src, const Level& dst, int grow, Comm* comm);
+    void define_faces(const IBox& domain, const bool periodic[3], const Level& L, int dir, const int ghost[3],
+                      Comm* comm);
     void run(const double* s, double* d, hipStream_t st) const;
     ExchangePlan plan;
 

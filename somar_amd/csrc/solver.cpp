@@ -254,6 +254,10 @@ bool PressureSolver::build_coarser(int depth)
 // value wins).  They already are identical when both come from one evaluation of the map.
 void PressureSolver::fill_metric_ghosts(Level& L)
 {
+    // on a level with coarse-fine boundaries the recomputed red ring also needs a neighbour's coefficient on a face
+    // that no box owns as a low face (see Copier::define_faces); the ordinary exchange then has the last word
+    for (int d = 0; d < 3; ++d)
+        if (L.cf_faces[d]) L.cf_faces[d]->run(L.dev.jg[d], L.dev.jg[d], st_);
     for (int d = 0; d < 3; ++d) L.exchange(L.dev.jg[d], st_);
     L.exchange(L.dev.jinv, st_);
 }
@@ -414,8 +418,9 @@ void PressureSolver::download_field(const double* field, int depth, int patch, d
 bool PressureSolver::fused_relax(int d, int iters) const
 {
     const Level& L = *lev[d];
-    return prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0 && L.ncf == 0 &&
-           !hasCF_ && L.active[2];
+    // levels with coarse-fine boundaries qualify when their layout allows it (Level::cf_fusable)
+    return prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0 &&
+           (L.ncf == 0 || L.cf_fusable) && L.active[2] && !no_cf_fused_(L);
 }
 
 void PressureSolver::relax(int d, double* e, const double* res, int iters, bool e_zero, const double* e_shift)
@@ -436,7 +441,10 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
         double* alt = f_pp[d];
         for (int it = 0; it < iters; ++it) {
             const bool zin = e_zero && it == 0;  // zeros need neither an exchange nor a read
-            if (!zin) L.exchange(cur, st_);
+            if (!zin) {
+                L.exchange(cur, st_);
+                L.cf_homog_ext(cur, st_);  // CF ghosts (faces + the edge ghosts the red ring reads), pre-sweep values
+            }
             if (profiling_ && d == 0) prof_begin(0);
             launch_gsrb_fused(st_, L.d_ftiles, L.nftiles, L.dev, alt, cur, res,
                               zin ? 1 : ((e_shift && it == 0) ? 2 : 0), e_shift);

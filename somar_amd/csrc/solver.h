@@ -90,6 +90,11 @@ public:
     //          legal when fused_relax(d, iters) holds
     void relax(int d, double* e, const double* res, int iters, bool e_zero = false, const double* e_shift = nullptr);
     bool fused_relax(int d, int iters) const;
+    static bool no_cf_fused_(const Level& L)  // A/B switch: SOMAR_NO_CF_FUSED=1 keeps CF levels on the two-pass kernel
+    {
+        static const bool off = getenv("SOMAR_NO_CF_FUSED") != nullptr;
+        return off && L.ncf > 0;
+    }
     void residual(int d, double* out, double* phi, const double* rhs);   // homogeneous CF ghosts, then residual_i
     void apply_op(int d, double* out, double* phi);
     void residual_i(int d, double* out, double* phi, const double* rhs); // residualI: CF ghosts as they are

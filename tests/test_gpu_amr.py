@@ -99,8 +99,16 @@ def test_composite_residual_bit_exact(oracle, am, layout):
 VCYCLES = [(LAYOUTS[0], 1, 0), (LAYOUTS[1], 1, 0), (LAYOUTS[3], 2, 0), (LAYOUTS[3], 2, 1), (LAYOUTS[3], 1, 1)]
 
 
-@pytest.mark.parametrize("case", VCYCLES)
-def test_amr_vcycle_bit_exact(oracle, am, case):
+@pytest.fixture(params=["twopass", "fused"])
+def sweep_kernel(request, monkeypatch):
+    """fine levels smooth either with the two-pass colour kernel or with the CF-aware fused red+black sweep (layouts
+    whose box faces are entirely coarse-fine or not at all; LAYOUTS[2] has a partly-CF face and falls back)"""
+    monkeypatch.setenv("SOMAR_FUSED_MIN_CELLS", "0" if request.param == "fused" else "1000000000000")
+    return request.param
+
+
+@pytest.mark.parametrize("case", VCYCLES + [(LAYOUTS[2], 1, 0), (LAYOUTS[4], 1, 0)])
+def test_amr_vcycle_bit_exact(oracle, am, case, sweep_kernel):
     """One AMRVCycle from identical inputs.  Every level here is small enough (<= 4096 cells) for the library
     to sum BiCGStab's scalars and the zero-average mean in the reference's serial order (k_reduce_ordered), so
     the whole cycle -- smoothing, CF interpolation, refluxed residual, restriction, bottom solve,
@@ -130,7 +138,7 @@ def test_amr_vcycle_bit_exact(oracle, am, case):
 
 
 @pytest.mark.parametrize("layout", LAYOUTS[:4])
-def test_composite_solve_history_matches(oracle, am, layout):
+def test_composite_solve_history_matches(oracle, am, layout, sweep_kernel):
     from somar_amd import api as F
     so = oracle
     levels, comp, gpu = _setup(so, am, layout)
