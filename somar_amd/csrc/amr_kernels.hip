@@ -26,12 +26,15 @@ __global__ void k_copy_items2(const CopyItem* __restrict__ items, const PatchDes
     const CopyItem it = items[blockIdx.x];
     const PatchDesc sp = spatches[it.src_patch];
     const PatchDesc dp = dpatches[it.dst_patch];
-    const int rows = it.n[1] * it.n[2];
-    for (int row = blockIdx.y * blockDim.y + threadIdx.y; row < rows; row += gridDim.y * blockDim.y) {
-        const int j = row % it.n[1], k = row / it.n[1];
-        const long long s = pidx(sp, it.src_lo[0], it.src_lo[1] + j, it.src_lo[2] + k);
-        const long long d = pidx(dp, it.dst_lo[0], it.dst_lo[1] + j, it.dst_lo[2] + k);
-        for (int i = threadIdx.x; i < it.n[0]; i += blockDim.x) dst[d + i] = src[s + i];
+    const int n0 = it.n[0], n01 = it.n[0] * it.n[1];
+    const long long cells = (long long)n01 * it.n[2];
+    for (long long idx = (long long)blockIdx.y * blockDim.x + threadIdx.x; idx < cells;
+         idx += (long long)gridDim.y * blockDim.x) {
+        const int k = (int)(idx / n01);
+        const int r = (int)(idx - (long long)k * n01);
+        const int j = r / n0, i = r - j * n0;
+        dst[pidx(dp, it.dst_lo[0] + i, it.dst_lo[1] + j, it.dst_lo[2] + k)] =
+            src[pidx(sp, it.src_lo[0] + i, it.src_lo[1] + j, it.src_lo[2] + k)];
     }
 }
 
@@ -224,7 +227,7 @@ void launch_copy_items2(hipStream_t st, const PatchDesc* spatches, const PatchDe
                         int nitems, const double* src, double* dst)
 {
     if (nitems == 0) return;
-    hipLaunchKernelGGL(k_copy_items2, dim3(nitems, 8), dim3(64, 4), 0, st, items, spatches, dpatches, src, dst);
+    hipLaunchKernelGGL(k_copy_items2, dim3(nitems, 16), dim3(256), 0, st, items, spatches, dpatches, src, dst);
 }
 void launch_fill_items(hipStream_t st, const PatchDesc* patches, const FillItem* items, int nitems, double* f, double v)
 {

@@ -454,23 +454,27 @@ __global__ void k_avg_face(const PatchDesc* __restrict__ cpatches, const PatchDe
 // ghost exchange inside one GPU: list of box-to-box copies (Chombo Copier motion items)
 // grid.x = item, grid.y = chunk of (j,k) rows
 // ------------------------------------------------------------------------------------
+// one cell per thread, cells of an item numbered i-fastest: a 2-cell-wide x-face (n[0] = 2) keeps all 256 lanes
+// busy instead of 2 of 64 (halo copies at 128-wide boxes took longer than a sweep of the box otherwise)
 __global__ void k_copy_items(const CopyItem* __restrict__ items, const PatchDesc* __restrict__ patches,
                              double* __restrict__ f)
 {
     const CopyItem it = items[blockIdx.x];
     const PatchDesc sp = patches[it.src_patch];
     const PatchDesc dp = patches[it.dst_patch];
-    const int rows = it.n[1] * it.n[2];
-    for (int row = blockIdx.y * blockDim.y + threadIdx.y; row < rows; row += gridDim.y * blockDim.y) {
-        const int j = row % it.n[1], k = row / it.n[1];
-        const long long s = cidx(sp, it.src_lo[0], it.src_lo[1] + j, it.src_lo[2] + k);
-        const long long d = cidx(dp, it.dst_lo[0], it.dst_lo[1] + j, it.dst_lo[2] + k);
-        for (int i = threadIdx.x; i < it.n[0]; i += blockDim.x) f[d + i] = f[s + i];
+    const int n0 = it.n[0], n01 = it.n[0] * it.n[1];
+    const long long cells = (long long)n01 * it.n[2];
+    for (long long idx = (long long)blockIdx.y * blockDim.x + threadIdx.x; idx < cells;
+         idx += (long long)gridDim.y * blockDim.x) {
+        const int k = (int)(idx / n01);
+        const int r = (int)(idx - (long long)k * n01);
+        const int j = r / n0, i = r - j * n0;
+        f[cidx(dp, it.dst_lo[0] + i, it.dst_lo[1] + j, it.dst_lo[2] + k)] =
+            f[cidx(sp, it.src_lo[0] + i, it.src_lo[1] + j, it.src_lo[2] + k)];
     }
 }
 
 // pack / unpack of halo regions into contiguous send/recv buffers (multi-GPU path).
-// items[].dst_lo[0] carries the offset (in elements) inside the buffer.
 template <bool PACK>
 __global__ void k_pack_items(const CopyItem* __restrict__ items, const PatchDesc* __restrict__ patches,
                              double* __restrict__ f, double* __restrict__ buf, const long long* __restrict__ bufoff)
@@ -479,15 +483,16 @@ __global__ void k_pack_items(const CopyItem* __restrict__ items, const PatchDesc
     const PatchDesc pp = patches[PACK ? it.src_patch : it.dst_patch];
     const int* lo = PACK ? it.src_lo : it.dst_lo;
     const long long b0 = bufoff[blockIdx.x];
-    const int rows = it.n[1] * it.n[2];
-    for (int row = blockIdx.y * blockDim.y + threadIdx.y; row < rows; row += gridDim.y * blockDim.y) {
-        const int j = row % it.n[1], k = row / it.n[1];
-        const long long a = cidx(pp, lo[0], lo[1] + j, lo[2] + k);
-        const long long b = b0 + (long long)row * it.n[0];
-        for (int i = threadIdx.x; i < it.n[0]; i += blockDim.x) {
-            if (PACK) buf[b + i] = f[a + i];
-            else      f[a + i] = buf[b + i];
-        }
+    const int n0 = it.n[0], n01 = it.n[0] * it.n[1];
+    const long long cells = (long long)n01 * it.n[2];
+    for (long long idx = (long long)blockIdx.y * blockDim.x + threadIdx.x; idx < cells;
+         idx += (long long)gridDim.y * blockDim.x) {
+        const int k = (int)(idx / n01);
+        const int r = (int)(idx - (long long)k * n01);
+        const int j = r / n0, i = r - j * n0;
+        const long long a = cidx(pp, lo[0] + i, lo[1] + j, lo[2] + k);
+        if (PACK) buf[b0 + idx] = f[a];
+        else      f[a] = buf[b0 + idx];
     }
 }
 
@@ -726,16 +731,16 @@ void launch_avg_face(hipStream_t st, const LevelDev& C, const LevelDev& F, int p
 void launch_copy_items(hipStream_t st, const LevelDev& L, const CopyItem* items, int nitems, double* f)
 {
     if (nitems == 0) return;
-    hipLaunchKernelGGL(k_copy_items, dim3(nitems, 8), dim3(64, 4), 0, st, items, L.patches, f);
+    hipLaunchKernelGGL(k_copy_items, dim3(nitems, 16), dim3(256), 0, st, items, L.patches, f);
 }
 void launch_pack(hipStream_t st, const LevelDev& L, const CopyItem* items, const long long* bufoff, int nitems,
                  double* f, double* buf, bool pack)
 {
     if (nitems == 0) return;
     if (pack)
-        hipLaunchKernelGGL(k_pack_items<true>, dim3(nitems, 8), dim3(64, 4), 0, st, items, L.patches, f, buf, bufoff);
+        hipLaunchKernelGGL(k_pack_items<true>, dim3(nitems, 16), dim3(256), 0, st, items, L.patches, f, buf, bufoff);
     else
-        hipLaunchKernelGGL(k_pack_items<false>, dim3(nitems, 8), dim3(64, 4), 0, st, items, L.patches, f, buf, bufoff);
+        hipLaunchKernelGGL(k_pack_items<false>, dim3(nitems, 16), dim3(256), 0, st, items, L.patches, f, buf, bufoff);
 }
 void launch_set(hipStream_t st, double* a, long long n, double v)
 {
