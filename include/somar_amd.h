@@ -110,6 +110,12 @@ int somar_solver_patch_box(somar_solver_t* s, int depth, int patch, int* box6, i
 /* Diagonal metric of local patch `patch`: Jg^{aa} over faces(valid,a) (1 comp), Jinv over valid. */
 int somar_solver_set_metric_ortho(somar_solver_t* s, int patch, const double* jg0, const double* jg1,
                                   const double* jg2, const double* jinv);
+/* Non-diagonal metric (LevelGeometry::isDiagonal() == false): jgD holds J g^{Db}, b = 0..2, over faces(valid, D),
+ * component slowest (the FluxBox layout of LevelGeometry::getFCJgupPtr).  Selects the 19-point kernels
+ * (GSRBITER3D, GSRBBOUNDARYITER3D, MAPPEDGETFLUX, fillExtrap / ExtrapolateFaceAndCopy, the cross-term Neumann
+ * ghost of EllipticBCUtils.cpp:128-214).  One AMR level, 3-D, LevelGSRB or Jacobi. */
+int somar_solver_set_metric_full(somar_solver_t* s, int patch, const double* jg0, const double* jg1, const double* jg2,
+                                 const double* jinv);
 int somar_solver_finalize(somar_solver_t* s);
 int somar_solver_depth(somar_solver_t* s, int* depth);
 int somar_solver_mg_ref_ratio(somar_solver_t* s, int depth, int* r3); /* depth -> depth+1 */

@@ -1269,6 +1269,53 @@ def make_diagonal_metric(grids, dx, L, ndim=3, variant="stretched", domain=None)
     return Jgup, Jinv
 
 
+def make_full_metric(grids, dx, L, domain, amp=(0.25, 0.2, 0.15), variant="sheared"):
+    """A smooth NON-orthogonal map for the 19-point path (SURVEY config C5's role, synthetic), k_a = 2 pi / L_a:
+        x = xi + a0 sin(k1 eta)/k1,  y = eta + a1 sin(k2 zeta)/k2,  z = zeta + a2 sin(k0 xi)/k0
+    ('sheared': a_i = largest shear dx_i/dxi_j), or the constant skew x = xi + a0 eta, y = eta + a1 zeta, z = zeta
+    ('skew', J = 1).
+    J g^{ab} = J (F^-1 F^-T)^{ab} with F = d x / d xi, evaluated at face centres (all 3 comps per face direction,
+    the layout of LevelGeometry::getFCJgup), Jinv = 1/det F at cell centres.  Indices wrap in periodic directions
+    so that the two stored copies of a periodic face are bitwise equal."""
+    Jgup = FluxData(grids, 3, 3)
+    Jinv = LevelData(grids, 1, (0, 0, 0), 1.0)
+    k = [2.0 * np.pi / L[d] for d in range(3)]
+
+    def coords(box, faceDir):
+        xs = []
+        for d in range(3):
+            idx = np.arange(box.lo[d], box.hi[d] + 1, dtype=np.float64)
+            if domain.periodic[d]:
+                nd = domain.box.size()[d]
+                idx = np.mod(idx - domain.box.lo[d], nd) + domain.box.lo[d]
+            xs.append((idx if d == faceDir else idx + 0.5) * dx[d])
+        return np.meshgrid(*xs, indexing="ij")
+
+    def jac(X):
+        F = np.zeros(X[0].shape + (3, 3))
+        for d in range(3):
+            F[..., d, d] = 1.0
+        if variant == "skew":
+            F[..., 0, 1] = amp[0]
+            F[..., 1, 2] = amp[1]
+        else:
+            F[..., 0, 1] = amp[0] * np.cos(k[1] * X[1])
+            F[..., 1, 2] = amp[1] * np.cos(k[2] * X[2])
+            F[..., 2, 0] = amp[2] * np.cos(k[0] * X[0])
+        return F
+
+    for i, g in enumerate(grids):
+        for d in range(3):
+            F = jac(coords(Jgup[i][d].box, d))
+            Fi = np.linalg.inv(F)
+            J = np.linalg.det(F)
+            G = np.einsum("...ai,...bi->...ab", Fi, Fi) * J[..., None, None]
+            for b in range(3):
+                Jgup[i][d].a[..., b] = G[..., d, b]
+        Jinv[i].a[..., 0] = 1.0 / np.linalg.det(jac(coords(g, -1)))
+    return Jgup, Jinv
+
+
 def random_field(grids, seed, ghost=(0, 0, 0), domainBox=None):
     """uniform(-1,1) keyed by GLOBAL cell index so the field is independent of the box layout."""
     ld = LevelData(grids, 1, ghost)

@@ -58,6 +58,7 @@ _SIGS = {
     "somar_solver_num_local_patches": [_H, _PI],
     "somar_solver_patch_box": [_H, C.c_int, C.c_int, _PI, _PI],
     "somar_solver_set_metric_ortho": [_H, C.c_int, _PD, _PD, _PD, _PD],
+    "somar_solver_set_metric_full": [_H, C.c_int, _PD, _PD, _PD, _PD],
     "somar_solver_finalize": [_H],
     "somar_solver_depth": [_H, _PI],
     "somar_solver_mg_ref_ratio": [_H, C.c_int, _PI],
@@ -259,6 +260,10 @@ class AMRPressureSolver:
     def setMetricOrtho(self, patch, jg0, jg1, jg2, jinv):
         _ck(lib().somar_solver_set_metric_ortho(self._h, patch, _dp(jg0), _dp(jg1), _dp(jg2) if jg2 is not None else None,
                                                 _dp(jinv)))
+
+    def setMetricFull(self, patch, jg0, jg1, jg2, jinv):
+        """jgD: array (faces(valid, D) shape + (3,)), Fortran order = component slowest"""
+        _ck(lib().somar_solver_set_metric_full(self._h, patch, _dp(jg0), _dp(jg1), _dp(jg2), _dp(jinv)))
 
     def finalize(self):
         if getattr(self, "_amr", None) is not None:

@@ -180,6 +180,15 @@ int somar_solver_set_metric_ortho(somar_solver_t* s, int patch, const double* jg
     API_END
 }
 
+int somar_solver_set_metric_full(somar_solver_t* s, int patch, const double* jg0, const double* jg1, const double* jg2,
+                                 const double* jinv)
+{
+    API_BEGIN
+    SOMAR_CHECK(jg0 && jg1 && jg2 && jinv, "null metric pointer");
+    s->ps->set_metric_full(patch, jg0, jg1, jg2, jinv);
+    API_END
+}
+
 int somar_solver_finalize(somar_solver_t* s)
 {
     API_BEGIN

@@ -78,6 +78,18 @@ struct CFCell {
     int dir;        // direction | 4 if the box is one cell wide in that direction
 };
 
+// One step of a ghost "program" of the non-diagonal (19-point) path (full19.hip): a region of one patch.
+enum { GHOST_COPY = 0, GHOST_EXTRAP = 1, GHOST_NEUM = 2 };
+struct GhostOp {
+    int patch, type;
+    int lo[3];       // local start of the region
+    int n[3];
+    int dir, sgn;    // EXTRAP / NEUM: direction and side sign (+1 high, -1 low)
+    int order;       // EXTRAP: 0, 1 or 2
+    int dstf, srcf;  // 0 = phi, 1 = psi (the extrapolated copy)
+    int pad_;
+};
+
 // Per-level constants handed to the stencil kernels by value.
 struct StencilParams {
     int dom_lo[3], dom_hi[3];  // domain box at this depth

@@ -1,0 +1,273 @@
+// somar_amd/csrc/full19.hip -- the NON-diagonal metric path: 19-point operator, 19-point GSRB, and the ghost
+// "programs" (extrapolation / copy / Neumann-with-cross-terms) that feed them.
+//
+// Reference kernels restated here (arithmetic in the Fortran's order; -ffp-contract=off => bit-identical to
+// oracle/kernels.c):
+//   MAPPEDGETFLUX                 calculus/AMRElliptic/MappedAMRPoissonOpF.ChF:335-427
+//   GSRBITER3D                    calculus/AMRElliptic/RelaxationMethods/GSRBF.ChF:36-282
+//   GSRBBOUNDARYITER3D            .../GSRBF.ChF:1024-1253
+//   EXTRAPOLATEFACENOEV           calculus/extrapolation/ExtrapolationUtilsF.ChF:35-138
+//   ELLIPTICCONSTNEUMBCGHOST      calculus/BCInterface/EllipticBCUtilsF.ChF (cross-term Neumann ghost)
+// and the call sequences of fillExtrap (MappedAMRPoissonOp.cpp:2244-2270), RelaxationMethod::
+// fillGhostsAndExtrapolate (RelaxationMethod.cpp:376-435), ExtrapolateFaceAndCopy (ExtrapolationUtils.cpp:
+// 109-155) and setSideNeumBC (EllipticBCUtils.cpp:128-214), which the host compiles into per-level op lists
+// (solver_full.cpp): one launch per op "stage", the ops of one stage touch different boxes.
+//
+// psi ("extrap") is the reference's second copy of phi whose out-of-domain ghosts hold EXTRAPOLATED values; the
+// cross-derivative terms read psi, the normal terms read phi.  In GSRB psi is a snapshot taken before each
+// colour pass, i.e. the cross terms lag -- reproduced as is.
+#include "common.h"
+#include "kernels.h"
+
+namespace somar {
+
+__device__ __forceinline__ long long fidx(const PatchDesc& p, int i, int j, int k)
+{
+    return p.off + i + (long long)p.pj * j + p.pk * k;
+}
+
+struct JgFull { const double* c[3][3]; };  // c[faceDir][component]
+
+// ------------------------------------------------------------------------------------
+// ghost programs
+// ------------------------------------------------------------------------------------
+__global__ void k_ghost_ops(const GhostOp* __restrict__ ops, const PatchDesc* __restrict__ patches,
+                            double* __restrict__ phi, double* __restrict__ psi, JgFull J, StencilParams P)
+{
+    const GhostOp op = ops[blockIdx.x];
+    const PatchDesc p = patches[op.patch];
+    const int n0 = op.n[0], n01 = op.n[0] * op.n[1];
+    const long long cells = (long long)n01 * op.n[2];
+    double* dst = op.dstf ? psi : phi;
+    const double* src = op.srcf ? psi : phi;
+    const long long st[3] = {1, (long long)p.pj, p.pk};
+    for (long long idx = (long long)blockIdx.y * blockDim.x + threadIdx.x; idx < cells;
+         idx += (long long)gridDim.y * blockDim.x) {
+        const int k = (int)(idx / n01);
+        const int r = (int)(idx - (long long)k * n01);
+        const int j = r / n0, i = r - j * n0;
+        const long long c = fidx(p, op.lo[0] + i, op.lo[1] + j, op.lo[2] + k);
+        if (op.type == GHOST_COPY) {
+            dst[c] = src[c];
+        } else if (op.type == GHOST_EXTRAP) {
+            const long long s = op.sgn * st[op.dir];  // towards the ghost; values come from c - s, c - 2s, ...
+            if (op.order == 0) dst[c] = src[c - s];
+            else if (op.order == 1) dst[c] = 2.0 * src[c - s] - src[c - 2 * s];
+            else dst[c] = 3.0 * (src[c - s] - src[c - 2 * s]) + src[c - 3 * s];
+        } else {  // GHOST_NEUM: phi ghost such that the boundary flux (cross terms from psi included) equals bcval = 0
+            const int a = op.dir, b = (a + 1) % 3, cc = (a + 2) % 3;
+            const long long sa = st[a], sb = st[b], sc = st[cc];
+            const long long g = c;                                  // ghost cell
+            const long long v = c - op.sgn * sa;                    // first valid cell
+            const long long f = (op.sgn < 0) ? c + sa : c;          // boundary face (index of the cell it is the low face of)
+            const double idxb = -0.25 / P.dx[b], idxc = -0.25 / P.dx[cc];
+            const double cross = (psi[g + sb] - psi[g - sb] + psi[v + sb] - psi[v - sb]) * J.c[a][b][f] * idxb +
+                                 (psi[g + sc] - psi[g - sc] + psi[v + sc] - psi[v - sc]) * J.c[a][cc][f] * idxc;
+            phi[g] = phi[v] + (0.0 - cross) * P.dx[a] / J.c[a][a][f];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 19-point operator / residual.  Thread = one i-pair, k-loop over the tile (as k_op_ortho).
+// MODE 0: out = rhs - L[phi]   MODE 1: out = L[phi]
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double flux19(const double* __restrict__ phi, const double* __restrict__ E, const JgFull& J,
+                                         long long c, int a, const long long st[3], const double dxi[3])
+{
+    // MAPPEDGETFLUX with beta = a_ref = 1 at the face that is the LOW face of cell c in direction a
+    const int b = (a + 1) % 3, cc = (a + 2) % 3;
+    const long long sa = st[a], sb = st[b], sc = st[cc];
+    const double aScale = 1.0 * dxi[a], bScale = 0.25 * 1.0 * dxi[b], cScale = 0.25 * 1.0 * dxi[cc];
+    return aScale * J.c[a][a][c] * (phi[c] - phi[c - sa]) +
+           bScale * J.c[a][b][c] * (E[c + sb] - E[c - sb] + E[c + sb - sa] - E[c - sb - sa]) +
+           cScale * J.c[a][cc][c] * (E[c + sc] - E[c - sc] + E[c + sc - sa] - E[c - sc - sa]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_op_full(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ patches,
+                                                 double* __restrict__ out, const double* __restrict__ phi,
+                                                 const double* __restrict__ psi, const double* __restrict__ rhs,
+                                                 JgFull J, const double* __restrict__ jinv, StencilParams P)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1] || li0 >= p.n[0]) return;
+    // aScale = beta / dx with beta = 1: the Fortran divides, it does not multiply by a reciprocal
+    const double dxi[3] = {1.0 / P.dx[0], 1.0 / P.dx[1], 1.0 / P.dx[2]};
+    const double dxinv[3] = {1.0 / P.dx[0], 1.0 / P.dx[1], 1.0 / P.dx[2]};
+    const long long st[3] = {1, (long long)p.pj, p.pk};
+    const int gj = p.lo[1] + lj;
+    const int npair = (li0 + 1 < p.n[0]) ? 2 : 1;
+    for (int kk = 0; kk < t.nk; ++kk) {
+        const int lk = t.k0 + kk;
+        const int gk = p.lo[2] + lk;
+        for (int q = 0; q < npair; ++q) {
+            const int li = li0 + q;
+            const int gi = p.lo[0] + li;
+            const long long c = fidx(p, li, lj, lk);
+            double fl[3], fh[3];
+            const int g[3] = {gi, gj, gk};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                fl[a] = flux19(phi, psi, J, c, a, st, dxi);
+                fh[a] = flux19(phi, psi, J, c + st[a], a, st, dxi);
+                // EllipticConstNeumBCFluxClass: boundary faces := 0 (homogeneous)
+                if (g[a] == P.dom_lo[a] && P.neum[a][0]) fl[a] = 0.0;
+                if (g[a] == P.dom_hi[a] && P.neum[a][1]) fh[a] = 0.0;
+                fl[a] *= P.beta;
+                fh[a] *= P.beta;
+            }
+            double l = jinv[c] * ((fh[0] - fl[0]) * dxinv[0] + (fh[1] - fl[1]) * dxinv[1] + (fh[2] - fl[2]) * dxinv[2]);
+            if (P.alpha != 0.0) l = P.alpha * phi[c] + 1.0 * l;
+            out[c] = (MODE == 0) ? (rhs[c] - l) : l;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 19-point GSRB, one colour.  Interior cells: GSRBITER3D; cells touching a domain face: GSRBBOUNDARYITER3D.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_gsrb_full(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ patches,
+                                                   double* __restrict__ phi, const double* __restrict__ E,
+                                                   const double* __restrict__ rhs, JgFull J,
+                                                   const double* __restrict__ jinv, const double* __restrict__ lapd,
+                                                   StencilParams P, int color)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1] || li0 >= p.n[0]) return;
+    const double xxScale = 1.0 / (P.dx[0] * P.dx[0]);
+    const double yyScale = 1.0 / (P.dx[1] * P.dx[1]);
+    const double zzScale = 1.0 / (P.dx[2] * P.dx[2]);
+    const double xyScale = 0.25 / (P.dx[0] * P.dx[1]);
+    const double yzScale = 0.25 / (P.dx[1] * P.dx[2]);
+    const double zxScale = 0.25 / (P.dx[2] * P.dx[0]);
+    const long long sj = p.pj, sk = p.pk;
+    const int gj = p.lo[1] + lj;
+    const double* Jx0 = J.c[0][0]; const double* Jx1 = J.c[0][1]; const double* Jx2 = J.c[0][2];
+    const double* Jy0 = J.c[1][0]; const double* Jy1 = J.c[1][1]; const double* Jy2 = J.c[1][2];
+    const double* Jz0 = J.c[2][0]; const double* Jz1 = J.c[2][1]; const double* Jz2 = J.c[2][2];
+    for (int kk = 0; kk < t.nk; ++kk) {
+        const int lk = t.k0 + kk;
+        const int gk = p.lo[2] + lk;
+        const int li = li0 + ((p.lo[0] + li0 + gj + gk + color) & 1);
+        if (li >= p.n[0]) continue;
+        const int gi = p.lo[0] + li;
+        const long long c = fidx(p, li, lj, lk);
+        const bool onb = (gi == P.dom_lo[0]) || (gi == P.dom_hi[0]) || (gj == P.dom_lo[1]) || (gj == P.dom_hi[1]) ||
+                         (gk == P.dom_lo[2]) || (gk == P.dom_hi[2]);
+#define EE(di, dj, dk) E[c + (di) + sj * (dj) + sk * (dk)]
+        double out;
+        if (!onb) {
+            const double pdx = EE(1, 0, 0) - EE(-1, 0, 0);
+            const double pdy = EE(0, 1, 0) - EE(0, -1, 0);
+            const double pdz = EE(0, 0, 1) - EE(0, 0, -1);
+            const double JDxx = Jx0[c + 1] * phi[c + 1] + Jx0[c] * phi[c - 1];
+            const double JDxy = Jx1[c + 1] * (EE(1, 1, 0) - EE(1, -1, 0) + pdy) - Jx1[c] * (pdy + EE(-1, 1, 0) - EE(-1, -1, 0));
+            const double JDxz = Jx2[c + 1] * (EE(1, 0, 1) - EE(1, 0, -1) + pdz) - Jx2[c] * (pdz + EE(-1, 0, 1) - EE(-1, 0, -1));
+            const double JDyx = Jy0[c + sj] * (EE(1, 1, 0) - EE(-1, 1, 0) + pdx) - Jy0[c] * (pdx + EE(1, -1, 0) - EE(-1, -1, 0));
+            const double JDyy = Jy1[c + sj] * phi[c + sj] + Jy1[c] * phi[c - sj];
+            const double JDyz = Jy2[c + sj] * (EE(0, 1, 1) - EE(0, 1, -1) + pdz) - Jy2[c] * (pdz + EE(0, -1, 1) - EE(0, -1, -1));
+            const double JDzx = Jz0[c + sk] * (EE(1, 0, 1) - EE(-1, 0, 1) + pdx) - Jz0[c] * (pdx + EE(1, 0, -1) - EE(-1, 0, -1));
+            const double JDzy = Jz1[c + sk] * (EE(0, 1, 1) - EE(0, -1, 1) + pdy) - Jz1[c] * (pdy + EE(0, 1, -1) - EE(0, -1, -1));
+            const double JDzz = Jz2[c + sk] * phi[c + sk] + Jz2[c] * phi[c - sk];
+            const double lphi = P.beta * jinv[c] *
+                                (JDxx * xxScale + JDyy * yyScale + JDzz * zzScale + (JDxy + JDyx) * xyScale +
+                                 (JDyz + JDzy) * yzScale + (JDzx + JDxz) * zxScale);
+            out = (rhs[c] - lphi) / (P.alpha + P.beta * lapd[c]);
+        } else {
+            const bool nxl = (gi == P.dom_lo[0]) && P.neum[0][0];
+            const bool nxh = (gi == P.dom_hi[0]) && P.neum[0][1];
+            const bool nyl = (gj == P.dom_lo[1]) && P.neum[1][0];
+            const bool nyh = (gj == P.dom_hi[1]) && P.neum[1][1];
+            const bool nzl = (gk == P.dom_lo[2]) && P.neum[2][0];
+            const bool nzh = (gk == P.dom_hi[2]) && P.neum[2][1];
+            double JDloX = 0, JDhiX = 0, JDloY = 0, JDhiY = 0, JDloZ = 0, JDhiZ = 0, ld = 0.0;
+            if (!nxl) {
+                JDloX = +xxScale * Jx0[c] * phi[c - 1] -
+                        xyScale * Jx1[c] * (EE(0, 1, 0) - EE(0, -1, 0) + EE(-1, 1, 0) - EE(-1, -1, 0)) -
+                        zxScale * Jx2[c] * (EE(0, 0, 1) - EE(0, 0, -1) + EE(-1, 0, 1) - EE(-1, 0, -1));
+                ld = ld - xxScale * Jx0[c];
+            }
+            if (!nxh) {
+                JDhiX = +xxScale * Jx0[c + 1] * phi[c + 1] +
+                        xyScale * Jx1[c + 1] * (EE(1, 1, 0) - EE(1, -1, 0) + EE(0, 1, 0) - EE(0, -1, 0)) +
+                        zxScale * Jx2[c + 1] * (EE(1, 0, 1) - EE(1, 0, -1) + EE(0, 0, 1) - EE(0, 0, -1));
+                ld = ld - xxScale * Jx0[c + 1];
+            }
+            if (!nyl) {
+                JDloY = -xyScale * Jy0[c] * (EE(1, 0, 0) - EE(-1, 0, 0) + EE(1, -1, 0) - EE(-1, -1, 0)) +
+                        yyScale * Jy1[c] * phi[c - sj] -
+                        yzScale * Jy2[c] * (EE(0, 0, 1) - EE(0, 0, -1) + EE(0, -1, 1) - EE(0, -1, -1));
+                ld = ld - yyScale * Jy1[c];
+            }
+            if (!nyh) {
+                JDhiY = +xyScale * Jy0[c + sj] * (EE(1, 1, 0) - EE(-1, 1, 0) + EE(1, 0, 0) - EE(-1, 0, 0)) +
+                        yyScale * Jy1[c + sj] * phi[c + sj] +
+                        yzScale * Jy2[c + sj] * (EE(0, 1, 1) - EE(0, 1, -1) + EE(0, 0, 1) - EE(0, 0, -1));
+                ld = ld - yyScale * Jy1[c + sj];
+            }
+            if (!nzl) {
+                JDloZ = -zxScale * Jz0[c] * (EE(1, 0, 0) - EE(-1, 0, 0) + EE(1, 0, -1) - EE(-1, 0, -1)) -
+                        yzScale * Jz1[c] * (EE(0, 1, 0) - EE(0, -1, 0) + EE(0, 1, -1) - EE(0, -1, -1)) +
+                        zzScale * Jz2[c] * phi[c - sk];
+                ld = ld - zzScale * Jz2[c];
+            }
+            if (!nzh) {
+                JDhiZ = +zxScale * Jz0[c + sk] * (EE(1, 0, 1) - EE(-1, 0, 1) + EE(1, 0, 0) - EE(-1, 0, 0)) +
+                        yzScale * Jz1[c + sk] * (EE(0, 1, 1) - EE(0, -1, 1) + EE(0, 1, 0) - EE(0, -1, 0)) +
+                        zzScale * Jz2[c + sk] * phi[c + sk];
+                ld = ld - zzScale * Jz2[c + sk];
+            }
+            ld = ld * jinv[c];
+            const double lphi = P.beta * jinv[c] * (JDloX + JDhiX + JDloY + JDhiY + JDloZ + JDhiZ);
+            out = (rhs[c] - lphi) / (P.alpha + P.beta * ld);
+        }
+#undef EE
+        phi[c] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+static JgFull jgfull(const LevelDev& L)
+{
+    JgFull J;
+    for (int d = 0; d < 3; ++d)
+        for (int c = 0; c < 3; ++c) J.c[d][c] = L.jgf[d][c];
+    return J;
+}
+
+void launch_ghost_ops(hipStream_t st, const LevelDev& L, const GhostOp* ops, int nops, double* phi, double* psi)
+{
+    if (nops == 0) return;
+    hipLaunchKernelGGL(k_ghost_ops, dim3(nops, 4), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), L.P);
+}
+
+void launch_op_full(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* psi,
+                    const double* rhs, int mode)
+{
+    if (L.ntiles == 0) return;
+    dim3 b(64, L.tile_j, 1);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_op_full<0>, dim3(L.ntiles), b, 0, st, L.tiles, L.patches, out, phi, psi, rhs, jgfull(L),
+                           L.jinv, L.P);
+    else
+        hipLaunchKernelGGL(k_op_full<1>, dim3(L.ntiles), b, 0, st, L.tiles, L.patches, out, phi, psi, rhs, jgfull(L),
+                           L.jinv, L.P);
+}
+
+void launch_gsrb_full(hipStream_t st, const LevelDev& L, double* phi, const double* psi, const double* rhs, int color)
+{
+    if (L.ntiles == 0) return;
+    hipLaunchKernelGGL(k_gsrb_full, dim3(L.ntiles), dim3(64, L.tile_j, 1), 0, st, L.tiles, L.patches, phi, psi, rhs,
+                       jgfull(L), L.jinv, L.lapdiag, L.P, color);
+}
+
+}  // namespace somar

@@ -14,8 +14,16 @@ struct LevelDev {
     double* jg[3] = {nullptr, nullptr, nullptr};  // J g^{aa} on a-faces
     double* jinv = nullptr;
     double* lapdiag = nullptr;
+    // non-diagonal metric: all components J g^{ab} on a-faces, jgf[a][b]; jgf[a][a] aliases jg[a]
+    double* jgf[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     StencilParams P;
 };
+
+// 19-point path (full19.hip)
+void launch_ghost_ops(hipStream_t st, const LevelDev& L, const GhostOp* ops, int nops, double* phi, double* psi);
+void launch_op_full(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* psi,
+                    const double* rhs, int mode);
+void launch_gsrb_full(hipStream_t st, const LevelDev& L, double* phi, const double* psi, const double* rhs, int color);
 
 // loose: 0 LevelGSRB pass; 1 / 2: interior / box-shell phase of LooseGSRB (see k_gsrb_ortho)
 void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color, int loose = 0);

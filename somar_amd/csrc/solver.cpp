@@ -38,6 +38,13 @@ PressureSolver::~PressureSolver()
     for (double* f : f_pp) hipFree(f);
     for (double* f : f_vel) hipFree(f);
     for (double* f : f_amr) hipFree(f);
+    for (double* f : f_psi) hipFree(f);
+    for (auto& pr : full_prog_)
+        for (auto& q : pr) hipFree(q.d_ops);
+    for (auto& L : lev)
+        for (int d = 0; d < 3; ++d)
+            for (int c = 0; c < 3; ++c)
+                if (c != d && L->dev.jgf[d][c]) { hipFree(L->dev.jgf[d][c]); L->dev.jgf[d][c] = nullptr; }
     hipFree(f_phi); hipFree(f_rhs); hipFree(f_uberRes); hipFree(f_uberCorr); hipFree(f_best);
     for (double* f : bicg) hipFree(f);
     hipFree(d_partials);
@@ -241,6 +248,14 @@ bool PressureSolver::build_coarser(int depth)
     for (int pi = 0; pi < C->npatches(); ++pi)
         for (int d = 0; d < nd; ++d)
             launch_avg_face(st_, C->dev, F.dev, pi, C->hpatches[pi].n, C->dev.jg[d], F.dev.jg[d], d, r);
+    if (full_) {
+        alloc_full_metric(*C);
+        for (int pi = 0; pi < C->npatches(); ++pi)
+            for (int d = 0; d < 3; ++d)
+                for (int c = 0; c < 3; ++c)
+                    if (c != d)
+                        launch_avg_face(st_, C->dev, F.dev, pi, C->hpatches[pi].n, C->dev.jgf[d][c], F.dev.jgf[d][c], d, r);
+    }
     launch_avg_harmonic(st_, C->dev, F.dev, C->dev.jinv, F.dev.jinv, r);
     launch_lapdiag(st_, C->dev);
     fill_metric_ghosts(*C);
@@ -259,6 +274,10 @@ void PressureSolver::fill_metric_ghosts(Level& L)
     for (int d = 0; d < 3; ++d)
         if (L.cf_faces[d]) L.cf_faces[d]->run(L.dev.jg[d], L.dev.jg[d], st_);
     for (int d = 0; d < 3; ++d) L.exchange(L.dev.jg[d], st_);
+    if (full_)
+        for (int d = 0; d < 3; ++d)
+            for (int c = 0; c < 3; ++c)
+                if (c != d && L.dev.jgf[d][c]) L.exchange(L.dev.jgf[d][c], st_);
     L.exchange(L.dev.jinv, st_);
 }
 
@@ -289,7 +308,7 @@ void PressureSolver::finalize()
     fill_metric_ghosts(*lev[0]);
     int depth = 1;
     while (build_coarser(depth)) {
-        if (comm_->size > 1 && lev[depth]->valid_cells_global <= agglom_cells_) {
+        if (comm_->size > 1 && lev[depth]->valid_cells_global <= agglom_cells_ && !full_) {
             build_agglomerated_tail(depth);
             break;
         }
@@ -303,6 +322,17 @@ void PressureSolver::finalize()
     f_corr.assign(D, nullptr);
     f_scratch.assign(D, nullptr);
     f_pp.assign(D, nullptr);
+    if (full_) {
+        SOMAR_CHECK(prm.relaxMode == RELAX_LEVEL_GSRB || prm.relaxMode == RELAX_JACOBI,
+                    "the non-diagonal metric path offers LevelGSRB and Jacobi");
+        SOMAR_CHECK(prm.precondMode != PRECOND_DIAG_LINE_RELAX, "no line relaxation with a non-diagonal metric");
+        f_psi.assign(D, nullptr);
+        full_prog_.resize(D);
+        for (int d = 0; d < D; ++d) {
+            f_psi[d] = lev[d]->alloc_field();
+            build_full_programs(d);
+        }
+    }
     for (int d = 0; d < D; ++d) {
         if (d > 0) { f_res[d] = lev[d]->alloc_field(); f_corr[d] = lev[d]->alloc_field(); }
         f_scratch[d] = lev[d]->alloc_field();
@@ -420,7 +450,7 @@ bool PressureSolver::fused_relax(int d, int iters) const
     const Level& L = *lev[d];
     // levels with coarse-fine boundaries qualify when their layout allows it (Level::cf_fusable)
     return prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0 &&
-           (L.ncf == 0 || L.cf_fusable) && L.active[2] && !no_cf_fused_(L);
+           (L.ncf == 0 || L.cf_fusable) && L.active[2] && !no_cf_fused_(L) && !full_;
 }
 
 void PressureSolver::relax(int d, double* e, const double* res, int iters, bool e_zero, const double* e_shift)
@@ -462,8 +492,10 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
             for (int pass = 0; pass < 2; ++pass) {
                 L.cf_homog(e, st_);  // homogeneousCFInterp (Relaxer::fillGhostsAndExtrapolate)
                 L.exchange(e, st_);
+                if (full_) run_full_program(d, 1, e);  // psi snapshot + extrapolation (order 1) + Neumann ghosts
                 if (profiling_ && d == 0) prof_begin(0);
-                launch_gsrb_ortho(st_, L.dev, e, res, pass);
+                if (full_) launch_gsrb_full(st_, L.dev, e, f_psi[d], res, pass);
+                else launch_gsrb_ortho(st_, L.dev, e, res, pass);
                 if (profiling_ && d == 0) prof_end(0);
             }
         } else if (prm.relaxMode == RELAX_LOOSE_GSRB) {
@@ -514,7 +546,11 @@ void PressureSolver::residual_i(int d, double* out, double* phi, const double* r
     Level& L = *lev[d];
     L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
     if (profiling_ && d == 0) prof_begin(1);
-    if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, rhs, 0);
+    if (full_) {
+        // exchangeComplete, fillExtrap (order 2), Neumann ghosts with cross terms, then the 19-point fluxes
+        run_full_program(d, 0, phi);
+        launch_op_full(st_, L.dev, out, phi, f_psi[d], rhs, 0);
+    } else if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, rhs, 0);
     else launch_op_ortho(st_, L.dev, out, phi, rhs, 0);
     if (profiling_ && d == 0) prof_end(1);
 }
@@ -523,7 +559,10 @@ void PressureSolver::apply_op_i(int d, double* out, double* phi)
 {
     Level& L = *lev[d];
     L.exchange(phi, st_);
-    if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, nullptr, 1);
+    if (full_) {
+        run_full_program(d, 0, phi);
+        launch_op_full(st_, L.dev, out, phi, f_psi[d], nullptr, 1);
+    } else if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, nullptr, 1);
     else launch_op_ortho(st_, L.dev, out, phi, nullptr, 1);
 }
 
@@ -549,7 +588,7 @@ void PressureSolver::restrict_residual(int d, double* resCoarse, double* phiFine
 {
     // restrictResidual, MappedAMRPoissonOp.cpp:1281-1304
     Level& F = *lev[d];
-    if (F.valid_cells_global >= march_min_cells_ && F.active[2]) {
+    if (F.valid_cells_global >= march_min_cells_ && F.active[2] && !full_) {
         // large level: residual and J-weighted average in one marching pass, the fine residual is never stored
         F.cf_homog(phiFine, st_);
         F.exchange(phiFine, st_);

@@ -53,6 +53,10 @@ public:
     bool has_cf() const { return hasCF_; }
     // Diagonal metric of one LOCAL patch in Chombo FRA layout: Jg_aa on faces(valid,a), Jinv on valid.
     void set_metric_ortho(int patch, const double* jg0, const double* jg1, const double* jg2, const double* jinv);
+    // Non-diagonal metric of one LOCAL patch: jgD = J g^{Db} on faces(valid, D), 3 components, component slowest
+    // (LevelGeometry::getFCJgup's FluxBox layout).  Switches the solver to the 19-point kernels (full19.hip).
+    void set_metric_full(int patch, const double* jg0, const double* jg1, const double* jg2, const double* jinv);
+    bool is_full() const { return full_; }
     void finalize();  // builds the semicoarsened hierarchy, coarse metrics, lapDiag, null-space probes
 
     // ---- data movement across the boundary (host FABs, caller-owned) ---------------------
@@ -161,6 +165,14 @@ private:
     double* d_scalars = nullptr;  // device scalar slots
     double* h_scalars = nullptr;  // pinned
     bool finalized = false;
+    // ---- non-diagonal metric (19-point) path, solver_full.cpp ----
+    struct FullProgram { GhostOp* d_ops = nullptr; std::vector<int> first, count; };
+    bool full_ = false;
+    std::vector<double*> f_psi;                            // per depth: the extrapolated copy of phi
+    std::vector<std::array<FullProgram, 2>> full_prog_;    // per depth: [0] operator, [1] smoother
+    void alloc_full_metric(Level& L);
+    void build_full_programs(int d);
+    void run_full_program(int d, int which, double* phi);
     std::unique_ptr<PressureSolver> coarse_;   // replicated tail of the hierarchy (agglomeration)
     int agglom_depth_ = -1;
     long long agglom_cells_ = 262144;
