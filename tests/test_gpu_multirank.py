@@ -93,6 +93,10 @@ def _worker(rank, nranks, name, mode, q):
         np.testing.assert_allclose(st["history"], amr.history, rtol=1e-6, atol=1e-9 * amr.history[0])
         gpu.undefine()
 
+        if nranks != 2:
+            F.comm_destroy(comm)
+            q.put((rank, "ok"))
+            return
         # ---- two AMR levels, each sharded over both ranks --------------------------------------------------
         periodic, ratios = (True, False, False), [(2, 2, 1)]
         fb = [[so.Box((0, 8, 0), (15, 23, 7)), so.Box((24, 8, 0), (31, 23, 7))]]
@@ -154,12 +158,12 @@ def _worker(rank, nranks, name, mode, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("mode", ["fused", "twopass"])
-def test_two_ranks_on_one_gpu(mode):
+@pytest.mark.parametrize("mode,nranks", [("fused", 2), ("twopass", 2), ("fused", 4)])
+def test_ranks_sharing_one_gpu(mode, nranks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     name = "/somar_%s" % uuid.uuid4().hex[:12]
-    procs = [ctx.Process(target=_worker, args=(r, 2, name, mode, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, nranks, name, mode, q)) for r in range(nranks)]
     for p in procs:
         p.start()
     out = {}
@@ -172,4 +176,4 @@ def test_two_ranks_on_one_gpu(mode):
             p.join(timeout=10)
             if p.is_alive():
                 p.kill()
-    assert out == {0: "ok", 1: "ok"}, "\n".join("rank %d: %s" % kv for kv in sorted(out.items()))
+    assert out == {r: "ok" for r in range(nranks)}, "\n".join("rank %d: %s" % kv for kv in sorted(out.items()))
