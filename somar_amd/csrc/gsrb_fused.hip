@@ -93,6 +93,8 @@ __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS,
 // 2: every value of phi_in is read as (value - sums[0]/sums[1]): the mean removal of ZeroAvgConstInterpPS
 //    (a_phiThisLevel[dit] -= avgPhi over the whole FAB, ProlongationStrategy.cpp:160-163) folded into the first
 //    post-smoothing sweep instead of a separate 16 B/cell pass.
+// 3: phi_in is read as value + crse(i / r): the prolongation (CONSTINTERPPS) folded into the first post-smoothing
+//    sweep -- ghosts included, which needs crse exchanged one cell deep.  4: as 3, minus sums[0]/sums[1].
 template <int FR_J, int INMODE>
 __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict__ tiles,
                                                      const PatchDesc* __restrict__ patches,
@@ -103,22 +105,42 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
                                                      const double* __restrict__ jgy,
                                                      const double* __restrict__ jgz,
                                                      const double* __restrict__ jinv, StencilParams P,
-                                                     const double* __restrict__ sums)
+                                                     const double* __restrict__ sums,
+                                                     const PatchDesc* __restrict__ cpatches,
+                                                     const double* __restrict__ crse, int r0, int r1, int r2)
 {
     __shared__ __attribute__((aligned(16))) double S[3][FR_J][FR_I];
     const Tile t = tiles[blockIdx.x];
     const PatchDesc p = patches[t.patch];
-    const double avg = (INMODE == 2) ? sums[0] / sums[1] : 0.0;
-    auto ldphi = [&](long long idx, bool ok0, bool ok1) {
-        if (INMODE == 1) return make_double2(0.0, 0.0);
-        double2 v = ld2(phi_in, idx, ok0, ok1, p.off);
-        if (INMODE == 2) { v.x = v.x - avg; v.y = v.y - avg; }
-        return v;
-    };
+    const double avg = (INMODE == 2 || INMODE == 4) ? sums[0] / sums[1] : 0.0;
     const int lane = threadIdx.x, row = threadIdx.y;
     const int ri = 2 * lane;       // region column of the pair's first cell
     const int li = t.i0 - 2 + ri;  // local i of the pair's first cell (even: rows are 16-byte aligned)
     const int lj = t.j0 - 2 + row;
+    // INMODE 3/4: where this pair's coarse parents live (floor division: ghosts map to coarse ghosts)
+    long long cbase = 0, cpk = 0;
+    int cstep = 0;
+    if (INMODE >= 3) {
+        const PatchDesc cp = cpatches[t.patch];
+        auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+        const int ci0 = fdiv(li, r0);
+        cstep = fdiv(li + 1, r0) - ci0;  // 0 when both cells share a parent
+        cbase = cp.off + ci0 + (long long)cp.pj * fdiv(lj, r1);
+        cpk = cp.pk;
+    }
+    auto ldphi = [&](int kp, bool ok0, bool ok1) {
+        if (INMODE == 1) return make_double2(0.0, 0.0);
+        double2 v = ld2(phi_in, p.off + li + (long long)p.pj * lj + p.pk * kp, ok0, ok1, p.off);
+        if (INMODE >= 3) {
+            const int ck = kp >= 0 ? kp / r2 : -((-kp + r2 - 1) / r2);
+            const long long c = (ok0 || ok1) ? cbase + cpk * ck : cbase - (cbase - cpatches[t.patch].off);
+            const double c0 = crse[c], c1 = crse[c + ((ok0 || ok1) ? cstep : 0)];
+            v.x = ok0 ? v.x + c0 : 0.0;
+            v.y = ok1 ? v.y + c1 : 0.0;
+        }
+        if (INMODE == 2 || INMODE == 4) { v.x = v.x - avg; v.y = v.y - avg; }
+        return v;
+    };
     const int gj = p.lo[1] + lj;
     const double xxS = 1.0 / (P.dx[0] * P.dx[0]);
     const double yyS = 1.0 / (P.dx[1] * P.dx[1]);
@@ -157,9 +179,9 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
     // ---- prologue: planes k0-2 and k0-1 ------------------------------------------------------------
     int k = t.k0 - 1;  // first red plane (the ring below the tile)
     bool fk = (k - 1 >= -FRAME) && (k - 1 < p.n[2] + FRAME);
-    double2 Pm = ldphi(base + sk * (k - 1), f0 && fk, f1 && fk);
+    double2 Pm = ldphi(k - 1, f0 && fk, f1 && fk);
     fk = (k >= -FRAME) && (k < p.n[2] + FRAME);
-    double2 Pc = ldphi(base + sk * k, f0 && fk, f1 && fk);
+    double2 Pc = ldphi(k, f0 && fk, f1 && fk);
     double2 Gzc = ld2(jgz, base + sk * k, c0 && fk, c1 && fk, p.off);  // Jg^zz on the LOW face of plane k
     // coefficients of the black cell of plane k-1 (column c), captured one step earlier
     double b_rhs = 0, b_ji = 1, b_gxl = 0, b_gxh = 0, b_gyl = 0, b_gyh = 0, b_gzl = 0;
@@ -171,7 +193,7 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         fk = (k >= -FRAME) && (k < p.n[2] + FRAME);
         const bool fkp = (k + 1 >= -FRAME) && (k + 1 < p.n[2] + FRAME);
         // ---- this step's loads: phi and Jg^zz of plane k+1, cell coefficients of plane k --------
-        const double2 Pp = ldphi(base + sk * (k + 1), f0 && fkp, f1 && fkp);
+        const double2 Pp = ldphi(k + 1, f0 && fkp, f1 && fkp);
         const double2 Gzp = ld2(jgz, base + sk * (k + 1), c0 && fkp, c1 && fkp, p.off);
         const double2 Rh = ld2(rhs, base + sk * k, c0 && fk, c1 && fk, p.off);
         const double2 Ji = ld2(jinv, base + sk * k, c0 && fk, c1 && fk, p.off);
@@ -263,21 +285,26 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
 }
 
 void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* phi_out,
-                       const double* phi_in, const double* rhs, int in_mode, const double* sums)
+                       const double* phi_in, const double* rhs, int in_mode, const double* sums,
+                       const LevelDev* C, const double* crse, const int* r)
 {
     if (ntiles == 0) return;
+    const PatchDesc* cpatches = C ? C->patches : nullptr;
+    const int r0 = r ? r[0] : 1, r1 = r ? r[1] : 1, r2 = r ? r[2] : 1;
 #define SOMAR_LAUNCH_FUSED(ROWS, M)                                                                                  \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gsrb_fused<ROWS, M>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
-                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums)
-    if (fused_rows() == 8) {
-        if (in_mode == 1) SOMAR_LAUNCH_FUSED(8, 1);
-        else if (in_mode == 2) SOMAR_LAUNCH_FUSED(8, 2);
-        else SOMAR_LAUNCH_FUSED(8, 0);
-    } else {
-        if (in_mode == 1) SOMAR_LAUNCH_FUSED(16, 1);
-        else if (in_mode == 2) SOMAR_LAUNCH_FUSED(16, 2);
-        else SOMAR_LAUNCH_FUSED(16, 0);
+                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2)
+#define SOMAR_LAUNCH_FUSED_MODES(ROWS)                 \
+    switch (in_mode) {                                 \
+        case 1: SOMAR_LAUNCH_FUSED(ROWS, 1); break;    \
+        case 2: SOMAR_LAUNCH_FUSED(ROWS, 2); break;    \
+        case 3: SOMAR_LAUNCH_FUSED(ROWS, 3); break;    \
+        case 4: SOMAR_LAUNCH_FUSED(ROWS, 4); break;    \
+        default: SOMAR_LAUNCH_FUSED(ROWS, 0);          \
     }
+    if (fused_rows() == 8) { SOMAR_LAUNCH_FUSED_MODES(8) }
+    else { SOMAR_LAUNCH_FUSED_MODES(16) }
+#undef SOMAR_LAUNCH_FUSED_MODES
 #undef SOMAR_LAUNCH_FUSED
 }
 

@@ -30,15 +30,24 @@ void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const dou
 // one full red+black sweep, phi_in -> phi_out (gsrb_fused.hip); needs phi_in ghosts 2 deep and
 // rhs / Jg / Jinv ghosts 1 deep wherever a neighbouring box or periodic image exists
 // in_mode 0: plain; 1: phi_in is taken to be all zeros and is not read; 2: phi_in is read as
-// (value - sums[0]/sums[1]) (deferred mean removal of the zero-average prolongation)
+// (value - sums[0]/sums[1]) (deferred mean removal of the zero-average prolongation); 3: phi_in is read as
+// value + crse(i / r) (prolongation folded in; C = coarse level, crse exchanged one deep); 4: 3 and 2 together
 void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* phi_out,
-                       const double* phi_in, const double* rhs, int in_mode = 0, const double* sums = nullptr);
+                       const double* phi_in, const double* rhs, int in_mode = 0, const double* sums = nullptr,
+                       const LevelDev* C = nullptr, const double* crse = nullptr, const int* r = nullptr);
 int fused_rows();
 // k-marching operator/residual of a large level (resid_march.hip); mode 0: out = rhs - L[phi], 1: out = L[phi]
 void launch_resid_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out,
                         const double* phi, const double* rhs, int mode);
 void launch_resid_restrict(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& F, const LevelDev& C,
-                           double* crse, const double* phi, const double* rhs, const int r[3]);
+                           double* crse, const double* phi, const double* rhs, const int r[3], double dxProduct = 0.0,
+                           double* volsum = nullptr);
+// crse(ic) = sum over the children of ic of dxProduct / fjinv(child): the volume a coarse value is spread over
+void launch_child_volume(hipStream_t st, const LevelDev& C, const LevelDev& F, double* crse, const int r[3],
+                         double dxProduct);
+void launch_sum_partials(hipStream_t st, const double* partials, int n, double* out);  // out[0] = sum (fixed order)
+// out[0] = a[0] + b[0]; out[1] = c[0]
+void launch_combine_sums(hipStream_t st, double* out, const double* a, const double* b, const double* c);
 // one colour of vertical-line GSRB (line_gsrb.hip); ctiles = whole-column tiles (k0 = 0, nk = n2)
 void launch_line_gsrb_ortho(hipStream_t st, const Tile* ctiles, int nctiles, int tile_j, const LevelDev& L,
                             double* phi, const double* rhs, double* dmod, int color);

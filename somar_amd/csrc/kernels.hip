@@ -323,6 +323,42 @@ __global__ __launch_bounds__(512) void k_restrict(const Tile* __restrict__ ctile
         }
 }
 
+// W(ic) = sum over children of dxProduct / Jinv(child): setup-time companion of the folded prolongation
+__global__ __launch_bounds__(512) void k_child_volume(const Tile* __restrict__ ctiles,
+                                                      const PatchDesc* __restrict__ cpatches,
+                                                      const PatchDesc* __restrict__ fpatches, double* __restrict__ crse,
+                                                      const double* __restrict__ fjinv, int r0, int r1, int r2,
+                                                      double dxProduct)
+{
+    const Tile t = ctiles[blockIdx.x];
+    const PatchDesc cp = cpatches[t.patch];
+    const PatchDesc fp = fpatches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= cp.n[1]) return;
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int li = li0 + q;
+            if (li >= cp.n[0]) continue;
+            const int lk = t.k0 + kk;
+            double s = 0.0;
+            for (int ii2 = 0; ii2 < r2; ++ii2)
+                for (int ii1 = 0; ii1 < r1; ++ii1)
+                    for (int ii0 = 0; ii0 < r0; ++ii0)
+                        s = s + dxProduct / fjinv[cidx(fp, li * r0 + ii0, lj * r1 + ii1, lk * r2 + ii2)];
+            crse[cidx(cp, li, lj, lk)] = s;
+        }
+}
+
+__global__ void k_combine_sums(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b,
+                               const double* __restrict__ c)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = a[0] + b[0];
+        out[1] = c[0];
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Prolongation: fine += coarse(i/m).  AVG also emits per-block partial sums of
 // dvol*fine and dvol (dvol = dxProduct/Jinv) for the zero-average variant; the mean is
@@ -709,6 +745,21 @@ void launch_prolong(hipStream_t st, const LevelDev& F, const LevelDev& C, double
         hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, F.ntiles, 2, 0, sums);
     }
     (void)fieldElems;
+}
+void launch_child_volume(hipStream_t st, const LevelDev& C, const LevelDev& F, double* crse, const int r[3],
+                         double dxProduct)
+{
+    if (C.ntiles == 0) return;
+    hipLaunchKernelGGL(k_child_volume, dim3(C.ntiles), tile_block(C), 0, st, C.tiles, C.patches, F.patches, crse, F.jinv,
+                       r[0], r[1], r[2], dxProduct);
+}
+void launch_sum_partials(hipStream_t st, const double* partials, int n, double* out)
+{
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, n, 1, 0, out);
+}
+void launch_combine_sums(hipStream_t st, double* out, const double* a, const double* b, const double* c)
+{
+    hipLaunchKernelGGL(k_combine_sums, dim3(1), dim3(64), 0, st, out, a, b, c);
 }
 void launch_sub_mean(hipStream_t st, double* f, long long n, const double* sums)
 {

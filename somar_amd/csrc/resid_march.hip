@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
                                                            const double* __restrict__ jgz,
                                                            const double* __restrict__ jinv, StencilParams P,
                                                            const PatchDesc* __restrict__ cpatches, int r0, int r1,
-                                                           int r2)
+                                                           int r2, double dxProduct, double* __restrict__ volsum)
 {
     __shared__ __attribute__((aligned(16))) double S[2][RM_J][RM_I];
     // MODE 2: (res/J, 1/J) of both cells of every pair, handed from the odd row of a coarse cell to the even one
@@ -124,6 +124,10 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
         }
     };
 
+    // MODE 2 with volsum: this block's sum of dvol * phi over its own cells (dvol = dxProduct / Jinv), the fine
+    // half of the zero-average prolongation's mean (see PressureSolver::cycle); tree order
+    double vsum = 0.0;
+
     int k = t.k0;
     double2 Pm = rm_ld2(phi, base + sk * (k - 1), o[0], o[1], p.off);
     double2 Pc = rm_ld2(phi, base + sk * k, f0, f1, p.off);
@@ -185,6 +189,10 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
                 pv[1] = o[1] ? res[1] / Ji.y : 0.0;
                 pv[2] = o[0] ? 1.0 / Ji.x : 0.0;
                 pv[3] = o[1] ? 1.0 / Ji.y : 0.0;
+                if (volsum) {
+                    if (o[0]) vsum = vsum + dxProduct * pv[2] * Pc.x;
+                    if (o[1]) vsum = vsum + dxProduct * pv[3] * Pc.y;
+                }
                 if (r1 == 2) {
                     double* dstT = T[k & 1][row][lane];
                     *reinterpret_cast<double2*>(dstT) = make_double2(pv[0], pv[1]);
@@ -204,6 +212,17 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
     if (MODE == 2) {
         __syncthreads();
         accumulate(kend - 1);
+        if (volsum) {
+            __shared__ double red[RM_J];
+            for (int o2 = 32; o2 > 0; o2 >>= 1) vsum += __shfl_down(vsum, o2, 64);
+            if (lane == 0) red[row] = vsum;
+            __syncthreads();
+            if (lane == 0 && row == 0) {
+                double tot = red[0];
+                for (int q = 1; q < RM_J; ++q) tot = tot + red[q];
+                volsum[blockIdx.x] = tot;
+            }
+        }
     }
 }
 
@@ -213,20 +232,22 @@ void launch_resid_march(hipStream_t st, const Tile* tiles, int ntiles, const Lev
     if (ntiles == 0) return;
     if (mode == 0)
         hipLaunchKernelGGL(k_resid_march<0>, dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, L.patches, out, phi, rhs,
-                           L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, nullptr, 1, 1, 1);
+                           L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, nullptr, 1, 1, 1, 0.0, nullptr);
     else
         hipLaunchKernelGGL(k_resid_march<1>, dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, L.patches, out, phi, rhs,
-                           L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, nullptr, 1, 1, 1);
+                           L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, nullptr, 1, 1, 1, 0.0, nullptr);
 }
 
 // restrictResidual in one pass: crse = J-weighted average (MAPPEDAVERAGE2) of rhs - L[phi]; the fine residual is
 // never written.  Needs tiles whose k-extent is even (Level::hrtiles are) and a coarsenable layout.
+// volsum (optional, ntiles doubles): per-block sums of (dxProduct / Jinv) * phi over the block's cells
 void launch_resid_restrict(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& F, const LevelDev& C,
-                           double* crse, const double* phi, const double* rhs, const int r[3])
+                           double* crse, const double* phi, const double* rhs, const int r[3], double dxProduct,
+                           double* volsum)
 {
     if (ntiles == 0) return;
     hipLaunchKernelGGL(k_resid_march<2>, dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, F.patches, crse, phi, rhs,
-                       F.jg[0], F.jg[1], F.jg[2], F.jinv, F.P, C.patches, r[0], r[1], r[2]);
+                       F.jg[0], F.jg[1], F.jg[2], F.jinv, F.P, C.patches, r[0], r[1], r[2], dxProduct, volsum);
 }
 
 }  // namespace somar

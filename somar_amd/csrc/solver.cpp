@@ -39,6 +39,8 @@ PressureSolver::~PressureSolver()
     for (double* f : f_vel) hipFree(f);
     for (double* f : f_amr) hipFree(f);
     for (double* f : f_psi) hipFree(f);
+    for (double* f : f_W) hipFree(f);
+    hipFree(d_fold);
     for (auto& pr : full_prog_)
         for (auto& q : pr) hipFree(q.d_ops);
     for (auto& L : lev)
@@ -315,7 +317,7 @@ void PressureSolver::finalize()
         ++depth;
     }
     int maxTiles = 1;
-    for (auto& L : lev) maxTiles = std::max(maxTiles, L->dev.ntiles);
+    for (auto& L : lev) maxTiles = std::max(std::max(maxTiles, L->dev.ntiles), std::max(L->nrtiles, L->nftiles));
     SOMAR_HIP(hipMalloc(&d_partials, (size_t)maxTiles * 2 * sizeof(double)));
     const int D = (int)lev.size();
     f_res.assign(D, nullptr);
@@ -344,6 +346,20 @@ void PressureSolver::finalize()
     f_uberRes = L0.alloc_field();
     f_uberCorr = L0.alloc_field();
     f_best = L0.alloc_field();
+    // folded prolongation: child volumes and total volume per depth
+    f_W.assign(D, nullptr);
+    sf_valid_.assign(D, 0);
+    SOMAR_HIP(hipMalloc(&d_fold, (size_t)D * 8 * sizeof(double)));
+    SOMAR_HIP(hipMemset(d_fold, 0, (size_t)D * 8 * sizeof(double)));
+    SOMAR_HIP(hipDeviceSynchronize());
+    for (int d = 0; d + 1 < D; ++d) {
+        Level& F = *lev[d];
+        Level& C = *lev[d + 1];
+        f_W[d + 1] = C.alloc_field();
+        launch_child_volume(st_, C.dev, F.dev, f_W[d + 1], F.mgCrseRefRatio, F.dxProduct);
+        launch_reduce(st_, C.dev, f_W[d + 1], nullptr, 2, d_partials, d_fold + 8 * d + 2);  // V = sum of volumes (> 0)
+        comm_->allreduce(d_fold + 8 * d + 2, 1, 0, st_);
+    }
     for (int i = 0; i < 8; ++i) bicg[i] = lev[D - 1]->alloc_field();
     for (int d = 0; d < D; ++d) probe_null_space(d);
     sync();
@@ -453,11 +469,12 @@ bool PressureSolver::fused_relax(int d, int iters) const
            (L.ncf == 0 || L.cf_fusable) && L.active[2] && !no_cf_fused_(L) && !full_;
 }
 
-void PressureSolver::relax(int d, double* e, const double* res, int iters, bool e_zero, const double* e_shift)
+void PressureSolver::relax(int d, double* e, const double* res, int iters, bool e_zero, const double* e_shift,
+                           const Level* e_plus_level, const double* e_plus)
 {
     Level& L = *lev[d];
     const bool fused_path = fused_relax(d, iters);
-    SOMAR_CHECK(!e_shift || fused_path, "deferred mean removal needs the fused sweep");
+    SOMAR_CHECK((!e_shift && !e_plus) || fused_path, "deferred mean removal / folded prolongation need the fused sweep");
     static const bool no_zero_start = getenv("SOMAR_NO_ZERO_START") != nullptr;  // A/B switch
     if (e_zero && (!fused_path || no_zero_start)) {
         launch_set(st_, e, L.field_elems, 0.0);
@@ -476,8 +493,12 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
                 L.cf_homog_ext(cur, st_);  // CF ghosts (faces + the edge ghosts the red ring reads), pre-sweep values
             }
             if (profiling_ && d == 0) prof_begin(0);
-            launch_gsrb_fused(st_, L.d_ftiles, L.nftiles, L.dev, alt, cur, res,
-                              zin ? 1 : ((e_shift && it == 0) ? 2 : 0), e_shift);
+            int mode = 0;
+            if (zin) mode = 1;
+            else if (it == 0 && e_plus) mode = e_shift ? 4 : 3;
+            else if (it == 0 && e_shift) mode = 2;
+            launch_gsrb_fused(st_, L.d_ftiles, L.nftiles, L.dev, alt, cur, res, mode, e_shift,
+                              e_plus_level ? &e_plus_level->dev : nullptr, e_plus, L.mgCrseRefRatio);
             if (profiling_ && d == 0) prof_end(0);
             std::swap(cur, alt);
         }
@@ -593,8 +614,11 @@ void PressureSolver::restrict_residual(int d, double* resCoarse, double* phiFine
         F.cf_homog(phiFine, st_);
         F.exchange(phiFine, st_);
         if (profiling_ && d == 0) prof_begin(1);
+        const bool want = F.zeroAvg && !ordered(d);  // the fine half of the folded prolongation's mean
         launch_resid_restrict(st_, F.d_rtiles, F.nrtiles, F.dev, lev[d + 1]->dev, resCoarse, phiFine, rhsFine,
-                              F.mgCrseRefRatio);
+                              F.mgCrseRefRatio, F.dxProduct, want ? d_partials : nullptr);
+        if (want) launch_sum_partials(st_, d_partials, F.nrtiles, d_fold + 8 * d);
+        sf_valid_[d] = want ? 1 : 0;
         if (profiling_ && d == 0) prof_end(1);
         return;
     }
@@ -758,9 +782,37 @@ void PressureSolver::cycle(int d, double* corr, const double* res, bool corr_zer
     relax(d, corr, res, prm.num_smooth_down, corr_zero && prm.num_smooth_down > 0);
     restrict_residual(d, f_res[d + 1], corr, res);
     for (int img = 0; img < prm.numMG; ++img) cycle(d + 1, f_corr[d + 1], f_res[d + 1], img == 0);
+    if (fold_prolong(d)) {
+        // Large level: neither the prolongation nor the zero-average mean removal gets a pass of its own -- the first
+        // post-smoothing sweep reads corr + coarse(i/r) - mean.  mean = (S_f + S_c) / V with S_f = sum dvol * corr
+        // (gathered by the fused restriction), S_c = sum over coarse cells of coarse * (volume of its children), V the
+        // level's volume: the same number as ZeroAvgConstInterpPS's sum dvol * (corr + coarse) / sum dvol up to the
+        // association of the (already tree-ordered) sum.
+        Level& F = *lev[d];
+        Level& C = *lev[d + 1];
+        C.exchange(f_corr[d + 1], st_);
+        const double* shift = nullptr;
+        if (F.zeroAvg) {
+            double* s = d_fold + 8 * d;
+            launch_reduce(st_, C.dev, f_corr[d + 1], f_W[d + 1], 0, d_partials, s + 1);
+            comm_->allreduce(s, 2, 0, st_);
+            launch_combine_sums(st_, s + 3, s, s + 1, s + 2);
+            shift = s + 3;
+        }
+        relax(d, corr, res, prm.num_smooth_up, false, shift, &C, f_corr[d + 1]);
+        return;
+    }
     // the zero-average mean is folded into the first post-smoothing sweep when that sweep is the fused kernel
     const double* shift = prolong_increment(d, corr, f_corr[d + 1], fused_relax(d, prm.num_smooth_up));
     relax(d, corr, res, prm.num_smooth_up, false, shift);
+}
+
+bool PressureSolver::fold_prolong(int d) const
+{
+    static const bool off = getenv("SOMAR_NO_FOLD_PROLONG") != nullptr;  // A/B switch
+    const Level& F = *lev[d];
+    if (off || !fused_relax(d, prm.num_smooth_up) || ordered(d) || hasCF_) return false;
+    return !F.zeroAvg || sf_valid_[d];
 }
 
 // ------------------------------------------------------------------------------------

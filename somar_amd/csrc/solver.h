@@ -92,7 +92,10 @@ public:
     // e_zero: e is to be taken as all zeros, whatever it holds (saves the memset and the first sweep's read)
     // e_shift: device pointer to (sum, volume): e is to be read as e - sum/volume (deferred mean removal); only
     //          legal when fused_relax(d, iters) holds
-    void relax(int d, double* e, const double* res, int iters, bool e_zero = false, const double* e_shift = nullptr);
+    // e_plus: (coarse level, coarse correction): e is to be read as e + coarse(i / r) -- the prolongation folded
+    //         into the first sweep; the coarse field must have been exchanged
+    void relax(int d, double* e, const double* res, int iters, bool e_zero = false, const double* e_shift = nullptr,
+               const Level* e_plus_level = nullptr, const double* e_plus = nullptr);
     bool fused_relax(int d, int iters) const;
     static bool no_cf_fused_(const Level& L)  // A/B switch: SOMAR_NO_CF_FUSED=1 keeps CF levels on the two-pass kernel
     {
@@ -165,6 +168,12 @@ private:
     double* d_scalars = nullptr;  // device scalar slots
     double* h_scalars = nullptr;  // pinned
     bool finalized = false;
+    // ---- prolongation folded into the first post-smoothing sweep (large levels) ----
+    // f_W[d+1]: per coarse cell the volume of its children on depth d; d_fold: per depth {S_f, S_c, V, sum, V}
+    std::vector<double*> f_W;
+    double* d_fold = nullptr;
+    std::vector<char> sf_valid_;
+    bool fold_prolong(int d) const;
     // ---- non-diagonal metric (19-point) path, solver_full.cpp ----
     struct FullProgram { GhostOp* d_ops = nullptr; std::vector<int> first, count; };
     bool full_ = false;
