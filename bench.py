@@ -37,7 +37,9 @@ N_FINE = 512
 
 def partition(n, ngpus):
     """one box per GPU; split z then y then x so x rows stay long (coalescing) as long as possible"""
-    split = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(ngpus)
+    # x is never split: the marching kernels' tiles are 124 cells wide, a 512-wide box wastes 3 % of its tile columns,
+    # a 256-wide one 28 % (DESIGN.md 7); the halo surface of 512x256x128 equals that of 256^3
+    split = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (1, 2, 4)}.get(ngpus)
     if split is None:
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
     boxes = []
