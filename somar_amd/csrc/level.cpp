@@ -590,7 +590,7 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
         }
         int best = 1;
         double best_eff = -1.0;
-        for (int nch = 1; nch <= 16 && (nch == 1 || maxn2 / nch >= 16); ++nch) {
+        for (int nch = 1; nch <= 64 && (nch == 1 || maxn2 / nch >= 4); ++nch) {  // small levels: short chunks, more workgroups
             const long long blocks = cols * nch;
             const long long rounds = (blocks + 255) / 256;
             const double nk = (double)maxn2 / nch;
