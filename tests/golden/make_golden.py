@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/oracle_small.npz: outputs of the CPU ORACLE (oracle/, this repository's restatement of
+the reference algorithm) on small seeded problems.
+
+These are NOT outputs of the reference: UNC-CFD/somar ships no golden vectors for this path and cannot be built in
+this environment.  The file pins the oracle against ITSELF, so that an edit to oracle/ that changes a
+single bit of its results is noticed (tests/test_oracle_golden.py), and gives later rounds a fixed target.
+
+    python tests/golden/make_golden.py            # rewrites oracle_small.npz
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def compute():
+    from oracle import somar_amr as am
+    from oracle import somar_oracle as so
+    from helpers import make_amr_levels, make_oracle_solver, make_problem
+    out = {}
+    # 1. single level, stretched diagonal metric, periodic y: GSRB sweep, residual, restriction, V-cycle history
+    dom, grids, dx, Jgup, Jinv = make_problem(so, (16, 16, 8), 8, "stretched", (False, True, False), (2.0, 1.0, 0.5))
+    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv)
+    op = amr.mg.ops[0]
+    phi = so.random_field(grids, 3, (1, 1, 1), dom.box)
+    rhs = so.random_field(grids, 4, (0, 0, 0), dom.box)
+    op.relax(phi, rhs, 2)
+    out["gsrb2_box0"] = phi[0].view(grids[0])[..., 0].copy()
+    res = so.LevelData(grids, 1)
+    op.residual(res, phi, rhs, True)
+    out["residual_box1"] = res[1].view(grids[1])[..., 0].copy()
+    cres = op.create_coarser(res)
+    op.restrict_residual(cres, phi, rhs)
+    out["restrict_box0"] = cres[0].view(cres.grids[0])[..., 0].copy()
+    b = so.random_field(grids, 12345, (0, 0, 0), dom.box)
+    so.remove_weighted_mean(b, Jinv)
+    x = so.LevelData(grids, 1, (1, 1, 1))
+    amr.solve(x, b)
+    out["solve_history"] = np.array(amr.history)
+    out["solve_iters_exit"] = np.array([amr.iters, amr.exitStatus])
+    # 2. vertical-line GSRB
+    fac = so.Factory(dom, grids, dx, so.BCHolder(), Jgup, Jinv, relaxMode=so.RELAX_LINE_GSRB, maxDepth=0)
+    opl = fac.mg_new_op(0, None)
+    phi = so.random_field(grids, 5, (1, 1, 1), dom.box)
+    opl.relax(phi, rhs, 1)
+    out["line_gsrb_box0"] = phi[0].view(grids[0])[..., 0].copy()
+    # 3. non-diagonal metric: 19-point residual and GSRB
+    Jgf, Jif = so.make_full_metric(grids, dx, (2.0, 1.0, 0.5), dom)
+    opf = so.Factory(dom, grids, dx, so.BCHolder(), Jgf, Jif, isDiagonal=False, maxDepth=0).mg_new_op(0, None)
+    phi = so.random_field(grids, 6, (1, 1, 1), dom.box)
+    resf = so.LevelData(grids, 1)
+    opf.residual(resf, phi, rhs, True)
+    out["full_residual_box0"] = resf[0].view(grids[0])[..., 0].copy()
+    opf.relax(phi, rhs, 1)
+    out["full_gsrb_box0"] = phi[0].view(grids[0])[..., 0].copy()
+    # 4. two AMR levels: quadratic CF interpolation, refluxed composite residual
+    fb = [[so.Box((8, 8, 4), (23, 23, 11))]]
+    levels = make_amr_levels(so, am, (16, 16, 8), (2.0, 1.0, 0.5), (False, False, False), [(2, 2, 2)], fb)
+    comp = am.AMRComposite(levels, [(2, 2, 2)], so.BCHolder(), so.BiCGStab())
+    phis = [so.random_field(L.grids, 5 + l, (1, 1, 1), L.domain.box) for l, L in enumerate(levels)]
+    rhss = [so.random_field(L.grids, 50 + l, (0, 0, 0), L.domain.box) for l, L in enumerate(levels)]
+    ress = [so.LevelData(L.grids, 1) for L in levels]
+    comp.init(phis, rhss, 1, 0)
+    comp.compute_amr_residual(ress, phis, rhss, 1, 0, True)
+    out["amr_res_level0_box0"] = ress[0][0].view(levels[0].grids[0])[..., 0].copy()
+    out["amr_res_level1"] = ress[1][0].view(levels[1].grids[0])[..., 0].copy()
+    out["amr_fine_phi_with_cf_ghosts"] = phis[1][0].a[..., 0].copy()
+    return out
+
+
+if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "oracle_small.npz"), **compute())
+    print("wrote", os.path.join(HERE, "oracle_small.npz"))

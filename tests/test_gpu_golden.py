@@ -1,0 +1,97 @@
+"""The HIP path against the committed vectors of tests/golden/oracle_small.npz (oracle outputs, see make_golden.py):
+same seeded inputs, results compared bit for bit without running the oracle's kernels."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import download_valid, make_amr_levels, make_gpu_amr, make_gpu_solver, make_problem, upload
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_small.npz"))
+
+
+def test_single_level_kernels_match_golden(oracle):
+    from somar_amd import api as F
+    so = oracle
+    dom, grids, dx, Jgup, Jinv = make_problem(so, (16, 16, 8), 8, "stretched", (False, True, False), (2.0, 1.0, 0.5))
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv)
+    try:
+        upload(gpu, F.F_PHI, so.random_field(grids, 3, (1, 1, 1), dom.box))
+        rhs = so.random_field(grids, 4, (0, 0, 0), dom.box)
+        upload(gpu, F.F_RHS, rhs)
+        gpu.relax(0, F.F_PHI, F.F_RHS, 2)
+        np.testing.assert_array_equal(download_valid(gpu, F.F_PHI, grids)[0], GOLD["gsrb2_box0"])
+        gpu.residual(0, F.F_RES, F.F_PHI, F.F_RHS)
+        np.testing.assert_array_equal(download_valid(gpu, F.F_RES, grids)[1], GOLD["residual_box1"])
+        gpu.restrictResidual(0, F.FIELD(1, F.F_RES), F.F_PHI, F.F_RHS)
+        cg = [g.coarsen(gpu.mgRefRatios()[0]) for g in grids]
+        np.testing.assert_array_equal(download_valid(gpu, F.FIELD(1, F.F_RES), cg, 1)[0], GOLD["restrict_box0"])
+        b = so.random_field(grids, 12345, (0, 0, 0), dom.box)
+        so.remove_weighted_mean(b, Jinv)
+        upload(gpu, F.F_RHS, b)
+        st = gpu.solveResident(True, False)
+        assert [st["iters"], st["exitStatus"]] == list(GOLD["solve_iters_exit"])
+        np.testing.assert_allclose(st["history"], GOLD["solve_history"], rtol=1e-10)
+    finally:
+        gpu.undefine()
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv, relaxMode=3, maxDepth=0)
+    try:
+        upload(gpu, F.F_PHI, so.random_field(grids, 5, (1, 1, 1), dom.box))
+        upload(gpu, F.F_RHS, rhs)
+        gpu.relax(0, F.F_PHI, F.F_RHS, 1)
+        np.testing.assert_array_equal(download_valid(gpu, F.F_PHI, grids)[0], GOLD["line_gsrb_box0"])
+    finally:
+        gpu.undefine()
+
+
+def test_full_metric_kernels_match_golden(oracle):
+    from somar_amd import AMRPressureSolver
+    from somar_amd import api as F
+    so = oracle
+    dom, grids, dx, _, _ = make_problem(so, (16, 16, 8), 8, "stretched", (False, True, False), (2.0, 1.0, 0.5))
+    Jgf, Jif = so.make_full_metric(grids, dx, (2.0, 1.0, 0.5), dom)
+    s = AMRPressureSolver()
+    p = s._p
+    s.setAMRMGParameters(p.imin, p.imax, p.eps, 0, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg, p.hang,
+                         p.norm_thresh, 0)
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids])
+    try:
+        for q in range(s.num_local_patches):
+            _, _, gi = s.patch_box(q)
+            s.setMetricFull(q, *[np.asfortranarray(Jgf[gi][d].a) for d in range(3)], np.asfortranarray(Jif[gi].a[..., 0]))
+        s.finalize()
+        upload(s, F.F_PHI, so.random_field(grids, 6, (1, 1, 1), dom.box))
+        upload(s, F.F_RHS, so.random_field(grids, 4, (0, 0, 0), dom.box))
+        s.residual(0, F.F_RES, F.F_PHI, F.F_RHS)
+        np.testing.assert_array_equal(download_valid(s, F.F_RES, grids)[0], GOLD["full_residual_box0"])
+        s.relax(0, F.F_PHI, F.F_RHS, 1)
+        np.testing.assert_array_equal(download_valid(s, F.F_PHI, grids)[0], GOLD["full_gsrb_box0"])
+    finally:
+        s.undefine()
+
+
+def test_amr_residual_matches_golden(oracle):
+    from oracle import somar_amr as am
+    from somar_amd import api as F
+    so = oracle
+    fb = [[so.Box((8, 8, 4), (23, 23, 11))]]
+    levels = make_amr_levels(so, am, (16, 16, 8), (2.0, 1.0, 0.5), (False, False, False), [(2, 2, 2)], fb)
+    gpu = make_gpu_amr(levels, [(2, 2, 2)])
+    try:
+        for l, v in enumerate(gpu.levels):
+            upload(v, F.F_PHI, so.random_field(levels[l].grids, 5 + l, (1, 1, 1), levels[l].domain.box))
+            upload(v, F.F_RHS, so.random_field(levels[l].grids, 50 + l, (0, 0, 0), levels[l].domain.box))
+        for ilev in (0, 1):
+            gpu.residualLevel(1, 0, ilev)
+        gpu.zeroCovered(0, F.F_RES)
+        np.testing.assert_array_equal(download_valid(gpu.levels[0], F.F_RES, levels[0].grids)[0], GOLD["amr_res_level0_box0"])
+        np.testing.assert_array_equal(download_valid(gpu.levels[1], F.F_RES, levels[1].grids)[0], GOLD["amr_res_level1"])
+        got = gpu.levels[1].download(F.F_PHI, 0, (1, 1, 1))
+        want = GOLD["amr_fine_phi_with_cf_ghosts"]
+        # faces only: edge / corner ghosts of the host array are not defined by the CF interpolation
+        for sl in [(0, slice(1, -1), slice(1, -1)), (-1, slice(1, -1), slice(1, -1)), (slice(1, -1), 0, slice(1, -1)),
+                   (slice(1, -1), -1, slice(1, -1)), (slice(1, -1), slice(1, -1), 0), (slice(1, -1), slice(1, -1), -1)]:
+            np.testing.assert_array_equal(got[sl], want[sl])
+    finally:
+        gpu.undefine()
