@@ -231,6 +231,9 @@ int somar_comm_create(void** comm, const unsigned char* id128, int rank, int nra
  * rank 0 creates it): a way to run the sharded path where RCCL cannot be used -- several ranks on ONE GPU of a
  * development box -- with the same message plans.  Synchronous; not for production. */
 int somar_comm_create_shm(void** comm, const char* name, int rank, int nranks, long long outbox_bytes);
+/* Transport self-test: all-reduce (sum, max) of rank-dependent values and a ring neighbour exchange
+ * (rank -> rank+1; a self send/recv on one rank), checked on the host.  Collective over the communicator. */
+int somar_comm_selftest(void* comm);
 int somar_comm_destroy(void* comm);
 
 #ifdef __cplusplus

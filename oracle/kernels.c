@@ -1011,3 +1011,66 @@ int orc_linegsrbiter3d(double *phi_, const int *plo, const int *phi_hi,
     free(D); free(B); free(DL); free(DU);
     return worst;
 }
+
+/* ------------------------------------------------------------------------
+ * K18 TriDiagPoissonNN1DFAB   utils/TridiagUtilsF.ChF:85-166
+ * Along every line that starts in bottomBox and runs Nx cells in direction dir: solves the homogeneous
+ * Neumann-Neumann 1-D Poisson problem  D(sigma D phi) = rhs  (sigma face-centred in dir) with the
+ * Thomas recurrence whose last row is special-cased, then removes the mean of the line.
+ * Single component (the only way LevelLepticSolver.cpp:1364-1371 calls it).
+ * ---------------------------------------------------------------------- */
+void orc_tridiagpoissonnn1dfab(double *phi_, const int *plo, const int *phi_hi,
+                               const double *rhs_, const int *rlo, const int *rhi,
+                               const double *sig_, const int *slo, const int *shi,
+                               const int *blo, const int *bhi, int Nx, double dx, int dir)
+{
+    fra_t phi = mk(phi_, plo, phi_hi), rhs = mk((double *)rhs_, rlo, rhi), sigma = mk((double *)sig_, slo, shi);
+    const int ii[3] = {dir == 0, dir == 1, dir == 2};
+    const double dxsq = dx * dx;
+    double *x = (double *)malloc(sizeof(double) * (size_t)Nx);
+    double *a = (double *)malloc(sizeof(double) * (size_t)Nx);
+    double *b = (double *)malloc(sizeof(double) * (size_t)Nx);
+    double *c = (double *)malloc(sizeof(double) * (size_t)Nx);
+    double *gam = (double *)malloc(sizeof(double) * (size_t)Nx);
+#define OFF(A, r) AT(A, i + (r) * ii[0], j + (r) * ii[1], k + (r) * ii[2], 0)
+    for (int k = blo[2]; k <= bhi[2]; ++k)
+        for (int j = blo[1]; j <= bhi[1]; ++j)
+            for (int i = blo[0]; i <= bhi[0]; ++i) {
+                double bet, avg;
+                int r;
+                c[0] = OFF(sigma, 1);
+                a[0] = 1.2345e10;
+                b[0] = -c[0];
+                x[0] = OFF(rhs, 0) * dxsq;
+                for (r = 1; r <= Nx - 2; ++r) {
+                    a[r] = OFF(sigma, r);
+                    c[r] = OFF(sigma, r + 1);
+                    b[r] = -(a[r] + c[r]);
+                    x[r] = OFF(rhs, r) * dxsq;
+                }
+                /* r == Nx-1 */
+                a[Nx - 1] = OFF(sigma, r);
+                b[Nx - 1] = -a[Nx - 1];
+                x[Nx - 1] = OFF(rhs, r) * dxsq;
+
+                bet = b[0];
+                x[0] = x[0] / bet;
+                gam[0] = c[0] / bet;
+                for (r = 1; r <= Nx - 2; ++r) {
+                    bet = b[r] - a[r] * gam[r - 1];
+                    x[r] = (x[r] - a[r] * x[r - 1]) / bet;
+                    gam[r] = c[r] / bet;
+                }
+                /* last index is a special case (as written in the reference: a(r-1), plain b(r)) */
+                x[r] = (x[r] - a[r - 1] * x[r - 1]) / b[r];
+                avg = x[r];
+                for (r = Nx - 2; r >= 0; --r) {
+                    x[r] = x[r] - gam[r] * x[r + 1];
+                    avg = avg + x[r];
+                }
+                avg = avg / (double)Nx;
+                for (r = 0; r <= Nx - 1; ++r) OFF(phi, r) = x[r] - avg;
+            }
+#undef OFF
+    free(x); free(a); free(b); free(c); free(gam);
+}

@@ -1,0 +1,290 @@
+"""oracle/somar_leptic.py -- TEST INFRASTRUCTURE: CPU restatement of the reference's leptic level solver.
+
+Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import this module.
+
+  LevelLepticSolver::define / solve      calculus/LepticSolver/LevelLepticSolver.cpp:147-437, 646-956
+  computeHorizRHS                        :981-1097
+  levelVertHorizGradient                 :1107-1176      (diagonal metric: boundary data := 0)
+  computeVerticalExcess                  :1183-1240
+  verticalLineSolver                     :1248-1421      (Neumann-Neumann columns: TriDiagPoissonNN1DFAB)
+  horizontalSolver, add*Correction       :1427-1517
+  setZeroAvg                             :1668-1710
+  UNMAPPEDVERTINTEGRAL, ADDEXTRUSION     utils/SubspaceF.ChF:33-110
+  LEPTICACCUMDIV                         calculus/LepticSolver/LevelLepticSolverF.ChF:285-331
+  createVertAvgFCJgupPtr / CCJinvPtr     geometry/LevelGeometryBasics.cpp:409-433, 500-569
+
+Scope (the same as the HIP path, csrc/leptic.cpp): one level whose boxes are vertically complete columns
+(the layout LepticBoxUtils::createVerticalSolverGrids produces), so the reference's orig <-> vertical and
+flat <-> horizontal re-layouts are identities; diagonal metric; Neumann (or any non-periodic) physical
+boundaries in the vertical and non-periodic horizontal directions (the reference never fills the face gradient on
+a periodic horizontal boundary, LevelLepticSolver.cpp:997-1001 + :1056-1061); no coarse-fine boundary.
+Parity unpinned w.r.t. reference tests: the reference ships none; pinned by the
+analytic known answers in tests/test_oracle_leptic.py.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import somar_oracle as so
+
+EXIT_NONE, EXIT_CONVERGE, EXIT_ITER, EXIT_HANG, EXIT_DIVERGE, EXIT_KABOOM = -1, 0, 1, 2, 3, 4
+
+
+def flatten_box(b, pos):
+    """LepticBoxUtils::FlattenTransform, LepticBoxUtils.cpp:39-49"""
+    return so.Box((b.lo[0], b.lo[1], pos), (b.hi[0], b.hi[1], pos))
+
+
+def vert_avg_metric(grids, Jgup, domBox):
+    """The horizontal problem's metric: vertical average of the horizontal J g^{aa} (diagonal metric), J^{-1} := 1.
+    createVertAvgFCJgupPtr: levelSum += func * (1/Nz), k ascending."""
+    pos = domBox.lo[2]
+    flat = [flatten_box(g, pos) for g in grids]
+    hJg = so.FluxData(flat, 2, ndim=2)
+    for i, g in enumerate(grids):
+        scale = 1.0 / float(g.size()[2])
+        for d in range(2):
+            src = Jgup[i][d].a[..., d]
+            acc = np.zeros(src.shape[:2])
+            for k in range(src.shape[2]):
+                acc = acc + src[:, :, k] * scale
+            hJg[i][d].a[:, :, 0, d] = acc
+    hJinv = so.LevelData(flat, 1, (0, 0, 0), fill=1.0)
+    return flat, hJg, hJinv
+
+
+class LevelLepticSolver:
+    def __init__(self, origOp, maxOrder=4, hang=1e-15, normType=0, horizRhsTol=1e-14, domainHeight=None,
+                 horiz=None, horizBottom=None, full=None, fullBottom=None):
+        # setDefaultParameters, LevelLepticSolver.cpp:461-508
+        hz = dict(imin=5, imax=20, pre=4, bottom=4, post=4, precond=2, relaxMode=so.RELAX_LEVEL_GSRB, maxDepth=-1,
+                  eps=1e-12, hang=1e-15, normThresh=1e-30)
+        hzb = dict(imax=80, eps=1e-12, numRestarts=5, hang=1e-15)
+        fl = dict(imin=5, imax=20, pre=4, bottom=4, post=4, precond=4, relaxMode=so.RELAX_LINE_GSRB, maxDepth=-1,
+                  eps=1e-6, hang=1e-15, normThresh=1e-30)
+        flb = dict(imax=80, numRestarts=5)
+        hz.update(horiz or {}); hzb.update(horizBottom or {}); fl.update(full or {}); flb.update(fullBottom or {})
+        assert normType == 0, "only the max norm (the reference's default) is restated"
+        self.maxOrder, self.hang, self.normType, self.horizRhsTol = maxOrder, hang, normType, horizRhsTol
+        op = self.origOp = origOp
+        assert op.isDiagonal and op.cf is None and op.ndim == 3
+        dom, grids, dx = op.domain, op.grids, op.dx
+        self.domain, self.grids, self.dx = dom, grids, dx
+        domBox = dom.box
+        for g in grids:
+            assert g.lo[2] == domBox.lo[2] and g.hi[2] == domBox.hi[2], "boxes must be vertically complete columns"
+        assert not any(dom.periodic), "periodic directions are not supported by the reference's leptic path"
+        self.H = dx[2] * domBox.size()[2] if domainHeight is None else domainHeight
+        # vertical grids == original grids; Jgup is shared, Jinv := 1 (the residual equation is scaled by J)
+        self.Jgup = op.Jgup
+        self.Jinv1 = so.LevelData(grids, 1, (0, 0, 0), fill=1.0)
+        # full 3-D MG solver (also supplies m_opPtr: alpha 0, beta 1)            :254-300
+        fac = so.Factory(dom, grids, dx, op.bc, self.Jgup, self.Jinv1, alpha=0.0, beta=1.0, isDiagonal=True, ndim=3,
+                         maxDepth=fl["maxDepth"], precondIters=fl["precond"], relaxMode=fl["relaxMode"])
+        bot = so.BiCGStab(imax=flb["imax"], numRestarts=flb["numRestarts"], normType=normType, hang=1e-8)
+        self.mgSolver = so.AMRMultiGrid(fac, bot, fl["maxDepth"])
+        self.mgSolver.imin = fl["imin"]
+        self.mgSolver.set_solver_parameters(fl["pre"], fl["post"], fl["bottom"], 1, fl["imax"], fl["eps"], fl["hang"],
+                                            fl["normThresh"])
+        self.op = self.mgSolver.op
+        # gatherVerticalBCTypes: physical Neumann at both ends => horizontal solves                 :1523-1640
+        self.doHorizSolve = True
+        # horizontal structures                                                   :304-432
+        self.flatGrids, hJg, hJinv = vert_avg_metric(grids, self.Jgup, domBox)
+        self.horizDomain = so.Domain(flatten_box(domBox, domBox.lo[2]), dom.periodic)
+        hfac = so.Factory(self.horizDomain, self.flatGrids, dx, so.BCHolder(), hJg, hJinv, alpha=0.0, beta=1.0,
+                          isDiagonal=True, ndim=2, maxDepth=hz["maxDepth"], precondIters=hz["precond"],
+                          relaxMode=hz["relaxMode"])
+        hbot = so.BiCGStab(imax=hzb["imax"], eps=hzb["eps"], numRestarts=hzb["numRestarts"], hang=hzb["hang"],
+                           normType=normType)
+        self.horizSolver = so.AMRMultiGrid(hfac, hbot, hz["maxDepth"])
+        self.horizSolver.imin = hz["imin"]
+        self.horizSolver.set_solver_parameters(hz["pre"], hz["post"], hz["bottom"], 1, hz["imax"], hz["eps"],
+                                               hz["hang"], hz["normThresh"])
+        npts = sum(g.numPts() for g in self.flatGrids)
+        self.horizRemoveAvg = npts == self.horizDomain.box.numPts()
+        self.exitStatus = EXIT_NONE
+        self.resNorms = []
+        self.usedFullSolver = False
+        self.horizSolves = 0
+
+    # -- pieces ---------------------------------------------------------------------------------------
+    def compute_vertical_excess(self, excess, rhs, bcLo, bcHi):
+        """excess = hiNeumBC - loNeumBC - Integral[rhs]                                :1183-1240"""
+        dzScale = -1.0 * self.dx[2]
+        for i, g in enumerate(self.grids):
+            e = bcHi[i].copy()
+            e = e + (-1.0) * bcLo[i]
+            r = rhs[i].view(g)[..., 0]
+            for k in range(r.shape[2]):
+                e = e + r[:, :, k] * dzScale
+            excess[i][...] = e
+
+    def vertical_line_solver(self, vertPhi, vertRhs, bcLo, bcHi):
+        """verticalLineSolver, Neumann-Neumann branch                                  :1248-1421"""
+        dz = self.dx[2]
+        L = so.lib()
+        for i, g in enumerate(self.grids):
+            Nz = g.size()[2]
+            r = vertRhs[i].view(g)[..., 0]
+            # roll the BC values in: rhs -/+ NeumBCVal/dz (rollInFAB := 0; plus(bc, scale); rhs.plus(rollIn, 1))
+            rollLo = 0.0 + bcLo[i] * (1.0 / dz)     # scale = -isign/dz, isign = -1
+            rollHi = 0.0 + bcHi[i] * (-1.0 / dz)
+            r[:, :, 0] = r[:, :, 0] + rollLo * 1.0
+            r[:, :, Nz - 1] = r[:, :, Nz - 1] + rollHi * 1.0
+            bottom = so.Box(g.lo, (g.hi[0], g.hi[1], g.lo[2]))
+            blo, bhi = so._b(bottom)
+            JgzF = self.Jgup[i][2]
+            L.orc_tridiagpoissonnn1dfab(*vertPhi[i].fra1(0), *vertRhs[i].fra1(0), *JgzF.fra1(2), blo, bhi, Nz,
+                                        C.c_double(dz), 2)
+            # unroll (rhs.plus(rollIn, -1)): NOT bit-identical to the rhs before, as in the reference
+            r[:, :, 0] = r[:, :, 0] + rollLo * (-1.0)
+            r[:, :, Nz - 1] = r[:, :, Nz - 1] + rollHi * (-1.0)
+
+    def compute_horiz_rhs(self, flatRhs, phi):
+        """-d_m bar(Jg^{mm} d_m phi), diagonal metric; boundary faces carry the (zero) boundary data   :981-1097"""
+        dom = self.domain
+        # extrapAllGhosts(phi, 2) only matters on faces whose gradient is then overwritten by boundary data or
+        # which the exchange refills; the exchange supplies the neighbour values
+        so.exchange(phi, dom, phi.ghost)
+        for i, g in enumerate(self.grids):
+            Nz = g.size()[2]
+            dzScale = 1.0 / float(Nz)
+            acc_rhs = np.zeros(g.size()[:2])
+            pF = phi[i]
+            for d in range(2):
+                fb = g.faces(d)
+                Jg = self.Jgup[i][d].view(fb, d)
+                e = [1 if q == d else 0 for q in range(3)]
+                hi_cells = so.Box(fb.lo, fb.hi)
+                lo_cells = hi_cells.shift([-x for x in e])
+                dxinv = 1.0 / self.dx[d]
+                grad = dxinv * Jg * (pF.view(hi_cells)[..., 0] - pF.view(lo_cells)[..., 0])
+                # faces on the physical boundary: gradPhiFAB.copy(bcFAB), zero for every order
+                if g.lo[d] == dom.box.lo[d]:
+                    sl = [slice(None)] * 3
+                    sl[d] = 0
+                    grad[tuple(sl)] = 0.0
+                if g.hi[d] == dom.box.hi[d]:
+                    sl = [slice(None)] * 3
+                    sl[d] = grad.shape[d] - 1
+                    grad[tuple(sl)] = 0.0
+                avg = np.zeros(grad.shape[:2])
+                for k in range(Nz):
+                    avg = avg + grad[:, :, k] * dzScale
+                dxScale = -1.0 / self.dx[d]
+                if d == 0:
+                    acc_rhs = acc_rhs + (avg[1:, :] - avg[:-1, :]) * dxScale
+                else:
+                    acc_rhs = acc_rhs + (avg[:, 1:] - avg[:, :-1]) * dxScale
+            flatRhs[i][...] = acc_rhs
+
+    @staticmethod
+    def set_zero_avg(phi):
+        tot, vol = 0.0, 0
+        for g, f in zip(phi.grids, phi.fabs):
+            tot += so._seqsum(f.view(g))
+            vol += g.numPts()
+        avg = tot / float(vol)
+        for f in phi.fabs:
+            f.a[...] -= avg
+
+    # -- solve ----------------------------------------------------------------------------------------
+    def solve(self, a_phi, a_rhs, homogeneous=False):
+        """LevelLepticSolver::solve                                                     :646-956"""
+        grids, op = self.grids, self.op
+        maxOrder, H = self.maxOrder, self.H
+        phiTotal = so.LevelData(grids, 1, (1, 1, 1))
+        vertPhi = so.LevelData(grids, 1, (1, 1, 1))
+        rhs = so.LevelData(grids, 1, (0, 0, 0))
+        tmpRhs = so.LevelData(grids, 1, (0, 0, 0))
+        flat2 = [g.size()[:2] for g in grids]
+        excess = [np.zeros(s) for s in flat2]
+        flatRhs = [np.zeros(s) for s in flat2]
+        bcLo = [np.zeros(s) for s in flat2]
+        bcHi = [np.zeros(s) for s in flat2]
+        horizPhi = so.LevelData(self.flatGrids, 1, (1, 1, 0))
+        horizRhs = so.LevelData(self.flatGrids, 1, (0, 0, 0))
+        useExcess = useHorizPhi = self.doHorizSolve
+
+        # J * residual
+        res = so.LevelData(grids, 1, (0, 0, 0))
+        self.origOp.residual(res, a_phi, a_rhs, homogeneous)
+        for i, g in enumerate(grids):
+            rhs[i].view(g)[...] = res[i].view(g) / self.origOp.Jinv[i].view(g)
+
+        self.resNorms = [so.ld_norm(rhs, self.normType)]
+        resNorm = self.resNorms[0]
+        so.ld_set(phiTotal, 0.0)
+        self.usedFullSolver = False
+        self.horizSolves = 0
+
+        for order in range(maxOrder + 1):
+            if self.doHorizSolve:
+                if order >= 1:   # levelVertHorizGradient: zero for a diagonal metric
+                    for a in bcLo + bcHi:
+                        a[...] = 0.0
+                if order >= 1 and useExcess:
+                    for i in range(len(grids)):
+                        bcHi[i][...] = bcHi[i] + excess[i] * 1.0
+                if useExcess:
+                    self.compute_vertical_excess(excess, rhs, bcLo, bcHi)
+                    if order == 1:
+                        useExcess = False
+                if order == 0 and useExcess:
+                    for i in range(len(grids)):
+                        bcHi[i][...] = bcHi[i] + excess[i] * (-1.0)
+
+            self.vertical_line_solver(vertPhi, rhs, bcLo, bcHi)
+
+            if useHorizPhi:
+                self.compute_horiz_rhs(flatRhs, vertPhi)
+                if useExcess:
+                    for i in range(len(grids)):
+                        flatRhs[i][...] = flatRhs[i] + excess[i] * (-1.0 / H)
+                so.ld_set(horizRhs, 0.0)
+                for i, g in enumerate(self.flatGrids):
+                    horizRhs[i].view(g)[:, :, 0, 0] += flatRhs[i]
+                horizRhsNorm = so.ld_norm(horizRhs, self.normType)
+                if self.horizRhsTol * self.resNorms[0] > horizRhsNorm:
+                    useHorizPhi = False
+
+            if useHorizPhi:
+                self.horizSolver.solve(horizPhi, horizRhs, zeroPhi=True, forceHomogeneous=True)
+                if self.horizRemoveAvg:
+                    self.set_zero_avg(horizPhi)
+                self.horizSolves += 1
+                for i, g in enumerate(grids):   # ADDEXTRUSION
+                    vertPhi[i].view(g)[..., 0] += horizPhi[i].view(self.flatGrids[i])[:, :, 0, 0][:, :, None]
+
+            op.residual(tmpRhs, vertPhi, rhs, True)
+            resNorm = so.ld_norm(tmpRhs, self.normType)
+            relResNorm = resNorm / self.resNorms[0]
+            prevRelResNorm = self.resNorms[-1] / self.resNorms[0]
+            redu = prevRelResNorm - relResNorm
+            if redu <= self.hang and order == maxOrder:
+                self.mgSolver.solve(vertPhi, rhs, zeroPhi=True, forceHomogeneous=True)
+                op.residual(tmpRhs, vertPhi, rhs, True)
+                resNorm = so.ld_norm(tmpRhs, self.normType)
+                relResNorm = resNorm / self.resNorms[0]
+                self.usedFullSolver = True
+            rhs, tmpRhs = tmpRhs, rhs
+            self.resNorms.append(resNorm)
+
+            redu = prevRelResNorm - relResNorm
+            if redu > self.hang or order < maxOrder:
+                for i, g in enumerate(grids):
+                    phiTotal[i].view(g)[...] += vertPhi[i].view(g)
+                self.exitStatus = EXIT_CONVERGE if order < maxOrder - 1 else EXIT_ITER
+            elif -redu > self.hang:
+                self.exitStatus = EXIT_KABOOM if order == 0 else EXIT_DIVERGE
+                break
+            else:
+                self.exitStatus = EXIT_KABOOM if order == 0 else EXIT_HANG
+                break
+            useHorizPhi = False   # LevelGeometry::isDiagonal()
+
+        if self.exitStatus != EXIT_KABOOM:
+            for i, g in enumerate(grids):
+                a_phi[i].view(g)[...] += phiTotal[i].view(g) * 1.0
+        return self.exitStatus

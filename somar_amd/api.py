@@ -109,6 +109,7 @@ _SIGS = {
     "somar_comm_unique_id": [C.POINTER(C.c_ubyte)],
     "somar_comm_create": [C.POINTER(_H), C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int],
     "somar_comm_create_shm": [C.POINTER(_H), C.c_char_p, C.c_int, C.c_int, C.c_longlong],
+    "somar_comm_selftest": [_H],
     "somar_comm_destroy": [_H],
 }
 EXPORTS = sorted(list(_SIGS) + ["somar_last_error"])
@@ -501,6 +502,10 @@ def comm_create_shm(name, rank, nranks, outbox_bytes=64 << 20):
     h = _H()
     _ck(lib().somar_comm_create_shm(C.byref(h), name.encode(), rank, nranks, outbox_bytes))
     return h
+
+
+def comm_selftest(h):
+    _ck(lib().somar_comm_selftest(h))
 
 
 def comm_destroy(h):

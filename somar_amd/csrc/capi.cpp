@@ -763,6 +763,54 @@ int somar_comm_create_shm(void** comm, const char* name, int rank, int nranks, l
     API_END
 }
 
+// Pushes real traffic through a transport: an all-reduce (sum and max) of rank-dependent values and a ring
+// neighbour exchange (rank -> rank+1; a self send/recv on one rank).  Returns an error if any value is wrong.
+int somar_comm_selftest(void* comm)
+{
+    API_BEGIN
+    SOMAR_CHECK(comm, "null communicator");
+    Comm* c = static_cast<Comm*>(comm);
+    const int n = 4096;
+    hipStream_t st;
+    SOMAR_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    double *d_red = nullptr, *d_send = nullptr, *d_recv = nullptr;
+    SOMAR_HIP(hipMalloc(&d_red, 2 * sizeof(double)));
+    SOMAR_HIP(hipMalloc(&d_send, n * sizeof(double)));
+    SOMAR_HIP(hipMalloc(&d_recv, n * sizeof(double)));
+    std::vector<double> h(n);
+    for (int i = 0; i < n; ++i) h[i] = 1000.0 * c->rank + i;
+    SOMAR_HIP(hipMemcpyAsync(d_send, h.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+    SOMAR_HIP(hipMemsetAsync(d_recv, 0, n * sizeof(double), st));
+    double hr[2] = {double(c->rank + 1), double(c->rank + 1)};
+    SOMAR_HIP(hipMemcpyAsync(d_red, hr, 2 * sizeof(double), hipMemcpyHostToDevice, st));
+    SOMAR_HIP(hipStreamSynchronize(st));
+    c->allreduce_raw(d_red, 1, 0, st);
+    c->allreduce_raw(d_red + 1, 1, 1, st);
+    const int nxt = (c->rank + 1) % c->size, prv = (c->rank + c->size - 1) % c->size;
+    if (nxt == prv) {
+        c->neighbor_exchange(d_send, d_recv, {nxt}, {0}, {n}, {0}, {n}, st);
+    } else {
+        // peers in ascending order, as the exchange plans list them
+        const bool nf = nxt < prv;
+        c->neighbor_exchange(d_send, d_recv, {nf ? nxt : prv, nf ? prv : nxt}, {0, 0},
+                             {nf ? (long long)n : 0, nf ? 0 : (long long)n}, {0, 0},
+                             {nf ? 0 : (long long)n, nf ? (long long)n : 0}, st);
+    }
+    std::vector<double> g(n);
+    SOMAR_HIP(hipMemcpyAsync(g.data(), d_recv, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    SOMAR_HIP(hipMemcpyAsync(hr, d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    SOMAR_HIP(hipStreamSynchronize(st));
+    hipFree(d_red);
+    hipFree(d_send);
+    hipFree(d_recv);
+    hipStreamDestroy(st);
+    SOMAR_CHECK(hr[0] == 0.5 * c->size * (c->size + 1), "comm selftest: all-reduce(sum) returned a wrong value");
+    SOMAR_CHECK(hr[1] == double(c->size), "comm selftest: all-reduce(max) returned a wrong value");
+    for (int i = 0; i < n; ++i)
+        SOMAR_CHECK(g[i] == 1000.0 * prv + i, "comm selftest: neighbour exchange delivered wrong data");
+    API_END
+}
+
 int somar_comm_destroy(void* comm)
 {
     API_BEGIN

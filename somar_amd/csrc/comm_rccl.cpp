@@ -78,6 +78,10 @@ struct RcclComm : Comm {
     void allreduce(double* dbuf, int n, int op, hipStream_t st) override
     {
         if (size == 1) return;
+        allreduce_raw(dbuf, n, op, st);
+    }
+    void allreduce_raw(double* dbuf, int n, int op, hipStream_t st) override
+    {
         SOMAR_NCCL(api().AllReduce(dbuf, dbuf, (size_t)n, ncclDouble, op ? ncclMax : ncclSum, comm, st));
     }
     void neighbor_exchange(const double* sendbuf, double* recvbuf, const std::vector<int>& peers,

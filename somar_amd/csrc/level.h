@@ -54,6 +54,8 @@ struct Comm {
     virtual ~Comm() {}
     // in-place on DEVICE memory, enqueued on st.  op: 0 sum, 1 max
     virtual void allreduce(double* dbuf, int n, int op, hipStream_t st) { (void)dbuf; (void)n; (void)op; (void)st; }
+    // the same without any single-rank shortcut (somar_comm_selftest)
+    virtual void allreduce_raw(double* dbuf, int n, int op, hipStream_t st) { allreduce(dbuf, n, op, st); }
     // grouped neighbour exchange: for every peer q: send sendbuf+soff[q] (scount[q] doubles) and
     // receive into recvbuf+roff[q] (rcount[q] doubles), enqueued on st.
     virtual void neighbor_exchange(const double* sendbuf, double* recvbuf, const std::vector<int>& peers,
