@@ -222,6 +222,42 @@ int somar_amr_residual_level(somar_amr_t* a, int l_max, int l_base, int ilev, in
 int somar_amr_zero_covered(somar_amr_t* a, int level, int field);
 int somar_amr_vcycle(somar_amr_t* a, int l_max, int l_base);
 
+/* ---- leptic level solver -------------------------------------------------------------------------------------
+ * Replaces LevelLepticSolver (calculus/LepticSolver/LevelLepticSolver.H:53-347): define(op) :147-437 and
+ * solve(phi, rhs) :646-956, for an operator that offers what LepticOperator asks (LepticOperator.H:33-45).
+ * The level's boxes must be vertically complete columns (the layout LepticBoxUtils::createVerticalSolverGrids makes);
+ * diagonal metric, homogeneous-Neumann physical boundaries, no periodic direction, no coarse-fine boundary.
+ * somar_leptic_params_t = setParameters / setHorizMGParameters / setHorizBottomParameters / setFullMGParameters /
+ * setFullBottomParameters (:516-640); defaults = setDefaultParameters (:461-508). */
+typedef struct somar_leptic somar_leptic_t; /* opaque */
+typedef struct somar_leptic_params {
+    int max_order, norm_type;
+    double hang, horiz_rhs_tol;
+    double domain_height; /* LevelGeometry::getDomainLength(SpaceDim-1); 0: dz * Nz */
+    somar_params_t horiz; /* flat (SpaceDim-1) multigrid + its BiCGStab */
+    somar_params_t full;  /* full 3-D multigrid used when the last order hangs + its BiCGStab */
+} somar_leptic_params_t;
+typedef struct somar_leptic_stats {
+    int exit_status; /* LevelLepticSolver::ExitStatus: 0 CONVERGE 1 ITER 2 HANG 3 DIVERGE 4 KABOOM */
+    int orders, horiz_solves, used_full_solver;
+    int nres;
+    double res_norms[SOMAR_MAX_HISTORY]; /* m_resNorms: [0] |J * initial residual|, [k] after order k-1 */
+    somar_stats_t horiz, full;           /* last horizontal / full multigrid solve */
+} somar_leptic_stats_t;
+int somar_leptic_params_default(somar_leptic_params_t* p);
+/* level_prm: parameters of the level's own operator/multigrid (the op handed to LevelLepticSolver::define) */
+int somar_leptic_create(somar_leptic_t** out, const int* domain_lo, const int* domain_hi, const int* periodic,
+                        const double* dx, const int* bc_type, int nboxes, const int* boxes, const int* owner,
+                        double alpha, double beta, const somar_params_t* level_prm, const somar_leptic_params_t* lp,
+                        void* comm);
+int somar_leptic_destroy(somar_leptic_t* h);
+/* the level's own operator: set its metric (somar_solver_set_metric_ortho) and move phi / rhs through it; do not
+ * finalize or destroy it -- somar_leptic_finalize / _destroy do */
+int somar_leptic_level(somar_leptic_t* h, somar_solver_t** level);
+int somar_leptic_finalize(somar_leptic_t* h);
+/* phi += leptic correction for L[phi] = rhs on the level's resident phi / rhs */
+int somar_leptic_solve(somar_leptic_t* h, int homogeneous, somar_leptic_stats_t* stats);
+
 /* one-process-per-GPU transport (RCCL over xGMI).  The unique id is created on rank 0 and
  * distributed by the launcher (torch.distributed store / MPI / file). */
 #define SOMAR_COMM_ID_BYTES 128

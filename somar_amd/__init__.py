@@ -8,9 +8,10 @@ used by tests and bench.py; it never computes anything itself and has NO CPU fal
 """
 from .api import (  # noqa: F401
     AMRPressureSolver,
+    LevelLepticSolver,
     SomarError,
     lib,
     lib_path,
 )
 
-__all__ = ["AMRPressureSolver", "SomarError", "lib", "lib_path"]
+__all__ = ["AMRPressureSolver", "LevelLepticSolver", "SomarError", "lib", "lib_path"]

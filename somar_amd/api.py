@@ -41,6 +41,17 @@ class Stats(C.Structure):
                 ("final_rnorm", C.c_double), ("history", C.c_double * MAX_HISTORY)]
 
 
+class LepticParams(C.Structure):
+    _fields_ = [("max_order", C.c_int), ("norm_type", C.c_int), ("hang", C.c_double), ("horiz_rhs_tol", C.c_double),
+                ("domain_height", C.c_double), ("horiz", Params), ("full", Params)]
+
+
+class LepticStats(C.Structure):
+    _fields_ = [("exit_status", C.c_int), ("orders", C.c_int), ("horiz_solves", C.c_int),
+                ("used_full_solver", C.c_int), ("nres", C.c_int), ("res_norms", C.c_double * MAX_HISTORY),
+                ("horiz", Stats), ("full", Stats)]
+
+
 def lib_path():
     return os.path.join(_HERE, "libsomar_amd.so")
 
@@ -106,6 +117,13 @@ _SIGS = {
     "somar_amr_residual_level": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     "somar_amr_zero_covered": [_H, C.c_int, C.c_int],
     "somar_amr_vcycle": [_H, C.c_int, C.c_int],
+    "somar_leptic_params_default": [C.POINTER(LepticParams)],
+    "somar_leptic_create": [C.POINTER(_H), _PI, _PI, _PI, _PD, _PI, C.c_int, _PI, _PI, C.c_double, C.c_double,
+                            C.POINTER(Params), C.POINTER(LepticParams), _H],
+    "somar_leptic_destroy": [_H],
+    "somar_leptic_level": [_H, C.POINTER(_H)],
+    "somar_leptic_finalize": [_H],
+    "somar_leptic_solve": [_H, C.c_int, C.POINTER(LepticStats)],
     "somar_comm_unique_id": [C.POINTER(C.c_ubyte)],
     "somar_comm_create": [C.POINTER(_H), C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int],
     "somar_comm_create_shm": [C.POINTER(_H), C.c_char_p, C.c_int, C.c_int, C.c_longlong],
@@ -456,6 +474,71 @@ class AMRPressureSolver:
         ms = C.c_double()
         _ck(lib().somar_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+
+class LevelLepticSolver:
+    """Mirror of calculus/LepticSolver/LevelLepticSolver.H: define(op) + solve(phi, rhs).  `level` is the level's own
+    operator (an AMRPressureSolver view: metric upload, field I/O); `params` the somar_leptic_params_t block."""
+
+    EXIT_NAMES = {-1: "NONE", 0: "CONVERGE", 1: "ITER", 2: "HANG", 3: "DIVERGE", 4: "KABOOM"}
+
+    def __init__(self):
+        self.params = LepticParams()
+        _ck(lib().somar_leptic_params_default(C.byref(self.params)))
+        self.level_params = Params()
+        _ck(lib().somar_params_default(C.byref(self.level_params)))
+        self._h = None
+        self.level = None
+
+    def define(self, domain_lo, domain_hi, periodic, dx, boxes, bc_type=None, owner=None, alpha=0.0, beta=1.0,
+               comm=None):
+        assert self._h is None, "already defined"
+        bc = bc_type if bc_type is not None else [BC_NEUM] * 6
+        flat = [int(x) for lo, hi in boxes for x in list(lo) + list(hi)]
+        own = _ia(owner) if owner is not None else None
+        h = _H()
+        _ck(lib().somar_leptic_create(C.byref(h), _ia(domain_lo), _ia(domain_hi), _ia([int(bool(x)) for x in periodic]),
+                                      _da(dx), _ia(bc), len(boxes), _ia(flat), own, float(alpha), float(beta),
+                                      C.byref(self.level_params), C.byref(self.params), comm))
+        self._h = h
+        v = AMRPressureSolver()
+        lh = _H()
+        _ck(lib().somar_leptic_level(h, C.byref(lh)))
+        v._h, v._borrowed = lh, True
+        n = C.c_int()
+        _ck(lib().somar_solver_num_local_patches(lh, C.byref(n)))
+        v.num_local_patches = n.value
+        self.level = v
+
+    def finalize(self):
+        _ck(lib().somar_leptic_finalize(self._h))
+
+    def solve(self, homogeneous=False):
+        """phi += leptic correction on the level's resident PHI / RHS"""
+        st = LepticStats()
+        _ck(lib().somar_leptic_solve(self._h, int(homogeneous), C.byref(st)))
+        self.exitStatus = st.exit_status
+        self.stats = {"exitStatus": st.exit_status, "orders": st.orders, "horizSolves": st.horiz_solves,
+                      "usedFullSolver": bool(st.used_full_solver),
+                      "resNorms": [st.res_norms[i] for i in range(st.nres)],
+                      "horiz": {"iters": st.horiz.iters, "exitStatus": st.horiz.exit_status,
+                                "history": [st.horiz.history[i] for i in range(st.horiz.nhistory)]},
+                      "full": {"iters": st.full.iters, "exitStatus": st.full.exit_status,
+                               "history": [st.full.history[i] for i in range(st.full.nhistory)]}}
+        return self.stats
+
+    def undefine(self):
+        if self._h is not None:
+            if self.level is not None:
+                self.level._h = None
+            _ck(lib().somar_leptic_destroy(self._h))
+            self._h, self.level = None, None
+
+    def __del__(self):
+        try:
+            self.undefine()
+        except Exception:
+            pass
 
 
 def plan_exchange(domain_lo, domain_hi, periodic, boxes, owner, rank, ghost=2, max_items=4096):

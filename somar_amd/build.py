@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsomar_amd.so")
-SOURCES = ["kernels.hip", "gsrb_fused.hip", "resid_march.hip", "full19.hip", "projection.hip", "line_gsrb.hip", "amr_kernels.hip", "level.cpp", "solver.cpp", "solver_full.cpp", "amr.cpp", "comm_rccl.cpp", "comm_shm.cpp", "capi.cpp"]
-HEADERS = ["common.h", "kernels.h", "level.h", "solver.h", "amr.h", os.path.join("..", "..", "include", "somar_amd.h")]
+SOURCES = ["kernels.hip", "gsrb_fused.hip", "resid_march.hip", "full19.hip", "projection.hip", "line_gsrb.hip", "amr_kernels.hip", "leptic_kernels.hip", "level.cpp", "solver.cpp", "solver_full.cpp", "amr.cpp", "leptic.cpp", "comm_rccl.cpp", "comm_shm.cpp", "capi.cpp"]
+HEADERS = ["common.h", "kernels.h", "level.h", "solver.h", "amr.h", "leptic.h", os.path.join("..", "..", "include", "somar_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-I/opt/rocm/include"]

@@ -4,6 +4,7 @@
 
 #include "../../include/somar_amd.h"
 #include "amr.h"
+#include "leptic.h"
 #include "solver.h"
 
 namespace somar {
@@ -18,6 +19,11 @@ struct somar_solver {
     PressureSolver* ps = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool owned = true;  // false: a level of a somar_amr (somar_amr_level)
+};
+
+struct somar_leptic {
+    LepticSolver* lep = nullptr;
+    somar_solver* level = nullptr;
 };
 
 struct somar_amr {
@@ -67,10 +73,8 @@ int somar_device_count(int* count)
     API_END
 }
 
-int somar_params_default(somar_params_t* p)
+static void from_params(const SolverParams& d, somar_params_t* p)
 {
-    API_BEGIN
-    SolverParams d;
     p->imin = d.imin; p->imax = d.imax; p->eps = d.eps; p->hang = d.hang; p->norm_thresh = d.normThresh;
     p->num_smooth_down = d.num_smooth_down; p->num_smooth_up = d.num_smooth_up;
     p->num_smooth_bottom = d.num_smooth_bottom; p->num_smooth_precond = d.num_smooth_precond;
@@ -81,6 +85,12 @@ int somar_params_default(somar_params_t* p)
     p->bottom_eps = d.bottom_eps; p->bottom_reps = d.bottom_reps; p->bottom_hang = d.bottom_hang;
     p->bottom_small = d.bottom_small;
     p->space_dim = d.spaceDim;
+}
+
+int somar_params_default(somar_params_t* p)
+{
+    API_BEGIN
+    from_params(SolverParams(), p);
     API_END
 }
 
@@ -760,6 +770,119 @@ int somar_comm_create_shm(void** comm, const char* name, int rank, int nranks, l
     API_BEGIN
     SOMAR_CHECK(comm && name && outbox_bytes > 0, "null/empty argument");
     *comm = shm_create(name, rank, nranks, (size_t)outbox_bytes);
+    API_END
+}
+
+// ---- leptic level solver -----------------------------------------------------------------------------------
+int somar_leptic_params_default(somar_leptic_params_t* p)
+{
+    API_BEGIN
+    SOMAR_CHECK(p, "null argument");
+    LepticParams d;
+    p->max_order = d.maxOrder; p->norm_type = d.normType;
+    p->hang = d.hang; p->horiz_rhs_tol = d.horizRhsTol; p->domain_height = d.domainHeight;
+    from_params(d.horiz, &p->horiz);
+    from_params(d.full, &p->full);
+    API_END
+}
+
+int somar_leptic_create(somar_leptic_t** out, const int* domain_lo, const int* domain_hi, const int* periodic,
+                        const double* dx, const int* bc_type, int nboxes, const int* boxes, const int* owner,
+                        double alpha, double beta, const somar_params_t* level_prm, const somar_leptic_params_t* lp,
+                        void* comm)
+{
+    API_BEGIN
+    SOMAR_CHECK(out && domain_lo && domain_hi && periodic && dx && bc_type && boxes && nboxes > 0, "null/empty argument");
+    IBox dom(domain_lo, domain_hi);
+    bool per[3] = {periodic[0] != 0, periodic[1] != 0, periodic[2] != 0};
+    int bct[3][2] = {{bc_type[0], bc_type[1]}, {bc_type[2], bc_type[3]}, {bc_type[4], bc_type[5]}};
+    std::vector<IBox> bx;
+    std::vector<int> own;
+    for (int b = 0; b < nboxes; ++b) {
+        IBox q(boxes + 6 * b, boxes + 6 * b + 3);
+        SOMAR_CHECK(!q.empty(), "empty box");
+        bx.push_back(q);
+        own.push_back(owner ? owner[b] : 0);
+    }
+    for (size_t a = 0; a < bx.size(); ++a) {
+        for (int d = 0; d < 3; ++d)
+            SOMAR_CHECK(bx[a].lo[d] >= dom.lo[d] && bx[a].hi[d] <= dom.hi[d], "box outside the domain");
+        for (size_t b = a + 1; b < bx.size(); ++b) SOMAR_CHECK((bx[a] & bx[b]).empty(), "boxes overlap");
+    }
+    LepticParams P;
+    if (lp) {
+        P.maxOrder = lp->max_order; P.normType = lp->norm_type;
+        P.hang = lp->hang; P.horizRhsTol = lp->horiz_rhs_tol; P.domainHeight = lp->domain_height;
+        P.horiz = to_params(&lp->horiz);
+        P.full = to_params(&lp->full);
+    }
+    somar_leptic* h = new somar_leptic;
+    try {
+        h->lep = new LepticSolver(static_cast<Comm*>(comm));
+        h->lep->define(dom, per, dx, bct, bx, own, alpha, beta, to_params(level_prm), P);
+        h->level = new somar_solver;
+        h->level->ps = &h->lep->orig();
+        h->level->owned = false;
+        SOMAR_HIP(hipEventCreate(&h->level->ev0));
+        SOMAR_HIP(hipEventCreate(&h->level->ev1));
+    } catch (...) {
+        delete h->level;
+        delete h->lep;
+        delete h;
+        throw;
+    }
+    *out = h;
+    API_END
+}
+
+int somar_leptic_destroy(somar_leptic_t* h)
+{
+    API_BEGIN
+    if (h) {
+        if (h->level) {
+            if (h->level->ev0) hipEventDestroy(h->level->ev0);
+            if (h->level->ev1) hipEventDestroy(h->level->ev1);
+            delete h->level;
+        }
+        delete h->lep;
+        delete h;
+    }
+    API_END
+}
+
+int somar_leptic_level(somar_leptic_t* h, somar_solver_t** out)
+{
+    API_BEGIN
+    SOMAR_CHECK(h && out, "null argument");
+    *out = h->level;
+    API_END
+}
+
+int somar_leptic_finalize(somar_leptic_t* h)
+{
+    API_BEGIN
+    SOMAR_CHECK(h, "null argument");
+    h->lep->finalize();
+    API_END
+}
+
+int somar_leptic_solve(somar_leptic_t* h, int homogeneous, somar_leptic_stats_t* stats)
+{
+    API_BEGIN
+    SOMAR_CHECK(h, "null argument");
+    LepticStats S;
+    h->lep->solve(homogeneous != 0, S);
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->exit_status = S.exitStatus;
+        stats->orders = S.orders;
+        stats->horiz_solves = S.horizSolves;
+        stats->used_full_solver = S.usedFullSolver;
+        stats->nres = (int)std::min<size_t>(S.resNorms.size(), SOMAR_MAX_HISTORY);
+        for (int i = 0; i < stats->nres; ++i) stats->res_norms[i] = S.resNorms[i];
+        fill_stats(S.horizStats, &stats->horiz);
+        fill_stats(S.fullStats, &stats->full);
+    }
     API_END
 }
 

@@ -1,0 +1,229 @@
+// somar_amd/csrc/leptic.cpp -- host side of the leptic level solver (see leptic.h).
+#include "leptic.h"
+
+#include <cmath>
+
+namespace somar {
+
+LepticParams::LepticParams()
+{
+    // horizontal 2-D multigrid + its bottom solver (setHorizMGParameters / setHorizBottomParameters defaults)
+    horiz.imin = 5; horiz.imax = 20;
+    horiz.num_smooth_down = horiz.num_smooth_up = horiz.num_smooth_bottom = 4;
+    horiz.num_smooth_precond = 2;
+    horiz.relaxMode = RELAX_LEVEL_GSRB; horiz.precondMode = PRECOND_DIAG_RELAX;
+    horiz.numMG = 1; horiz.maxDepth = -1;
+    horiz.eps = 1e-12; horiz.hang = 1e-15; horiz.normThresh = 1e-30;
+    horiz.bottom_imax = 80; horiz.bottom_eps = 1e-12; horiz.bottom_numRestarts = 5; horiz.bottom_hang = 1e-15;
+    horiz.bottom_normType = 0;
+    horiz.spaceDim = 2;
+    // full 3-D multigrid (setFullMGParameters); its bottom solver only gets imax / restarts / normType
+    // (LevelLepticSolver.cpp:270-276), the rest are Chombo's BiCGStabSolver defaults
+    full.imin = 5; full.imax = 20;
+    full.num_smooth_down = full.num_smooth_up = full.num_smooth_bottom = 4;
+    full.num_smooth_precond = 4;
+    full.relaxMode = RELAX_LINE_GSRB; full.precondMode = PRECOND_DIAG_LINE_RELAX;
+    full.numMG = 1; full.maxDepth = -1;
+    full.eps = 1e-6; full.hang = 1e-15; full.normThresh = 1e-30;
+    full.bottom_imax = 80; full.bottom_numRestarts = 5; full.bottom_eps = 1e-6; full.bottom_hang = 1e-8;
+    full.bottom_normType = 0;
+    full.spaceDim = 3;
+}
+
+LepticSolver::LepticSolver(Comm* comm) : comm_(comm)
+{
+    SOMAR_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+}
+
+LepticSolver::~LepticSolver()
+{
+    for (double* f : {f_total, f_rhsA, f_rhsB, f_gam, h_excess, h_bcLo, h_bcHi, h_gx, h_gy}) Level::free_field(f);
+    hipFree(d_avg);
+    horiz_.reset();
+    vert_.reset();
+    orig_.reset();
+    if (st_) hipStreamDestroy(st_);
+}
+
+void LepticSolver::define(const IBox& domain, const bool periodic[3], const double dx[3], const int bc_type[3][2],
+                          const std::vector<IBox>& boxes, const std::vector<int>& owner, double alpha, double beta,
+                          const SolverParams& prmOrig, const LepticParams& lp)
+{
+    SOMAR_CHECK(!orig_, "leptic solver already defined");
+    prm = lp;
+    SOMAR_CHECK(prmOrig.spaceDim == 3, "the leptic solver is implemented for space_dim 3");
+    SOMAR_CHECK(prm.normType == 0, "the leptic solver offers the max norm (norm_type 0, the reference's default)");
+    SOMAR_CHECK(prm.maxOrder >= 0, "max_order must be >= 0");
+    SOMAR_CHECK(domain.size(2) >= 2, "the vertical line solver wants at least two cells per column");
+    for (int d = 0; d < 3; ++d)
+        SOMAR_CHECK(!periodic[d], "the leptic solver does not support periodic directions (neither does the reference: "
+                                  "LevelLepticSolver.cpp:997-1001, 1315)");
+    for (const IBox& b : boxes)
+        SOMAR_CHECK(b.lo[2] == domain.lo[2] && b.hi[2] == domain.hi[2],
+                    "the leptic solver wants vertically complete boxes (LepticBoxUtils::createVerticalSolverGrids layout)");
+    for (int d = 0; d < 3; ++d) dx_[d] = dx[d];
+    H_ = prm.domainHeight > 0.0 ? prm.domainHeight : dx[2] * domain.size(2);
+    orig_.reset(new PressureSolver(comm_, st_));
+    orig_->define(domain, periodic, dx, bc_type, boxes, owner, alpha, beta, prmOrig);
+    // the J-scaled operator and the full multigrid on it (alpha 0, beta 1)            LevelLepticSolver.cpp:214-300
+    SolverParams pf = prm.full;
+    pf.spaceDim = 3;
+    vert_.reset(new PressureSolver(comm_, st_));
+    vert_->define(domain, periodic, dx, bc_type, boxes, owner, 0.0, 1.0, pf);
+    vert_->probe_eps = prmOrig.eps;
+    // flat grids: the same boxes, one cell thick at the domain's lowest vertical index           :304-432
+    IBox flatDom = domain;
+    flatDom.hi[2] = flatDom.lo[2];
+    std::vector<IBox> flat(boxes);
+    horizCells_ = 0;
+    for (IBox& b : flat) {
+        b.hi[2] = b.lo[2];
+        horizCells_ += b.numPts();
+    }
+    horizRemoveAvg_ = horizCells_ == flatDom.numPts();
+    SolverParams ph = prm.horiz;
+    ph.spaceDim = 2;
+    horiz_.reset(new PressureSolver(comm_, st_));
+    horiz_->define(flatDom, periodic, dx, bc_type, flat, owner, 0.0, 1.0, ph);
+    horiz_->probe_eps = prmOrig.eps;
+}
+
+void LepticSolver::finalize()
+{
+    SOMAR_CHECK(orig_ && !finalized_, "finalize before define / twice");
+    SOMAR_CHECK(!orig_->is_full(), "the leptic solver is implemented for a diagonal metric");
+    orig_->finalize();
+    Level& O = orig_->level(0);
+    Level& V = vert_->level(0);
+    Level& F = horiz_->level(0);
+    SOMAR_CHECK(O.field_elems == V.field_elems && O.npatches() == V.npatches() && V.npatches() == F.npatches(),
+                "internal: layouts differ");
+    // metric of the J-scaled operator: the level's J g^{aa}, J^{-1} := 1
+    for (int d = 0; d < 3; ++d) launch_copy(st_, V.dev.jg[d], O.dev.jg[d], V.field_elems);
+    launch_set(st_, V.dev.jinv, V.field_elems, 1.0);
+    // metric of the flat problem: vertical average of the horizontal components, J^{-1} := 1
+    launch_lep_avg_metric(st_, V.d_ctiles, V.nctiles, V.ctile_j, V.dev, F.dev);
+    launch_set(st_, F.dev.jinv, F.field_elems, 1.0);
+    sync();
+    vert_->finalize();
+    horiz_->finalize();
+    f_total = V.alloc_field();
+    f_rhsA = V.alloc_field();
+    f_rhsB = V.alloc_field();
+    f_gam = V.alloc_field();
+    h_excess = F.alloc_field();
+    h_bcLo = F.alloc_field();
+    h_bcHi = F.alloc_field();
+    h_gx = F.alloc_field();
+    h_gy = F.alloc_field();
+    SOMAR_HIP(hipMalloc(&d_avg, 2 * sizeof(double)));
+    SOMAR_HIP(hipDeviceSynchronize());
+    finalized_ = true;
+}
+
+// setZeroAvg, LevelLepticSolver.cpp:1668-1710: plain (unweighted) mean over the valid cells, removed from the whole FAB
+void LepticSolver::set_zero_avg(double* hphi)
+{
+    Level& F = horiz_->level(0);
+    const double sum = horiz_->dot(0, hphi, F.dev.jinv);  // J^{-1} == 1: the dot product is the sum, in the same order
+    const double pair[2] = {sum, (double)horizCells_};
+    SOMAR_HIP(hipMemcpyAsync(d_avg, pair, sizeof(pair), hipMemcpyHostToDevice, st_));
+    SOMAR_HIP(hipStreamSynchronize(st_));
+    launch_sub_mean(st_, hphi, F.field_elems, d_avg);
+}
+
+void LepticSolver::solve(bool homogeneous, LepticStats& S)
+{
+    SOMAR_CHECK(finalized_, "solve before finalize");
+    (void)homogeneous;  // physical BCs are homogeneous Neumann and there is no coarse-fine boundary: nothing differs
+    PressureSolver &Os = *orig_, &Vs = *vert_, &Hs = *horiz_;
+    Level& V = Vs.level(0);
+    Level& F = Hs.level(0);
+    const Tile* ct = V.d_ctiles;
+    const int nct = V.nctiles, tj = V.ctile_j;
+    const long long n = V.field_elems, hn = F.field_elems;
+    const int maxOrder = prm.maxOrder;
+    const double dz = dx_[2];
+    double* vertPhi = Vs.phi();  // the full multigrid solves in place
+    double* rhsP = f_rhsA;
+    double* tmpP = f_rhsB;
+    bool useExcess = true, useHorizPhi = true;  // m_doHorizSolve: Neumann at both vertical ends
+    S = LepticStats();
+
+    // J * residual of the level's own operator                                                   :697-715
+    Os.residual(0, rhsP, Os.phi(), Os.rhs());
+    launch_lep_divide(st_, ct, nct, tj, V.dev, rhsP, rhsP, Os.level(0).dev.jinv);
+    double resNorm = Vs.norm(0, rhsP, prm.normType);
+    S.resNorms.push_back(resNorm);
+    launch_set(st_, f_total, n, 0.0);
+    launch_set(st_, h_bcLo, hn, 0.0);
+    launch_set(st_, h_bcHi, hn, 0.0);
+    int exitStatus = -1;
+
+    for (int order = 0; order <= maxOrder; ++order) {
+        S.orders = order + 1;
+        if (order >= 1) {  // levelVertHorizGradient: zero for a diagonal metric                   :1107-1176
+            launch_set(st_, h_bcLo, hn, 0.0);
+            launch_set(st_, h_bcHi, hn, 0.0);
+        }
+        if (order >= 1 && useExcess) launch_incr(st_, h_bcHi, h_excess, 1.0, hn);
+        if (useExcess) {
+            launch_lep_excess(st_, ct, nct, tj, V.dev, F.dev, rhsP, h_bcLo, h_bcHi, h_excess, -1.0 * dz);
+            if (order == 1) useExcess = false;
+        }
+        if (order == 0 && useExcess) launch_incr(st_, h_bcHi, h_excess, -1.0, hn);
+
+        launch_lep_vsolve(st_, ct, nct, tj, V.dev, F.dev, vertPhi, rhsP, f_gam, h_bcLo, h_bcHi, dz);
+
+        if (useHorizPhi) {
+            V.exchange(vertPhi, st_);
+            launch_lep_hgrad(st_, ct, nct, tj, V.dev, F.dev, vertPhi, h_gx, h_gy);
+            launch_lep_hrhs(st_, ct, nct, tj, V.dev, F.dev, h_gx, h_gy, h_excess, Hs.rhs(), -1.0 / dx_[0],
+                            -1.0 / dx_[1], -1.0 / H_, useExcess);
+            const double horizRhsNorm = Hs.norm(0, Hs.rhs(), prm.normType);
+            if (prm.horizRhsTol * S.resNorms[0] > horizRhsNorm) useHorizPhi = false;
+        }
+        if (useHorizPhi) {
+            Hs.solve(true, true, S.horizStats);
+            if (horizRemoveAvg_) set_zero_avg(Hs.phi());
+            launch_lep_extrude(st_, ct, nct, tj, V.dev, F.dev, vertPhi, Hs.phi());
+            ++S.horizSolves;
+        }
+
+        // finalize the order                                                                     :836-933
+        Vs.residual(0, tmpP, vertPhi, rhsP);
+        resNorm = Vs.norm(0, tmpP, prm.normType);
+        double relResNorm = resNorm / S.resNorms[0];
+        const double prevRelResNorm = S.resNorms.back() / S.resNorms[0];
+        double redu = prevRelResNorm - relResNorm;
+        if (redu <= prm.hang && order == maxOrder) {
+            launch_copy(st_, Vs.rhs(), rhsP, n);
+            Vs.solve(true, true, S.fullStats);  // initial guess 0, homogeneous
+            Vs.residual(0, tmpP, vertPhi, rhsP);
+            resNorm = Vs.norm(0, tmpP, prm.normType);
+            relResNorm = resNorm / S.resNorms[0];
+            S.usedFullSolver = 1;
+        }
+        std::swap(rhsP, tmpP);
+        S.resNorms.push_back(resNorm);
+
+        redu = prevRelResNorm - relResNorm;
+        if (redu > prm.hang || order < maxOrder) {
+            launch_lep_axpy(st_, ct, nct, tj, V.dev, f_total, vertPhi, 1.0);
+            exitStatus = (order < maxOrder - 1) ? 0 : 1;
+        } else if (-redu > prm.hang) {
+            exitStatus = (order == 0) ? 4 : 3;
+            break;
+        } else {
+            exitStatus = (order == 0) ? 4 : 2;
+            break;
+        }
+        useHorizPhi = false;  // LevelGeometry::isDiagonal()
+    }
+
+    if (exitStatus != 4) launch_lep_axpy(st_, ct, nct, tj, V.dev, Os.phi(), f_total, 1.0);
+    S.exitStatus = exitStatus;
+    sync();
+}
+
+}  // namespace somar

@@ -1,0 +1,94 @@
+// somar_amd/csrc/leptic.h -- the leptic level solver: the MI355X counterpart of
+//   LevelLepticSolver::define / solve     calculus/LepticSolver/LevelLepticSolver.cpp:147-437, 646-956
+//   LepticOperator (what it asks of the level operator)   calculus/LepticSolver/LepticOperator.H:33-45
+//
+// Design (not a port): the level's boxes are vertically complete columns -- the layout the reference re-creates
+// with LepticBoxUtils::createVerticalSolverGrids before every solve path; here the caller hands it over once, a
+// 288 GB HBM holds such columns whole -- so the reference's four re-layout Copiers (orig <-> vertical, flat <->
+// horizontal) disappear.  Three PressureSolvers share one stream and the layout: the level's own operator (for
+// the initial residual), the J-scaled operator (J^{-1} := 1, alpha 0, beta 1) with the full 3-D multigrid used
+// as fallback, and the flat 2-D multigrid on the vertically averaged metric.  Everything in between is column
+// kernels (leptic_kernels.hip); the host sequences launches and reads back one norm per order.
+//
+// Scope: diagonal metric, one AMR level (no coarse-fine boundary), homogeneous-Neumann physical boundaries,
+// non-periodic directions (the reference leaves the averaged gradient on a periodic horizontal boundary face
+// unset, LevelLepticSolver.cpp:997-1001, and refuses a periodic vertical, :1315).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "solver.h"
+
+namespace somar {
+
+struct LepticParams {
+    // setDefaultParameters, LevelLepticSolver.cpp:461-508
+    int maxOrder = 4;
+    double hang = 1e-15;
+    int normType = 0;
+    double horizRhsTol = 1e-14;
+    double domainHeight = 0.0;  // LevelGeometry::getDomainLength(SpaceDim-1); 0: dz * Nz
+    SolverParams horiz, full;
+    LepticParams();
+};
+
+struct LepticStats {
+    int exitStatus = -1;  // LevelLepticSolver::ExitStatus: 0 converge, 1 iter, 2 hang, 3 diverge, 4 kaboom
+    int orders = 0;
+    int horizSolves = 0;
+    int usedFullSolver = 0;
+    std::vector<double> resNorms;  // [0] initial |J res|, [k] after order k-1
+    SolveStats horizStats, fullStats;
+};
+
+class LepticSolver {
+public:
+    explicit LepticSolver(Comm* comm = nullptr);
+    ~LepticSolver();
+    void define(const IBox& domain, const bool periodic[3], const double dx[3], const int bc_type[3][2],
+                const std::vector<IBox>& boxes, const std::vector<int>& owner, double alpha, double beta,
+                const SolverParams& prmOrig, const LepticParams& lp);
+    // the level's own operator: metric, phi and rhs go through it (somar_solver_* entry points)
+    PressureSolver& orig() { return *orig_; }
+    PressureSolver& vert() { return *vert_; }
+    PressureSolver& horiz() { return *horiz_; }
+    void finalize();  // after the metric of orig() is set: finalizes all three solvers
+    // LevelLepticSolver::solve(phi, rhs) on orig()'s resident phi / rhs: phi += leptic correction
+    void solve(bool homogeneous, LepticStats& S);
+    void sync() { SOMAR_HIP(hipStreamSynchronize(st_)); }
+    LepticParams prm;
+
+private:
+    void set_zero_avg(double* hphi);
+    Comm* comm_;
+    hipStream_t st_ = nullptr;
+    std::unique_ptr<PressureSolver> orig_, vert_, horiz_;
+    double dx_[3] = {1, 1, 1};
+    double H_ = 1.0;
+    bool horizRemoveAvg_ = false;
+    long long horizCells_ = 0;
+    bool finalized_ = false;
+    // 3-D work fields (vertical layout) and flat ones (horizontal layout)
+    double *f_total = nullptr, *f_rhsA = nullptr, *f_rhsB = nullptr, *f_gam = nullptr;
+    double *h_excess = nullptr, *h_bcLo = nullptr, *h_bcHi = nullptr, *h_gx = nullptr, *h_gy = nullptr;
+    double* d_avg = nullptr;  // (sum, count) for setZeroAvg
+};
+
+void launch_lep_avg_metric(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H);
+void launch_lep_excess(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
+                       const double* rhs, const double* bcLo, const double* bcHi, double* excess, double dzScale);
+void launch_lep_vsolve(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
+                       double* phi, double* rhs, double* gam, const double* bcLo, const double* bcHi, double dz);
+void launch_lep_hgrad(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
+                      const double* phi, double* gx, double* gy);
+void launch_lep_hrhs(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
+                     const double* gx, const double* gy, const double* excess, double* hrhs, double sx, double sy,
+                     double negInvH, bool useExcess);
+void launch_lep_extrude(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
+                        double* phi, const double* flat);
+void launch_lep_divide(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, double* y, const double* x,
+                       const double* b);
+void launch_lep_axpy(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, double* y, const double* x,
+                     double a);
+
+}  // namespace somar

@@ -297,7 +297,7 @@ void PressureSolver::probe_null_space(int d)
     launch_reduce(st_, L.dev, res, nullptr, 3, d_partials, d_scalars + SLOT_TMP);
     comm_->allreduce(d_scalars + SLOT_TMP, 1, 1, st_);
     const double maxNorm = std::fabs(fetch_scalar(SLOT_TMP));
-    L.zeroAvg = maxNorm < 0.01 * prm.eps;
+    L.zeroAvg = maxNorm < 0.01 * (probe_eps > 0.0 ? probe_eps : prm.eps);
     Level::free_field(phi);
     Level::free_field(rhs0);
     Level::free_field(res);
@@ -375,6 +375,7 @@ void PressureSolver::build_agglomerated_tail(int depth)
     SolverParams cp = prm;
     if (cp.maxDepth >= 0) cp.maxDepth = std::max(0, cp.maxDepth - depth);
     coarse_.reset(new PressureSolver(nullptr, st_));
+    coarse_->probe_eps = probe_eps > 0.0 ? probe_eps : prm.eps;
     std::vector<int> own(T.boxes.size(), 0);
     coarse_->define(T.domain, T.periodic, T.dx, T.bc_type, T.boxes, own, T.alpha, T.beta, cp,
                     hasCF_ ? dxCrse_ : nullptr);

@@ -134,6 +134,9 @@ public:
     hipStream_t stream() const { return st_; }
 
     SolverParams prm;
+    // The null-space probe compares against ProblemContext's GLOBAL AMRMG.eps (MappedAMRPoissonOpFactory.cpp:679), not
+    // against this solver's own eps; a solver set up by another one (leptic: horizontal / full multigrid) inherits it.
+    double probe_eps = -1.0;
     // bottom-solver state shared with MappedAMRMultiGrid (setConvergenceMetrics)
     double bottom_metric = -1.0, bottom_eps_eff = 1e-6;
     int bottom_iters = 0, bottom_exit = 0;

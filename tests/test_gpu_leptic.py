@@ -1,0 +1,111 @@
+"""Leptic level solver on the GPU (csrc/leptic.cpp, leptic_kernels.hip) against the oracle's restatement of
+LevelLepticSolver (oracle/somar_leptic.py): same synthetic inputs, through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import somar_leptic as sl
+from oracle import somar_oracle as so
+from tests.helpers import download_valid, make_oracle_solver, upload, valid_of
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n, box, H, variant, seed=3):
+    L = (1.0, 1.0, H)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, box)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_diagonal_metric(grids, dx, L, 3, variant, domain=dom)
+    rhs = so.random_field(grids, seed, domainBox=dom.box)
+    so.remove_weighted_mean(rhs, Jinv)
+    return dom, grids, dx, Jgup, Jinv, rhs
+
+
+def _gpu_leptic(dom, grids, dx, Jgup, Jinv, maxOrder, H, full_relax=None):
+    from somar_amd import LevelLepticSolver
+    s = LevelLepticSolver()
+    s.params.max_order = maxOrder
+    s.params.domain_height = H
+    if full_relax is not None:
+        s.params.full.relax_mode, s.params.full.precond_mode = full_relax
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids])
+    lv = s.level
+    for p_ in range(lv.num_local_patches):
+        _, _, gi = lv.patch_box(p_)
+        jg = [np.asfortranarray(Jgup[gi][d].a[..., d]) for d in range(3)]
+        lv.setMetricOrtho(p_, jg[0], jg[1], jg[2], np.asfortranarray(Jinv[gi].a[..., 0]))
+    s.finalize()
+    return s
+
+
+CASES = [
+    # n, box, H, variant, maxOrder
+    ((32, 32, 8), (16, 16, 8), 0.005, "stretched", 4),
+    ((32, 32, 8), (16, 16, 8), 0.005, "cartesian", 5),
+    ((32, 16, 12), (8, 16, 12), 0.02, "stretched", 2),
+    ((32, 32, 8), (32, 32, 8), 0.001, "stretched", 3),   # one box
+    ((16, 16, 2), (8, 8, 2), 0.001, "stretched", 2),     # two-cell columns: the reference's a(0) sentinel row
+]
+
+
+@pytest.mark.parametrize("n,box,H,variant,maxOrder", CASES)
+def test_leptic_solve_matches_oracle(n, box, H, variant, maxOrder):
+    from somar_amd.api import F_PHI, F_RHS
+    dom, grids, dx, Jgup, Jinv, rhs = _problem(n, box, H, variant)
+    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv)
+    lep = sl.LevelLepticSolver(amr.op, maxOrder=maxOrder, domainHeight=H)
+    phi = so.random_field(grids, 11, ghost=(1, 1, 1), domainBox=dom.box)   # non-trivial initial guess
+    for f in phi.fabs:
+        f.a[...] *= 1e-3
+    phi0 = [v.copy() for v in valid_of(phi)]
+    gpu = _gpu_leptic(dom, grids, dx, Jgup, Jinv, maxOrder, H)
+    upload(gpu.level, F_PHI, phi)
+    upload(gpu.level, F_RHS, rhs)
+    status = lep.solve(phi, rhs)
+    st = gpu.solve()
+    assert st["exitStatus"] == status
+    assert st["horizSolves"] == lep.horizSolves and st["usedFullSolver"] == lep.usedFullSolver
+    assert len(st["resNorms"]) == len(lep.resNorms)
+    np.testing.assert_allclose(st["resNorms"], lep.resNorms, rtol=1e-10, atol=1e-13 * lep.resNorms[0])
+    got = download_valid(gpu.level, F_PHI, grids)
+    want = valid_of(phi)
+    scale = max(float(np.max(np.abs(w - p0))) for w, p0 in zip(want, phi0))
+    for g_, w_ in zip(got, want):
+        np.testing.assert_allclose(g_, w_, rtol=0, atol=1e-10 * scale)
+
+
+def test_leptic_full_multigrid_fallback_matches_oracle():
+    """maxOrder 0: the O(1) residual exceeds the initial one by construction, the full 3-D multigrid (LINE_GSRB
+    4/4/4, DiagLineRelax) takes over; both sides must take the same branch and agree."""
+    from somar_amd.api import F_PHI, F_RHS
+    n, box, H = (32, 32, 8), (16, 16, 8), 0.02
+    dom, grids, dx, Jgup, Jinv, rhs = _problem(n, box, H, "stretched")
+    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv)
+    lep = sl.LevelLepticSolver(amr.op, maxOrder=0, domainHeight=H)
+    phi = so.LevelData(grids, 1, (1, 1, 1))
+    gpu = _gpu_leptic(dom, grids, dx, Jgup, Jinv, 0, H)
+    upload(gpu.level, F_PHI, phi)
+    upload(gpu.level, F_RHS, rhs)
+    status = lep.solve(phi, rhs)
+    st = gpu.solve()
+    assert lep.usedFullSolver and st["usedFullSolver"]
+    assert st["exitStatus"] == status
+    assert st["full"]["iters"] == lep.mgSolver.iters
+    np.testing.assert_allclose(st["full"]["history"], lep.mgSolver.history, rtol=1e-8)
+    np.testing.assert_allclose(st["resNorms"], lep.resNorms, rtol=1e-8)
+    got = download_valid(gpu.level, F_PHI, grids)
+    want = valid_of(phi)
+    scale = max(float(np.max(np.abs(w))) for w in want)
+    for g_, w_ in zip(got, want):
+        np.testing.assert_allclose(g_, w_, rtol=0, atol=1e-8 * scale)
+
+
+def test_leptic_rejects_what_the_reference_cannot_do():
+    from somar_amd import LevelLepticSolver, SomarError
+    s = LevelLepticSolver()
+    with pytest.raises(SomarError, match="vertically complete"):
+        s.define((0, 0, 0), (15, 15, 7), (False, False, False), (0.1, 0.1, 0.01),
+                 [((0, 0, 0), (15, 15, 3)), ((0, 0, 4), (15, 15, 7))])
+    s = LevelLepticSolver()
+    with pytest.raises(SomarError, match="periodic"):
+        s.define((0, 0, 0), (15, 15, 7), (True, False, False), (0.1, 0.1, 0.01), [((0, 0, 0), (15, 15, 7))])
