@@ -254,6 +254,10 @@ int somar_leptic_destroy(somar_leptic_t* h);
 /* the level's own operator: set its metric (somar_solver_set_metric_ortho) and move phi / rhs through it; do not
  * finalize or destroy it -- somar_leptic_finalize / _destroy do */
 int somar_leptic_level(somar_leptic_t* h, somar_solver_t** level);
+/* read-only views of the two internal solvers after a solve (tests, diagnostics): which = 1 the J-scaled operator
+ * with the full 3-D multigrid (m_opPtr / m_mgSolverPtr; its PHI holds the last order's correction), which = 2 the
+ * flat multigrid (m_horizSolverPtr; PHI / RHS = last horizontal solution / right-hand side) */
+int somar_leptic_part(somar_leptic_t* h, int which, somar_solver_t** solver);
 int somar_leptic_finalize(somar_leptic_t* h);
 /* phi += leptic correction for L[phi] = rhs on the level's resident phi / rhs */
 int somar_leptic_solve(somar_leptic_t* h, int homogeneous, somar_leptic_stats_t* stats);

@@ -284,6 +284,7 @@ class LevelLepticSolver:
                 break
             useHorizPhi = False   # LevelGeometry::isDiagonal()
 
+        self.last = {"vertPhi": vertPhi, "horizPhi": horizPhi, "horizRhs": horizRhs, "phiTotal": phiTotal}
         if self.exitStatus != EXIT_KABOOM:
             for i, g in enumerate(grids):
                 a_phi[i].view(g)[...] += phiTotal[i].view(g) * 1.0

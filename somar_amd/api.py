@@ -122,6 +122,7 @@ _SIGS = {
                             C.POINTER(Params), C.POINTER(LepticParams), _H],
     "somar_leptic_destroy": [_H],
     "somar_leptic_level": [_H, C.POINTER(_H)],
+    "somar_leptic_part": [_H, C.c_int, C.POINTER(_H)],
     "somar_leptic_finalize": [_H],
     "somar_leptic_solve": [_H, C.c_int, C.POINTER(LepticStats)],
     "somar_comm_unique_id": [C.POINTER(C.c_ubyte)],
@@ -509,6 +510,17 @@ class LevelLepticSolver:
         _ck(lib().somar_solver_num_local_patches(lh, C.byref(n)))
         v.num_local_patches = n.value
         self.level = v
+        self.vert, self.horiz = self._view(1), self._view(2)
+
+    def _view(self, which):
+        v = AMRPressureSolver()
+        lh = _H()
+        _ck(lib().somar_leptic_part(self._h, which, C.byref(lh)))
+        v._h, v._borrowed = lh, True
+        n = C.c_int()
+        _ck(lib().somar_solver_num_local_patches(lh, C.byref(n)))
+        v.num_local_patches = n.value
+        return v
 
     def finalize(self):
         _ck(lib().somar_leptic_finalize(self._h))
@@ -529,8 +541,9 @@ class LevelLepticSolver:
 
     def undefine(self):
         if self._h is not None:
-            if self.level is not None:
-                self.level._h = None
+            for v in (self.level, getattr(self, "vert", None), getattr(self, "horiz", None)):
+                if v is not None:
+                    v._h = None
             _ck(lib().somar_leptic_destroy(self._h))
             self._h, self.level = None, None
 

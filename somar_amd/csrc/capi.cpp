@@ -24,6 +24,7 @@ struct somar_solver {
 struct somar_leptic {
     LepticSolver* lep = nullptr;
     somar_solver* level = nullptr;
+    somar_solver* parts[2] = {nullptr, nullptr};  // J-scaled operator + full multigrid, flat multigrid
 };
 
 struct somar_amr {
@@ -825,7 +826,16 @@ int somar_leptic_create(somar_leptic_t** out, const int* domain_lo, const int* d
         h->level->owned = false;
         SOMAR_HIP(hipEventCreate(&h->level->ev0));
         SOMAR_HIP(hipEventCreate(&h->level->ev1));
+        for (int q = 0; q < 2; ++q) {
+            h->parts[q] = new somar_solver;
+            h->parts[q]->ps = q == 0 ? &h->lep->vert() : &h->lep->horiz();
+            h->parts[q]->owned = false;
+            SOMAR_HIP(hipEventCreate(&h->parts[q]->ev0));
+            SOMAR_HIP(hipEventCreate(&h->parts[q]->ev1));
+        }
     } catch (...) {
+        delete h->parts[0];
+        delete h->parts[1];
         delete h->level;
         delete h->lep;
         delete h;
@@ -839,10 +849,11 @@ int somar_leptic_destroy(somar_leptic_t* h)
 {
     API_BEGIN
     if (h) {
-        if (h->level) {
-            if (h->level->ev0) hipEventDestroy(h->level->ev0);
-            if (h->level->ev1) hipEventDestroy(h->level->ev1);
-            delete h->level;
+        for (somar_solver* q : {h->level, h->parts[0], h->parts[1]}) {
+            if (!q) continue;
+            if (q->ev0) hipEventDestroy(q->ev0);
+            if (q->ev1) hipEventDestroy(q->ev1);
+            delete q;
         }
         delete h->lep;
         delete h;
@@ -855,6 +866,14 @@ int somar_leptic_level(somar_leptic_t* h, somar_solver_t** out)
     API_BEGIN
     SOMAR_CHECK(h && out, "null argument");
     *out = h->level;
+    API_END
+}
+
+int somar_leptic_part(somar_leptic_t* h, int which, somar_solver_t** out)
+{
+    API_BEGIN
+    SOMAR_CHECK(h && out && (which == 1 || which == 2), "which: 1 (J-scaled 3-D solver) or 2 (flat solver)");
+    *out = h->parts[which - 1];
     API_END
 }
 

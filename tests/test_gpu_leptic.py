@@ -66,12 +66,25 @@ def test_leptic_solve_matches_oracle(n, box, H, variant, maxOrder):
     assert st["exitStatus"] == status
     assert st["horizSolves"] == lep.horizSolves and st["usedFullSolver"] == lep.usedFullSolver
     assert len(st["resNorms"]) == len(lep.resNorms)
-    np.testing.assert_allclose(st["resNorms"], lep.resNorms, rtol=1e-10, atol=1e-13 * lep.resNorms[0])
     got = download_valid(gpu.level, F_PHI, grids)
     want = valid_of(phi)
-    scale = max(float(np.max(np.abs(w - p0))) for w, p0 in zip(want, phi0))
-    for g_, w_ in zip(got, want):
-        np.testing.assert_allclose(g_, w_, rtol=0, atol=1e-10 * scale)
+    if not lep.usedFullSolver:
+        # the column kernels follow the Fortran term by term and every reduction that steers the flat multigrid
+        # runs in the reference's order at these sizes (k_reduce_ordered) => bit-identical
+        assert st["resNorms"] == lep.resNorms
+        for g_, w_ in zip(got, want):
+            np.testing.assert_array_equal(g_, w_)
+        for name, view, fld in (("vertPhi", gpu.vert, F_PHI), ("horizPhi", gpu.horiz, F_PHI), ("horizRhs", gpu.horiz, F_RHS)):
+            ld = lep.last[name]
+            for g_, w_ in zip(download_valid(view, fld, ld.grids), valid_of(ld)):
+                np.testing.assert_array_equal(g_, w_, err_msg=name)
+    else:
+        # the full 3-D multigrid (8192 cells at depth 0: tree sums in the zero-average prolongation) agrees to
+        # round-off, not bit for bit
+        np.testing.assert_allclose(st["resNorms"], lep.resNorms, rtol=1e-9)
+        scale = max(float(np.max(np.abs(w - p0))) for w, p0 in zip(want, phi0))
+        for g_, w_ in zip(got, want):
+            np.testing.assert_allclose(g_, w_, rtol=0, atol=1e-12 * scale)
 
 
 def test_leptic_full_multigrid_fallback_matches_oracle():
