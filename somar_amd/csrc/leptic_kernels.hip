@@ -54,6 +54,7 @@ __global__ __launch_bounds__(512) void k_lep_avg_metric(const Tile* __restrict__
         const bool xh = o.li == p.n[0] - 1, yh = o.lj == p.n[1] - 1;
         double ax = 0.0, ay = 0.0, axh = 0.0, ayh = 0.0;
         long long c = o.c;
+#pragma unroll 8
         for (int k = 0; k < p.n[2]; ++k, c += p.pk) {
             ax = ax + jgx[c] * scale;
             ay = ay + jgy[c] * scale;
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(512) void k_lep_excess(const Tile* __restrict__ til
         double e = bcHi[o.h];
         e = e + (-1.0) * bcLo[o.h];
         long long c = o.c;
+#pragma unroll 8
         for (int k = 0; k < p.n[2]; ++k, c += p.pk) e = e + rhs[c] * dzScale;
         excess[o.h] = e;
     }
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(512) void k_lep_vsolve(const Tile* __restrict__ til
         gam[c0] = g;
         double a_prev = 1.2345e10;  // a(0): the reference's sentinel, read by the last row when N == 2
         long long c = c0 + sk;
+#pragma unroll 4
         for (int r = 1; r <= N - 2; ++r, c += sk) {
             const double a = sig;
             sig = jgz[c + sk];
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(512) void k_lep_vsolve(const Tile* __restrict__ til
         }
         double avg = x;
         c = cN - sk;
+#pragma unroll 4
         for (int r = N - 2; r >= 0; --r, c -= sk) {
             x = phi[c] - gam[c] * x;
             avg = avg + x;
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(512) void k_lep_vsolve(const Tile* __restrict__ til
         }
         avg = avg / (double)N;
         c = c0;
+#pragma unroll 8
         for (int r = 0; r < N; ++r, c += sk) phi[c] = phi[c] - avg;
         rhs[c0] = r0 + rollLo * (-1.0);
         rhs[cN] = rN + rollHi * (-1.0);
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(512) void k_lep_hgrad(const Tile* __restrict__ tile
         const bool byl = gj == P.dom_lo[1], byh = gj == P.dom_hi[1];
         double ax = 0.0, ay = 0.0, axh = 0.0, ayh = 0.0;
         long long c = o.c;
+#pragma unroll 4
         for (int k = 0; k < p.n[2]; ++k, c += p.pk) {
             const double pc = phi[c];
             if (!bxl) ax = ax + ((dxinv * jgx[c]) * (pc - phi[c - 1])) * dzScale;
@@ -220,6 +226,7 @@ __global__ __launch_bounds__(512) void k_lep_extrude(const Tile* __restrict__ ti
         if (!o.ok) continue;
         const double v = flat[o.h];
         long long c = o.c;
+#pragma unroll 8
         for (int k = 0; k < p.n[2]; ++k, c += p.pk) phi[c] = phi[c] + v;
     }
 }
@@ -236,6 +243,7 @@ __global__ __launch_bounds__(512) void k_lep_valid(const Tile* __restrict__ tile
         const int li = t.i0 + threadIdx.x + 64 * q, lj = t.j0 + threadIdx.y;
         if (li >= p.n[0] || lj >= p.n[1]) continue;
         long long c = p.off + li + (long long)p.pj * lj;
+#pragma unroll 8
         for (int k = 0; k < p.n[2]; ++k, c += p.pk) {
             if (MODE == 0) y[c] = x[c] / b[c];
             else y[c] = y[c] + a * x[c];
