@@ -122,3 +122,79 @@ def test_leptic_rejects_what_the_reference_cannot_do():
     s = LevelLepticSolver()
     with pytest.raises(SomarError, match="periodic"):
         s.define((0, 0, 0), (15, 15, 7), (True, False, False), (0.1, 0.1, 0.01), [((0, 0, 0), (15, 15, 7))])
+
+
+# ---- two ranks sharing the test box's GPU (shared-memory transport, as in test_gpu_multirank.py) -------------------
+def _leptic_worker(rank, nranks, name, q):
+    import os
+    import sys
+    import traceback
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, os.path.dirname(here))
+        from somar_amd import LevelLepticSolver
+        from somar_amd import api as F
+        comm = F.comm_create_shm(name, rank, nranks)
+        n, box, H, maxOrder = (32, 32, 8), (16, 16, 8), 0.005, 3
+        dom, grids, dx, Jgup, Jinv, rhs = _problem(n, box, H, "stretched")
+        owner = [i % nranks for i in range(len(grids))]
+        amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv)
+        lep = sl.LevelLepticSolver(amr.op, maxOrder=maxOrder, domainHeight=H)
+        phi = so.LevelData(grids, 1, (1, 1, 1))
+        s = LevelLepticSolver()
+        s.params.max_order = maxOrder
+        s.params.domain_height = H
+        s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids], owner=owner, comm=comm)
+        lv = s.level
+        assert lv.num_local_patches == len(grids) // nranks
+        for p_ in range(lv.num_local_patches):
+            _, _, gi = lv.patch_box(p_)
+            assert owner[gi] == rank
+            jg = [np.asfortranarray(Jgup[gi][d].a[..., d]) for d in range(3)]
+            lv.setMetricOrtho(p_, jg[0], jg[1], jg[2], np.asfortranarray(Jinv[gi].a[..., 0]))
+        s.finalize()
+        upload(lv, F.F_PHI, phi)
+        upload(lv, F.F_RHS, rhs)
+        status = lep.solve(phi, rhs)
+        st = s.solve()
+        assert st["exitStatus"] == status and st["horizSolves"] == lep.horizSolves
+        assert st["usedFullSolver"] == lep.usedFullSolver
+        # rank-wise association of the scalar sums differs from the serial box order (BiCGStab amplifies it)
+        np.testing.assert_allclose(st["resNorms"], lep.resNorms, rtol=1e-6)
+        want = valid_of(phi)
+        scale = max(float(np.max(np.abs(w))) for w in want)
+        nmine = 0
+        for g_, w_ in zip(download_valid(lv, F.F_PHI, grids), want):
+            if g_ is None:
+                continue
+            np.testing.assert_allclose(g_, w_, rtol=0, atol=1e-8 * scale)
+            nmine += 1
+        assert nmine == len(grids) // nranks
+        s.undefine()
+        F.comm_destroy(comm)
+        q.put((rank, "ok"))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+def test_leptic_two_ranks_sharing_one_gpu():
+    import multiprocessing as mp
+    import uuid
+    nranks = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "/somar_lep_%s" % uuid.uuid4().hex[:10]
+    procs = [ctx.Process(target=_leptic_worker, args=(r, nranks, name, q)) for r in range(nranks)]
+    for p in procs:
+        p.start()
+    out = {}
+    try:
+        for _ in procs:
+            rank, msg = q.get(timeout=240)
+            out[rank] = msg
+    finally:
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    assert out == {r: "ok" for r in range(nranks)}, "\n".join("rank %d: %s" % kv for kv in sorted(out.items()))
