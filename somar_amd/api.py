@@ -5,6 +5,7 @@ CPU fallback: a missing library or a missing GPU raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -142,6 +143,17 @@ def lib():
         if not os.path.exists(p):
             raise SomarError("%s is missing: run `python -m somar_amd.build` (hipcc, gfx950). "
                              "somar_amd has no CPU fallback." % p)
+        # One HIP runtime per process: PyTorch-ROCm carries its own copies of libamdhip64 / libhsa-runtime64 /
+        # librccl and loads them by path.  If this library pulled in /opt/rocm's copies first, a later `import torch`
+        # (bench.py's torch.distributed control plane, a test) would bring a SECOND runtime that finds no GPU, and
+        # RCCL would fail with "unhandled cuda error".  Loading torch's first makes the dynamic loader satisfy this
+        # library's DT_NEEDED entries with the same objects (matching SONAMEs).  A process without PyTorch installed
+        # (a SOMAR build linking the C ABI) has only one runtime anyway.
+        if "torch" not in sys.modules and os.environ.get("SOMAR_NO_TORCH_PRELOAD") is None:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(p)
         for name, args in _SIGS.items():
             fn = getattr(L, name)

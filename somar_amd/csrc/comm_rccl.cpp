@@ -114,8 +114,14 @@ Comm* rccl_create(const unsigned char* id128, int rank, int nranks, int device)
     c->size = nranks;
     ncclUniqueId id;
     std::memcpy(&id, id128, 128);
+    // RCCL polls hipGetLastError() during init and reports whatever it finds as its own "unhandled cuda error":
+    // a sticky error left behind by an unrelated earlier call in this process must not take the communicator down
+    const hipError_t stale = hipGetLastError();
     try {
-        SOMAR_NCCL(api().CommInitRank(&c->comm, nranks, id, rank));
+        ncclResult_t r_ = api().CommInitRank(&c->comm, nranks, id, rank);
+        if (r_ != ncclSuccess)
+            throw Error(-3, std::string("RCCL error ") + api().GetErrorString(r_) + " in ncclCommInitRank (HIP error pending before the call: " +
+                                hipGetErrorString(stale) + ")");
     } catch (...) {
         delete c;
         throw;

@@ -27,10 +27,12 @@ PressureSolver::PressureSolver(Comm* comm, hipStream_t shared) : comm_(comm ? co
     // make whole solves reproduce the oracle's histories to the last bits
     if (const char* e = getenv("SOMAR_ORDERED_REDUCE_MAX")) ordered_max_cells_ = atoll(e);
     if (const char* e = getenv("SOMAR_AGGLOM_CELLS")) agglom_cells_ = atoll(e);
+    if (const char* e = getenv("SOMAR_GRAPH_CELLS")) graph_cells_ = atoll(e);
 }
 
 PressureSolver::~PressureSolver()
 {
+    drop_graphs();
     if (st_) hipStreamSynchronize(st_);
     for (double* f : f_res) hipFree(f);
     for (double* f : f_corr) hipFree(f);
@@ -362,6 +364,11 @@ void PressureSolver::finalize()
     }
     for (int i = 0; i < 8; ++i) bicg[i] = lev[D - 1]->alloc_field();
     for (int d = 0; d < D; ++d) probe_null_space(d);
+    // first depth whose V-cycle leg is launch-bound (see solver.h); one rank only, never inside a sharded region
+    graph_from_ = -1;
+    if (comm_->size == 1 && !coarse_ && graph_cells_ > 0)
+        for (int d = 0; d <= D - 2; ++d)
+            if (lev[d]->valid_cells_global <= graph_cells_) { graph_from_ = d; break; }
     sync();
     finalized = true;
 }
@@ -761,28 +768,26 @@ void PressureSolver::vcycle(double* e, const double* res, bool e_zero) { cycle(0
 // corr_zero: the correction is to be taken as zero whatever the array holds (the reference zeroes it with
 // setToZero right before: MappedMultiGrid.H:589, MappedAMRMultiGrid.H:1203); a smoother that knows this skips the
 // memset and the read.  Only honoured when at least one smoothing sweep will overwrite the whole array.
-void PressureSolver::cycle(int d, double* corr, const double* res, bool corr_zero)
+void PressureSolver::cycle_bottom_relax(double* corr, const double* res, bool corr_zero)
 {
-    if (coarse_ && d == agglom_depth_) {
-        agglom_cycle(corr, res, corr_zero);
+    const int d = (int)lev.size() - 1;
+    if (lev[d]->domain.numPts() == 1) {
+        relax(d, corr, res, 1, corr_zero);
         return;
     }
-    const int D = (int)lev.size();
-    if (d == D - 1) {
-        if (lev[d]->domain.numPts() == 1) {
-            relax(d, corr, res, 1, corr_zero);
-        } else {
-            if (corr_zero && prm.num_smooth_bottom == 0) launch_set(st_, corr, lev[d]->field_elems, 0.0);
-            relax(d, corr, res, prm.num_smooth_bottom, corr_zero && prm.num_smooth_bottom > 0);
-            bottom_solve(corr, res);
-        }
-        return;
-    }
-    SOMAR_CHECK(prm.numMG > 0, "F-cycles (numMG < 0) are not implemented");
+    if (corr_zero && prm.num_smooth_bottom == 0) launch_set(st_, corr, lev[d]->field_elems, 0.0);
+    relax(d, corr, res, prm.num_smooth_bottom, corr_zero && prm.num_smooth_bottom > 0);
+}
+
+void PressureSolver::cycle_down(int d, double* corr, const double* res, bool corr_zero)
+{
     if (corr_zero && prm.num_smooth_down == 0) launch_set(st_, corr, lev[d]->field_elems, 0.0);
     relax(d, corr, res, prm.num_smooth_down, corr_zero && prm.num_smooth_down > 0);
     restrict_residual(d, f_res[d + 1], corr, res);
-    for (int img = 0; img < prm.numMG; ++img) cycle(d + 1, f_corr[d + 1], f_res[d + 1], img == 0);
+}
+
+void PressureSolver::cycle_up(int d, double* corr, const double* res)
+{
     if (fold_prolong(d)) {
         // Large level: neither the prolongation nor the zero-average mean removal gets a pass of its own -- the first
         // post-smoothing sweep reads corr + coarse(i/r) - mean.  mean = (S_f + S_c) / V with S_f = sum dvol * corr
@@ -806,6 +811,86 @@ void PressureSolver::cycle(int d, double* corr, const double* res, bool corr_zer
     // the zero-average mean is folded into the first post-smoothing sweep when that sweep is the fused kernel
     const double* shift = prolong_increment(d, corr, f_corr[d + 1], fused_relax(d, prm.num_smooth_up));
     relax(d, corr, res, prm.num_smooth_up, false, shift);
+}
+
+void PressureSolver::cycle(int d, double* corr, const double* res, bool corr_zero)
+{
+    if (coarse_ && d == agglom_depth_) {
+        agglom_cycle(corr, res, corr_zero);
+        return;
+    }
+    const int D = (int)lev.size();
+    if (d == D - 1) {
+        cycle_bottom_relax(corr, res, corr_zero);
+        if (lev[d]->domain.numPts() != 1) bottom_solve(corr, res);
+        return;
+    }
+    SOMAR_CHECK(prm.numMG > 0, "F-cycles (numMG < 0) are not implemented");
+    if (graph_cycle(d, corr, res, corr_zero)) return;
+    cycle_down(d, corr, res, corr_zero);
+    for (int img = 0; img < prm.numMG; ++img) cycle(d + 1, f_corr[d + 1], f_res[d + 1], img == 0);
+    cycle_up(d, corr, res);
+}
+
+void PressureSolver::drop_graphs()
+{
+    if (cg_.down) hipGraphExecDestroy(cg_.down);
+    if (cg_.up) hipGraphExecDestroy(cg_.up);
+    cg_ = CoarseGraph();
+}
+
+// The V-cycle from depth d down to the bottom and back as two graph replays around the bottom solve.  Returns
+// false when this call is not the one the graphs describe (the caller then runs the launches one by one).
+bool PressureSolver::graph_cycle(int d, double* corr, const double* res, bool corr_zero)
+{
+    const int D = (int)lev.size();
+    if (graph_from_ < 0 || d != graph_from_ || capturing_ || !corr_zero || prm.numMG != 1 || comm_->size != 1 ||
+        coarse_ || profiling_ || d > D - 2)
+        return false;
+    if (cg_.down && (cg_.d0 != d || cg_.corr != corr || cg_.res != res || cg_.pre != prm.num_smooth_down ||
+                     cg_.post != prm.num_smooth_up || cg_.bottom != prm.num_smooth_bottom))
+        drop_graphs();
+    if (!cg_.down) {
+        auto capture = [&](bool down) -> hipGraphExec_t {
+            hipGraph_t g = nullptr;
+            capturing_ = true;
+            SOMAR_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+            try {
+                if (down) {
+                    cycle_down(d, corr, res, true);
+                    for (int q = d + 1; q <= D - 2; ++q) cycle_down(q, f_corr[q], f_res[q], true);
+                    cycle_bottom_relax(f_corr[D - 1], f_res[D - 1], true);
+                } else {
+                    for (int q = D - 2; q > d; --q) cycle_up(q, f_corr[q], f_res[q]);
+                    cycle_up(d, corr, res);
+                }
+            } catch (...) {
+                hipStreamEndCapture(st_, &g);
+                if (g) hipGraphDestroy(g);
+                capturing_ = false;
+                throw;
+            }
+            capturing_ = false;
+            SOMAR_HIP(hipStreamEndCapture(st_, &g));
+            hipGraphExec_t e = nullptr;
+            const hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+            hipGraphDestroy(g);
+            SOMAR_HIP(rc);
+            return e;
+        };
+        cg_.down = capture(true);
+        cg_.up = capture(false);
+        cg_.d0 = d;
+        cg_.corr = corr;
+        cg_.res = res;
+        cg_.pre = prm.num_smooth_down;
+        cg_.post = prm.num_smooth_up;
+        cg_.bottom = prm.num_smooth_bottom;
+    }
+    SOMAR_HIP(hipGraphLaunch(cg_.down, st_));
+    if (lev[D - 1]->domain.numPts() != 1) bottom_solve(f_corr[D - 1], f_res[D - 1]);
+    SOMAR_HIP(hipGraphLaunch(cg_.up, st_));
+    return true;
 }
 
 bool PressureSolver::fold_prolong(int d) const

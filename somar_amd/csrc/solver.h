@@ -193,6 +193,24 @@ private:
     int n_agglom_back_ = 0;
     void build_agglomerated_tail(int depth);
     void agglom_cycle(double* corr, const double* res, bool corr_zero);
+    // ---- launch-bound coarse depths replayed as HIP graphs ----
+    // From the first depth with at most graph_cells_ cells on, one V-cycle is ~20 microsecond-sized launches per
+    // depth; the legs on either side of the bottom solve (whose loop needs host decisions) are captured once and
+    // replayed.  Only where nothing but kernels is enqueued: one rank (which includes the replicated tail).
+    struct CoarseGraph {
+        hipGraphExec_t down = nullptr, up = nullptr;
+        int d0 = -1, pre = -1, post = -1, bottom = -1;
+        const double *corr = nullptr, *res = nullptr;
+    };
+    CoarseGraph cg_;
+    long long graph_cells_ = 262144;
+    int graph_from_ = -1;
+    bool capturing_ = false;
+    void cycle_down(int d, double* corr, const double* res, bool corr_zero);  // pre-smoothing + restriction
+    void cycle_up(int d, double* corr, const double* res);                    // prolongation + post-smoothing
+    void cycle_bottom_relax(double* corr, const double* res, bool corr_zero);
+    bool graph_cycle(int d, double* corr, const double* res, bool corr_zero);
+    void drop_graphs();
     struct Prof { std::vector<hipEvent_t> a, b; int used = 0; };
     Prof prof_[2];
     bool profiling_ = false;
