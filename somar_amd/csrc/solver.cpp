@@ -383,6 +383,7 @@ void PressureSolver::build_agglomerated_tail(int depth)
     if (cp.maxDepth >= 0) cp.maxDepth = std::max(0, cp.maxDepth - depth);
     coarse_.reset(new PressureSolver(nullptr, st_));
     coarse_->probe_eps = probe_eps > 0.0 ? probe_eps : prm.eps;
+    coarse_->graph_cells_ = 0;  // graph replay is exercised (and measured) on single-process runs only
     std::vector<int> own(T.boxes.size(), 0);
     coarse_->define(T.domain, T.periodic, T.dx, T.bc_type, T.boxes, own, T.alpha, T.beta, cp,
                     hasCF_ ? dxCrse_ : nullptr);
