@@ -12,8 +12,8 @@ CPU restatement of the multi-level (AMR) part of SOMAR's pressure solve, on top 
   MappedAMRPoissonOp AMR* members        calculus/AMRElliptic/MappedAMRPoissonOp.cpp:1311-1707
   MappedAMRMultiGrid AMRVCycle & friends calculus/AMRElliptic/MappedAMRMultiGrid.H:736-927, 979-1215, 1320-1598
 
-Scope: diagonal metric, zero-Neumann/periodic physical BCs, AMR refinement ratios with entries in {1, 2}
-(no mini V-cycles), LevelGSRB.  Parity unpinned w.r.t. reference tests (there are none); pinned by
+Scope: diagonal metric, zero-Neumann/periodic physical BCs, AMR refinement ratios with entries in {1, 2, 4}
+(entries > 2: mini V-cycles through forced MG depths), LevelGSRB.  Parity unpinned w.r.t. reference tests (there are none); pinned by
 tests/test_oracle_amr.py (exactness of the quadratic CF interpolation on quadratics, conservation of the
 refluxed composite operator, composite convergence).
 """
@@ -540,8 +540,7 @@ class AMRComposite:
         n = len(levels)
         assert len(self.refRatios) >= n - 1
         for r in self.refRatios[:n - 1]:
-            if max(r) > 2:
-                raise NotImplementedError("refinement ratios > 2 need the mini V-cycle (MappedAMRMultiGrid.H:742-754)")
+            assert all(x in (1, 2, 4) for x in r), "refinement ratios are 1, 2 or 4 per direction"
         self.eps, self.hang, self.normThresh = 1e-6, 1e-15, 1e-30
         self.imin, self.iterMax = 5, 20
         self.pre = self.post = self.bottom = 2
@@ -556,7 +555,21 @@ class AMRComposite:
             dxCrse = levels[l - 1].dx if l > 0 else None
             fac = so.Factory(L.domain, L.grids, L.dx, bc, L.Jgup, L.Jinv, alpha=alpha, beta=beta, maxDepth=maxDepth,
                              precondIters=precondIters, relaxMode=relaxMode, amrmg_eps=amrmg_eps, dxCrse=dxCrse, cf=cf)
-            mg = so.MultiGrid(fac, NoOpSolver(), maxDepth)
+            # the mini V-cycle's coarsening pattern, MappedAMRMultiGrid.H:1455-1482
+            force = None
+            if l > 0:
+                force = []
+                r = list(self.refRatios[l - 1])
+                while max(r) > 2:
+                    this = [1, 1, 1]
+                    for d in range(3):
+                        if r[d] > 2:
+                            r[d] //= 2
+                            this[d] = 2
+                    if this[0] * this[1] * this[2] > 1:
+                        force.append(tuple(this))
+                force.reverse()
+            mg = so.MultiGrid(fac, NoOpSolver(), maxDepth, forceAllMGRefRatios=force)
             op = mg.ops[0]
             op.level = l
             op.refToCoarser = self.refRatios[l - 1] if l > 0 else None
@@ -680,8 +693,20 @@ class AMRComposite:
 
     # ---- MappedAMRMultiGrid ---------------------------------------------------------------------------
     def relax(self, l, correction, residual, n):
-        """relax, MappedAMRMultiGrid.H:736-766 (ratios <= 2: plain smoothing)."""
-        self.ops[l].relax(correction, residual, n)
+        """relax, MappedAMRMultiGrid.H:736-766: plain smoothing, or -- when MG depths lie between this level and the
+        next coarser AMR level (a ratio entry > 2) -- a mini V-cycle over those depths."""
+        op, mg = self.ops[l], self.mg[l]
+        if op.refToCoarser is not None and max(op.refToCoarser) > 2:
+            assert mg.maxForcedDepth > 0
+            keep = mg.depth
+            mg.depth = mg.maxForcedDepth + 1
+            mg.pre, mg.post, mg.bottom, mg.cycle_type = self.pre, self.post, self.bottom, self.numMG
+            try:
+                mg.cycle(0, correction, residual)
+            finally:
+                mg.depth = keep
+        else:
+            op.relax(correction, residual, n)
 
     def compute_amr_residual_level(self, resid, phi, rhs, l_max, l_base, ilev, homogeneous):
         """computeAMRResidualLevel, :884-927."""
@@ -720,6 +745,11 @@ class AMRComposite:
             if i == l_base:
                 self.mg[i].init(phi[i], rhs[i])
             else:
+                if self.mg[i].maxForcedDepth > 0:   # "This triggers the mini V-cycles when the AMR ref ratio > 2."
+                    keep = self.mg[i].depth
+                    self.mg[i].depth = self.mg[i].maxForcedDepth + 1
+                    self.mg[i].init(phi[i], rhs[i])
+                    self.mg[i].depth = keep
                 r = self.ops[i].refToCoarser
                 self.m_resC[i] = LevelData([g.coarsen(r) for g in self.ops[i].grids], rhs[i].ncomp, rhs[i].ghost)
 

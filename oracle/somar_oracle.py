@@ -880,23 +880,31 @@ class Factory:
         fill_lap_diag(lapDiag, Jgup, Jinv, grids, dx, ndim)
         self.metrics = [(list(grids), Jgup, Jinv, lapDiag)]  # m_vvJgup[ref][depth] ...
 
-    def mg_new_op(self, depth, allMGRefRatios):
+    def mg_new_op(self, depth, allMGRefRatios, forceAll=None):
         if self.maxDepth >= 0 and depth > self.maxDepth:
+            if forceAll is not None and depth <= len(forceAll):
+                raise ValueError("You must make the maxDepth large enough to accomodate the mini V-cycles")
             return None
         ndim = self.ndim
         domain, dx = self.domain, list(self.dx)
         coarsening = [1, 1, 1]
         mgRefRatio = (1, 1, 1)
+        mmc = self.maskedMaxCoarse
+        forced = forceAll is not None and depth <= len(forceAll)
         for i in range(depth):
-            if allMGRefRatios is not None and i < depth - 1:
+            if forced:
+                mgRefRatio = tuple(forceAll[i])        # Factory.cpp:414-424: the mini V-cycle's coarsening pattern
+            elif allMGRefRatios is not None and i < depth - 1:
                 mgRefRatio = allMGRefRatios[i]
             else:
                 mgRefRatio = choose_mg_ref_ratio(dx, ndim)
             domain = domain.coarsen(mgRefRatio)
             dx = [a * b for a, b in zip(dx, mgRefRatio)]
             coarsening = [a * b for a, b in zip(coarsening, mgRefRatio)]
-        mmc = self.maskedMaxCoarse
-        if int(np.prod(coarsening)) > 1 and not coarsenable(self.grids, [a * b for a, b in zip(coarsening, mmc)]):
+        if forced and int(np.prod(coarsening)) > 1 and not coarsenable(self.grids, [a * b for a, b in zip(coarsening, mmc)]):
+            raise ValueError("Could not coarsen grids for mini V-cycle. Your block factor needs to be at least %d"
+                             % max(a * b for a, b in zip(coarsening, mmc)))
+        if (not forced) and int(np.prod(coarsening)) > 1 and not coarsenable(self.grids, [a * b for a, b in zip(coarsening, mmc)]):
             # fallback, Factory.cpp:504-550
             domain = domain.refine(mgRefRatio)
             dx = [a / b for a, b in zip(dx, mgRefRatio)]
@@ -1064,10 +1072,11 @@ class MultiGrid:
     """MappedMultiGrid<T>, AMRElliptic/MappedMultiGrid.H:328-404 (define), 421-434 (init),
     555-653 (cycle)."""
 
-    def __init__(self, factory, bottomSolver, maxDepth=-1, pre=2, post=2, bottom=2, cycle=1):
+    def __init__(self, factory, bottomSolver, maxDepth=-1, pre=2, post=2, bottom=2, cycle=1, forceAllMGRefRatios=None):
         self.pre, self.post, self.bottom, self.cycle_type = pre, post, bottom, cycle
         self.ops = []
         self.mgRefRatios = []
+        self.maxForcedDepth = len(forceAllMGRefRatios) if forceAllMGRefRatios is not None else 0
         nextOp = factory.mg_new_op(0, None)
         depth = 0
         while nextOp is not None:
@@ -1075,7 +1084,7 @@ class MultiGrid:
             depth += 1
             if depth < maxDepth or maxDepth < 0:
                 fineOp = nextOp
-                nextOp = factory.mg_new_op(depth, self.mgRefRatios)
+                nextOp = factory.mg_new_op(depth, self.mgRefRatios, forceAllMGRefRatios)
                 if nextOp is not None:
                     fineOp.mgCrseRefRatio = self.mgRefRatios[-1]
             else:

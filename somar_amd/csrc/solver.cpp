@@ -968,8 +968,13 @@ void PressureSolver::bottom_solve(double* phi, const double* rhs)
         if (nrm[0] > eps * initial_norm && nrm[0] > prm.bottom_reps * initial_rnorm) {
             pre_cond(d, s_tilde, r);
             apply_op(d, t, s_tilde);
-            const double tr = dot(d, t, r);
-            const double tt = dot(d, t, t);
+            // (t,r) and (t,t) in one host round trip
+            launch_reduce(st_, lev[d]->dev, t, r, 0, d_partials, d_scalars + SLOT_TMP, ordered(d));
+            launch_reduce(st_, lev[d]->dev, t, t, 0, d_partials, d_scalars + SLOT_TMP + 1, ordered(d));
+            comm_->allreduce(d_scalars + SLOT_TMP, 2, 0, st_);
+            SOMAR_HIP(hipMemcpyAsync(h_scalars + SLOT_TMP, d_scalars + SLOT_TMP, 2 * sizeof(double), hipMemcpyDeviceToHost, st_));
+            SOMAR_HIP(hipStreamSynchronize(st_));
+            const double tr = h_scalars[SLOT_TMP], tt = h_scalars[SLOT_TMP + 1];
             omega[0] = tr / tt;
             launch_incr(st_, e, s_tilde, omega[0], n);
             launch_incr(st_, r, t, -omega[0], n);
