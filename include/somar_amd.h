@@ -153,6 +153,10 @@ int somar_vcycle(somar_solver_t* s, int corr_field, int res_field);
  * (uberCorrection is setToZero'ed in postVCycleOps, MappedAMRMultiGrid.H:1203): the contents of corr_field are
  * ignored and overwritten, which saves the memset and the first sweep's read */
 int somar_vcycle_from_zero(somar_solver_t* s, int corr_field, int res_field);
+/* MappedAMRMultiGrid::relax on a level refined by more than 2 against its coarser level (MappedAMRMultiGrid.H:742-754):
+ * one V-cycle over the forced MG depths only (define :1455-1482), smoothing but no solve at its bottom.  Only on
+ * such a level of a somar_amr hierarchy. */
+int somar_mini_vcycle(somar_solver_t* s, int corr_field, int res_field);
 int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* iters, int* exit_code);
 
 /* MAC level projection of a face-centred velocity given in flux form (J u^a on a-faces, one host array per

@@ -94,6 +94,7 @@ _SIGS = {
     "somar_level_precond": [_H, C.c_int, C.c_int, C.c_int],
     "somar_vcycle": [_H, C.c_int, C.c_int],
     "somar_vcycle_from_zero": [_H, C.c_int, C.c_int],
+    "somar_mini_vcycle": [_H, C.c_int, C.c_int],
     "somar_bottom_solve": [_H, C.c_int, C.c_int, _PI, _PI],
     "somar_vel_upload": [_H, C.c_int, C.c_int, _PD],
     "somar_vel_download": [_H, C.c_int, C.c_int, _PD],
@@ -432,6 +433,9 @@ class AMRPressureSolver:
 
     def vcycle(self, corr_field=F_CORR, res_field=F_RES):
         _ck(lib().somar_vcycle(self._h, corr_field, res_field))
+
+    def miniVCycle(self, corr_field=F_CORR, res_field=F_RES):
+        _ck(lib().somar_mini_vcycle(self._h, corr_field, res_field))
 
     def vcycleFromZero(self, corr_field=F_CORR, res_field=F_RES):
         """oneCycle on a correction taken to be zero (contents of corr_field are ignored and overwritten)"""

@@ -71,8 +71,7 @@ void AMRSolver::define(const IBox& domain0, const bool periodic[3], const double
         if (l > 0) {
             const int* r = ratios[l - 1].data();
             for (int d = 0; d < 3; ++d) {
-                SOMAR_CHECK(r[d] == 1 || r[d] == 2,
-                            "refinement ratios > 2 need the mini V-cycle (MappedAMRMultiGrid.H:742-754): not implemented");
+                SOMAR_CHECK(r[d] == 1 || r[d] == 2 || r[d] == 4, "refinement ratios are 1, 2 or 4 per direction");
                 dxc[d] = dx[d];
                 dx[d] = dx[d] / (double)r[d];
             }
@@ -85,6 +84,18 @@ void AMRSolver::define(const IBox& domain0, const bool periodic[3], const double
         }
         std::unique_ptr<PressureSolver> ps(new PressureSolver(comm_, st_));
         ps->define(dom, periodic, dx, bc_type, boxes[l], owners[l], alpha, beta, p, l > 0 ? dxc : nullptr);
+        if (l > 0) {
+            // the mini V-cycle's coarsening pattern, MappedAMRMultiGrid.H:1455-1482 (anisotropic coarsening first)
+            int r[3] = {ratios[l - 1][0], ratios[l - 1][1], ratios[l - 1][2]};
+            std::vector<std::array<int, 3>> all;
+            while (r[0] > 2 || r[1] > 2 || r[2] > 2) {
+                std::array<int, 3> t = {1, 1, 1};
+                for (int d = 0; d < 3; ++d)
+                    if (r[d] > 2) { r[d] /= 2; t[d] = 2; }
+                if (t[0] * t[1] * t[2] > 1) all.push_back(t);
+            }
+            ps->forcedRatios.assign(all.rbegin(), all.rend());
+        }
         S.push_back(std::move(ps));
     }
 }
@@ -682,6 +693,20 @@ double AMRSolver::compute_residual(double* const* resid, double* const* phi, dou
     return rnorm;
 }
 
+// MappedAMRMultiGrid::relax, MappedAMRMultiGrid.H:736-766
+void AMRSolver::level_relax(int l, double* corr, const double* res, int iters)
+{
+    if (!S[l]->forcedRatios.empty()) {
+        S[l]->prm.num_smooth_down = prm.num_smooth_down;
+        S[l]->prm.num_smooth_up = prm.num_smooth_up;
+        S[l]->prm.num_smooth_bottom = prm.num_smooth_bottom;
+        S[l]->prm.numMG = prm.numMG;
+        S[l]->mini_vcycle(corr, res);
+    } else {
+        S[l]->relax(0, corr, res, iters);
+    }
+}
+
 void AMRSolver::vcycle(double* const* uberCorr, double* const* uberRes, int ilev, int l_max, int l_base)
 {
     if (ilev == l_max)
@@ -697,7 +722,7 @@ void AMRSolver::vcycle(double* const* uberCorr, double* const* uberRes, int ilev
         S[l_base]->vcycle(corr_[ilev], res_[ilev], true);  // m_correction was set to zero above
         launch_incr(st_, uberCorr[ilev], corr_[ilev], 1.0, n);
     } else {
-        S[ilev]->relax(0, corr_[ilev], res_[ilev], prm.num_smooth_down);
+        level_relax(ilev, corr_[ilev], res_[ilev], prm.num_smooth_down);
         launch_incr(st_, uberCorr[ilev], corr_[ilev], 1.0, n);
         launch_set(st_, corr_[ilev - 1], S[ilev - 1]->level(0).field_elems, 0.0);
         compute_residual_level(res_.data(), uberCorr, uberRes, l_max, l_base, ilev - 1, true);
@@ -709,7 +734,7 @@ void AMRSolver::vcycle(double* const* uberCorr, double* const* uberRes, int ilev
         amr_update_residual(ilev, res_[ilev], corr_[ilev], corr_[ilev - 1]);
         double* dCorr = uberCorr[ilev];
         launch_set(st_, dCorr, n, 0.0);
-        S[ilev]->relax(0, dCorr, res_[ilev], prm.num_smooth_up);
+        level_relax(ilev, dCorr, res_[ilev], prm.num_smooth_up);
         launch_incr(st_, corr_[ilev], dCorr, 1.0, n);
         launch_copy(st_, uberCorr[ilev], corr_[ilev], n);
     }

@@ -150,6 +150,7 @@ public:
     double compute_residual(double* const* resid, double* const* phi, double* const* rhs, int l_max, int l_base,
                             bool homogeneous);
     void vcycle(double* const* uberCorr, double* const* uberRes, int ilev, int l_max, int l_base);
+    void level_relax(int l, double* corr, const double* res, int iters);
     double* corr(int l) { return corr_[l]; }
     double* res(int l) { return res_[l]; }
     AMRLink& link(int l) { return *links_[l]; }

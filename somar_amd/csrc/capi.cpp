@@ -441,6 +441,18 @@ int somar_vcycle(somar_solver_t* s, int corr_field, int res_field)
     API_END
 }
 
+int somar_mini_vcycle(somar_solver_t* s, int corr_field, int res_field)
+{
+    API_BEGIN
+    int d1, d2;
+    double* e = field_ptr(s, corr_field, &d1);
+    double* r = field_ptr(s, res_field, &d2);
+    SOMAR_CHECK(d1 == 0 && d2 == 0 && e != r, "the mini V-cycle starts at depth 0");
+    s->ps->mini_vcycle(e, r);
+    s->ps->sync();
+    API_END
+}
+
 int somar_vcycle_from_zero(somar_solver_t* s, int corr_field, int res_field)
 {
     API_BEGIN

@@ -199,7 +199,10 @@ void PressureSolver::set_metric_ortho(int patch, const double* jg0, const double
 // Semicoarsening rule + fallback, MappedAMRPoissonOpFactory.cpp:476-550
 bool PressureSolver::build_coarser(int depth)
 {
-    if (prm.maxDepth >= 0 && depth > prm.maxDepth) return false;
+    if (prm.maxDepth >= 0 && depth > prm.maxDepth) {
+        SOMAR_CHECK(depth > (int)forcedRatios.size(), "You must make the maxDepth large enough to accomodate the mini V-cycles");
+        return false;
+    }
     Level& F = *lev[depth - 1];
     int prev[3] = {1, 1, 1};
     for (auto& r : mgRefRatios)
@@ -207,15 +210,23 @@ bool PressureSolver::build_coarser(int depth)
     const int nd = prm.spaceDim;
     const int mmc[3] = {S_MAX_COARSE, S_MAX_COARSE, nd == 3 ? S_MAX_COARSE : 1};
     int r[3] = {1, 1, 1};
+    const bool forced = depth <= (int)forcedRatios.size();  // the mini V-cycle's coarsening pattern, Factory.cpp:414-441
+    if (forced) {
+        for (int d = 0; d < 3; ++d) r[d] = forcedRatios[depth - 1][d];
+        int tot[3];
+        for (int d = 0; d < 3; ++d) tot[d] = prev[d] * r[d] * mmc[d];
+        SOMAR_CHECK(coarsenable(lev[0]->boxes, tot),
+                    "Could not coarsen grids for mini V-cycle: the block factor is too small for this refinement ratio");
+    }
     double maxDx = 0.0;
     for (int d = 0; d < nd; ++d) maxDx = std::max(maxDx, F.dx[d]);
-    for (int d = 0; d < nd; ++d)
+    for (int d = 0; d < nd && !forced; ++d)
         if (F.dx[d] <= maxDx / 2.0) r[d] = 2;
-    if (r[0] * r[1] * r[2] == 1) { r[0] = r[1] = 2; r[2] = nd == 3 ? 2 : 1; }
+    if (!forced && r[0] * r[1] * r[2] == 1) { r[0] = r[1] = 2; r[2] = nd == 3 ? 2 : 1; }
     int tot[3];
     for (int d = 0; d < 3; ++d) tot[d] = prev[d] * r[d] * mmc[d];
     const std::vector<IBox>& base = lev[0]->boxes;
-    if (!coarsenable(base, tot)) {
+    if (!forced && !coarsenable(base, tot)) {
         int q[3] = {1, 1, 1};
         for (int d = 0; d < nd; ++d) {
             q[d] = 2;
@@ -821,16 +832,40 @@ void PressureSolver::cycle(int d, double* corr, const double* res, bool corr_zer
         return;
     }
     const int D = (int)lev.size();
+    if (mini_depth_ > 0 && d == mini_depth_ - 1) {
+        // Bottom of a mini V-cycle: the reference smooths here (m_bottom sweeps) and then calls the AMR solver's
+        // NoOpSolver, whose solve() is Chombo 3.1's "m_op->setToZero(a_phi)" -- so what goes back up is ZERO and the
+        // sweeps are dead work.  Reproduced as the reference behaves (not as its name suggests): just the zero.
+        (void)corr_zero;
+        launch_set(st_, corr, lev[d]->field_elems, 0.0);
+        return;
+    }
     if (d == D - 1) {
         cycle_bottom_relax(corr, res, corr_zero);
         if (lev[d]->domain.numPts() != 1) bottom_solve(corr, res);
         return;
     }
     SOMAR_CHECK(prm.numMG > 0, "F-cycles (numMG < 0) are not implemented");
-    if (graph_cycle(d, corr, res, corr_zero)) return;
+    if (mini_depth_ == 0 && graph_cycle(d, corr, res, corr_zero)) return;
     cycle_down(d, corr, res, corr_zero);
     for (int img = 0; img < prm.numMG; ++img) cycle(d + 1, f_corr[d + 1], f_res[d + 1], img == 0);
     cycle_up(d, corr, res);
+}
+
+// MappedAMRMultiGrid::relax on a level whose refinement ratio to the coarser AMR level has an entry > 2
+// (MappedAMRMultiGrid.H:742-754): a V-cycle over the forced depths only, nothing solved at its bottom.
+void PressureSolver::mini_vcycle(double* corr, const double* res)
+{
+    SOMAR_CHECK(!forcedRatios.empty() && (int)lev.size() > (int)forcedRatios.size(), "no forced MG depths on this level");
+    SOMAR_CHECK(!coarse_ || agglom_depth_ > (int)forcedRatios.size(), "internal: forced depths inside the replicated tail");
+    mini_depth_ = (int)forcedRatios.size() + 1;
+    try {
+        cycle(0, corr, res, false);
+    } catch (...) {
+        mini_depth_ = 0;
+        throw;
+    }
+    mini_depth_ = 0;
 }
 
 void PressureSolver::drop_graphs()

@@ -115,6 +115,10 @@ public:
     const double* prolong_increment(int d, double* phiFine, const double* corrCoarse, bool defer_mean = false);
     void pre_cond(int d, double* phi, const double* rhs);
     void vcycle(double* e, const double* res, bool e_zero = false);  // MappedMultiGrid::oneCycle
+    // MG ratios imposed on the first depths (set before finalize): the coarsening pattern of the mini V-cycle of a
+    // level refined by more than 2 (MappedAMRMultiGrid.H:1455-1482), and that mini V-cycle itself (:742-754)
+    std::vector<std::array<int, 3>> forcedRatios;
+    void mini_vcycle(double* corr, const double* res);
     void bottom_solve(double* phi, const double* rhs);
     double norm(int d, const double* a, int ord);
     double dot(int d, const double* a, const double* b);
@@ -206,6 +210,7 @@ private:
     long long graph_cells_ = 262144;
     int graph_from_ = -1;
     bool capturing_ = false;
+    int mini_depth_ = 0;  // > 0 while a mini V-cycle runs: the depth count it is limited to
     void cycle_down(int d, double* corr, const double* res, bool corr_zero);  // pre-smoothing + restriction
     void cycle_up(int d, double* corr, const double* res);                    // prolongation + post-smoothing
     void cycle_bottom_relax(double* corr, const double* res, bool corr_zero);

@@ -18,7 +18,12 @@ LAYOUTS = [
     ((True, False, False), [(2, 2, 2), (2, 2, 1)], [[((8, 8, 4), (23, 23, 11))], [((24, 24, 6), (39, 39, 9))]]),
     # a fine slab against the walls: one-sided / dropped CF stencils
     ((False, False, False), [(2, 2, 2)], [[((8, 0, 0), (23, 15, 15)), ((8, 16, 0), (23, 31, 15))]]),
+    # refinement by 4 (the reference's LockExchange inputs use (4,1,1)): forced MG depths + mini V-cycles
+    ((False, True, False), [(4, 1, 1)], [[((16, 0, 0), (31, 15, 7)), ((32, 0, 0), (47, 15, 7))]]),
+    ((False, False, False), [(4, 4, 1)], [[((16, 16, 0), (47, 47, 7))]]),
+    ((True, False, False), [(2, 2, 1), (4, 1, 1)], [[((8, 8, 0), (23, 23, 7))], [((40, 12, 0), (71, 19, 7))]]),
 ]
+RATIO4 = LAYOUTS[5:]
 
 
 @pytest.fixture(scope="module")
@@ -107,7 +112,8 @@ def sweep_kernel(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("case", VCYCLES + [(LAYOUTS[2], 1, 0), (LAYOUTS[4], 1, 0)])
+@pytest.mark.parametrize("case", VCYCLES + [(LAYOUTS[2], 1, 0), (LAYOUTS[4], 1, 0), (LAYOUTS[5], 1, 0), (LAYOUTS[6], 1, 0),
+                                            (LAYOUTS[7], 2, 0), (LAYOUTS[7], 2, 1)])
 def test_amr_vcycle_bit_exact(oracle, am, case, sweep_kernel):
     """One AMRVCycle from identical inputs.  Every level here is small enough (<= 4096 cells) for the library
     to sum BiCGStab's scalars and the zero-average mean in the reference's serial order (k_reduce_ordered), so
@@ -137,7 +143,34 @@ def test_amr_vcycle_bit_exact(oracle, am, case, sweep_kernel):
         gpu.undefine()
 
 
-@pytest.mark.parametrize("layout", LAYOUTS[:4])
+@pytest.mark.parametrize("layout", [LAYOUTS[5], LAYOUTS[6]])
+def test_mini_vcycle_bit_exact(oracle, am, layout):
+    """MappedAMRMultiGrid::relax on a level refined by 4: a V-cycle over the forced (2,.,.) depth whose bottom is
+    smoothed and then ZEROED by the AMR solver's NoOpSolver (Chombo 3.1: solve() = setToZero) -- reproduced as is."""
+    from somar_amd import api as F
+    so = oracle
+    levels, comp, gpu = _setup(so, am, layout)
+    try:
+        L, v = levels[1], gpu.levels[1]
+        assert v.mgRefRatios() == [tuple(r) for r in comp.mg[1].mgRefRatios]
+        assert comp.mg[1].maxForcedDepth == 1 and max(comp.mg[1].mgRefRatios[0]) == 2
+        res = so.random_field(L.grids, 70, (0, 0, 0), L.domain.box)
+        corr = so.random_field(L.grids, 71, (1, 1, 1), L.domain.box)
+        zero = [so.LevelData(X.grids, 1, (1, 1, 1)) for X in levels]
+        zres = [so.LevelData(X.grids, 1, (0, 0, 0)) for X in levels]
+        comp.init(zero, zres, 1, 0)
+        comp.set_bottom_solver(1, 0)
+        upload(v, F.F_RES, res)
+        upload(v, F.F_CORR, corr)
+        comp.relax(1, corr, res, 2)
+        v.miniVCycle(F.F_CORR, F.F_RES)
+        for g, w in zip(download_valid(v, F.F_CORR, L.grids), valid_of(corr)):
+            np.testing.assert_array_equal(g, w)
+    finally:
+        gpu.undefine()
+
+
+@pytest.mark.parametrize("layout", LAYOUTS[:4] + RATIO4)
 def test_composite_solve_history_matches(oracle, am, layout, sweep_kernel):
     from somar_amd import api as F
     so = oracle
