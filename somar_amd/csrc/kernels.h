@@ -68,6 +68,9 @@ void launch_copy_items(hipStream_t st, const LevelDev& L, const CopyItem* items,
 void launch_pack(hipStream_t st, const LevelDev& L, const CopyItem* items, const long long* bufoff, int nitems,
                  double* f, double* buf, bool pack);
 void launch_set(hipStream_t st, double* a, long long n, double v);
+// n device values -> coherent host memory, then the sequence number (system-scope release)
+void launch_publish(hipStream_t st, const double* src, int n, double* host_dst, unsigned long long* host_seq,
+                    unsigned long long seq);
 void launch_copy(hipStream_t st, double* d, const double* s, long long n);
 void launch_incr(hipStream_t st, double* y, const double* x, double a, long long n);
 void launch_scale(hipStream_t st, double* y, double a, long long n);

@@ -631,11 +631,28 @@ __global__ __launch_bounds__(64) void k_reduce_ordered(const PatchDesc* __restri
                 else { const double y = dxProduct / b[c]; Y[q] = y; X[q] = y * a[c]; }
             }
             __syncthreads();
+            // the chain of dependent adds is the critical path: fetch 16 values (uniform LDS reads) ahead of it so that
+            // their latency overlaps instead of sitting between every two adds (133 -> ~20 us per 4096 cells)
             if (MODE == 6) {
-                for (int q = 0; q < cnt; ++q) { run_s = run_s + X[q]; run_v = run_v + Y[q]; }
+                int q = 0;
+                for (; q + 16 <= cnt; q += 16) {
+                    double xv[16], yv[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { xv[j] = X[q + j]; yv[j] = Y[q + j]; }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { run_s = run_s + xv[j]; run_v = run_v + yv[j]; }
+                }
+                for (; q < cnt; ++q) { run_s = run_s + X[q]; run_v = run_v + Y[q]; }
             } else {
                 int q = 0;
                 if (base == 0) { sbox = X[0]; q = 1; }
+                for (; q + 16 <= cnt; q += 16) {
+                    double xv[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xv[j] = X[q + j];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) sbox = sbox + xv[j];
+                }
                 for (; q < cnt; ++q) sbox = sbox + X[q];
             }
         }
@@ -800,6 +817,19 @@ void launch_set(hipStream_t st, double* a, long long n, double v)
 void launch_copy(hipStream_t st, double* d, const double* s, long long n)
 {
     hipLaunchKernelGGL(k_copy, dim3(flat_grid(n)), dim3(256), 0, st, d, s, n);
+}
+__global__ void k_publish(const double* __restrict__ src, int n, double* host_dst, unsigned long long* host_seq,
+                          unsigned long long seq)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int i = 0; i < n; ++i) __hip_atomic_store(host_dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+void launch_publish(hipStream_t st, const double* src, int n, double* host_dst, unsigned long long* host_seq,
+                    unsigned long long seq)
+{
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, src, n, host_dst, host_seq, seq);
 }
 void launch_incr(hipStream_t st, double* y, const double* x, double a, long long n)
 {

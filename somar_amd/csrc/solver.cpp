@@ -17,7 +17,9 @@ PressureSolver::PressureSolver(Comm* comm, hipStream_t shared) : comm_(comm ? co
     SOMAR_HIP(hipMalloc(&d_scalars, NSLOTS * sizeof(double)));
     SOMAR_HIP(hipMemset(d_scalars, 0, NSLOTS * sizeof(double)));
     SOMAR_HIP(hipDeviceSynchronize());
-    SOMAR_HIP(hipHostMalloc(&h_scalars, NSLOTS * sizeof(double)));
+    SOMAR_HIP(hipHostMalloc(&h_scalars, (NSLOTS + 2) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+    h_seq_ = reinterpret_cast<unsigned long long*>(h_scalars + NSLOTS);
+    *h_seq_ = 0;
     // levels smaller than this use the two-pass colour kernel (launch-latency bound anyway);
     // SOMAR_FUSED_MIN_CELLS=0 forces the fused sweep everywhere (tests), a huge value disables it.
     if (const char* e = getenv("SOMAR_FUSED_MIN_CELLS")) fused_min_cells_ = atoll(e);
@@ -110,9 +112,35 @@ void PressureSolver::profile_get(int kernel, int* count, double* total_ms)
 
 double PressureSolver::fetch_scalar(int slot)
 {
-    SOMAR_HIP(hipMemcpyAsync(h_scalars + slot, d_scalars + slot, sizeof(double), hipMemcpyDeviceToHost, st_));
-    SOMAR_HIP(hipStreamSynchronize(st_));
+    fetch_scalars(slot, 1);
     return h_scalars[slot];
+}
+
+// d_scalars[slot .. slot+n) -> h_scalars[slot .. slot+n).  The stopping tests of BiCGStab and of the outer iteration need
+// a handful of scalars per V-cycle on the host; a copy + stream synchronize costs ~25 us each.  Instead a one-thread
+// kernel stores the values into coherent host memory followed by a sequence number, and the host spins on that
+// number: the round trip drops to the latency of a PCIe write (SOMAR_POLL_FETCH=0 restores copy + synchronize).
+void PressureSolver::fetch_scalars(int slot, int n)
+{
+    static const bool poll = !(getenv("SOMAR_POLL_FETCH") && atoi(getenv("SOMAR_POLL_FETCH")) == 0);
+    if (!poll || capturing_) {
+        SOMAR_HIP(hipMemcpyAsync(h_scalars + slot, d_scalars + slot, n * sizeof(double), hipMemcpyDeviceToHost, st_));
+        SOMAR_HIP(hipStreamSynchronize(st_));
+        return;
+    }
+    const unsigned long long want = ++fetch_seq_;
+    launch_publish(st_, d_scalars + slot, n, h_scalars + slot, h_seq_, want);
+    unsigned long long spins = 0;
+    while (__atomic_load_n(h_seq_, __ATOMIC_ACQUIRE) != want) {
+        if ((++spins & 0xfffff) == 0) {  // every ~1M spins: has the stream died or drained without publishing?
+            const hipError_t q = hipStreamQuery(st_);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(h_seq_, __ATOMIC_ACQUIRE) == want) break;
+                throw Error(-2, "scalar publish kernel finished without publishing");
+            }
+            if (q != hipErrorNotReady) SOMAR_HIP(q);
+        }
+    }
 }
 
 double* PressureSolver::work(int which)
@@ -1007,8 +1035,7 @@ void PressureSolver::bottom_solve(double* phi, const double* rhs)
             launch_reduce(st_, lev[d]->dev, t, r, 0, d_partials, d_scalars + SLOT_TMP, ordered(d));
             launch_reduce(st_, lev[d]->dev, t, t, 0, d_partials, d_scalars + SLOT_TMP + 1, ordered(d));
             comm_->allreduce(d_scalars + SLOT_TMP, 2, 0, st_);
-            SOMAR_HIP(hipMemcpyAsync(h_scalars + SLOT_TMP, d_scalars + SLOT_TMP, 2 * sizeof(double), hipMemcpyDeviceToHost, st_));
-            SOMAR_HIP(hipStreamSynchronize(st_));
+            fetch_scalars(SLOT_TMP, 2);
             const double tr = h_scalars[SLOT_TMP], tt = h_scalars[SLOT_TMP + 1];
             omega[0] = tr / tt;
             launch_incr(st_, e, s_tilde, omega[0], n);

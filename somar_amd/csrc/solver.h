@@ -149,6 +149,9 @@ public:
 private:
     void cycle(int d, double* corr, const double* res, bool corr_zero = false);
     double fetch_scalar(int slot);
+    void fetch_scalars(int slot, int n);
+    unsigned long long fetch_seq_ = 0;
+    unsigned long long* h_seq_ = nullptr;  // in the coherent host block behind h_scalars
     bool build_coarser(int depth);
     void probe_null_space(int d);
     void fill_metric_ghosts(Level& L);

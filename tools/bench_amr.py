@@ -5,6 +5,9 @@
 
 C3: 512x512x64 base, L = (15,3,2), y periodic, level 1 = (2,2,1) refinement of the central half in x.
 C4: 1024x1024x128 base + two (2,2,1) levels (central half, central quarter in x).
+le3d: the reference's own exec/inputs.LockExchange_Cartesian3D.machine shape -- base nx = 64 x 96 x 64 times
+      --mult (default 4: 256x384x256), one level refined by (4,1,1) (amr.refratio_lev0) over the central half in x:
+      forced (2,1,1) MG depth + mini V-cycles on the fine level.
 --scale s divides every extent by s (parity-sized runs).  A step = one AMRVCycle (MappedAMRMultiGrid.H:1498) from a
 zero correction on a hash-random residual with covered cells zeroed; pre/post/bottom = 4/4/2.
 Prints one JSON line.  Not the driver's bench (that is bench.py, config C2)."""
@@ -30,26 +33,29 @@ def boxes_of(lo, hi, bs):
     return out
 
 
-def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2):
+def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult=4):
     """-> (AMRPressureSolver (finalized), levels' boxes, cells per level, define seconds)"""
     from somar_amd import api as F
     s = scale
     if config == "c3":
         n0, nlev = (512 // s, 512 // s, 64 // s), 2
+    elif config == "le3d":
+        n0, nlev = (64 * mult // s, 96 * mult // s, 64 * mult // s), 2
     else:
         n0, nlev = (1024 // s, 1024 // s, 128 // s), 3
     L = (15.0, 3.0, 2.0)
-    ratios = [(2, 2, 1)] * (nlev - 1)
+    ratios = [(4, 1, 1)] * (nlev - 1) if config == "le3d" else [(2, 2, 1)] * (nlev - 1)
     dx0 = tuple(L[d] / n0[d] for d in range(3))
     bs = (max(box // s, 8), max(box // s, 8), n0[2])
     levels = [boxes_of((0, 0, 0), tuple(a - 1 for a in n0), bs)]
     n = list(n0)
     frac = 2
     for l in range(1, nlev):
-        n = [n[0] * 2, n[1] * 2, n[2]]
+        r = ratios[l - 1]
+        n = [n[0] * r[0], n[1] * r[1], n[2] * r[2]]
         w = n[0] // frac          # central half, then central quarter (of the refined index space)
         lo_x = (n[0] - w) // 2
-        lo_x -= lo_x % (2 * bs[0])
+        lo_x -= lo_x % ((2 if config != "le3d" else 1) * bs[0])
         levels.append(boxes_of((lo_x, 0, 0), (lo_x + w - 1, n[1] - 1, n[2] - 1), bs))
         frac *= 2
     gpu = F.AMRPressureSolver()
@@ -79,10 +85,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--box", type=int, default=128, help="box edge in x,y (z is never split)")
+    ap.add_argument("--mult", type=int, default=4, help="le3d: multiple of the reference input's 64x96x64 base grid")
     args = ap.parse_args()
     from somar_amd import api as F
     s = args.scale
-    gpu, levels, cells, t_def, dx0, ratios = build_hierarchy(args.config, s, args.box)
+    gpu, levels, cells, t_def, dx0, ratios = build_hierarchy(args.config, s, args.box, mult=args.mult)
     nlev = len(levels)
     for l, v in enumerate(gpu.levels):
         v.fillHash(F.F_RES, 12345 + l)
