@@ -71,6 +71,36 @@ def compute():
     out["amr_res_level0_box0"] = ress[0][0].view(levels[0].grids[0])[..., 0].copy()
     out["amr_res_level1"] = ress[1][0].view(levels[1].grids[0])[..., 0].copy()
     out["amr_fine_phi_with_cf_ghosts"] = phis[1][0].a[..., 0].copy()
+    # 5. refinement by (4,1,1): one AMR V-cycle (forced MG depth + mini V-cycle on the fine level)
+    fb = [[so.Box((16, 0, 0), (31, 15, 7)), so.Box((32, 0, 0), (47, 15, 7))]]
+    levels = make_amr_levels(so, am, (16, 16, 8), (2.0, 1.0, 0.5), (False, True, False), [(4, 1, 1)], fb)
+    comp = am.AMRComposite(levels, [(4, 1, 1)], so.BCHolder(), so.BiCGStab())
+    zero = [so.LevelData(L.grids, 1, (1, 1, 1)) for L in levels]
+    res2 = [so.random_field(L.grids, 70 + l, (0, 0, 0), L.domain.box) for l, L in enumerate(levels)]
+    comp.zero_covered(0, res2[0])
+    comp.init(zero, res2, 1, 0)
+    comp.set_bottom_solver(1, 0)
+    corr = [so.LevelData(L.grids, 1, (1, 1, 1)) for L in levels]
+    comp.amr_vcycle(corr, res2, 1, 1, 0)
+    out["amr_ratio4_vcycle_corr_level1_box0"] = corr[1][0].view(levels[1].grids[0])[..., 0].copy()
+    out["amr_ratio4_fine_mg_ratios"] = np.array(comp.mg[1].mgRefRatios)
+    # 6. leptic level solver on a thin domain: residual norms per order, final phi
+    from oracle import somar_leptic as sl
+    H = 0.005
+    n, L = (32, 32, 8), (1.0, 1.0, H)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, (16, 16, 8))
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_diagonal_metric(grids, dx, L, 3, "stretched", domain=dom)
+    rhs = so.random_field(grids, 3, domainBox=dom.box)
+    so.remove_weighted_mean(rhs, Jinv)
+    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv)
+    lep = sl.LevelLepticSolver(amr.op, maxOrder=3, domainHeight=H)
+    phi = so.LevelData(grids, 1, (1, 1, 1))
+    status = lep.solve(phi, rhs)
+    out["leptic_res_norms"] = np.array(lep.resNorms)
+    out["leptic_status_horiz_full"] = np.array([status, lep.horizSolves, int(lep.usedFullSolver)])
+    out["leptic_phi_box0"] = phi[0].view(grids[0])[..., 0].copy()
     return out
 
 

@@ -95,3 +95,62 @@ def test_amr_residual_matches_golden(oracle):
             np.testing.assert_array_equal(got[sl], want[sl])
     finally:
         gpu.undefine()
+
+
+def test_ratio4_vcycle_and_leptic_match_golden(oracle):
+    """Refinement by (4,1,1) (forced MG depth + mini V-cycle) and the leptic level solver against the committed
+    oracle vectors: inputs are rebuilt from seeds, only the GPU computes."""
+    from oracle import somar_amr as am
+    from somar_amd import api as F
+    from helpers import download_valid, make_amr_levels, make_gpu_amr, upload
+    so = oracle
+    fb = [[so.Box((16, 0, 0), (31, 15, 7)), so.Box((32, 0, 0), (47, 15, 7))]]
+    levels = make_amr_levels(so, am, (16, 16, 8), (2.0, 1.0, 0.5), (False, True, False), [(4, 1, 1)], fb)
+    gpu = make_gpu_amr(levels, [(4, 1, 1)])
+    try:
+        assert np.array_equal(np.array(gpu.levels[1].mgRefRatios()), GOLD["amr_ratio4_fine_mg_ratios"])
+        res2 = [so.random_field(L.grids, 70 + l, (0, 0, 0), L.domain.box) for l, L in enumerate(levels)]
+        for fbx in levels[1].grids:   # zeroCovered on level 0
+            for cb, f in zip(res2[0].grids, res2[0].fabs):
+                reg = fbx.coarsen((4, 1, 1)) & cb
+                if not reg.isEmpty():
+                    f.view(reg)[...] = 0.0
+        for l, v in enumerate(gpu.levels):
+            upload(v, F.F_RES, res2[l])
+            v.setVal(F.F_CORR, 0.0)
+        gpu.vcycleAMR(1, 0)
+        got = download_valid(gpu.levels[1], F.F_CORR, levels[1].grids)[0]
+        np.testing.assert_array_equal(got, GOLD["amr_ratio4_vcycle_corr_level1_box0"])
+    finally:
+        gpu.undefine()
+    # leptic
+    from somar_amd import LevelLepticSolver
+    H, n = 0.005, (32, 32, 8)
+    L = (1.0, 1.0, H)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, (16, 16, 8))
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_diagonal_metric(grids, dx, L, 3, "stretched", domain=dom)
+    rhs = so.random_field(grids, 3, domainBox=dom.box)
+    so.remove_weighted_mean(rhs, Jinv)
+    s = LevelLepticSolver()
+    s.params.max_order = 3
+    s.params.domain_height = H
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids])
+    for p_ in range(s.level.num_local_patches):
+        _, _, gi = s.level.patch_box(p_)
+        jg = [np.asfortranarray(Jgup[gi][d].a[..., d]) for d in range(3)]
+        s.level.setMetricOrtho(p_, jg[0], jg[1], jg[2], np.asfortranarray(Jinv[gi].a[..., 0]))
+    s.finalize()
+    s.level.setVal(F.F_PHI, 0.0)
+    upload(s.level, F.F_RHS, rhs)
+    st = s.solve()
+    assert [st["exitStatus"], st["horizSolves"], int(st["usedFullSolver"])] == list(GOLD["leptic_status_horiz_full"])
+    if not st["usedFullSolver"]:
+        assert st["resNorms"] == list(GOLD["leptic_res_norms"])
+        np.testing.assert_array_equal(download_valid(s.level, F.F_PHI, grids)[0], GOLD["leptic_phi_box0"])
+    else:
+        np.testing.assert_allclose(st["resNorms"], GOLD["leptic_res_norms"], rtol=1e-9)
+        scale = float(np.max(np.abs(GOLD["leptic_phi_box0"])))
+        np.testing.assert_allclose(download_valid(s.level, F.F_PHI, grids)[0], GOLD["leptic_phi_box0"], rtol=0,
+                                   atol=1e-11 * scale)
