@@ -113,7 +113,9 @@ int somar_solver_set_metric_ortho(somar_solver_t* s, int patch, const double* jg
 /* Non-diagonal metric (LevelGeometry::isDiagonal() == false): jgD holds J g^{Db}, b = 0..2, over faces(valid, D),
  * component slowest (the FluxBox layout of LevelGeometry::getFCJgupPtr).  Selects the 19-point kernels
  * (GSRBITER3D, GSRBBOUNDARYITER3D, MAPPEDGETFLUX, fillExtrap / ExtrapolateFaceAndCopy, the cross-term Neumann
- * ghost of EllipticBCUtils.cpp:128-214).  One AMR level, 3-D, LevelGSRB or Jacobi. */
+ * ghost of EllipticBCUtils.cpp:128-214).  One AMR level, LevelGSRB or Jacobi.  space_dim 2: jgD holds 2 components over
+ * faces(valid, D), jg2 = NULL; the 9-point kernels GSRBITER2D / GSRBBOUNDARYITER2D (GSRBF.ChF:155-281, 858-1022) and
+ * MAPPEDGETFLUX / ELLIPTICCONSTNEUMBCGHOST with CH_SPACEDIM = 2 are reproduced. */
 int somar_solver_set_metric_full(somar_solver_t* s, int patch, const double* jg0, const double* jg1, const double* jg2,
                                  const double* jinv);
 int somar_solver_finalize(somar_solver_t* s);

@@ -1074,3 +1074,160 @@ void orc_tridiagpoissonnn1dfab(double *phi_, const int *plo, const int *phi_hi,
 #undef OFF
     free(x); free(a); free(b); free(c); free(gam);
 }
+
+/* ========================================================================
+ * Non-diagonal metric in 2-D (CH_SPACEDIM = 2, or a flat "horizontal" operator of a 3-D build): 9-point stencil.
+ * Arrays are one cell thick in k (k = 0 on every index).
+ * ====================================================================== */
+
+/* GSRBITER2D   RelaxationMethods/GSRBF.ChF:155-281.  NOTE the cross sums are written out term by term
+ * (a - b + c - d, left to right), unlike GSRBITER3D which goes through the pdx / pdy temporaries: the two round
+ * differently, so the 2-D kernel is NOT the 3-D one with the z terms dropped. */
+void orc_gsrbiter2d(double *phi_, const int *plo, const int *phi_hi, int ncomp,
+                    const double *ext_, const int *elo, const int *ehi,
+                    const double *rhs_, const int *rlo, const int *rhi,
+                    const double *jg0_, const int *xlo, const int *xhi,
+                    const double *jg1_, const int *ylo, const int *yhi,
+                    const double *jinv_, const int *jlo, const int *jhi,
+                    const double *lapd_, const int *dlo, const int *dhi,
+                    const int *reglo, const int *reghi, const double *dx,
+                    double alpha, double beta, int redBlack)
+{
+    fra_t phi = mk(phi_, plo, phi_hi), extrap = mk((double *)ext_, elo, ehi);
+    fra_t rhs = mk((double *)rhs_, rlo, rhi);
+    fra_t Jg0 = mk((double *)jg0_, xlo, xhi), Jg1 = mk((double *)jg1_, ylo, yhi);
+    fra_t Jinv = mk((double *)jinv_, jlo, jhi), lapDiag = mk((double *)lapd_, dlo, dhi);
+    const double xxScale = 1.0 / (dx[0] * dx[0]);
+    const double xyScale = 0.25 / (dx[0] * dx[1]);
+    const double yyScale = 1.0 / (dx[1] * dx[1]);
+    const int k = reglo[2];
+#define E(a, b) AT(extrap, a, b, k, n)
+    for (int n = 0; n < ncomp; ++n)
+        for (int j = reglo[1]; j <= reghi[1]; ++j) {
+            int imin = reglo[0];
+            imin = imin + abs((imin + j + redBlack) % 2);
+            for (int i = imin; i <= reghi[0]; i += 2) {
+                double JDxx = AT(Jg0, i + 1, j, k, 0) * AT(phi, i + 1, j, k, n) +
+                              AT(Jg0, i, j, k, 0) * AT(phi, i - 1, j, k, n);
+                double JDxy = AT(Jg0, i + 1, j, k, 1) * (E(i + 1, j + 1) - E(i + 1, j - 1) + E(i, j + 1) - E(i, j - 1)) -
+                              AT(Jg0, i, j, k, 1) * (E(i, j + 1) - E(i, j - 1) + E(i - 1, j + 1) - E(i - 1, j - 1));
+                double JDyx = AT(Jg1, i, j + 1, k, 0) * (E(i + 1, j + 1) - E(i - 1, j + 1) + E(i + 1, j) - E(i - 1, j)) -
+                              AT(Jg1, i, j, k, 0) * (E(i + 1, j) - E(i - 1, j) + E(i + 1, j - 1) - E(i - 1, j - 1));
+                double JDyy = AT(Jg1, i, j + 1, k, 1) * AT(phi, i, j + 1, k, n) +
+                              AT(Jg1, i, j, k, 1) * AT(phi, i, j - 1, k, n);
+                double lphi = beta * AT(Jinv, i, j, k, 0) * (JDxx * xxScale + JDyy * yyScale + (JDxy + JDyx) * xyScale);
+                AT(phi, i, j, k, n) = (AT(rhs, i, j, k, n) - lphi) / (alpha + beta * AT(lapDiag, i, j, k, 0));
+            }
+        }
+#undef E
+}
+
+/* GSRBBOUNDARYITER2D   GSRBF.ChF:858-1022 */
+void orc_gsrbboundaryiter2d(double *phi_, const int *plo, const int *phi_hi, int ncomp,
+                            const double *ext_, const int *elo, const int *ehi,
+                            const double *rhs_, const int *rlo, const int *rhi,
+                            const double *jg0_, const int *xlo, const int *xhi,
+                            const double *jg1_, const int *ylo, const int *yhi,
+                            const double *jinv_, const int *jlo, const int *jhi,
+                            const int *reglo, const int *reghi, const double *dx,
+                            double alpha, double beta, const int *stencil, int redBlack)
+{
+    fra_t phi = mk(phi_, plo, phi_hi), extrap = mk((double *)ext_, elo, ehi);
+    fra_t rhs = mk((double *)rhs_, rlo, rhi);
+    fra_t Jg0 = mk((double *)jg0_, xlo, xhi), Jg1 = mk((double *)jg1_, ylo, yhi);
+    fra_t Jinv = mk((double *)jinv_, jlo, jhi);
+    const int loX = stencil[0], hiX = stencil[1], loY = stencil[2], hiY = stencil[3];
+    double JDloX = 0, JDhiX = 0, JDloY = 0, JDhiY = 0;
+    const double xxScale = 1.0 / (dx[0] * dx[0]);
+    const double yyScale = 1.0 / (dx[1] * dx[1]);
+    const double xyScale = 0.25 / (dx[0] * dx[1]);
+    const int k = reglo[2];
+#define E(a, b) AT(extrap, a, b, k, n)
+    for (int n = 0; n < ncomp; ++n)
+        for (int j = reglo[1]; j <= reghi[1]; ++j) {
+            int imin = reglo[0];
+            imin = imin + abs((imin + j + redBlack) % 2);
+            for (int i = imin; i <= reghi[0]; i += 2) {
+                double lapDiag = 0.0;
+                if (loX != BC_NEUM) {
+                    JDloX = +xxScale * AT(Jg0, i, j, k, 0) * AT(phi, i - 1, j, k, n) -
+                            xyScale * AT(Jg0, i, j, k, 1) * (E(i, j + 1) - E(i, j - 1) + E(i - 1, j + 1) - E(i - 1, j - 1));
+                    lapDiag = lapDiag - xxScale * AT(Jg0, i, j, k, 0);
+                }
+                if (hiX != BC_NEUM) {
+                    JDhiX = +xxScale * AT(Jg0, i + 1, j, k, 0) * AT(phi, i + 1, j, k, n) +
+                            xyScale * AT(Jg0, i + 1, j, k, 1) * (E(i + 1, j + 1) - E(i + 1, j - 1) + E(i, j + 1) - E(i, j - 1));
+                    lapDiag = lapDiag - xxScale * AT(Jg0, i + 1, j, k, 0);
+                }
+                if (loY != BC_NEUM) {
+                    JDloY = -xyScale * AT(Jg1, i, j, k, 0) * (E(i + 1, j) - E(i - 1, j) + E(i + 1, j - 1) - E(i - 1, j - 1)) +
+                            yyScale * AT(Jg1, i, j, k, 1) * AT(phi, i, j - 1, k, n);
+                    lapDiag = lapDiag - yyScale * AT(Jg1, i, j, k, 1);
+                }
+                if (hiY != BC_NEUM) {
+                    JDhiY = +xyScale * AT(Jg1, i, j + 1, k, 0) * (E(i + 1, j + 1) - E(i - 1, j + 1) + E(i + 1, j) - E(i - 1, j)) +
+                            yyScale * AT(Jg1, i, j + 1, k, 1) * AT(phi, i, j + 1, k, n);
+                    lapDiag = lapDiag - yyScale * AT(Jg1, i, j + 1, k, 1);
+                }
+                lapDiag = lapDiag * AT(Jinv, i, j, k, 0);
+                double lphi = beta * AT(Jinv, i, j, k, 0) * (JDloX + JDhiX + JDloY + JDhiY);
+                AT(phi, i, j, k, n) = (AT(rhs, i, j, k, n) - lphi) / (alpha + beta * lapDiag);
+            }
+        }
+#undef E
+}
+
+/* MAPPEDGETFLUX with CH_SPACEDIM = 2 (MappedAMRPoissonOpF.ChF:335-427): bdir = mod(adir + 1, 2), no c term */
+void orc_mappedgetflux2d(double *flux_, const int *flo, const int *fhi, int ncomp,
+                         const double *phi_, const int *plo, const int *phi_hi,
+                         const double *ext_, const int *elo, const int *ehi,
+                         const double *jga_, const int *glo, const int *ghi,
+                         const int *reglo, const int *reghi, double beta, const double *dx, int adir)
+{
+    fra_t flux = mk(flux_, flo, fhi), phi = mk((double *)phi_, plo, phi_hi);
+    fra_t extrap = mk((double *)ext_, elo, ehi), Jga = mk((double *)jga_, glo, ghi);
+    const int bdir = (adir + 1) % 2;
+    const int ai = adir == 0, aj = adir == 1;
+    const int bi = bdir == 0, bj = bdir == 1;
+    const double aScale = beta / dx[adir];
+    const double bScale = 0.25 * beta / dx[bdir];
+    const int k = reglo[2];
+#define E(a, b) AT(extrap, a, b, k, n)
+    for (int n = 0; n < ncomp; ++n)
+        for (int j = reglo[1]; j <= reghi[1]; ++j)
+            for (int i = reglo[0]; i <= reghi[0]; ++i)
+                AT(flux, i, j, k, n) =
+                    aScale * AT(Jga, i, j, k, adir) * (AT(phi, i, j, k, n) - AT(phi, i - ai, j - aj, k, n)) +
+                    bScale * AT(Jga, i, j, k, bdir) *
+                        (E(i + bi, j + bj) - E(i - bi, j - bj) + E(i + bi - ai, j + bj - aj) - E(i - bi - ai, j - bj - aj));
+#undef E
+}
+
+/* ELLIPTICCONSTNEUMBCGHOST with CH_SPACEDIM = 2 (BCInterface/EllipticBCUtilsF.ChF): one cross term */
+void orc_ellipticconstneumbcghost2d(double *phi_, const int *plo, const int *phi_hi, int ncomp,
+                                    const double *ext_, const int *elo, const int *ehi,
+                                    const double *nhat_, const int *nlo, const int *nhi,
+                                    const int *glo, const int *ghi, double bcval, int fdir,
+                                    int fsign, const double *dx)
+{
+    fra_t phi = mk(phi_, plo, phi_hi), extrap = mk((double *)ext_, elo, ehi);
+    fra_t nhat = mk((double *)nhat_, nlo, nhi);
+    const int adir = fdir, bdir = (fdir + 1) % 2;
+    const int bi = bdir == 0, bj = bdir == 1;
+    const int foffset = (1 - fsign) / 2;
+    const int fio = foffset * (adir == 0), fjo = foffset * (adir == 1);
+    const int vio = -fsign * (adir == 0), vjo = -fsign * (adir == 1);
+    const double idxb = -0.25 / dx[bdir];
+    const int k = glo[2];
+#define E(a, b) AT(extrap, a, b, k, n)
+    for (int n = 0; n < ncomp; ++n)
+        for (int gj = glo[1]; gj <= ghi[1]; ++gj)
+            for (int gi = glo[0]; gi <= ghi[0]; ++gi) {
+                int fi = gi + fio, fj = gj + fjo;
+                int vi = gi + vio, vj = gj + vjo;
+                double cross = (E(gi + bi, gj + bj) - E(gi - bi, gj - bj) + E(vi + bi, vj + bj) - E(vi - bi, vj - bj)) *
+                               AT(nhat, fi, fj, k, bdir) * idxb;
+                AT(phi, gi, gj, k, n) = AT(phi, vi, vj, k, n) + (bcval - cross) * dx[adir] / AT(nhat, fi, fj, k, adir);
+            }
+#undef E
+}

@@ -378,7 +378,7 @@ def extrapolate_face_and_copy(dest, src, valid, d, side, order, num_layers=1):
         nearBox = nearBox.growDir(e, 1) & src.box
 
 
-def set_side_neum_bc(state, valid, domain, value, d, side, Jgup_d, extrap, dx, is_diagonal):
+def set_side_neum_bc(state, valid, domain, value, d, side, Jgup_d, extrap, dx, is_diagonal, ndim=3):
     """setSideNeumBC, BCInterface/EllipticBCUtils.cpp:128-214 (a_homogeneous is unused there)."""
     if domain.periodic[d]:
         return
@@ -397,8 +397,8 @@ def set_side_neum_bc(state, valid, domain, value, d, side, Jgup_d, extrap, dx, i
     else:
         ex = extrap if extrap is not None else Fab(state.box, state.ncomp)
         extrapolate_face_and_copy(ex, state, valid, d, side, 2)
-        lib().orc_ellipticconstneumbcghost(*state.fra(), *ex.fran(), *Jgup_d.fran(), lo, hi,
-                                           C.c_double(value), d, sgn, _rv(dx))
+        fn = lib().orc_ellipticconstneumbcghost if ndim == 3 else lib().orc_ellipticconstneumbcghost2d
+        fn(*state.fra(), *ex.fran(), *Jgup_d.fran(), lo, hi, C.c_double(value), d, sgn, _rv(dx))
 
 
 def bc_set_ghosts(bc, state, extrap, valid, domain, dx, Jgup, homogeneous, is_diagonal, ndim=3):
@@ -408,7 +408,7 @@ def bc_set_ghosts(bc, state, extrap, valid, domain, dx, Jgup, homogeneous, is_di
             continue
         for side in (0, 1):
             if bc.types[d][side] == BC_NEUM:
-                set_side_neum_bc(state, valid, domain, bc.values[d][side], d, side, Jgup[d], extrap, dx, is_diagonal)
+                set_side_neum_bc(state, valid, domain, bc.values[d][side], d, side, Jgup[d], extrap, dx, is_diagonal, ndim)
             else:
                 raise NotImplementedError("only Neumann pressure BCs are restated so far")
 
@@ -558,7 +558,8 @@ class LevelGSRB(Relaxer):
                 L.orc_gsrbiter2dortho(*phiF.fra(), *rhsF.fran(), *Jg[0].fra1(0), *Jg[1].fra1(1),
                                       *Jinv.fra1(0), *lapd.fra1(0), lo, hi, _rv(op.dx), a, b, whichPass)
             else:
-                raise NotImplementedError("GSRBITER2D (9-point) not restated yet")
+                L.orc_gsrbiter2d(*phiF.fra(), *ex.fran(), *rhsF.fran(), *Jg[0].fran(), *Jg[1].fran(),
+                                 *Jinv.fra1(0), *lapd.fra1(0), lo, hi, _rv(op.dx), a, b, whichPass)
 
     def boundary_gsrb(self, phi, rhs, whichPass, doAll):
         op = self.op
@@ -584,7 +585,8 @@ class LevelGSRB(Relaxer):
                     L.orc_gsrbboundaryiter2dortho(*phi[i].fra(), *rhs[i].fran(), *Jg[0].fra1(0), *Jg[1].fra1(1),
                                                   *Jinv.fra1(0), lo, hi, _rv(op.dx), a, b, st, whichPass)
                 else:
-                    raise NotImplementedError("GSRBBOUNDARYITER2D not restated yet")
+                    L.orc_gsrbboundaryiter2d(*phi[i].fra(), *ex.fran(), *rhs[i].fran(), *Jg[0].fran(), *Jg[1].fran(),
+                                             *Jinv.fra1(0), lo, hi, _rv(op.dx), a, b, st, whichPass)
 
 
 class LooseGSRB(LevelGSRB):
@@ -728,7 +730,9 @@ class PoissonOp:
             lib().orc_mappedgetfluxortho(*fluxF.fra(), *phiF.fran(), *Jg.fra1(d), lo, hi, C.c_double(scale), d)
         else:
             if self.ndim != 3:
-                raise NotImplementedError("MAPPEDGETFLUX 2-D not restated yet")
+                lib().orc_mappedgetflux2d(*fluxF.fra(), *phiF.fran(), *extrap.fran(), *Jg.fran(), lo, hi,
+                                          C.c_double(float(ref)), _rv(self.dx), d)
+                return
             lib().orc_mappedgetflux(*fluxF.fra(), *phiF.fran(), *extrap.fran(), *Jg.fran(), lo, hi,
                                     C.c_double(float(ref)), _rv(self.dx), d)
 
@@ -1322,6 +1326,42 @@ def make_full_metric(grids, dx, L, domain, amp=(0.25, 0.2, 0.15), variant="shear
             for b in range(3):
                 Jgup[i][d].a[..., b] = G[..., d, b]
         Jinv[i].a[..., 0] = 1.0 / np.linalg.det(jac(coords(g, -1)))
+    return Jgup, Jinv
+
+
+def make_full_metric_2d(grids, dx, L, domain, amp=(0.25, 0.2)):
+    """2-D counterpart of make_full_metric: x = xi + a0 sin(k1 eta)/k1, y = eta + a1 sin(k0 xi)/k0 on boxes one cell
+    thick in z.  J g^{ab} (2 comps per face direction), Jinv = 1/det F."""
+    Jgup = FluxData(grids, 2, 2)
+    Jinv = LevelData(grids, 1, (0, 0, 0), 1.0)
+    k = [2.0 * np.pi / L[d] for d in range(2)]
+
+    def coords(box, faceDir):
+        xs = []
+        for d in range(2):
+            idx = np.arange(box.lo[d], box.hi[d] + 1, dtype=np.float64)
+            if domain.periodic[d]:
+                nd = domain.box.size()[d]
+                idx = np.mod(idx - domain.box.lo[d], nd) + domain.box.lo[d]
+            xs.append((idx if d == faceDir else idx + 0.5) * dx[d])
+        return np.meshgrid(*xs, indexing="ij")
+
+    def jac(X):
+        F = np.zeros(X[0].shape + (2, 2))
+        F[..., 0, 0] = F[..., 1, 1] = 1.0
+        F[..., 0, 1] = amp[0] * np.cos(k[1] * X[1])
+        F[..., 1, 0] = amp[1] * np.cos(k[0] * X[0])
+        return F
+
+    for i, g in enumerate(grids):
+        for d in range(2):
+            F = jac(coords(Jgup[i][d].box, d))
+            Fi = np.linalg.inv(F)
+            J = np.linalg.det(F)
+            G = np.einsum("...ai,...bi->...ab", Fi, Fi) * J[..., None, None]
+            for b in range(2):
+                Jgup[i][d].a[:, :, 0, b] = G[..., d, b]
+        Jinv[i].a[:, :, 0, 0] = 1.0 / np.linalg.det(jac(coords(g, -1)))
     return Jgup, Jinv
 
 

@@ -295,8 +295,9 @@ class AMRPressureSolver:
                                                 _dp(jinv)))
 
     def setMetricFull(self, patch, jg0, jg1, jg2, jinv):
-        """jgD: array (faces(valid, D) shape + (3,)), Fortran order = component slowest"""
-        _ck(lib().somar_solver_set_metric_full(self._h, patch, _dp(jg0), _dp(jg1), _dp(jg2), _dp(jinv)))
+        """jgD: array (faces(valid, D) shape + (SpaceDim,)), Fortran order = component slowest; jg2 = None in 2-D"""
+        _ck(lib().somar_solver_set_metric_full(self._h, patch, _dp(jg0), _dp(jg1), _dp(jg2) if jg2 is not None else None,
+                                               _dp(jinv)))
 
     def finalize(self):
         if getattr(self, "_amr", None) is not None:

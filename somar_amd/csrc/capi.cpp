@@ -195,7 +195,7 @@ int somar_solver_set_metric_full(somar_solver_t* s, int patch, const double* jg0
                                  const double* jinv)
 {
     API_BEGIN
-    SOMAR_CHECK(jg0 && jg1 && jg2 && jinv, "null metric pointer");
+    SOMAR_CHECK(jg0 && jg1 && jinv && (jg2 || s->ps->prm.spaceDim == 2), "null metric pointer");
     s->ps->set_metric_full(patch, jg0, jg1, jg2, jinv);
     API_END
 }

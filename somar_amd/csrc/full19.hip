@@ -159,11 +159,23 @@ __global__ __launch_bounds__(512) void k_gsrb_full(const Tile* __restrict__ tile
         if (li >= p.n[0]) continue;
         const int gi = p.lo[0] + li;
         const long long c = fidx(p, li, lj, lk);
+        const bool flat = !P.active[2];  // SpaceDim 2: the 9-point kernels GSRBITER2D / GSRBBOUNDARYITER2D
         const bool onb = (gi == P.dom_lo[0]) || (gi == P.dom_hi[0]) || (gj == P.dom_lo[1]) || (gj == P.dom_hi[1]) ||
-                         (gk == P.dom_lo[2]) || (gk == P.dom_hi[2]);
+                         (!flat && ((gk == P.dom_lo[2]) || (gk == P.dom_hi[2])));
 #define EE(di, dj, dk) E[c + (di) + sj * (dj) + sk * (dk)]
         double out;
-        if (!onb) {
+        if (!onb && flat) {
+            // GSRBITER2D (GSRBF.ChF:155-281) writes its cross sums out term by term (a - b + c - d) where GSRBITER3D
+            // goes through pdx / pdy: they round differently, so this is not the 3-D branch with z dropped
+            const double JDxx = Jx0[c + 1] * phi[c + 1] + Jx0[c] * phi[c - 1];
+            const double JDxy = Jx1[c + 1] * (EE(1, 1, 0) - EE(1, -1, 0) + EE(0, 1, 0) - EE(0, -1, 0)) -
+                                Jx1[c] * (EE(0, 1, 0) - EE(0, -1, 0) + EE(-1, 1, 0) - EE(-1, -1, 0));
+            const double JDyx = Jy0[c + sj] * (EE(1, 1, 0) - EE(-1, 1, 0) + EE(1, 0, 0) - EE(-1, 0, 0)) -
+                                Jy0[c] * (EE(1, 0, 0) - EE(-1, 0, 0) + EE(1, -1, 0) - EE(-1, -1, 0));
+            const double JDyy = Jy1[c + sj] * phi[c + sj] + Jy1[c] * phi[c - sj];
+            const double lphi = P.beta * jinv[c] * (JDxx * xxScale + JDyy * yyScale + (JDxy + JDyx) * xyScale);
+            out = (rhs[c] - lphi) / (P.alpha + P.beta * lapd[c]);
+        } else if (!onb) {
             const double pdx = EE(1, 0, 0) - EE(-1, 0, 0);
             const double pdy = EE(0, 1, 0) - EE(0, -1, 0);
             const double pdz = EE(0, 0, 1) - EE(0, 0, -1);
@@ -185,8 +197,9 @@ __global__ __launch_bounds__(512) void k_gsrb_full(const Tile* __restrict__ tile
             const bool nxh = (gi == P.dom_hi[0]) && P.neum[0][1];
             const bool nyl = (gj == P.dom_lo[1]) && P.neum[1][0];
             const bool nyh = (gj == P.dom_hi[1]) && P.neum[1][1];
-            const bool nzl = (gk == P.dom_lo[2]) && P.neum[2][0];
-            const bool nzh = (gk == P.dom_hi[2]) && P.neum[2][1];
+            // flat: no z faces at all; the zx / yz terms of the x and y faces below multiply all-zero metric planes
+            const bool nzl = flat || ((gk == P.dom_lo[2]) && P.neum[2][0]);
+            const bool nzh = flat || ((gk == P.dom_hi[2]) && P.neum[2][1]);
             double JDloX = 0, JDhiX = 0, JDloY = 0, JDhiY = 0, JDloZ = 0, JDhiZ = 0, ld = 0.0;
             if (!nxl) {
                 JDloX = +xxScale * Jx0[c] * phi[c - 1] -

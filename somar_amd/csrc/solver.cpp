@@ -294,8 +294,8 @@ bool PressureSolver::build_coarser(int depth)
     if (full_) {
         alloc_full_metric(*C);
         for (int pi = 0; pi < C->npatches(); ++pi)
-            for (int d = 0; d < 3; ++d)
-                for (int c = 0; c < 3; ++c)
+            for (int d = 0; d < nd; ++d)
+                for (int c = 0; c < nd; ++c)
                     if (c != d)
                         launch_avg_face(st_, C->dev, F.dev, pi, C->hpatches[pi].n, C->dev.jgf[d][c], F.dev.jgf[d][c], d, r);
     }

@@ -178,19 +178,20 @@ void PressureSolver::set_metric_full(int patch, const double* jg0, const double*
                                      const double* jinv)
 {
     SOMAR_CHECK(!lev.empty() && !finalized, "set_metric before define / after finalize");
-    SOMAR_CHECK(prm.spaceDim == 3 && !hasCF_, "the non-diagonal metric path is implemented for one AMR level in 3-D");
+    SOMAR_CHECK(!hasCF_, "the non-diagonal metric path is implemented for one AMR level");
     Level& L = *lev[0];
     SOMAR_CHECK(patch >= 0 && patch < L.npatches(), "bad patch index");
     full_ = true;
-    alloc_full_metric(L);
+    alloc_full_metric(L);  // SpaceDim 2: the planes with a z index stay zero, the 3-D operator / ghost kernels see 0 * finite
     const IBox valid = L.boxes[L.local[patch]];
     const double* jg[3] = {jg0, jg1, jg2};
-    for (int d = 0; d < 3; ++d) {
+    const int nd = prm.spaceDim;
+    for (int d = 0; d < nd; ++d) {
         SOMAR_CHECK(jg[d] != nullptr, "null metric array");
         IBox fb = valid;
         fb.hi[d] += 1;
         const long long plane = fb.numPts();
-        for (int c = 0; c < 3; ++c) L.upload(L.dev.jgf[d][c], patch, jg[d] + c * plane, fb, fb, st_);  // comp slowest
+        for (int c = 0; c < nd; ++c) L.upload(L.dev.jgf[d][c], patch, jg[d] + c * plane, fb, fb, st_);  // comp slowest
     }
     L.upload(L.dev.jinv, patch, jinv, valid, valid, st_);
     sync();

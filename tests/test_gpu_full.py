@@ -84,3 +84,84 @@ def test_full_metric_solve_history_matches(oracle):
         assert st["history"][-1] <= 1e-6 * st["history"][0]
     finally:
         gpu.undefine()
+
+
+# ---- SpaceDim 2: the 9-point kernels (GSRBITER2D, GSRBBOUNDARYITER2D, MAPPEDGETFLUX / Neumann ghost with one cross term) ----
+CASES_2D = [
+    ((32, 32), 16, (False, False), (2.0, 1.0)),
+    ((32, 16), 8, (False, True), (1.0, 1.0)),
+    ((24, 16), (12, 8), (True, False), (1.5, 1.0)),
+]
+
+
+def _setup2(so, case, **kw):
+    from somar_amd import AMRPressureSolver
+    n, bs, per, L = case
+    dom = so.Domain(so.Box((0, 0, 0), (n[0] - 1, n[1] - 1, 0)), (per[0], per[1], False))
+    bsz = (bs, bs, 1) if isinstance(bs, int) else (bs[0], bs[1], 1)
+    grids = so.split_domain(dom.box, bsz)
+    dx = (L[0] / n[0], L[1] / n[1], 1.0)
+    Jgup, Jinv = so.make_full_metric_2d(grids, dx, L, dom)
+    fac = so.Factory(dom, grids, dx, so.BCHolder(), Jgup, Jinv, isDiagonal=False, ndim=2, **kw)
+    s = AMRPressureSolver()
+    s.setSpaceDim(2)
+    p = s._p
+    s.setAMRMGParameters(p.imin, p.imax, p.eps, kw.get("maxDepth", -1), p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1,
+                         p.num_mg, p.hang, p.norm_thresh, 0)
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids])
+    for q in range(s.num_local_patches):
+        _, _, gi = s.patch_box(q)
+        s.setMetricFull(q, np.asfortranarray(Jgup[gi][0].a), np.asfortranarray(Jgup[gi][1].a), None,
+                        np.asfortranarray(Jinv[gi].a[..., 0]))
+    s.finalize()
+    return dom, grids, fac, s
+
+
+@pytest.mark.parametrize("case", CASES_2D)
+def test_2d_full_operator_and_gsrb_bit_exact(oracle, case):
+    from somar_amd import api as F
+    so = oracle
+    dom, grids, fac, gpu = _setup2(so, case)
+    try:
+        mg = so.MultiGrid(fac, so.BiCGStab())
+        assert gpu.depth() == mg.depth
+        for d in range(min(mg.depth, 2)):
+            op = mg.ops[d]
+            g = op.grids
+            phi = so.random_field(g, 7 + d, (1, 1, 0), op.domain.box)
+            rhs = so.random_field(g, 8 + d, (0, 0, 0), op.domain.box)
+            fc, fr, fs = ((F.F_PHI, F.F_RHS, F.F_RES) if d == 0 else
+                          (F.FIELD(d, F.F_CORR), F.FIELD(d, F.F_RES), F.FIELD(d, F.F_SCRATCH)))
+            upload(gpu, fc, phi, depth=d)
+            upload(gpu, fr, rhs, depth=d)
+            res = so.LevelData(g, 1)
+            op.residual(res, phi, rhs, True)
+            gpu.residual(d, fs, fc, fr)
+            for a, b in zip(download_valid(gpu, fs, g, d), valid_of(res)):
+                np.testing.assert_array_equal(a, b)
+            op.relax(phi, rhs, 2)
+            gpu.relax(d, fc, fr, 2)
+            for a, b in zip(download_valid(gpu, fc, g, d), valid_of(phi)):
+                np.testing.assert_array_equal(a, b)
+    finally:
+        gpu.undefine()
+
+
+def test_2d_full_metric_solve_history_matches(oracle):
+    so = oracle
+    dom, grids, fac, gpu = _setup2(so, CASES_2D[0])
+    try:
+        amr = so.AMRMultiGrid(fac, so.BiCGStab())
+        phi0 = so.random_field(grids, 3, (1, 1, 0), dom.box)
+        b = so.LevelData(grids, 1)
+        amr.op.apply_op(b, phi0, True)
+        x = so.LevelData(grids, 1, (1, 1, 0))
+        amr.solve(x, b)
+        gx = [np.zeros(f.a.shape[:3], order="F") for f in x.fabs]
+        gb = [np.asfortranarray(f.a[..., 0]) for f in b.fabs]
+        st = gpu.solve(gx, gb, 0, 0, True, False, phi_ghost=(1, 1, 0))
+        assert st["iters"] == amr.iters and st["exitStatus"] == amr.exitStatus
+        np.testing.assert_allclose(st["history"], amr.history, rtol=1e-9, atol=1e-12 * amr.history[0])
+        assert st["history"][-1] <= 1e-6 * st["history"][0]
+    finally:
+        gpu.undefine()

@@ -80,3 +80,57 @@ def test_constants_are_in_the_null_space_with_cross_term_neumann_ghosts(oracle):
     op.apply_op(out, one, True)
     assert so.ld_norm(out, 0) == 0.0
     assert op.zeroAvg
+
+
+# ---- the same three pins for the 2-D (9-point) kernels: GSRBITER2D, GSRBBOUNDARYITER2D, MAPPEDGETFLUX (SpaceDim 2) ----
+def _prob2(so, n, per, bs, L=(1.0, 1.0)):
+    dom = so.Domain(so.Box((0, 0, 0), (n[0] - 1, n[1] - 1, 0)), (per[0], per[1], False))
+    grids = so.split_domain(dom.box, (bs, bs, 1))
+    dx = (L[0] / n[0], L[1] / n[1], 1.0)
+    return dom, grids, dx
+
+
+def test_2d_full_path_reduces_to_ortho_kernels_on_a_diagonal_metric(oracle):
+    so = oracle
+    dom, grids, dx = _prob2(so, (16, 16), (False, True), 8)
+    Jg, Ji = so.make_diagonal_metric(grids, dx, (1, 1, 1), 2, "stretched", domain=dom)
+    opD = so.Factory(dom, grids, dx, so.BCHolder(), Jg, Ji, isDiagonal=True, ndim=2, maxDepth=0).mg_new_op(0, None)
+    opF = so.Factory(dom, grids, dx, so.BCHolder(), Jg, Ji, isDiagonal=False, ndim=2, maxDepth=0).mg_new_op(0, None)
+    phi = so.random_field(grids, 3, (1, 1, 0), dom.box)
+    rhs = so.random_field(grids, 4, (0, 0, 0), dom.box)
+    p1, p2 = so.ld_create(phi), so.ld_create(phi)
+    so.ld_assign(p1, phi)
+    so.ld_assign(p2, phi)
+    a, b = so.LevelData(grids, 1), so.LevelData(grids, 1)
+    opD.residual(a, p1, rhs, True)
+    opF.residual(b, p2, rhs, True)
+    for g, x, y in zip(grids, a.fabs, b.fabs):
+        np.testing.assert_array_equal(x.view(g), y.view(g))
+    opD.relax(p1, rhs, 2)
+    opF.relax(p2, rhs, 2)
+    for g, x, y in zip(grids, p1.fabs, p2.fabs):
+        np.testing.assert_allclose(x.view(g), y.view(g), rtol=0, atol=1e-14)
+
+
+def test_2d_constants_in_null_space_and_multigrid_converges_on_a_sheared_map(oracle):
+    so = oracle
+    L = (2.0, 1.0)
+    dom, grids, dx = _prob2(so, (32, 32), (False, False), 16, L)
+    Jg, Ji = so.make_full_metric_2d(grids, dx, L, dom)
+    fac = so.Factory(dom, grids, dx, so.BCHolder(), Jg, Ji, isDiagonal=False, ndim=2)
+    amr = so.AMRMultiGrid(fac, so.BiCGStab())
+    op = amr.op
+    one, out = so.LevelData(grids, 1, (1, 1, 0)), so.LevelData(grids, 1)
+    so.ld_set(one, 1.0)
+    op.apply_op(out, one, True)
+    assert so.ld_norm(out, 0) < 1e-12
+    assert all(o.zeroAvg for o in amr.mg.ops)
+    # compatible right-hand side: L[random]
+    phi = so.random_field(grids, 5, (1, 1, 0), dom.box)
+    rhs = so.LevelData(grids, 1)
+    op.apply_op(rhs, phi, True)
+    x = so.LevelData(grids, 1, (1, 1, 0))
+    amr.solve(x, rhs)
+    h = amr.history
+    assert amr.exitStatus == 1 and h[-1] <= 1e-6 * h[0]
+    assert amr.mg.depth >= 3
