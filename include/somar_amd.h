@@ -228,6 +228,19 @@ int somar_amr_residual_level(somar_amr_t* a, int l_max, int l_base, int ilev, in
 int somar_amr_zero_covered(somar_amr_t* a, int level, int field);
 int somar_amr_vcycle(somar_amr_t* a, int l_max, int l_base);
 
+/* ---- AlteredMetric ------------------------------------------------------------------------------------------------
+ * Replaces the algebra of AlteredMetric::fill_Jgup (projection/AlteredMetric.cpp:82-198), the FillJgupInterface that
+ * the implicit-gravity / Coriolis projections install in the operator factory:
+ *   dest = J * ( g^{mu nu} / (1 + f~^2) + ( f~^2/(1+f~^2) - w^2/(1+w^2) ) dXi^mu/dz dXi^nu/dz [+ f~/(1+f~^2) (ix jy - iy jx)] )
+ * with w^2 = (dt theta)^2 N^2, f~ = f dt theta, one value per face of the destination face box (n faces, flat arrays).
+ * The caller evaluates its GeoSourceInterface / background scalar on that box (map evaluation is out of scope):
+ * nsq_fc = N^2 averaged to the faces (Chombo CellToEdge of :114-137's NsqFAB), dximu_dz / dxinu_dz = fill_dXidx(mu|nu,
+ * SpaceDim-1), gup = fill_gup(mu, nu), J = fill_J(scale); ix, jy, iy, jx = fill_dXidx(mu,0), (nu,1), (mu,1), (nu,0),
+ * all four NULL when mu == nu.  The result feeds somar_solver_set_metric_ortho / _full. */
+int somar_altered_jgup(long long n, double* dest, const double* nsq_fc, const double* dximu_dz, const double* dxinu_dz,
+                       const double* ix, const double* jy, const double* iy, const double* jx, const double* gup,
+                       const double* J, double dt_theta, double coriolis_f);
+
 /* ---- leptic level solver -------------------------------------------------------------------------------------
  * Replaces LevelLepticSolver (calculus/LepticSolver/LevelLepticSolver.H:53-347): define(op) :147-437 and
  * solve(phi, rhs) :646-956, for an operator that offers what LepticOperator asks (LepticOperator.H:33-45).

@@ -1471,3 +1471,27 @@ def mac_level_project(amr, vel, phi, dt, zeroPhi=True, ndim=3):
         for d in range(ndim):
             vel[i][d].a += dtScale * corr[i][d].a   # FArrayBox::plus(src, scale)
     return rhs
+
+
+# ----------------------------------------------------------------------------
+# AlteredMetric::fill_Jgup (projection/AlteredMetric.cpp:82-198): the whole-FAB statements after the map has been
+# evaluated, one numpy statement per FArrayBox operation (same roundings).
+# ----------------------------------------------------------------------------
+def altered_jgup(nsq_fc, dximu_dz, dxinu_dz, gup, J, dt_theta, coriolis_f, hjac=None):
+    theta = float(dt_theta)
+    d = np.array(nsq_fc, dtype=np.float64)
+    d = d * (theta * theta)
+    tmp = d + 1.0
+    d = d / tmp
+    d = d * -1.0
+    ftilde = float(coriolis_f) * theta
+    ftildesq = ftilde * ftilde
+    invfCoeff = 1.0 / (1.0 + ftildesq)
+    d = d + ftildesq * invfCoeff
+    d = d * np.asarray(dximu_dz)
+    d = d * np.asarray(dxinu_dz)
+    if hjac is not None:
+        ix, jy, iy, jx = [np.asarray(a) for a in hjac]
+        d = d + ftilde * invfCoeff * (ix * jy - iy * jx)
+    d = d + np.asarray(gup) * invfCoeff
+    return d * np.asarray(J)

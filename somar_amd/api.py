@@ -119,6 +119,7 @@ _SIGS = {
     "somar_amr_residual_level": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     "somar_amr_zero_covered": [_H, C.c_int, C.c_int],
     "somar_amr_vcycle": [_H, C.c_int, C.c_int],
+    "somar_altered_jgup": [C.c_longlong, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, C.c_double, C.c_double],
     "somar_leptic_params_default": [C.POINTER(LepticParams)],
     "somar_leptic_create": [C.POINTER(_H), _PI, _PI, _PI, _PD, _PI, C.c_int, _PI, _PI, C.c_double, C.c_double,
                             C.POINTER(Params), C.POINTER(LepticParams), _H],
@@ -492,6 +493,22 @@ class AMRPressureSolver:
         ms = C.c_double()
         _ck(lib().somar_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+
+def altered_jgup(nsq_fc, dximu_dz, dxinu_dz, gup, J, dt_theta, coriolis_f, hjac=None):
+    """AlteredMetric::fill_Jgup on flat float64 arrays; hjac = (ix, jy, iy, jx) when mu != nu."""
+    arrs = [np.ascontiguousarray(a, dtype=np.float64).ravel() for a in (nsq_fc, dximu_dz, dxinu_dz, gup, J)]
+    n = arrs[0].size
+    assert all(a.size == n for a in arrs)
+    h = [None] * 4
+    if hjac is not None:
+        h = [np.ascontiguousarray(a, dtype=np.float64).ravel() for a in hjac]
+        assert all(a.size == n for a in h)
+    out = np.empty(n)
+    p = lambda a: a.ctypes.data_as(_PD) if a is not None else None   # noqa: E731
+    _ck(lib().somar_altered_jgup(n, p(out), p(arrs[0]), p(arrs[1]), p(arrs[2]), p(h[0]), p(h[1]), p(h[2]), p(h[3]),
+                                 p(arrs[3]), p(arrs[4]), float(dt_theta), float(coriolis_f)))
+    return out
 
 
 class LevelLepticSolver:

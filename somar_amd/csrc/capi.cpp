@@ -786,6 +786,36 @@ int somar_comm_create_shm(void** comm, const char* name, int rank, int nranks, l
     API_END
 }
 
+// ---- AlteredMetric::fill_Jgup (implicit-gravity / Coriolis projection metric) ----
+int somar_altered_jgup(long long n, double* dest, const double* nsq_fc, const double* dximu_dz, const double* dxinu_dz,
+                       const double* ix, const double* jy, const double* iy, const double* jx, const double* gup,
+                       const double* J, double dt_theta, double coriolis_f)
+{
+    API_BEGIN
+    SOMAR_CHECK(n > 0 && dest && nsq_fc && dximu_dz && dxinu_dz && gup && J, "null/empty argument");
+    const bool offdiag = ix || jy || iy || jx;
+    SOMAR_CHECK(!offdiag || (ix && jy && iy && jx), "the four horizontal map derivatives come together (mu != nu) or not at all");
+    const int nin = offdiag ? 9 : 5;
+    const double* in[9] = {nsq_fc, dximu_dz, dxinu_dz, gup, J, ix, jy, iy, jx};
+    double* dev = nullptr;
+    SOMAR_HIP(hipMalloc(&dev, (size_t)(nin + 1) * n * sizeof(double)));
+    try {
+        for (int q = 0; q < nin; ++q)
+            SOMAR_HIP(hipMemcpy(dev + (size_t)(q + 1) * n, in[q], (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        double* d[10];
+        for (int q = 0; q <= 9; ++q) d[q] = q <= nin ? dev + (size_t)q * n : nullptr;
+        SOMAR_HIP(hipDeviceSynchronize());
+        launch_altered_jgup(nullptr, n, d[0], d[1], d[2], d[3], d[6], d[7], d[8], d[9], d[4], d[5], dt_theta, coriolis_f, offdiag);
+        SOMAR_HIP(hipDeviceSynchronize());
+        SOMAR_HIP(hipMemcpy(dest, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    } catch (...) {
+        hipFree(dev);
+        throw;
+    }
+    hipFree(dev);
+    API_END
+}
+
 // ---- leptic level solver -----------------------------------------------------------------------------------
 int somar_leptic_params_default(somar_leptic_params_t* p)
 {

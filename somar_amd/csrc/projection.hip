@@ -81,6 +81,44 @@ __global__ __launch_bounds__(512) void k_mac_correct(const Tile* __restrict__ ti
         }
 }
 
+// AlteredMetric::fill_Jgup (projection/AlteredMetric.cpp:82-198), the algebra after the map has been evaluated: one
+// thread per face of the destination box, FArrayBox operation by FArrayBox operation (each line below is one of the
+// reference's whole-FAB statements, so the roundings are the same).
+__global__ void k_altered_jgup(long long n, double* __restrict__ dest, const double* __restrict__ nsq,
+                               const double* __restrict__ dmu, const double* __restrict__ dnu,
+                               const double* __restrict__ ix, const double* __restrict__ jy,
+                               const double* __restrict__ iy, const double* __restrict__ jx,
+                               const double* __restrict__ gup, const double* __restrict__ J, double theta,
+                               double coriolisF, int offdiag)
+{
+    const double ftilde = coriolisF * theta;
+    const double ftildesq = ftilde * ftilde;
+    const double invfCoeff = 1.0 / (1.0 + ftildesq);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        double d = nsq[i];
+        d = d * (theta * theta);             // destAlias *= m_theta*m_theta
+        const double t = d + 1.0;            // tmpFAB = destAlias + 1
+        d = d / t;                           // destAlias /= tmpFAB
+        d = d * -1.0;                        // = -omega^2/(1+omega^2)
+        d = d + ftildesq * invfCoeff;        // + ftilde^2/(1+ftilde^2)
+        d = d * dmu[i];                      // * dXi^mu/dz
+        d = d * dnu[i];                      // * dXi^nu/dz
+        if (offdiag) d = d + ftilde * invfCoeff * (ix[i] * jy[i] - iy[i] * jx[i]);
+        d = d + gup[i] * invfCoeff;          // + g^{mu nu} * invfCoeff
+        dest[i] = d * J[i];                  // * J * a_scale
+    }
+}
+
+void launch_altered_jgup(hipStream_t st, long long n, double* dest, const double* nsq, const double* dmu,
+                         const double* dnu, const double* ix, const double* jy, const double* iy, const double* jx,
+                         const double* gup, const double* J, double theta, double coriolisF, bool offdiag)
+{
+    if (n <= 0) return;
+    const int blocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    hipLaunchKernelGGL(k_altered_jgup, dim3(blocks), dim3(256), 0, st, n, dest, nsq, dmu, dnu, ix, jy, iy, jx, gup, J, theta,
+                       coriolisF, offdiag ? 1 : 0);
+}
+
 void launch_div_mac(hipStream_t st, const LevelDev& L, double* out, const double* u0, const double* u1,
                     const double* u2, double dt)
 {
