@@ -64,6 +64,8 @@ void AMRSolver::define(const IBox& domain0, const bool periodic[3], const double
     const int n = (int)boxes.size();
     SOMAR_CHECK(n >= 1 && (int)ratios.size() >= n - 1 && (int)owners.size() == n, "bad level count");
     prm = p;
+    SOMAR_CHECK(p.spaceDim == 3, "several AMR levels are implemented for space_dim 3 (the coarse-fine stencils and the "
+                                 "flux register of a CH_SPACEDIM = 2 build have one tangential direction: not built yet)");
     ratios_ = ratios;
     IBox dom = domain0;
     double dx[3] = {dx0[0], dx0[1], dx0[2]}, dxc[3] = {0, 0, 0};

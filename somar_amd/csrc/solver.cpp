@@ -175,11 +175,8 @@ void PressureSolver::define(const IBox& domain, const bool periodic[3], const do
     SOMAR_CHECK(lev.empty(), "solver already defined");
     prm = p;
     hasCF_ = dxCrse != nullptr;
-    if (hasCF_) {
+    if (hasCF_)
         for (int d = 0; d < 3; ++d) dxCrse_[d] = dxCrse[d];
-        SOMAR_CHECK(prm.relaxMode != RELAX_LINE_GSRB && prm.precondMode != PRECOND_DIAG_LINE_RELAX,
-                    "line relaxation on a level with coarse-fine boundaries is not implemented");
-    }
     SOMAR_CHECK(prm.relaxMode == RELAX_LEVEL_GSRB || prm.relaxMode == RELAX_JACOBI || prm.relaxMode == RELAX_LINE_GSRB ||
                     prm.relaxMode == RELAX_LOOSE_GSRB,
                 "relax_mode must be 0 (Jacobi), 1 (LevelGSRB), 2 (LooseGSRB) or 3 (LineGSRB)");
@@ -202,7 +199,13 @@ void PressureSolver::define(const IBox& domain, const bool periodic[3], const do
     L->beta = beta;
     L->define(domain, periodic, dx, bc_type, boxes, owner, comm_);
     L->alloc_metric();
-    if (hasCF_) L->define_cf(dxCrse_);
+    if (hasCF_) {
+        L->define_cf(dxCrse_);
+        if (prm.relaxMode == RELAX_LINE_GSRB || prm.precondMode == PRECOND_DIAG_LINE_RELAX)
+            for (const CFCell& c : L->hcf)
+                SOMAR_CHECK((c.dir & 3) != 2, "line relaxation: coarse-fine boundaries at the vertical ends of a column "
+                                              "(the CF row of LineGSRBIter3D, GSRBF.ChF:1804-1817) are not implemented");
+    }
     lev.push_back(std::move(L));
 }
 
@@ -594,6 +597,7 @@ void PressureSolver::line_relax(int d, double* e, const double* res)
     Level& L = *lev[d];
     for (int pass = 0; pass < 2; ++pass) {
         L.exchange(e, st_);
+        L.cf_homog(e, st_);  // fillGhostsAndExtrapolate: homogeneous CF values in the lateral ghost cells
         launch_line_gsrb_ortho(st_, L.d_ctiles, L.nctiles, L.ctile_j, L.dev, e, res, f_pp[d], pass);
     }
 }

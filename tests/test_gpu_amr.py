@@ -217,3 +217,33 @@ def test_level_solve_with_coarse_cf_values(oracle, am):
         assert max_rel_diff(got, valid_of(phi1)) < 1e-8
     finally:
         gpu.undefine()
+
+
+@pytest.mark.parametrize("layout", [LAYOUTS[1], LAYOUTS[5]])
+def test_amr_vcycle_with_line_relaxation(oracle, am, layout):
+    """relax_mode 3 (vertical-line GSRB) on a fine level whose lateral faces are coarse-fine boundaries and whose
+    columns span the domain: homogeneous CF values in the lateral ghosts, then the column solves."""
+    from somar_amd import api as F
+    so = oracle
+    periodic, ratios, boxes = layout
+    fb = [[so.Box(lo, hi) for lo, hi in lev] for lev in boxes]
+    levels = make_amr_levels(so, am, (16, 16, 8), (2.0, 1.0, 0.5), periodic, ratios, fb)
+    comp = am.AMRComposite(levels, ratios, so.BCHolder(), so.BiCGStab(), relaxMode=so.RELAX_LINE_GSRB)
+    gpu = make_gpu_amr(levels, ratios, relaxMode=3)
+    try:
+        phi = [so.LevelData(L.grids, 1, (1, 1, 1)) for L in levels]
+        res = [so.random_field(L.grids, 70 + l, (0, 0, 0), L.domain.box) for l, L in enumerate(levels)]
+        comp.zero_covered(0, res[0])
+        comp.init(phi, res, 1, 0)
+        comp.set_bottom_solver(1, 0)
+        corr = [so.LevelData(L.grids, 1, (1, 1, 1)) for L in levels]
+        for l, v in enumerate(gpu.levels):
+            upload(v, F.F_RES, res[l])
+            v.setVal(F.F_CORR, 0.0)
+        comp.amr_vcycle(corr, res, 1, 1, 0)
+        gpu.vcycleAMR(1, 0)
+        for l in (0, 1):
+            for g, w in zip(download_valid(gpu.levels[l], F.F_CORR, levels[l].grids), valid_of(corr[l])):
+                np.testing.assert_allclose(g, w, rtol=0, atol=1e-12 * float(np.max(np.abs(w))))
+    finally:
+        gpu.undefine()
