@@ -111,10 +111,9 @@ class CFRegion:
 class QuadCFStencil:
     """MappedQuadCFStencil for one fine box, one direction, one side (MappedCFStencil.cpp:831-1232)."""
 
-    def __init__(self, fineDomain, grid, fineImgs, crseImgsOfFine, coarBoxes, r, direction, side):
+    def __init__(self, fineDomain, grid, fineImgs, crseImgsOfFine, coarBoxes, r, direction, side, dims=3):
         self.dir, self.side = direction, side
         self.empty = True
-        dims = 3
         edge = grid.adjCell(direction, side, 1) & fineDomain.box.grow([1 if p else 0 for p in fineDomain.periodic])
         # MappedCFStencil::define_2: edgebox = a_fineDomain & edgebox (ProblemDomain & keeps periodic images)
         if edge.isEmpty():
@@ -200,7 +199,8 @@ def shrink_mask(m, axis):
 class QuadCFInterp:
     """MappedQuadCFInterp::define / coarseFineInterp."""
 
-    def __init__(self, fineGrids, coarGrids, dxFine, refRatio, fineDomain):
+    def __init__(self, fineGrids, coarGrids, dxFine, refRatio, fineDomain, ndim=3):
+        self.ndim = ndim
         self.fineGrids, self.coarGrids = list(fineGrids), list(coarGrids)
         self.dxf = tuple(dxFine)
         self.r = _iv(refRatio)
@@ -216,9 +216,10 @@ class QuadCFInterp:
         crseImgs = [b.coarsen(self.r) for b in fineImgs]
         self.sten = {}
         for i, g in enumerate(self.fineGrids):
-            for d in range(3):
+            for d in range(ndim):
                 for s in (0, 1):
-                    self.sten[(i, d, s)] = QuadCFStencil(fineDomain, g, fineImgs, crseImgs, self.coarGrids, self.r, d, s)
+                    self.sten[(i, d, s)] = QuadCFStencil(fineDomain, g, fineImgs, crseImgs, self.coarGrids, self.r, d, s,
+                                                         dims=ndim)
 
     def fill_buffer(self, phic):
         """a_phic.copyTo(m_coarBuffer, m_copier): coarse valid data (and periodic images) into the grown
@@ -319,7 +320,7 @@ class QuadCFInterp:
         if self.level == 0:
             return
         bufs = self.fill_buffer(phic)
-        for d in range(3):
+        for d in range(self.ndim):
             if phif.ghost[d] == 0:
                 continue
             for i in range(len(self.fineGrids)):
@@ -331,8 +332,9 @@ class QuadCFInterp:
     def _interp_one(self, f, phic, st):
         d, s = st.dir, st.side
         ihilo = 1 if s else -1
-        tran = [a for a in range(3) if a != d]
-        you1, you2 = tran
+        tran = [a for a in range(self.ndim) if a != d]
+        # CH_SPACEDIM == 2 (MappedQuadCFInterp.cpp:300-310, 386-400): one tangential direction, no mixed derivative
+        you1, you2 = (tran[0], tran[1]) if self.ndim == 3 else (tran[0], None)
         st._drop = {}
         # slopes on the coarse IVS.  buildStencils visits the mixed stencil first (it decides dropOrd), then
         # the tangential directions in order
@@ -341,7 +343,7 @@ class QuadCFInterp:
         for q in cidx:
             iv = [st.coarBox.lo[a] + int(q[a]) for a in range(3)]
             key = tuple(iv)
-            mixed[key] = self._mixed(st, phic, iv, you1, you2)
+            mixed[key] = self._mixed(st, phic, iv, you1, you2) if you2 is not None else 0.0
             sl, cu = {}, {}
             for t in tran:
                 fst, sec = self._first_second(st, phic, iv, t)
@@ -368,12 +370,19 @@ class QuadCFInterp:
             pc = float(phic.view(Box(ivc, ivc))[0, 0, 0, 0])
             xs = []
             for t in (you1, you2):
+                if t is None:
+                    xs.append(0.0)
+                    continue
                 xf = (ivf[t] + 0.5) * self.dxf[t]
                 xc = (ivc[t] + 0.5) * self.dxc[t]
                 xs.append(xf - xc)
             x1, x2 = xs
             sl, cu = slope[ivc], curva[ivc]
-            if st.packed:
+            if you2 is None:
+                # SpaceDim 2: always the C++ path (MAPPEDPHISTAR is an error there); update2 = update3 = 0
+                update1 = x1 * sl[you1] + 0.5 * x1 * x1 * cu[you1]
+                pstar = pc + update1 + 0.0 + 0.0
+            elif st.packed:
                 # MAPPEDPHISTAR (MappedQuadCFInterpF.ChF:51-127)
                 pstar = pc + (x1 * sl[you1] + 0.5 * x1 * x1 * cu[you1]) + (x2 * sl[you2] + 0.5 * x2 * x2 * cu[you2]) \
                     + x1 * x2 * mixed[ivc]
@@ -535,7 +544,8 @@ class AMRComposite:
     """MappedAMRMultiGrid<LevelData<FArrayBox>> over several AMR levels (define :1407-1490)."""
 
     def __init__(self, levels, refRatios, bc, bottomSolver, alpha=0.0, beta=1.0, maxDepth=-1,
-                 relaxMode=so.RELAX_LEVEL_GSRB, precondIters=2, amrmg_eps=1e-6):
+                 relaxMode=so.RELAX_LEVEL_GSRB, precondIters=2, amrmg_eps=1e-6, ndim=3):
+        self.ndim = ndim
         self.levels, self.refRatios = levels, [_iv(r) for r in refRatios]
         n = len(levels)
         assert len(self.refRatios) >= n - 1
@@ -554,7 +564,8 @@ class AMRComposite:
             cf = CFRegion(L.grids, L.domain) if l > 0 else None
             dxCrse = levels[l - 1].dx if l > 0 else None
             fac = so.Factory(L.domain, L.grids, L.dx, bc, L.Jgup, L.Jinv, alpha=alpha, beta=beta, maxDepth=maxDepth,
-                             precondIters=precondIters, relaxMode=relaxMode, amrmg_eps=amrmg_eps, dxCrse=dxCrse, cf=cf)
+                             precondIters=precondIters, relaxMode=relaxMode, amrmg_eps=amrmg_eps, dxCrse=dxCrse, cf=cf,
+                             ndim=ndim)
             # the mini V-cycle's coarsening pattern, MappedAMRMultiGrid.H:1455-1482
             force = None
             if l > 0:
@@ -575,7 +586,8 @@ class AMRComposite:
             op.refToCoarser = self.refRatios[l - 1] if l > 0 else None
             op.refToFiner = self.refRatios[l] if l < n - 1 else None
             # define(...) with a coarser level: m_interpWithCoarser (MappedAMRPoissonOp.cpp:193-196, 236-239)
-            op.quad = (QuadCFInterp(L.grids, levels[l - 1].grids, L.dx, op.refToCoarser, L.domain) if l > 0 else None)
+            op.quad = (QuadCFInterp(L.grids, levels[l - 1].grids, L.dx, op.refToCoarser, L.domain, ndim=ndim)
+                       if l > 0 else None)
             # define(...) with a finer level: m_levfluxreg (:141-147, 243-249)
             op.fluxreg = (FluxRegister(levels[l + 1].grids, L.grids, levels[l + 1].domain, op.refToFiner)
                           if l < n - 1 else None)

@@ -65,7 +65,7 @@ def max_rel_diff(a_list, b_list):
     return num / den if den > 0 else num
 
 
-def make_amr_levels(so, am, n, L, periodic, ratios, fine_boxes, variant="stretched", cbox=8):
+def make_amr_levels(so, am, n, L, periodic, ratios, fine_boxes, variant="stretched", cbox=8, ndim=3):
     """A nested hierarchy: level 0 covers the domain (n cells, boxes of cbox), level l>0 is the list
     fine_boxes[l-1] given in level-l index space.  The metric is evaluated analytically at every level's own
     resolution, as the reference's LevelGeometry does."""
@@ -77,7 +77,7 @@ def make_amr_levels(so, am, n, L, periodic, ratios, fine_boxes, variant="stretch
         if l > 0:
             dom = dom.refine(ratios[l - 1])
             dx = tuple(a / b for a, b in zip(dx, ratios[l - 1]))
-        Jgup, Jinv = so.make_diagonal_metric(g, dx, L, variant=variant, domain=dom)
+        Jgup, Jinv = so.make_diagonal_metric(g, dx, L, ndim, variant=variant, domain=dom)
         levels.append(am.AMRLevel(dom, g, dx, Jgup, Jinv))
     return levels
 

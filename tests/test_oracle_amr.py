@@ -174,3 +174,78 @@ def test_level_solve_takes_its_cf_values_from_the_coarser_level(oracle, am):
     so.ld_scale(coarse, 2.0)
     comp.solve([coarse, phi2], [None, rhs1], 1, 1)
     assert max(float(np.max(np.abs(a.view(g) - b.view(g)))) for g, a, b in zip(phi1.grids, phi1.fabs, phi2.fabs)) > 1e-3
+
+
+# ---- CH_SPACEDIM = 2 (the reference's 2-D lock-exchange decks refine by (4,1) and (4,2)) ---------------------------
+def test_2d_quadratic_cf_interpolation_is_exact_on_quadratics(oracle, am):
+    so = oracle
+    for r, fboxes in (((2, 2, 1), [so.Box((16, 8, 0), (47, 23, 0))]),
+                      ((4, 1, 1), [so.Box((32, 0, 0), (63, 15, 0)), so.Box((64, 0, 0), (95, 15, 0))]),
+                      ((4, 2, 1), [so.Box((32, 8, 0), (95, 23, 0))])):
+        cdom = so.Domain(so.Box((0, 0, 0), (31, 15, 0)), (False, False, False))
+        fdom = cdom.refine(r)
+        cgr = so.split_domain(cdom.box, (8, 8, 1))
+        dxc = (1 / 16, 1 / 8, 1.0)
+        dxf = tuple(a / b for a, b in zip(dxc, r))
+        q = am.QuadCFInterp(fboxes, cgr, dxf, r, fdom, ndim=2)
+
+        def fill(ld, dx):
+            for f in ld.fabs:
+                b = f.box
+                X, Y = np.meshgrid(*[(np.arange(b.lo[d], b.hi[d] + 1) + 0.5) * dx[d] for d in range(2)], indexing="ij")
+                f.a[:, :, 0, 0] = 1.0 + 0.3 * X + 0.2 * Y + 0.5 * X * X - 0.25 * Y * Y + 0.3 * X * Y
+
+        phic = so.LevelData(cgr, 1, (1, 1, 0))
+        phif = so.LevelData(fboxes, 1, (1, 1, 0))
+        fill(phic, dxc)
+        fill(phif, dxf)
+        exact = [f.a.copy() for f in phif.fabs]
+        cf = am.CFRegion(fboxes, fdom)
+        ncf = 0
+        for (i, d, s), (gb, m) in cf.ivs.items():
+            if m is not None:
+                phif[i].view(gb)[..., 0][m] = 1e30
+                ncf += int(m.sum())
+        assert ncf > 0
+        q.coarse_fine_interp(phif, phic)
+        for (i, d, s), (gb, m) in cf.ivs.items():
+            if m is not None:
+                got = phif[i].view(gb)[..., 0]
+                want = exact[i][gb.slices(phif[i].box.lo) + (0,)]
+                assert float((np.abs(got - want) * m).max()) < 1e-14, (r, i, d, s)
+
+
+LAYOUTS_2D = [
+    ((False, False, False), [(2, 2, 1)], [[((16, 8, 0), (47, 23, 0))]]),
+    ((False, False, False), [(4, 1, 1)], [[((32, 0, 0), (95, 15, 0))]]),
+    ((False, True, False), [(4, 1, 1)], [[((32, 0, 0), (63, 15, 0)), ((64, 0, 0), (95, 15, 0))]]),
+]
+
+
+@pytest.mark.parametrize("layout", LAYOUTS_2D)
+def test_2d_composite_operator_is_conservative_and_solve_converges(oracle, am, layout):
+    so = oracle
+    periodic, ratios, boxes = layout
+    fb = [[so.Box(lo, hi) for lo, hi in lev] for lev in boxes]
+    levels = make_amr_levels(so, am, (32, 16, 1), (2.0, 1.0, 1.0), periodic, ratios, fb, cbox=(8, 8, 1), ndim=2)
+    comp = am.AMRComposite(levels, ratios, so.BCHolder(), so.BiCGStab(), ndim=2)
+    g = (1, 1, 0)
+    phi = [so.random_field(L.grids, 5 + l, g, L.domain.box) for l, L in enumerate(levels)]
+    res = [so.LevelData(L.grids, 1) for L in levels]
+    zero = [so.LevelData(L.grids, 1) for L in levels]
+    comp.init(phi, zero, 1, 0)
+    comp.compute_amr_residual(res, phi, zero, 1, 0, True)
+    tot = 0.0
+    for L, r in zip(levels, res):
+        for i, gg in enumerate(L.grids):
+            tot += float((r[i].view(gg)[..., 0] / L.Jinv[i].view(gg)[..., 0]).sum()) * float(np.prod(L.dx[:2]))
+    assert abs(tot) < 1e-13 * max(so.ld_norm(r, 0) for r in res)
+    rhs = [so.ld_create(r) for r in res]
+    for a, b in zip(rhs, res):
+        so.ld_assign(a, b)
+        so.ld_scale(a, -1.0)
+    sol = [so.LevelData(L.grids, 1, g) for L in levels]
+    comp.solve(sol, rhs, 1, 0)
+    h = comp.history
+    assert comp.exitStatus == 1 and h[-1] <= 1e-6 * h[0]
+    assert all(b < a for a, b in zip(h, h[1:]))
