@@ -64,8 +64,9 @@ void AMRSolver::define(const IBox& domain0, const bool periodic[3], const double
     const int n = (int)boxes.size();
     SOMAR_CHECK(n >= 1 && (int)ratios.size() >= n - 1 && (int)owners.size() == n, "bad level count");
     prm = p;
-    SOMAR_CHECK(p.spaceDim == 3, "several AMR levels are implemented for space_dim 3 (the coarse-fine stencils and the "
-                                 "flux register of a CH_SPACEDIM = 2 build have one tangential direction: not built yet)");
+    SOMAR_CHECK(p.spaceDim == 3 || p.spaceDim == 2, "space_dim must be 2 or 3");
+    if (p.spaceDim == 2)
+        for (const auto& r : ratios) SOMAR_CHECK(r[2] == 1, "space_dim 2: the refinement ratio in z must be 1");
     ratios_ = ratios;
     IBox dom = domain0;
     double dx[3] = {dx0[0], dx0[1], dx0[2]}, dxc[3] = {0, 0, 0};
@@ -128,6 +129,7 @@ void AMRSolver::build_link(int l)
     std::vector<IBox> cb;
     for (const IBox& b : F.boxes) cb.push_back(b.coarsen(K->r));
     K->cfl.reset(new Level);
+    K->cfl->active[2] = C.active[2];
     K->cfl->define(C.domain, C.periodic, C.dx, C.bc_type, cb, F.owner, comm_);
     K->buf = K->cfl->alloc_field();
     K->resC = K->cfl->alloc_field();
@@ -221,7 +223,11 @@ void AMRSolver::build_quad_tables(int l)
         const long long fst[3] = {1, fp.pj, fp.pk};
         const long long cst[3] = {1, cp.pj, cp.pk};
         const IBox coarseGrid = grid.coarsen(r);
-        for (int dir = 0; dir < 3; ++dir) {
+        // CH_SPACEDIM = 2 (MappedQuadCFInterp.cpp:300-310, 386-400): one tangential direction, no mixed derivative.  The
+        // records keep their layout; the z slots (t2, mixed) are empty for non-standard cells and multiply the zero
+        // offset x2 = 0 for standard ones (the buffer's z ghost planes hold zeros).
+        const bool flat = !F.active[2];
+        for (int dir = 0; dir < (flat ? 2 : 3); ++dir) {
             const int t1 = dir == 0 ? 1 : 0, t2 = dir == 2 ? 1 : 2;
             for (int s = 0; s < 2; ++s) {
                 const IBox edge = adj_cell(grid, dir, s) & fdomG;
@@ -238,8 +244,12 @@ void AMRSolver::build_quad_tables(int l)
                 for (const IBox& u : fineIVS) coar.set_box(u.coarsen(r), 1);
                 // "all good" coarse cells: not under the fine level, covered by the coarse level
                 IBox g2 = adj_cell(coarseGrid, dir, s), g1 = g2;
-                g2.lo[t1] -= 2; g2.hi[t1] += 2; g2.lo[t2] -= 2; g2.hi[t2] += 2;
-                g1.lo[t1] -= 1; g1.hi[t1] += 1; g1.lo[t2] -= 1; g1.hi[t2] += 1;
+                g2.lo[t1] -= 2; g2.hi[t1] += 2;
+                g1.lo[t1] -= 1; g1.hi[t1] += 1;
+                if (!flat) {
+                    g2.lo[t2] -= 2; g2.hi[t2] += 2;
+                    g1.lo[t2] -= 1; g1.hi[t2] += 1;
+                }
                 g2 = g2 & cdomG6;
                 g1 = g1 & cdomG6;
                 Mask good;
@@ -256,6 +266,7 @@ void AMRSolver::build_quad_tables(int l)
                         for (iv[1] = r1.lo[1]; iv[1] <= r1.hi[1]; ++iv[1])
                             for (iv[0] = r1.lo[0]; iv[0] <= r1.hi[0]; ++iv[0]) stdm.m[stdm.idx(iv)] = good.m[good.idx(iv)];
                     for (int t : {t1, t2}) {
+                        if (flat && t == t2) continue;
                         Mask nxt = stdm;
                         for (iv[2] = g2.lo[2]; iv[2] <= g2.hi[2]; ++iv[2])
                             for (iv[1] = g2.lo[1]; iv[1] <= g2.hi[1]; ++iv[1])
@@ -298,7 +309,7 @@ void AMRSolver::build_quad_tables(int l)
                                 std::vector<std::pair<std::pair<int, int>, double>> mix;
                                 int nused = 0;
                                 const int quad[4][2] = {{-1, 0}, {0, 0}, {0, -1}, {-1, -1}};
-                                for (int qd = 0; qd < 4; ++qd) {
+                                for (int qd = 0; qd < (flat ? 0 : 4); ++qd) {
                                     const int la = quad[qd][0], lb = quad[qd][1];
                                     if (!(G(la, lb) && G(la + 1, lb) && G(la, lb + 1) && G(la + 1, lb + 1))) continue;
                                     ++nused;
@@ -312,10 +323,10 @@ void AMRSolver::build_quad_tables(int l)
                                             if (!found) mix.push_back({key, w});
                                         }
                                 }
-                                if (nused == 0) drop = true;
+                                if (nused == 0 && !flat) drop = true;
                                 // first/second derivatives per tangential direction, :1077-1178
                                 std::vector<QPoint> d1[2], d2[2];
-                                for (int ti = 0; ti < 2; ++ti) {
+                                for (int ti = 0; ti < (flat ? 1 : 2); ++ti) {
                                     const long long sst = ti == 0 ? cst[t1] : cst[t2];
                                     auto g = [&](int k) { return ti == 0 ? G(k, 0) : G(0, k); };
                                     auto P = [&](std::vector<QPoint>& v, int k, double w) { v.push_back({k * sst, w}); };

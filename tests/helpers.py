@@ -82,10 +82,11 @@ def make_amr_levels(so, am, n, L, periodic, ratios, fine_boxes, variant="stretch
     return levels
 
 
-def make_gpu_amr(levels, ratios, alpha=0.0, beta=1.0, pre=2, post=2, bottom=2, maxDepth=-1, relaxMode=1):
+def make_gpu_amr(levels, ratios, alpha=0.0, beta=1.0, pre=2, post=2, bottom=2, maxDepth=-1, relaxMode=1, ndim=3):
     """The same hierarchy (oracle AMRLevel list) on the GPU through the C ABI."""
     from somar_amd import AMRPressureSolver
     s = AMRPressureSolver()
+    s.setSpaceDim(ndim)
     p = s._p
     s.setAMRMGParameters(p.imin, p.imax, p.eps, maxDepth, p.num_smooth_precond, pre, post, bottom, p.precond_mode,
                          relaxMode, p.num_mg, p.hang, p.norm_thresh, 0)
@@ -95,7 +96,7 @@ def make_gpu_amr(levels, ratios, alpha=0.0, beta=1.0, pre=2, post=2, bottom=2, m
     for L, v in zip(levels, s.levels):
         for p_ in range(v.num_local_patches):
             _, _, gi = v.patch_box(p_)
-            jg = [np.asfortranarray(L.Jgup[gi][d].a[..., d]) for d in range(3)]
+            jg = [np.asfortranarray(L.Jgup[gi][d].a[..., d]) for d in range(ndim)] + [None] * (3 - ndim)
             v.setMetricOrtho(p_, jg[0], jg[1], jg[2], np.asfortranarray(L.Jinv[gi].a[..., 0]))
     s.finalize()
     return s
