@@ -8,6 +8,8 @@ C4: 1024x1024x128 base + two (2,2,1) levels (central half, central quarter in x)
 le3d: the reference's own exec/inputs.LockExchange_Cartesian3D.machine shape -- base nx = 64 x 96 x 64 times
       --mult (default 4: 256x384x256), one level refined by (4,1,1) (amr.refratio_lev0) over the central half in x:
       forced (2,1,1) MG depth + mini V-cycles on the fine level.
+le2d: exec/inputs.LockExchange_Cartesian2D.machine -- 2-D (space_dim 2), base nx = 128 x 64 times --mult, L = (15, 2),
+      one level refined by (4,1) over the central half in x.
 --scale s divides every extent by s (parity-sized runs).  A step = one AMRVCycle (MappedAMRMultiGrid.H:1498) from a
 zero correction on a hash-random residual with covered cells zeroed; pre/post/bottom = 4/4/2.
 Prints one JSON line.  Not the driver's bench (that is bench.py, config C2)."""
@@ -41,10 +43,15 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
         n0, nlev = (512 // s, 512 // s, 64 // s), 2
     elif config == "le3d":
         n0, nlev = (64 * mult // s, 96 * mult // s, 64 * mult // s), 2
+    elif config == "le2d":
+        n0, nlev = (128 * mult // s, 64 * mult // s, 1), 2
     else:
         n0, nlev = (1024 // s, 1024 // s, 128 // s), 3
     L = (15.0, 3.0, 2.0)
-    ratios = [(4, 1, 1)] * (nlev - 1) if config == "le3d" else [(2, 2, 1)] * (nlev - 1)
+    ratios = [(4, 1, 1)] * (nlev - 1) if config in ("le3d", "le2d") else [(2, 2, 1)] * (nlev - 1)
+    flat = config == "le2d"
+    if flat:
+        L = (15.0, 2.0, 1.0)
     dx0 = tuple(L[d] / n0[d] for d in range(3))
     bs = (max(box // s, 8), max(box // s, 8), n0[2])
     levels = [boxes_of((0, 0, 0), tuple(a - 1 for a in n0), bs)]
@@ -55,15 +62,18 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
         n = [n[0] * r[0], n[1] * r[1], n[2] * r[2]]
         w = n[0] // frac          # central half, then central quarter (of the refined index space)
         lo_x = (n[0] - w) // 2
-        lo_x -= lo_x % ((2 if config != "le3d" else 1) * bs[0])
+        lo_x -= lo_x % ((2 if config not in ("le3d", "le2d") else 1) * bs[0])
         levels.append(boxes_of((lo_x, 0, 0), (lo_x + w - 1, n[1] - 1, n[2] - 1), bs))
         frac *= 2
     gpu = F.AMRPressureSolver()
+    if flat:
+        gpu.setSpaceDim(2)
     p = gpu._p
     gpu.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, pre, post, bottom, p.precond_mode, 1, p.num_mg,
                            p.hang, p.norm_thresh, 0)
     t0 = time.perf_counter()
-    gpu.defineAMR((0, 0, 0), tuple(a - 1 for a in n0), (False, True, False), dx0, ratios, levels)
+    gpu.defineAMR((0, 0, 0), tuple(a - 1 for a in n0), (False, False, False) if flat else (False, True, False), dx0, ratios,
+                  levels)
     cells = []
     for l, v in enumerate(gpu.levels):
         tot = 0
@@ -72,7 +82,7 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
             shp = [h - a + 1 for a, h in zip(lo, hi)]
             tot += shp[0] * shp[1] * shp[2]
             ones = [np.ones((shp[0] + (d == 0), shp[1] + (d == 1), shp[2] + (d == 2)), order="F") for d in range(3)]
-            v.setMetricOrtho(q, ones[0], ones[1], ones[2], np.ones(shp, order="F"))   # Cartesian: J = 1, Jg^aa = 1
+            v.setMetricOrtho(q, ones[0], ones[1], None if flat else ones[2], np.ones(shp, order="F"))   # Cartesian: J = 1, Jg^aa = 1
         cells.append(tot)
     gpu.finalize()
     return gpu, levels, cells, time.perf_counter() - t0, dx0, ratios
