@@ -100,9 +100,62 @@ class CFRegion:
                     ghost[m] = new[m]
 
     def extrapolate_cf_ev(self, phi, order, activeDirs):
-        """ExtrapolateCFEV fills edge/vertex ghosts next to CF faces; only the 19-point operator reads them.
-        Not restated (diagonal-metric scope)."""
-        return
+        """ExtrapolateCFEV (LevelData version), extrapolation/ExtrapolationUtils.cpp:165-372: edge and vertex ghosts
+        next to the coarse-fine faces, which only the cross terms of a non-diagonal metric read.  Works on the
+        bounding box (minBox) of each face's CF cells, as the reference does.  Order 2 only (the callers' choice)."""
+        assert order == 2
+        ndim = 3 if activeDirs[2] else 2
+
+        def quad(f, near, step):
+            """state(near - step) := quadraticExtrap(state(near), state(near + step), state(near + 2 step))"""
+            g = lambda q: float(f.view(Box(q, q))[0, 0, 0, 0])
+            add = lambda a, k: [a[t] + k * step[t] for t in range(3)]
+            dst = add(near, -1)
+            if any(dst[t] < f.box.lo[t] or dst[t] > f.box.hi[t] for t in range(3)):
+                return
+            f.view(Box(dst, dst))[...] = 3.0 * (g(near) - g(add(near, 1))) + g(add(near, 2))
+
+        for d in range(3):
+            if activeDirs[d] == 0:
+                continue
+            for i in range(len(self.grids)):
+                f = phi[i]
+                for s in (0, 1):
+                    gb, m = self.ivs[(i, d, s)]
+                    if m is None:
+                        continue
+                    idx = np.argwhere(m)
+                    lo = [gb.lo[t] + int(idx[:, t].min()) for t in range(3)]
+                    hi = [gb.lo[t] + int(idx[:, t].max()) for t in range(3)]
+                    faceBox = Box(lo, hi) & f.box
+                    if faceBox.isEmpty():
+                        continue
+                    if ndim == 2:
+                        vdir = 1 - d
+                        if activeDirs[vdir] == 0:
+                            continue
+                        v = [0, 0, 0]
+                        v[vdir] = 1
+                        quad(f, list(faceBox.lo), v)
+                        quad(f, list(faceBox.hi), [-a for a in v])
+                        continue
+                    for edir in range(3):
+                        if edir == d or activeDirs[edir] == 0:
+                            continue
+                        for es in (0, 1):
+                            edgeBox = faceBox.adjCell(edir, es, 1) & f.box
+                            if edgeBox.isEmpty():
+                                continue
+                            elo, ehi = _b(edgeBox)
+                            rc = lib().orc_extrapolatefacenoev(*f.fra(), *f.fran(), elo, ehi, edir, 1 if es else -1, order)
+                            assert rc == 0
+                            vdir = 3 - edir - d
+                            if activeDirs[vdir] == 0:
+                                continue
+                            v = [0, 0, 0]
+                            v[vdir] = 1
+                            quad(f, list(edgeBox.lo), v)
+                            quad(f, list(edgeBox.hi), [-a for a in v])
 
 
 # ----------------------------------------------------------------------------
@@ -544,7 +597,7 @@ class AMRComposite:
     """MappedAMRMultiGrid<LevelData<FArrayBox>> over several AMR levels (define :1407-1490)."""
 
     def __init__(self, levels, refRatios, bc, bottomSolver, alpha=0.0, beta=1.0, maxDepth=-1,
-                 relaxMode=so.RELAX_LEVEL_GSRB, precondIters=2, amrmg_eps=1e-6, ndim=3):
+                 relaxMode=so.RELAX_LEVEL_GSRB, precondIters=2, amrmg_eps=1e-6, ndim=3, isDiagonal=True):
         self.ndim = ndim
         self.levels, self.refRatios = levels, [_iv(r) for r in refRatios]
         n = len(levels)
@@ -565,7 +618,7 @@ class AMRComposite:
             dxCrse = levels[l - 1].dx if l > 0 else None
             fac = so.Factory(L.domain, L.grids, L.dx, bc, L.Jgup, L.Jinv, alpha=alpha, beta=beta, maxDepth=maxDepth,
                              precondIters=precondIters, relaxMode=relaxMode, amrmg_eps=amrmg_eps, dxCrse=dxCrse, cf=cf,
-                             ndim=ndim)
+                             ndim=ndim, isDiagonal=isDiagonal)
             # the mini V-cycle's coarsening pattern, MappedAMRMultiGrid.H:1455-1482
             force = None
             if l > 0:
