@@ -1231,3 +1231,36 @@ void orc_ellipticconstneumbcghost2d(double *phi_, const int *plo, const int *phi
             }
 #undef E
 }
+
+/* ------------------------------------------------------------------------
+ * ELLIPTICCONSTDIRIBCGHOST   BCInterface/EllipticBCUtilsF.ChF:29-110: ghost cells of a Dirichlet side.
+ * order 0: bcval;  1: 2 bcval - near (-near when bcval == 0);  2: (8 bcval - 6 near + far) / 3
+ * (far/3 - 2 near when bcval == 0).  near / far = first / second cell inside.
+ * ---------------------------------------------------------------------- */
+int orc_ellipticconstdiribcghost(double *st_, const int *slo, const int *shi, int ncomp,
+                                 const int *glo, const int *ghi, double bcval, int fdir, int fsign, int order)
+{
+    fra_t state = mk(st_, slo, shi);
+    int ii[3] = {fdir == 0, fdir == 1, fdir == 2};
+    if (fsign == 1) { ii[0] = -ii[0]; ii[1] = -ii[1]; ii[2] = -ii[2]; }
+    if (order < 0 || order > 2) return 1;
+    for (int n = 0; n < ncomp; ++n)
+        for (int k = glo[2]; k <= ghi[2]; ++k)
+            for (int j = glo[1]; j <= ghi[1]; ++j)
+                for (int i = glo[0]; i <= ghi[0]; ++i) {
+                    if (order == 0) {
+                        AT(state, i, j, k, n) = bcval;
+                    } else if (order == 1) {
+                        if (bcval == 0.0) AT(state, i, j, k, n) = -AT(state, i + ii[0], j + ii[1], k + ii[2], n);
+                        else AT(state, i, j, k, n) = 2.0 * bcval - AT(state, i + ii[0], j + ii[1], k + ii[2], n);
+                    } else {
+                        if (bcval == 0.0)
+                            AT(state, i, j, k, n) = (1.0 / 3.0) * AT(state, i + 2 * ii[0], j + 2 * ii[1], k + 2 * ii[2], n) -
+                                                    2.0 * AT(state, i + ii[0], j + ii[1], k + ii[2], n);
+                        else
+                            AT(state, i, j, k, n) = (8.0 * bcval - 6.0 * AT(state, i + ii[0], j + ii[1], k + ii[2], n) +
+                                                     AT(state, i + 2 * ii[0], j + 2 * ii[1], k + 2 * ii[2], n)) / 3.0;
+                    }
+                }
+    return 0;
+}

@@ -401,6 +401,24 @@ def set_side_neum_bc(state, valid, domain, value, d, side, Jgup_d, extrap, dx, i
         fn(*state.fra(), *ex.fran(), *Jgup_d.fran(), lo, hi, C.c_double(value), d, sgn, _rv(dx))
 
 
+def set_side_diri_bc(state, valid, domain, value, d, side, homogeneous, order):
+    """setSideDiriBC (cell-centred branch), BCInterface/EllipticBCUtils.cpp:41-119; EllipticConstDiriBCGhostClass
+    calls it with order 1 (:414-421)."""
+    if domain.periodic[d]:
+        return
+    vend = valid.lo[d] if side == 0 else valid.hi[d]
+    dend = domain.box.lo[d] if side == 0 else domain.box.hi[d]
+    if vend != dend:
+        return
+    ghostBox = valid.adjCell(d, side, 1) & state.box
+    if ghostBox.isEmpty():
+        return
+    lo, hi = _b(ghostBox)
+    bcval = 0.0 if homogeneous else value
+    rc = lib().orc_ellipticconstdiribcghost(*state.fra(), lo, hi, C.c_double(bcval), d, 1 if side else -1, order)
+    assert rc == 0
+
+
 def bc_set_ghosts(bc, state, extrap, valid, domain, dx, Jgup, homogeneous, is_diagonal, ndim=3):
     """EllipticConstNeumBCGhostClass::operator(), EllipticBCUtils.cpp:431-482."""
     for d in range(ndim):
@@ -409,8 +427,10 @@ def bc_set_ghosts(bc, state, extrap, valid, domain, dx, Jgup, homogeneous, is_di
         for side in (0, 1):
             if bc.types[d][side] == BC_NEUM:
                 set_side_neum_bc(state, valid, domain, bc.values[d][side], d, side, Jgup[d], extrap, dx, is_diagonal, ndim)
+            elif bc.types[d][side] == BC_DIRI:
+                set_side_diri_bc(state, valid, domain, bc.values[d][side], d, side, homogeneous, 1)
             else:
-                raise NotImplementedError("only Neumann pressure BCs are restated so far")
+                raise NotImplementedError("BC type %r" % (bc.types[d][side],))
 
 
 def bc_set_fluxes(bc, flux, valid, domain, homogeneous, ndim=3):
@@ -423,6 +443,8 @@ def bc_set_fluxes(bc, flux, valid, domain, homogeneous, ndim=3):
             vend = valid.lo[d] if side == 0 else valid.hi[d]
             dend = domain.box.lo[d] if side == 0 else domain.box.hi[d]
             if vend != dend:
+                continue
+            if bc.types[d][side] != BC_NEUM:   # a Dirichlet side has no flux method: the flux comes from the ghost
                 continue
             fb = valid.faces(d)
             lo, hi = list(fb.lo), list(fb.hi)

@@ -257,3 +257,55 @@ def test_semicoarsening_rule(oracle):
     assert so.choose_mg_ref_ratio((0.1, 0.06, 0.1), 3) == (2, 2, 2)   # nothing <= max/2 -> isotropic
     assert so.choose_mg_ref_ratio((0.1, 0.05, 0.1), 3) == (1, 2, 1)
     assert so.choose_mg_ref_ratio((0.1, 0.05, 1.0), 2) == (1, 2, 1)
+
+
+# ---- Dirichlet sides (setSideDiriBC + ELLIPTICCONSTDIRIBCGHOST, order 1): the viscous / diffusive Helmholtz solves -------
+def _diri_setup(so, types, values=None, n=(16, 16, 8), alpha=0.0, beta=1.0, variant="cartesian"):
+    from helpers import make_problem
+    dom, grids, dx, Jgup, Jinv = make_problem(so, n, 8, variant, (False, False, False), (1.0, 1.0, 0.5))
+    bc = so.BCHolder([list(t) for t in types], [list(v) for v in values] if values else None)
+    fac = so.Factory(dom, grids, dx, bc, Jgup, Jinv, alpha=alpha, beta=beta)
+    return dom, grids, dx, Jinv, so.AMRMultiGrid(fac, so.BiCGStab())
+
+
+def test_dirichlet_sides_remove_the_null_space_and_the_solve_converges(oracle):
+    so = oracle
+    D, N = so.BC_DIRI, so.BC_NEUM
+    dom, grids, dx, Jinv, amr = _diri_setup(so, [(D, D), (N, N), (N, D)], variant="stretched")
+    assert not any(op.zeroAvg for op in amr.mg.ops)
+    phi0 = so.random_field(grids, 3, (1, 1, 1), dom.box)
+    b = so.LevelData(grids, 1)
+    amr.op.apply_op(b, phi0, True)
+    x = so.LevelData(grids, 1, (1, 1, 1))
+    amr.solve(x, b, forceHomogeneous=True)
+    assert amr.exitStatus == 1 and amr.history[-1] <= 1e-6 * amr.history[0]
+    # unique solution: x == phi0 up to the solver tolerance
+    err = max(float(np.max(np.abs(a.view(g) - c.view(g)))) for g, a, c in zip(grids, x.fabs, phi0.fabs))
+    assert err < 1e-4
+
+
+def test_inhomogeneous_dirichlet_values_reproduce_a_linear_profile(oracle):
+    """Cartesian metric, Dirichlet values 1 and 3 on the x sides, Neumann elsewhere, rhs = 0: the discrete solution
+    is the linear profile (the order-1 ghost 2 bcval - phi is exact for it)."""
+    so = oracle
+    D, N = so.BC_DIRI, so.BC_NEUM
+    dom, grids, dx, Jinv, amr = _diri_setup(so, [(D, D), (N, N), (N, N)], [(1.0, 3.0), (0, 0), (0, 0)])
+    amr.eps = 1e-10
+    rhs = so.LevelData(grids, 1)
+    x = so.LevelData(grids, 1, (1, 1, 1))
+    amr.solve(x, rhs, zeroPhi=True, forceHomogeneous=False)
+    for g, f in zip(grids, x.fabs):
+        X = (np.arange(g.lo[0], g.hi[0] + 1) + 0.5) * dx[0]
+        want = 1.0 + 2.0 * X[:, None, None]
+        np.testing.assert_allclose(f.view(g)[..., 0], np.broadcast_to(want, f.view(g)[..., 0].shape), atol=1e-8)
+
+
+def test_helmholtz_with_dirichlet_walls_converges_fast(oracle):
+    """alpha = 1, beta = -nu dt (a viscous backward-Euler step): strongly diagonally dominant."""
+    so = oracle
+    D = so.BC_DIRI
+    dom, grids, dx, Jinv, amr = _diri_setup(so, [(D, D), (D, D), (D, D)], alpha=1.0, beta=-1e-3, variant="stretched")
+    b = so.random_field(grids, 8, (0, 0, 0), dom.box)
+    x = so.LevelData(grids, 1, (1, 1, 1))
+    amr.solve(x, b, forceHomogeneous=True)
+    assert amr.exitStatus == 1 and amr.iters <= 6
