@@ -110,6 +110,12 @@ int somar_solver_patch_box(somar_solver_t* s, int depth, int patch, int* box6, i
 /* Diagonal metric of local patch `patch`: Jg^{aa} over faces(valid,a) (1 comp), Jinv over valid. */
 int somar_solver_set_metric_ortho(somar_solver_t* s, int patch, const double* jg0, const double* jg1,
                                   const double* jg2, const double* jinv);
+/* Values of the Dirichlet sides (bc_type SOMAR_BC_DIRI), {loX,hiX,loY,hiY,loZ,hiZ}, before finalize: the constants of
+ * EllipticConstDiriBCGhostClass (BCInterface/EllipticBCUtils.H:114-147; ghost = 2 value - first cell, order 1,
+ * EllipticBCUtilsF.ChF:71-84).  They enter the residuals of somar_solver_solve unless force_homogeneous is set; the
+ * corrections always see zero.  Entries of Neumann / periodic sides are ignored.  A solver with Dirichlet sides runs
+ * the two-pass GSRB and direct-load operator kernels (diagonal metric, no line relaxation). */
+int somar_solver_set_bc_values(somar_solver_t* s, const double* values6);
 /* Non-diagonal metric (LevelGeometry::isDiagonal() == false): jgD holds J g^{Db}, b = 0..2, over faces(valid, D),
  * component slowest (the FluxBox layout of LevelGeometry::getFCJgupPtr).  Selects the 19-point kernels
  * (GSRBITER3D, GSRBBOUNDARYITER3D, MAPPEDGETFLUX, fillExtrap / ExtrapolateFaceAndCopy, the cross-term Neumann

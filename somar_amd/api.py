@@ -71,6 +71,7 @@ _SIGS = {
     "somar_solver_patch_box": [_H, C.c_int, C.c_int, _PI, _PI],
     "somar_solver_set_metric_ortho": [_H, C.c_int, _PD, _PD, _PD, _PD],
     "somar_solver_set_metric_full": [_H, C.c_int, _PD, _PD, _PD, _PD],
+    "somar_solver_set_bc_values": [_H, _PD],
     "somar_solver_finalize": [_H],
     "somar_solver_depth": [_H, _PI],
     "somar_solver_mg_ref_ratio": [_H, C.c_int, _PI],
@@ -294,6 +295,10 @@ class AMRPressureSolver:
     def setMetricOrtho(self, patch, jg0, jg1, jg2, jinv):
         _ck(lib().somar_solver_set_metric_ortho(self._h, patch, _dp(jg0), _dp(jg1), _dp(jg2) if jg2 is not None else None,
                                                 _dp(jinv)))
+
+    def setBCValues(self, values6):
+        """values of the Dirichlet sides {loX,hiX,loY,hiY,loZ,hiZ} (before finalize)"""
+        _ck(lib().somar_solver_set_bc_values(self._h, _da(values6)))
 
     def setMetricFull(self, patch, jg0, jg1, jg2, jinv):
         """jgD: array (faces(valid, D) shape + (SpaceDim,)), Fortran order = component slowest; jg2 = None in 2-D"""

@@ -757,6 +757,9 @@ void AMRSolver::solve(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous
 {
     SOMAR_CHECK(finalized_, "solve before finalize");
     SOMAR_CHECK(0 <= l_base && l_base <= l_max && l_max < nlevels(), "bad level range");
+    for (auto& q : S)
+        SOMAR_CHECK(forceHomogeneous || !q->has_diri() || q->bc_values_zero(),
+                    "composite solves with non-zero Dirichlet values are not implemented (single-level solves are)");
     const int n = nlevels();
     std::vector<double*> phi(n), rhs(n), uRes(n), uCorr(n), best(n);
     for (int l = 0; l < n; ++l) {

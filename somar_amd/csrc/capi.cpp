@@ -191,6 +191,14 @@ int somar_solver_set_metric_ortho(somar_solver_t* s, int patch, const double* jg
     API_END
 }
 
+int somar_solver_set_bc_values(somar_solver_t* s, const double* values6)
+{
+    API_BEGIN
+    SOMAR_CHECK(s && values6, "null argument");
+    s->ps->set_bc_values(values6);
+    API_END
+}
+
 int somar_solver_set_metric_full(somar_solver_t* s, int patch, const double* jg0, const double* jg1, const double* jg2,
                                  const double* jinv)
 {

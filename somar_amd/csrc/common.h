@@ -79,7 +79,7 @@ struct CFCell {
 };
 
 // One step of a ghost "program" of the non-diagonal (19-point) path (full19.hip): a region of one patch.
-enum { GHOST_COPY = 0, GHOST_EXTRAP = 1, GHOST_NEUM = 2 };
+enum { GHOST_COPY = 0, GHOST_EXTRAP = 1, GHOST_NEUM = 2, GHOST_DIRI = 3 };
 struct GhostOp {
     int patch, type;
     int lo[3];       // local start of the region
@@ -88,6 +88,7 @@ struct GhostOp {
     int order;       // EXTRAP: 0, 1 or 2
     int dstf, srcf;  // 0 = phi, 1 = psi (the extrapolated copy)
     int pad_;
+    double val;      // DIRI: the boundary value of that side
 };
 
 // Per-level constants handed to the stencil kernels by value.
@@ -99,6 +100,8 @@ struct StencilParams {
     double dx[3];
     double alpha, beta;
     double cf_c1[3], cf_c2[3];  // homogeneous CF interpolation: ghost = c1 * first valid + c2 * second valid
+    int bc_homog;               // ghost programs: Dirichlet sides take the value 0 instead of their own
+    int pad2_;
 };
 
 }  // namespace somar

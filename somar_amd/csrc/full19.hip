@@ -54,6 +54,12 @@ __global__ void k_ghost_ops(const GhostOp* __restrict__ ops, const PatchDesc* __
             if (op.order == 0) dst[c] = src[c - s];
             else if (op.order == 1) dst[c] = 2.0 * src[c - s] - src[c - 2 * s];
             else dst[c] = 3.0 * (src[c - s] - src[c - 2 * s]) + src[c - 3 * s];
+        } else if (op.type == GHOST_DIRI) {
+            // ELLIPTICCONSTDIRIBCGHOST, order 1 (EllipticBCUtilsF.ChF:71-84): the value sits on the face
+            const long long s = op.sgn * st[op.dir];
+            const double bcval = P.bc_homog ? 0.0 : op.val;
+            if (bcval == 0.0) dst[c] = -src[c - s];
+            else dst[c] = 2.0 * bcval - src[c - s];
         } else {  // GHOST_NEUM: phi ghost such that the boundary flux (cross terms from psi included) equals bcval = 0
             const int a = op.dir, b = (a + 1) % 3, cc = (a + 2) % 3;
             const long long sa = st[a], sb = st[b], sc = st[cc];
@@ -257,10 +263,13 @@ static JgFull jgfull(const LevelDev& L)
     return J;
 }
 
-void launch_ghost_ops(hipStream_t st, const LevelDev& L, const GhostOp* ops, int nops, double* phi, double* psi)
+void launch_ghost_ops(hipStream_t st, const LevelDev& L, const GhostOp* ops, int nops, double* phi, double* psi,
+                      bool bc_homog)
 {
     if (nops == 0) return;
-    hipLaunchKernelGGL(k_ghost_ops, dim3(nops, 4), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), L.P);
+    StencilParams P = L.P;
+    P.bc_homog = bc_homog ? 1 : 0;
+    hipLaunchKernelGGL(k_ghost_ops, dim3(nops, 4), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
 }
 
 void launch_op_full(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* psi,

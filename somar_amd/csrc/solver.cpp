@@ -35,6 +35,7 @@ PressureSolver::PressureSolver(Comm* comm, hipStream_t shared) : comm_(comm ? co
 PressureSolver::~PressureSolver()
 {
     drop_graphs();
+    for (GhostOp* q : d_diri_ops_) hipFree(q);
     if (st_) hipStreamSynchronize(st_);
     for (double* f : f_res) hipFree(f);
     for (double* f : f_corr) hipFree(f);
@@ -185,9 +186,16 @@ void PressureSolver::define(const IBox& domain, const bool periodic[3], const do
                 "bad precondMode");
     for (int d = 0; d < p.spaceDim; ++d)
         for (int s = 0; s < 2; ++s)
-            SOMAR_CHECK(periodic[d] || bc_type[d][s] == BC_NEUM,
-                        "only homogeneous-Neumann (pressure) physical BCs are implemented");
+            SOMAR_CHECK(periodic[d] || bc_type[d][s] == BC_NEUM || bc_type[d][s] == BC_DIRI,
+                        "physical BCs are Neumann (0) or Dirichlet (1)");
     SOMAR_CHECK(prm.spaceDim == 2 || prm.spaceDim == 3, "space_dim must be 2 or 3");
+    diri_ = false;
+    for (int d = 0; d < p.spaceDim; ++d)
+        for (int s = 0; s < 2; ++s)
+            if (!periodic[d] && bc_type[d][s] == BC_DIRI) diri_ = true;
+    if (diri_)
+        SOMAR_CHECK(prm.relaxMode != RELAX_LINE_GSRB && prm.precondMode != PRECOND_DIAG_LINE_RELAX,
+                    "line relaxation with Dirichlet sides is not implemented");
     std::unique_ptr<Level> L(new Level);
     if (prm.spaceDim == 2) {
         SOMAR_CHECK(domain.size(2) == 1, "space_dim 2 wants a domain (and boxes) one cell thick in z");
@@ -379,6 +387,11 @@ void PressureSolver::finalize()
             build_full_programs(d);
         }
     }
+    SOMAR_CHECK(!(diri_ && full_), "Dirichlet sides with a non-diagonal metric are not implemented");
+    d_diri_ops_.assign(D, nullptr);
+    n_diri_ops_.assign(D, 0);
+    if (diri_)
+        for (int d = 0; d < D; ++d) build_diri_ops(d);
     for (int d = 0; d < D; ++d) {
         if (d > 0) { f_res[d] = lev[d]->alloc_field(); f_corr[d] = lev[d]->alloc_field(); }
         f_scratch[d] = lev[d]->alloc_field();
@@ -426,6 +439,8 @@ void PressureSolver::build_agglomerated_tail(int depth)
     coarse_.reset(new PressureSolver(nullptr, st_));
     coarse_->probe_eps = probe_eps > 0.0 ? probe_eps : prm.eps;
     coarse_->graph_cells_ = 0;  // graph replay is exercised (and measured) on single-process runs only
+    for (int a = 0; a < 3; ++a)
+        for (int q = 0; q < 2; ++q) coarse_->bc_value_[a][q] = bc_value_[a][q];
     std::vector<int> own(T.boxes.size(), 0);
     coarse_->define(T.domain, T.periodic, T.dx, T.bc_type, T.boxes, own, T.alpha, T.beta, cp,
                     hasCF_ ? dxCrse_ : nullptr);
@@ -517,7 +532,7 @@ bool PressureSolver::fused_relax(int d, int iters) const
     const Level& L = *lev[d];
     // levels with coarse-fine boundaries qualify when their layout allows it (Level::cf_fusable)
     return prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0 &&
-           (L.ncf == 0 || L.cf_fusable) && L.active[2] && !no_cf_fused_(L) && !full_;
+           (L.ncf == 0 || L.cf_fusable) && L.active[2] && !no_cf_fused_(L) && !full_ && !diri_;
 }
 
 void PressureSolver::relax(int d, double* e, const double* res, int iters, bool e_zero, const double* e_shift,
@@ -564,6 +579,7 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
             for (int pass = 0; pass < 2; ++pass) {
                 L.cf_homog(e, st_);  // homogeneousCFInterp (Relaxer::fillGhostsAndExtrapolate)
                 L.exchange(e, st_);
+                if (diri_) apply_diri(d, e, true);  // ... and its physical ghosts (doBCs)
                 if (full_) run_full_program(d, 1, e);  // psi snapshot + extrapolation (order 1) + Neumann ghosts
                 if (profiling_ && d == 0) prof_begin(0);
                 if (full_) launch_gsrb_full(st_, L.dev, e, f_psi[d], res, pass);
@@ -576,6 +592,7 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
             // carries shell cells, which that phase does not touch: completing it first changes nothing.)
             L.cf_homog(e, st_);
             L.exchange(e, st_);
+            if (diri_) apply_diri(d, e, true);
             launch_gsrb_ortho(st_, L.dev, e, res, 0, 1);
             launch_gsrb_ortho(st_, L.dev, e, res, 1, 1);
             launch_gsrb_ortho(st_, L.dev, e, res, 0, 2);
@@ -602,40 +619,42 @@ void PressureSolver::line_relax(int d, double* e, const double* res)
     }
 }
 
-void PressureSolver::residual(int d, double* out, double* phi, const double* rhs)
+void PressureSolver::residual(int d, double* out, double* phi, const double* rhs, bool homogeneous)
 {
     lev[d]->cf_homog(phi, st_);  // interpCFGhosts(homogeneous), MappedAMRPoissonOp.cpp:628-640
-    residual_i(d, out, phi, rhs);
+    residual_i(d, out, phi, rhs, homogeneous);
 }
 
-void PressureSolver::apply_op(int d, double* out, double* phi)
+void PressureSolver::apply_op(int d, double* out, double* phi, bool homogeneous)
 {
     lev[d]->cf_homog(phi, st_);
-    apply_op_i(d, out, phi);
+    apply_op_i(d, out, phi, homogeneous);
 }
 
-void PressureSolver::residual_i(int d, double* out, double* phi, const double* rhs)
+void PressureSolver::residual_i(int d, double* out, double* phi, const double* rhs, bool homogeneous)
 {
     Level& L = *lev[d];
     L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
+    if (diri_) apply_diri(d, phi, homogeneous);  // m_bc.setGhosts, :822
     if (profiling_ && d == 0) prof_begin(1);
     if (full_) {
         // exchangeComplete, fillExtrap (order 2), Neumann ghosts with cross terms, then the 19-point fluxes
         run_full_program(d, 0, phi);
         launch_op_full(st_, L.dev, out, phi, f_psi[d], rhs, 0);
-    } else if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, rhs, 0);
+    } else if (L.valid_cells_global >= march_min_cells_ && L.active[2] && !diri_) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, rhs, 0);
     else launch_op_ortho(st_, L.dev, out, phi, rhs, 0);
     if (profiling_ && d == 0) prof_end(1);
 }
 
-void PressureSolver::apply_op_i(int d, double* out, double* phi)
+void PressureSolver::apply_op_i(int d, double* out, double* phi, bool homogeneous)
 {
     Level& L = *lev[d];
     L.exchange(phi, st_);
+    if (diri_) apply_diri(d, phi, homogeneous);
     if (full_) {
         run_full_program(d, 0, phi);
         launch_op_full(st_, L.dev, out, phi, f_psi[d], nullptr, 1);
-    } else if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, nullptr, 1);
+    } else if (L.valid_cells_global >= march_min_cells_ && L.active[2] && !diri_) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, nullptr, 1);
     else launch_op_ortho(st_, L.dev, out, phi, nullptr, 1);
 }
 
@@ -661,7 +680,7 @@ void PressureSolver::restrict_residual(int d, double* resCoarse, double* phiFine
 {
     // restrictResidual, MappedAMRPoissonOp.cpp:1281-1304
     Level& F = *lev[d];
-    if (F.valid_cells_global >= march_min_cells_ && F.active[2] && !full_) {
+    if (F.valid_cells_global >= march_min_cells_ && F.active[2] && !full_ && !diri_) {
         // large level: residual and J-weighted average in one marching pass, the fine residual is never stored
         F.cf_homog(phiFine, st_);
         F.exchange(phiFine, st_);
@@ -900,6 +919,51 @@ void PressureSolver::mini_vcycle(double* corr, const double* res)
     mini_depth_ = 0;
 }
 
+void PressureSolver::set_bc_values(const double v[6])
+{
+    SOMAR_CHECK(!lev.empty() && !finalized, "set_bc_values before define / after finalize");
+    for (int d = 0; d < 3; ++d)
+        for (int s = 0; s < 2; ++s) bc_value_[d][s] = v[2 * d + s];
+}
+
+// one GHOST_DIRI op per (patch, Dirichlet side it touches): the face-adjacent ghost layer, setSideDiriBC's destBox
+void PressureSolver::build_diri_ops(int d)
+{
+    Level& L = *lev[d];
+    std::vector<GhostOp> ops;
+    for (int pi = 0; pi < L.npatches(); ++pi) {
+        const IBox valid = L.boxes[L.local[pi]];
+        for (int a = 0; a < 3; ++a) {
+            if (!L.active[a] || L.periodic[a]) continue;
+            for (int s = 0; s < 2; ++s) {
+                if (L.bc_type[a][s] != BC_DIRI) continue;
+                if ((s ? valid.hi[a] : valid.lo[a]) != (s ? L.domain.hi[a] : L.domain.lo[a])) continue;
+                GhostOp op;
+                std::memset(&op, 0, sizeof(op));
+                op.patch = pi;
+                op.type = GHOST_DIRI;
+                for (int q = 0; q < 3; ++q) { op.lo[q] = 0; op.n[q] = valid.size(q); }
+                op.lo[a] = s ? valid.size(a) : -1;
+                op.n[a] = 1;
+                op.dir = a;
+                op.sgn = s ? 1 : -1;
+                op.val = bc_value_[a][s];
+                ops.push_back(op);
+            }
+        }
+    }
+    n_diri_ops_[d] = (int)ops.size();
+    if (!ops.empty()) {
+        SOMAR_HIP(hipMalloc(&d_diri_ops_[d], ops.size() * sizeof(GhostOp)));
+        SOMAR_HIP(hipMemcpy(d_diri_ops_[d], ops.data(), ops.size() * sizeof(GhostOp), hipMemcpyHostToDevice));
+    }
+}
+
+void PressureSolver::apply_diri(int d, double* phi, bool homogeneous)
+{
+    launch_ghost_ops(st_, lev[d]->dev, d_diri_ops_[d], n_diri_ops_[d], phi, phi, homogeneous);
+}
+
 void PressureSolver::drop_graphs()
 {
     if (cg_.down) hipGraphExecDestroy(cg_.down);
@@ -1081,7 +1145,6 @@ void PressureSolver::bottom_solve(double* phi, const double* rhs)
 // ------------------------------------------------------------------------------------
 void PressureSolver::solve(bool zeroPhi, bool forceHomogeneous, SolveStats& s)
 {
-    (void)forceHomogeneous;  // zero-Neumann data: homogeneous and inhomogeneous BCs coincide
     SOMAR_CHECK(finalized, "solve before finalize");
     Level& L = *lev[0];
     const long long n = L.field_elems;
@@ -1089,7 +1152,7 @@ void PressureSolver::solve(bool zeroPhi, bool forceHomogeneous, SolveStats& s)
     launch_set(st_, f_uberCorr, n, 0.0);
     if (zeroPhi) launch_set(st_, f_phi, n, 0.0);
     launch_copy(st_, f_best, f_phi, n);
-    residual(0, f_uberRes, f_phi, f_rhs);
+    residual(0, f_uberRes, f_phi, f_rhs, forceHomogeneous);  // computeAMRResidual(..., a_forceHomogeneous), :1021
     double initial_rnorm = norm(0, f_uberRes, 0);
     double rnorm = initial_rnorm, norm_last = 2 * initial_rnorm, best_rnorm = rnorm;
     bool useBestPhi = false, somethingConverged = false;
@@ -1106,7 +1169,7 @@ void PressureSolver::solve(bool zeroPhi, bool forceHomogeneous, SolveStats& s)
         norm_last = rnorm;
         vcycle(f_uberCorr, f_uberRes, true);          // uberCorrection is zero here (setToZero, :1203)
         launch_incr(st_, f_phi, f_uberCorr, 1.0, n);   // postVCycleOps, :1189-1215
-        residual(0, f_uberRes, f_phi, f_rhs);
+        residual(0, f_uberRes, f_phi, f_rhs, forceHomogeneous);
         rnorm = norm(0, f_uberRes, 0);
         ++iter;
         s.history.push_back(rnorm);

@@ -102,10 +102,22 @@ public:
         static const bool off = getenv("SOMAR_NO_CF_FUSED") != nullptr;
         return off && L.ncf > 0;
     }
-    void residual(int d, double* out, double* phi, const double* rhs);   // homogeneous CF ghosts, then residual_i
-    void apply_op(int d, double* out, double* phi);
-    void residual_i(int d, double* out, double* phi, const double* rhs); // residualI: CF ghosts as they are
-    void apply_op_i(int d, double* out, double* phi);
+    // homogeneous: physical BC values taken as zero (only Dirichlet sides can carry a value here)
+    void residual(int d, double* out, double* phi, const double* rhs, bool homogeneous = true);   // homogeneous CF ghosts, then residual_i
+    void apply_op(int d, double* out, double* phi, bool homogeneous = true);
+    void residual_i(int d, double* out, double* phi, const double* rhs, bool homogeneous = true); // residualI: CF ghosts as they are
+    void apply_op_i(int d, double* out, double* phi, bool homogeneous = true);
+    // Dirichlet sides (EllipticConstDiriBCGhostClass, BCInterface/EllipticBCUtils.cpp:382-424): values per
+    // {loX,hiX,loY,hiY,loZ,hiZ}, before finalize.  Such a solver runs the two-pass / direct-load kernels.
+    void set_bc_values(const double v[6]);
+    bool has_diri() const { return diri_; }
+    bool bc_values_zero() const
+    {
+        for (int d = 0; d < 3; ++d)
+            for (int s = 0; s < 2; ++s)
+                if (bc_value_[d][s] != 0.0) return false;
+        return true;
+    }
     // ConstInterpPS / ZeroAvgConstInterpPS of depth 0 from a coarse field living on layout C (AMRProlong)
     void prolong_from(const LevelDev& C, const double* crse, const int r[3], double* fine);
     double* amr_field(int which);  // 0 m_correction, 1 m_residual of MappedAMRMultiGrid (allocated on first use)
@@ -213,6 +225,12 @@ private:
     long long graph_cells_ = 262144;
     int graph_from_ = -1;
     bool capturing_ = false;
+    bool diri_ = false;
+    double bc_value_[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    std::vector<GhostOp*> d_diri_ops_;
+    std::vector<int> n_diri_ops_;
+    void build_diri_ops(int d);
+    void apply_diri(int d, double* phi, bool homogeneous);
     int mini_depth_ = 0;  // > 0 while a mini V-cycle runs: the depth count it is limited to
     void cycle_down(int d, double* corr, const double* res, bool corr_zero);  // pre-smoothing + restriction
     void cycle_up(int d, double* corr, const double* res);                    // prolongation + post-smoothing

@@ -21,7 +21,7 @@ def make_oracle_solver(so, dom, grids, dx, Jgup, Jinv, alpha=0.0, beta=1.0, pre=
 
 
 def make_gpu_solver(dom, grids, dx, Jgup, Jinv, alpha=0.0, beta=1.0, pre=2, post=2, bottom=2, maxDepth=-1,
-                    relaxMode=1, owner=None, comm=None, ndim=3, eps=None):
+                    relaxMode=1, owner=None, comm=None, ndim=3, eps=None, bc_type=None, bc_values=None):
     from somar_amd import AMRPressureSolver
     s = AMRPressureSolver()
     p = s._p
@@ -31,7 +31,9 @@ def make_gpu_solver(dom, grids, dx, Jgup, Jinv, alpha=0.0, beta=1.0, pre=2, post
     s.setAMRMGParameters(p.imin, p.imax, p.eps, maxDepth, p.num_smooth_precond, pre, post, bottom, p.precond_mode,
                          relaxMode, p.num_mg, p.hang, p.norm_thresh, 0)
     s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids], owner=owner, alpha=alpha,
-             beta=beta, comm=comm)
+             beta=beta, comm=comm, bc_type=bc_type)
+    if bc_values is not None:
+        s.setBCValues(bc_values)
     for p_ in range(s.num_local_patches):
         _, _, gi = s.patch_box(p_)
         jg = [np.asfortranarray(Jgup[gi][d].a[..., d]) for d in range(ndim)] + [None] * (3 - ndim)

@@ -1,0 +1,98 @@
+"""Dirichlet sides on the GPU (GHOST_DIRI ops + two-pass kernels) vs the oracle's setSideDiriBC / ELLIPTICCONSTDIRIBCGHOST:
+level operator pieces bit for bit, homogeneous and inhomogeneous solves, the viscous-type Helmholtz operator."""
+import numpy as np
+import pytest
+
+from helpers import download_valid, make_gpu_solver, make_problem, max_rel_diff, upload, valid_of
+
+pytestmark = pytest.mark.gpu
+D, N = 1, 0
+
+CASES = [
+    # n, box, periodic, bc types (x, y, z) lo/hi, alpha, beta
+    ((16, 16, 8), 8, (False, False, False), [(D, D), (N, N), (N, D)], 0.0, 1.0),
+    ((16, 16, 8), 8, (False, True, False), [(D, N), (N, N), (D, D)], 0.0, 1.0),
+    ((32, 16, 16), (16, 8, 8), (False, False, False), [(D, D), (D, D), (D, D)], 1.0, -1e-3),
+]
+
+
+def _setup(so, case, values=None, **kw):
+    n, bs, per, types, alpha, beta = case
+    dom, grids, dx, Jgup, Jinv = make_problem(so, n, bs, "stretched", per, (1.0, 1.0, 0.5))
+    bc = so.BCHolder([list(t) for t in types], [list(v) for v in values] if values else None)
+    fac = so.Factory(dom, grids, dx, bc, Jgup, Jinv, alpha=alpha, beta=beta)
+    amr = so.AMRMultiGrid(fac, so.BiCGStab())
+    flat_types = [t for pair in types for t in pair]
+    flat_vals = [v for pair in values for v in pair] if values else None
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv, alpha=alpha, beta=beta, bc_type=flat_types, bc_values=flat_vals, **kw)
+    return dom, grids, amr, gpu
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_dirichlet_pieces_bit_exact(oracle, case):
+    from somar_amd import api as F
+    so = oracle
+    dom, grids, amr, gpu = _setup(so, case)
+    try:
+        assert gpu.depth() == amr.mg.depth
+        assert [gpu.zeroAvg(d) for d in range(gpu.depth())] == [bool(op.zeroAvg) for op in amr.mg.ops]
+        for d in range(min(amr.mg.depth, 2)):
+            op = amr.mg.ops[d]
+            g = op.grids
+            phi = so.random_field(g, 7 + d, (1, 1, 1), op.domain.box)
+            rhs = so.random_field(g, 8 + d, (0, 0, 0), op.domain.box)
+            fc, fr, fs = ((F.F_PHI, F.F_RHS, F.F_RES) if d == 0 else
+                          (F.FIELD(d, F.F_CORR), F.FIELD(d, F.F_RES), F.FIELD(d, F.F_SCRATCH)))
+            upload(gpu, fc, phi, depth=d)
+            upload(gpu, fr, rhs, depth=d)
+            res = so.LevelData(g, 1)
+            op.residual(res, phi, rhs, True)
+            gpu.residual(d, fs, fc, fr)
+            for a, b in zip(download_valid(gpu, fs, g, d), valid_of(res)):
+                np.testing.assert_array_equal(a, b)
+            op.relax(phi, rhs, 2)
+            gpu.relax(d, fc, fr, 2)
+            for a, b in zip(download_valid(gpu, fc, g, d), valid_of(phi)):
+                np.testing.assert_array_equal(a, b)
+    finally:
+        gpu.undefine()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_dirichlet_homogeneous_solve_history(oracle, case):
+    so = oracle
+    dom, grids, amr, gpu = _setup(so, case)
+    try:
+        phi0 = so.random_field(grids, 3, (1, 1, 1), dom.box)
+        b = so.LevelData(grids, 1)
+        amr.op.apply_op(b, phi0, True)
+        x = so.LevelData(grids, 1, (1, 1, 1))
+        amr.solve(x, b, forceHomogeneous=True)
+        gx = [np.zeros(f.a.shape[:3], order="F") for f in x.fabs]
+        gb = [np.asfortranarray(f.a[..., 0]) for f in b.fabs]
+        st = gpu.solve(gx, gb, 0, 0, True, True)
+        assert st["iters"] == amr.iters and st["exitStatus"] == amr.exitStatus
+        np.testing.assert_allclose(st["history"], amr.history, rtol=1e-10, atol=1e-13 * amr.history[0])
+        assert st["history"][-1] <= 1e-6 * st["history"][0]
+    finally:
+        gpu.undefine()
+
+
+def test_inhomogeneous_dirichlet_values(oracle):
+    """Values 1 and 3 on the x sides and -2 on the z-high side enter the outer residuals (force_homogeneous = false)."""
+    so = oracle
+    vals = [(1.0, 3.0), (0.0, 0.0), (0.0, -2.0)]
+    dom, grids, amr, gpu = _setup(so, CASES[0], values=vals)
+    try:
+        rhs = so.random_field(grids, 9, (0, 0, 0), dom.box)
+        x = so.LevelData(grids, 1, (1, 1, 1))
+        amr.solve(x, rhs, zeroPhi=True, forceHomogeneous=False)
+        gx = [np.zeros(f.a.shape[:3], order="F") for f in x.fabs]
+        gb = [np.asfortranarray(f.a[..., 0]) for f in rhs.fabs]
+        st = gpu.solve(gx, gb, 0, 0, True, False)
+        assert st["iters"] == amr.iters and st["exitStatus"] == amr.exitStatus
+        np.testing.assert_allclose(st["history"], amr.history, rtol=1e-10, atol=1e-13 * amr.history[0])
+        got = [a[1:-1, 1:-1, 1:-1] for a in gx]
+        assert max_rel_diff(got, valid_of(x)) < 1e-8
+    finally:
+        gpu.undefine()
