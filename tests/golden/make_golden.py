@@ -70,6 +70,7 @@ def compute():
     comp.compute_amr_residual(ress, phis, rhss, 1, 0, True)
     out["amr_res_level0_box0"] = ress[0][0].view(levels[0].grids[0])[..., 0].copy()
     out["amr_res_level1"] = ress[1][0].view(levels[1].grids[0])[..., 0].copy()
+    # (edge / vertex ghosts next to the CF faces included: interpCFGhosts ends with ExtrapolateCFEV)
     out["amr_fine_phi_with_cf_ghosts"] = phis[1][0].a[..., 0].copy()
     # 5. refinement by (4,1,1): one AMR V-cycle (forced MG depth + mini V-cycle on the fine level)
     fb = [[so.Box((16, 0, 0), (31, 15, 7)), so.Box((32, 0, 0), (47, 15, 7))]]
