@@ -134,3 +134,33 @@ def test_2d_constants_in_null_space_and_multigrid_converges_on_a_sheared_map(ora
     h = amr.history
     assert amr.exitStatus == 1 and h[-1] <= 1e-6 * h[0]
     assert amr.mg.depth >= 3
+
+
+def test_nondiagonal_operator_depends_on_the_layout_where_a_box_edge_meets_a_wall(oracle):
+    """Reference behaviour as restated (not fixed): setSideNeumBC extrapolates `extrap` with ExtrapolateFaceAndCopy from
+    the box's OWN valid cells (EllipticBCUtils.cpp:128-214), edges included, so the corner ghost beyond a box edge that
+    sits on a physical wall is extrapolated along the wall instead of holding the neighbour box's data.  The two copies
+    of a face shared by two boxes then differ next to the wall: the non-diagonal operator is layout dependent in the
+    two cells either side of every such junction (and only there), and exactly conservative on one box only."""
+    so = oracle
+    L = (2.0, 1.0)
+    res = {}
+    for bs in ((32, 16, 1), (16, 16, 1)):
+        dom = so.Domain(so.Box((0, 0, 0), (31, 15, 0)), (False, False, False))
+        grids = so.split_domain(dom.box, bs)
+        dx = (L[0] / 32, L[1] / 16, 1.0)
+        Jg, Ji = so.make_full_metric_2d(grids, dx, L, dom)
+        op = so.Factory(dom, grids, dx, so.BCHolder(), Jg, Ji, isDiagonal=False, ndim=2, maxDepth=0).mg_new_op(0, None)
+        phi = so.random_field(grids, 5, (1, 1, 0), dom.box)
+        out = so.LevelData(grids, 1)
+        op.apply_op(out, phi, True)
+        full = np.zeros((32, 16))
+        tot = 0.0
+        for i, g in enumerate(grids):
+            full[g.lo[0]:g.hi[0] + 1, g.lo[1]:g.hi[1] + 1] = out[i].view(g)[:, :, 0, 0]
+            tot += float((out[i].view(g)[..., 0] / Ji[i].view(g)[..., 0]).sum())
+        res[bs] = (full, tot)
+    one, two = res[(32, 16, 1)], res[(16, 16, 1)]
+    assert abs(one[1]) < 1e-9 * np.abs(one[0]).sum()           # one box: conservative
+    differ = {tuple(q) for q in np.argwhere(np.abs(one[0] - two[0]) > 1e-9).tolist()}
+    assert differ == {(15, 0), (15, 1), (15, 14), (15, 15), (16, 0), (16, 1), (16, 14), (16, 15)}
