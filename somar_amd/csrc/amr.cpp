@@ -604,6 +604,7 @@ void AMRSolver::interp_cf(int l, double* phiFine, const double* phiCoarse)
     K.gather.run(phiCoarse, K.buf, st_);
     launch_cf_slopes(st_, K.d_cc, K.ncc, K.d_pts, K.buf, K.d_der, dxc);
     launch_cf_quad(st_, K.d_fc, K.nfc, K.d_cc, K.d_der, K.buf, phiFine, F.dx, dxc, K.r);
+    S[l]->cf_ev(0, phiFine);  // ExtrapolateCFEV: non-diagonal metric only (interpCFGhosts, MappedAMRPoissonOp.cpp:2193-2216)
 }
 
 void AMRSolver::amr_operator(int l, double* LofPhi, double* phiFine, double* phi, const double* phiCoarse)
@@ -634,13 +635,17 @@ void AMRSolver::reflux(int l, double* phiFine, double* phi, double* LofPhi)
     if (!K.fluxDefined) return;
     Level& F = S[l + 1]->level(0);
     Level& C = S[l]->level(0);
-    launch_fine_register(st_, K.d_reg, K.nreg_local, F.dev.patches, phiFine, F.dev.jg, F.dx, K.sc_fine, K.r, K.d_regvals);
+    // non-diagonal metric: getFlux = fillExtrap + MAPPEDGETFLUX, evaluated once per level into face fields
+    double* const* flC = S[l]->is_full() ? S[l]->flux_fields(phi) : nullptr;
+    double* const* flF = S[l + 1]->is_full() ? S[l + 1]->flux_fields(phiFine) : nullptr;
+    launch_fine_register(st_, K.d_reg, K.nreg_local, F.dev.patches, phiFine, F.dev.jg, F.dx, K.sc_fine, K.r, K.d_regvals,
+                         flF);
     if (!K.peers.empty()) {
         launch_gather(st_, K.d_sendidx, K.nsend, K.d_regvals, K.d_sendbuf);
         comm_->neighbor_exchange(K.d_sendbuf, K.d_regvals + K.nreg_local, K.peers, K.soff, K.scount, K.roff, K.rcount, st_);
     }
     launch_reflux(st_, K.d_reflux, K.nreflux, K.d_A, K.d_B, C.dev.patches, phi, C.dev.jg, C.dev.jinv, C.dx, K.d_regvals,
-                  LofPhi);
+                  LofPhi, flC);
 }
 
 void AMRSolver::amr_restrict(int l, double* residual, double* correction, const double* coarseCorrection,

@@ -157,8 +157,10 @@ __global__ void k_cf_quad(const QFine* __restrict__ fc, int nfc, const QCoarse* 
 struct JG3 { const double* v[3]; };
 struct SC6 { double v[3][2]; };
 
+// fl: precomputed face fluxes (getFlux of a non-diagonal metric: PressureSolver::flux_fields) or all null
 __global__ void k_fine_register(const FRegCell* __restrict__ cells, int n, const PatchDesc* __restrict__ fpatches,
-                                const double* __restrict__ phi, JG3 jg, D3 dxf, SC6 sc, I3 r, double* __restrict__ out)
+                                const double* __restrict__ phi, JG3 jg, JG3 fl, D3 dxf, SC6 sc, I3 r,
+                                double* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -175,7 +177,7 @@ __global__ void k_fine_register(const FRegCell* __restrict__ cells, int n, const
         for (int o1 = 0; o1 < n1; ++o1)
             for (int o0 = 0; o0 < n0; ++o0) {
                 const long long f = c.cell0 + o0 + st[1] * o1 + st[2] * o2;
-                const double flux = J[f] * scale * (phi[f] - phi[f - st[d]]);
+                const double flux = fl.v[d] ? fl.v[d][f] : J[f] * scale * (phi[f] - phi[f - st[d]]);
                 acc = acc + s * flux;
             }
     out[i] = acc;
@@ -190,7 +192,7 @@ __global__ void k_gather(const int* __restrict__ idx, long long n, const double*
 
 __global__ void k_reflux(const RefluxCell* __restrict__ cells, int n, const RefluxA* __restrict__ A,
                          const int* __restrict__ B, const PatchDesc* __restrict__ cpatches,
-                         const double* __restrict__ phi, JG3 jg, const double* __restrict__ jinv, D3 dxc,
+                         const double* __restrict__ phi, JG3 jg, JG3 fl, const double* __restrict__ jinv, D3 dxc,
                          const double* __restrict__ freg, double* __restrict__ L)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,7 +204,8 @@ __global__ void k_reflux(const RefluxCell* __restrict__ cells, int n, const Refl
     for (int a = c.a0; a < c.a0 + c.na; ++a) {
         const RefluxA e = A[a];
         const double scale = 1.0 / dxc.v[e.dir];
-        const double flux = jg.v[e.dir][e.face] * scale * (phi[e.face] - phi[e.face - st[e.dir]]);
+        const double flux = fl.v[e.dir] ? fl.v[e.dir][e.face]
+                                        : jg.v[e.dir][e.face] * scale * (phi[e.face] - phi[e.face - st[e.dir]]);
         coar = coar + e.sc * flux;
     }
     double inc = 0.0;
@@ -248,13 +251,19 @@ void launch_cf_quad(hipStream_t st, const QFine* fc, int nfc, const QCoarse* cc,
                        i3(r));
 }
 void launch_fine_register(hipStream_t st, const FRegCell* cells, int n, const PatchDesc* fpatches, const double* phi,
-                          double* const jg[3], const double dxf[3], const double sc[3][2], const int r[3], double* out)
+                          double* const jg[3], const double dxf[3], const double sc[3][2], const int r[3], double* out,
+                          double* const* fluxes)
 {
     if (n == 0) return;
-    JG3 J;
+    JG3 J, FL;
     SC6 S;
-    for (int d = 0; d < 3; ++d) { J.v[d] = jg[d]; S.v[d][0] = sc[d][0]; S.v[d][1] = sc[d][1]; }
-    hipLaunchKernelGGL(k_fine_register, dim3(grid1(n)), dim3(256), 0, st, cells, n, fpatches, phi, J, d3(dxf), S, i3(r),
+    for (int d = 0; d < 3; ++d) {
+        J.v[d] = jg[d];
+        FL.v[d] = fluxes ? fluxes[d] : nullptr;
+        S.v[d][0] = sc[d][0];
+        S.v[d][1] = sc[d][1];
+    }
+    hipLaunchKernelGGL(k_fine_register, dim3(grid1(n)), dim3(256), 0, st, cells, n, fpatches, phi, J, FL, d3(dxf), S, i3(r),
                        out);
 }
 void launch_gather(hipStream_t st, const int* idx, long long n, const double* src, double* dst)
@@ -264,13 +273,13 @@ void launch_gather(hipStream_t st, const int* idx, long long n, const double* sr
 }
 void launch_reflux(hipStream_t st, const RefluxCell* cells, int n, const RefluxA* A, const int* B,
                    const PatchDesc* cpatches, const double* phi, double* const jg[3], const double* jinv,
-                   const double dxc[3], const double* freg, double* LofPhi)
+                   const double dxc[3], const double* freg, double* LofPhi, double* const* fluxes)
 {
     if (n == 0) return;
-    JG3 J;
-    for (int d = 0; d < 3; ++d) J.v[d] = jg[d];
-    hipLaunchKernelGGL(k_reflux, dim3(grid1(n)), dim3(256), 0, st, cells, n, A, B, cpatches, phi, J, jinv, d3(dxc), freg,
-                       LofPhi);
+    JG3 J, FL;
+    for (int d = 0; d < 3; ++d) { J.v[d] = jg[d]; FL.v[d] = fluxes ? fluxes[d] : nullptr; }
+    hipLaunchKernelGGL(k_reflux, dim3(grid1(n)), dim3(256), 0, st, cells, n, A, B, cpatches, phi, J, FL, jinv, d3(dxc),
+                       freg, LofPhi);
 }
 
 }  // namespace somar

@@ -90,6 +90,36 @@ __device__ __forceinline__ double flux19(const double* __restrict__ phi, const d
            cScale * J.c[a][cc][c] * (E[c + sc] - E[c - sc] + E[c + sc - sa] - E[c - sc - sa]);
 }
 
+// MAPPEDGETFLUX (beta = a_ref = 1) on every face of every patch: cell c holds its low face, the last cell of a row
+// also fills the high face (the next cell's slot in the frame)
+struct F3 { double* v[3]; };
+__global__ __launch_bounds__(512) void k_flux_full(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ patches,
+                                                   F3 out, const double* __restrict__ phi, const double* __restrict__ psi,
+                                                   JgFull J, StencilParams P)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1] || li0 >= p.n[0]) return;
+    const double dxi[3] = {1.0 / P.dx[0], 1.0 / P.dx[1], 1.0 / P.dx[2]};
+    const long long st[3] = {1, (long long)p.pj, p.pk};
+    const int npair = (li0 + 1 < p.n[0]) ? 2 : 1;
+    for (int kk = 0; kk < t.nk; ++kk) {
+        const int lk = t.k0 + kk;
+        for (int q = 0; q < npair; ++q) {
+            const int l[3] = {li0 + q, lj, lk};
+            const long long c = fidx(p, l[0], l[1], l[2]);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (!P.active[a]) continue;
+                out.v[a][c] = flux19(phi, psi, J, c, a, st, dxi);
+                if (l[a] == p.n[a] - 1) out.v[a][c + st[a]] = flux19(phi, psi, J, c + st[a], a, st, dxi);
+            }
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512) void k_op_full(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ patches,
                                                  double* __restrict__ out, const double* __restrict__ phi,
@@ -270,6 +300,14 @@ void launch_ghost_ops(hipStream_t st, const LevelDev& L, const GhostOp* ops, int
     StencilParams P = L.P;
     P.bc_homog = bc_homog ? 1 : 0;
     hipLaunchKernelGGL(k_ghost_ops, dim3(nops, 4), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
+}
+
+void launch_flux_full(hipStream_t st, const LevelDev& L, double* const out[3], const double* phi, const double* psi)
+{
+    if (L.ntiles == 0) return;
+    F3 o;
+    for (int a = 0; a < 3; ++a) o.v[a] = out[a];
+    hipLaunchKernelGGL(k_flux_full, dim3(L.ntiles), dim3(64, L.tile_j, 1), 0, st, L.tiles, L.patches, o, phi, psi, jgfull(L), L.P);
 }
 
 void launch_op_full(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* psi,

@@ -22,6 +22,7 @@ struct LevelDev {
 // 19-point path (full19.hip)
 void launch_ghost_ops(hipStream_t st, const LevelDev& L, const GhostOp* ops, int nops, double* phi, double* psi,
                       bool bc_homog = true);
+void launch_flux_full(hipStream_t st, const LevelDev& L, double* const out[3], const double* phi, const double* psi);
 void launch_op_full(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* psi,
                     const double* rhs, int mode);
 void launch_gsrb_full(hipStream_t st, const LevelDev& L, double* phi, const double* psi, const double* rhs, int color);

@@ -36,6 +36,7 @@ PressureSolver::~PressureSolver()
 {
     drop_graphs();
     for (GhostOp* q : d_diri_ops_) hipFree(q);
+    for (double* q : f_flux) Level::free_field(q);
     if (st_) hipStreamSynchronize(st_);
     for (double* f : f_res) hipFree(f);
     for (double* f : f_corr) hipFree(f);
@@ -622,12 +623,14 @@ void PressureSolver::line_relax(int d, double* e, const double* res)
 void PressureSolver::residual(int d, double* out, double* phi, const double* rhs, bool homogeneous)
 {
     lev[d]->cf_homog(phi, st_);  // interpCFGhosts(homogeneous), MappedAMRPoissonOp.cpp:628-640
+    cf_ev(d, phi);
     residual_i(d, out, phi, rhs, homogeneous);
 }
 
 void PressureSolver::apply_op(int d, double* out, double* phi, bool homogeneous)
 {
     lev[d]->cf_homog(phi, st_);
+    cf_ev(d, phi);
     apply_op_i(d, out, phi, homogeneous);
 }
 

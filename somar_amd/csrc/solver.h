@@ -110,6 +110,12 @@ public:
     // Dirichlet sides (EllipticConstDiriBCGhostClass, BCInterface/EllipticBCUtils.cpp:382-424): values per
     // {loX,hiX,loY,hiY,loZ,hiZ}, before finalize.  Such a solver runs the two-pass / direct-load kernels.
     void set_bc_values(const double v[6]);
+    // Non-diagonal metric on a level with coarse-fine boundaries:
+    //   cf_ev: ExtrapolateCFEV(phi, cfregion, 2) -- the edge / vertex ghosts next to the CF faces, after a CF fill
+    //   (interpCFGhosts, MappedAMRPoissonOp.cpp:2193-2216);  flux_fields: getFlux (fillExtrap + MAPPEDGETFLUX, beta = 1)
+    //   on every face of depth 0, for the flux register (reflux, :1615-1707)
+    void cf_ev(int d, double* phi);
+    double* const* flux_fields(double* phi);
     bool has_diri() const { return diri_; }
     bool bc_values_zero() const
     {
@@ -200,7 +206,9 @@ private:
     struct FullProgram { GhostOp* d_ops = nullptr; std::vector<int> first, count; };
     bool full_ = false;
     std::vector<double*> f_psi;                            // per depth: the extrapolated copy of phi
-    std::vector<std::array<FullProgram, 2>> full_prog_;    // per depth: [0] operator, [1] smoother
+    // per depth: [0] operator, [1] smoother, [2] fillExtrap alone (getFlux of the flux register), [3] ExtrapolateCFEV
+    std::vector<std::array<FullProgram, 4>> full_prog_;
+    double* f_flux[3] = {nullptr, nullptr, nullptr};  // face fluxes of depth 0 (refluxing with a non-diagonal metric)
     void alloc_full_metric(Level& L);
     void build_full_programs(int d);
     void run_full_program(int d, int which, double* phi);

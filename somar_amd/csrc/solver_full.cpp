@@ -92,6 +92,69 @@ struct Builder {
 static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which)
 {
     std::vector<std::vector<GhostOp>> perPatch(L.npatches());
+    if (which == 3) {
+        // ExtrapolateCFEV (LevelData version, ExtrapolationUtils.cpp:165-372): per box, per direction, low then high
+        // side: on the bounding box of that side's CF cells (cfivs.minBox & FAB) -- SpaceDim 2: the two cells beyond
+        // its ends; SpaceDim 3: per tangential direction and side the edge cells (EXTRAPOLATEFACENOEV along that
+        // direction), then the two vertex cells beyond the ends of that edge.  All of order 2, in place.
+        int g1[3], gp[3];
+        for (int d = 0; d < 3; ++d) { g1[d] = L.active[d] ? 1 : 0; gp[d] = (L.periodic[d] && L.active[d]) ? 1 : 0; }
+        const IBox domG = L.domain.grow(gp);
+        const bool flat = !L.active[2];
+        for (int pi = 0; pi < L.npatches(); ++pi) {
+            const IBox valid = L.boxes[L.local[pi]];
+            Builder B{valid, valid.grow(g1), pi, perPatch[pi]};
+            auto point_extrap = [&](const IBox& cell, int vdir, int sgn) {
+                // the cell one step beyond `cell` in direction vdir (sign sgn), from cell, cell -+ 1, cell -+ 2
+                IBox dst = cell;
+                dst.lo[vdir] += sgn;
+                dst.hi[vdir] += sgn;
+                if ((dst & B.fab).empty()) return;
+                B.push(GHOST_EXTRAP, dst, vdir, sgn, 2, 0, 0);
+            };
+            for (int dir = 0; dir < 3; ++dir) {
+                if (!L.active[dir]) continue;
+                for (int s = 0; s < 2; ++s) {
+                    const IBox gb = adj_cell(valid, dir, s) & domG;
+                    if (gb.empty()) continue;
+                    const std::vector<IBox> un = uncovered(gb, L.boxes, L.domain, L.periodic);
+                    if (un.empty()) continue;
+                    IBox face = un[0];
+                    for (const IBox& u : un)
+                        for (int q = 0; q < 3; ++q) { face.lo[q] = std::min(face.lo[q], u.lo[q]); face.hi[q] = std::max(face.hi[q], u.hi[q]); }
+                    face = face & B.fab;
+                    if (face.empty()) continue;
+                    auto lo_cell = [](const IBox& b) { IBox c = b; for (int q = 0; q < 3; ++q) c.hi[q] = c.lo[q]; return c; };
+                    auto hi_cell = [](const IBox& b) { IBox c = b; for (int q = 0; q < 3; ++q) c.lo[q] = c.hi[q]; return c; };
+                    if (flat) {
+                        const int vdir = 1 - dir;
+                        if (!L.active[vdir]) continue;
+                        point_extrap(lo_cell(face), vdir, -1);
+                        point_extrap(hi_cell(face), vdir, +1);
+                        continue;
+                    }
+                    for (int edir = 0; edir < 3; ++edir) {
+                        if (edir == dir || !L.active[edir]) continue;
+                        for (int es = 0; es < 2; ++es) {
+                            const IBox edge = adj_cell(face, edir, es) & B.fab;
+                            if (edge.empty()) continue;
+                            B.push(GHOST_EXTRAP, edge, edir, es ? 1 : -1, 2, 0, 0);
+                            const int vdir = 3 - edir - dir;
+                            if (!L.active[vdir]) continue;
+                            point_extrap(lo_cell(edge), vdir, -1);
+                            point_extrap(hi_cell(edge), vdir, +1);
+                        }
+                    }
+                }
+            }
+        }
+        size_t nse = 0;
+        for (auto& v : perPatch) nse = std::max(nse, v.size());
+        std::vector<std::vector<GhostOp>> stagesE(nse);
+        for (auto& v : perPatch)
+            for (size_t q = 0; q < v.size(); ++q) stagesE[q].push_back(v[q]);
+        return stagesE;
+    }
     int g1[3];
     for (int d = 0; d < 3; ++d) g1[d] = L.active[d] ? 1 : 0;
     int gper[3];
@@ -100,7 +163,7 @@ static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which
     for (int pi = 0; pi < L.npatches(); ++pi) {
         const IBox valid = L.boxes[L.local[pi]];
         Builder B{valid, valid.grow(g1), pi, perPatch[pi]};
-        if (which == 0) {
+        if (which == 0 || which == 2) {
             IBox validPhi = B.fab & validDomain;
             for (int fdir = 0; fdir < 3; ++fdir) {
                 if (!L.active[fdir]) continue;
@@ -118,7 +181,7 @@ static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which
             }
         }
         // bc_set_ghosts: for every non-periodic direction and side with a Neumann BC, where the box touches the domain
-        for (int d = 0; d < 3; ++d) {
+        for (int d = 0; d < 3 && which != 2; ++d) {
             if (!L.active[d] || L.periodic[d]) continue;
             for (int side = 0; side < 2; ++side) {
                 if (L.bc_type[d][side] != BC_NEUM) continue;
@@ -144,7 +207,9 @@ static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which
 void PressureSolver::build_full_programs(int d)
 {
     Level& L = *lev[d];
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < 4; ++which) {
+        if (which >= 2 && !(hasCF_ || d == 0)) continue;  // [2] serves the flux register (depth 0), [3] needs CF faces
+        if (which == 3 && !hasCF_) continue;
         FullProgram& P = full_prog_[d][which];
         const auto stages = build_program(L, which);
         std::vector<GhostOp> flat;
@@ -174,11 +239,33 @@ void PressureSolver::run_full_program(int d, int which, double* phi)
         launch_ghost_ops(st_, L.dev, P.d_ops + P.first[s], P.count[s], phi, f_psi[d]);
 }
 
+void PressureSolver::cf_ev(int d, double* phi)
+{
+    if (!full_ || !hasCF_) return;
+    Level& L = *lev[d];
+    const FullProgram& P = full_prog_[d][3];
+    for (size_t q = 0; q < P.first.size(); ++q)
+        launch_ghost_ops(st_, L.dev, P.d_ops + P.first[q], P.count[q], phi, phi);
+}
+
+double* const* PressureSolver::flux_fields(double* phi)
+{
+    SOMAR_CHECK(full_ && finalized, "flux fields are for the non-diagonal path");
+    Level& L = *lev[0];
+    for (int a = 0; a < prm.spaceDim; ++a)
+        if (!f_flux[a]) f_flux[a] = L.alloc_field();
+    launch_copy(st_, f_psi[0], phi, L.field_elems);
+    const FullProgram& P = full_prog_[0][2];
+    for (size_t q = 0; q < P.first.size(); ++q)
+        launch_ghost_ops(st_, L.dev, P.d_ops + P.first[q], P.count[q], phi, f_psi[0]);
+    launch_flux_full(st_, L.dev, f_flux, phi, f_psi[0]);
+    return f_flux;
+}
+
 void PressureSolver::set_metric_full(int patch, const double* jg0, const double* jg1, const double* jg2,
                                      const double* jinv)
 {
     SOMAR_CHECK(!lev.empty() && !finalized, "set_metric before define / after finalize");
-    SOMAR_CHECK(!hasCF_, "the non-diagonal metric path is implemented for one AMR level");
     Level& L = *lev[0];
     SOMAR_CHECK(patch >= 0 && patch < L.npatches(), "bad patch index");
     full_ = true;

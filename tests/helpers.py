@@ -84,7 +84,26 @@ def make_amr_levels(so, am, n, L, periodic, ratios, fine_boxes, variant="stretch
     return levels
 
 
-def make_gpu_amr(levels, ratios, alpha=0.0, beta=1.0, pre=2, post=2, bottom=2, maxDepth=-1, relaxMode=1, ndim=3):
+def make_full_amr_levels(so, am, n, L, periodic, ratios, fine_boxes, cbox=8, ndim=3):
+    """make_amr_levels with the sheared (non-diagonal) map evaluated at every level's own resolution"""
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), periodic)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    grids = [so.split_domain(dom.box, cbox)] + [list(b) for b in fine_boxes]
+    levels = []
+    for l, g in enumerate(grids):
+        if l > 0:
+            dom = dom.refine(ratios[l - 1])
+            dx = tuple(a / b for a, b in zip(dx, ratios[l - 1]))
+        if ndim == 3:
+            Jgup, Jinv = so.make_full_metric(g, dx, L, dom)
+        else:
+            Jgup, Jinv = so.make_full_metric_2d(g, dx, L[:2], dom)
+        levels.append(am.AMRLevel(dom, g, dx, Jgup, Jinv))
+    return levels
+
+
+def make_gpu_amr(levels, ratios, alpha=0.0, beta=1.0, pre=2, post=2, bottom=2, maxDepth=-1, relaxMode=1, ndim=3,
+                 full=False):
     """The same hierarchy (oracle AMRLevel list) on the GPU through the C ABI."""
     from somar_amd import AMRPressureSolver
     s = AMRPressureSolver()
@@ -98,6 +117,10 @@ def make_gpu_amr(levels, ratios, alpha=0.0, beta=1.0, pre=2, post=2, bottom=2, m
     for L, v in zip(levels, s.levels):
         for p_ in range(v.num_local_patches):
             _, _, gi = v.patch_box(p_)
+            if full:
+                jg = [np.asfortranarray(L.Jgup[gi][d].a) for d in range(ndim)] + [None] * (3 - ndim)
+                v.setMetricFull(p_, jg[0], jg[1], jg[2], np.asfortranarray(L.Jinv[gi].a[..., 0]))
+                continue
             jg = [np.asfortranarray(L.Jgup[gi][d].a[..., d]) for d in range(ndim)] + [None] * (3 - ndim)
             v.setMetricOrtho(p_, jg[0], jg[1], jg[2], np.asfortranarray(L.Jinv[gi].a[..., 0]))
     s.finalize()

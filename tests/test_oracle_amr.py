@@ -252,11 +252,10 @@ def test_2d_composite_operator_is_conservative_and_solve_converges(oracle, am, l
 
 
 def test_nondiagonal_amr_path_reduces_to_the_diagonal_one(oracle, am):
-    """Groundwork for the 19-point path on AMR fine levels (HIP side not built yet): AMRComposite(isDiagonal=False) runs
-    fillExtrap / ExtrapolateCFEV / MAPPEDGETFLUX through interpolation, operator and refluxing; fed a DIAGONAL metric it
-    must reproduce the 7-point composite residual bit for bit.  (On a sheared map the refluxed composite operator is
-    conservative only to ~5e-5 of its magnitude in this restatement -- whether that is the reference's behaviour or a
-    restatement error is open, so no convergence claim is made for that case.)"""
+    """AMRComposite(isDiagonal=False) runs fillExtrap / ExtrapolateCFEV / MAPPEDGETFLUX through interpolation, operator and
+    refluxing; fed a DIAGONAL metric it must reproduce the 7-point composite residual bit for bit.  (On a sheared map
+    the refluxed composite operator is conservative to round-off on a one-box coarse level; on multi-box levels it
+    inherits the layout quirk of the non-diagonal Neumann ghost, tests/test_oracle_full.py.)"""
     so = oracle
     fb = [[so.Box((8, 8, 4), (23, 23, 11))]]
     lv = make_amr_levels(so, am, (16, 16, 8), (2.0, 1.0, 0.5), (False, False, False), [(2, 2, 2)], fb)
@@ -272,3 +271,25 @@ def test_nondiagonal_amr_path_reduces_to_the_diagonal_one(oracle, am):
     for a, b, L in zip(out[0], out[1], lv):
         for i, g in enumerate(L.grids):
             np.testing.assert_array_equal(a[i].view(g), b[i].view(g))
+
+
+def test_nondiagonal_composite_operator_is_conservative_on_a_one_box_coarse_level(oracle, am):
+    from helpers import make_full_amr_levels
+    so = oracle
+    for ndim, n, L, cbox, ratios, fb in (
+            (2, (32, 16, 1), (2.0, 1.0, 1.0), (32, 16, 1), [(2, 2, 1)], [[so.Box((16, 8, 0), (47, 23, 0))]]),
+            (2, (32, 16, 1), (2.0, 1.0, 1.0), (32, 16, 1), [(4, 1, 1)], [[so.Box((32, 0, 0), (95, 15, 0))]]),
+            (3, (16, 16, 8), (2.0, 1.0, 0.5), (16, 16, 8), [(2, 2, 2)], [[so.Box((8, 8, 4), (23, 23, 11))]])):
+        levels = make_full_amr_levels(so, am, n, L, (False, False, False), ratios, fb, cbox=cbox, ndim=ndim)
+        comp = am.AMRComposite(levels, ratios, so.BCHolder(), so.BiCGStab(), ndim=ndim, isDiagonal=False)
+        G = (1, 1, 1) if ndim == 3 else (1, 1, 0)
+        phi = [so.random_field(Lv.grids, 5 + l, G, Lv.domain.box) for l, Lv in enumerate(levels)]
+        res = [so.LevelData(Lv.grids, 1) for Lv in levels]
+        zero = [so.LevelData(Lv.grids, 1) for Lv in levels]
+        comp.init(phi, zero, 1, 0)
+        comp.compute_amr_residual(res, phi, zero, 1, 0, True)
+        tot = 0.0
+        for Lv, r in zip(levels, res):
+            for i, gg in enumerate(Lv.grids):
+                tot += float((r[i].view(gg)[..., 0] / Lv.Jinv[i].view(gg)[..., 0]).sum()) * float(np.prod(Lv.dx[:ndim]))
+        assert abs(tot) < 1e-12 * max(so.ld_norm(r, 0) for r in res), (ndim, ratios, tot)
