@@ -1465,9 +1465,20 @@ def set_extrap_ghosts(phiF, valid, domain, order, ndim=3):
             assert rc == 0
 
 
-def level_gradient_mac(grad, phi, grids, domain, Jgup, dx, ndim=3):
-    """one-component (normal) MAC gradient, diagonal metric"""
+def level_gradient_mac(grad, phi, grids, domain, Jgup, dx, ndim=3, op=None):
+    """one-component (normal) MAC gradient.  Diagonal metric: MAPPEDMACGRADORTHO.  Non-diagonal (pass the level
+    operator): singleBoxMacGrad's sequence (Gradient.cpp:946-1101) -- extrap := fillExtrap-type extrapolation of phi
+    (order 2, from the FAB clipped to the valid domain) BEFORE the gradient BC fills phi's own ghosts, then MAPPEDMACGRAD
+    (DivCurlGradF.ChF:87-155), whose normal branch is MAPPEDGETFLUX with beta = 1 term for term."""
     exchange(phi, domain, phi.ghost)
+    if op is not None and not op.isDiagonal:
+        for i, g in enumerate(grids):
+            extrap = Fab(phi[i].box, phi.ncomp, np.nan)
+            op.fill_extrap(extrap, phi[i], 2)
+            set_extrap_ghosts(phi[i], g, domain, 2, ndim)
+            for d in range(ndim):
+                op.get_flux_complete(grad[i][d], phi[i], extrap, g.faces(d), i, d)
+        return
     for i, g in enumerate(grids):
         set_extrap_ghosts(phi[i], g, domain, 2, ndim)
         for d in range(ndim):
@@ -1487,7 +1498,7 @@ def mac_level_project(amr, vel, phi, dt, zeroPhi=True, ndim=3):
             f.a /= dt
     amr.solve(phi, rhs, zeroPhi=zeroPhi)
     corr = FluxData(op.grids, 1, ndim)
-    level_gradient_mac(corr, phi, op.grids, op.domain, op.Jgup, op.dx, ndim)
+    level_gradient_mac(corr, phi, op.grids, op.domain, op.Jgup, op.dx, ndim, op=op)
     dtScale = -1.0 if dt == 0.0 else -dt
     for i in range(len(op.grids)):
         for d in range(ndim):

@@ -86,6 +86,7 @@ void launch_div_mac(hipStream_t st, const LevelDev& L, double* out, const double
 void launch_altered_jgup(hipStream_t st, long long n, double* dest, const double* nsq, const double* dmu,
                          const double* dnu, const double* ix, const double* jy, const double* iy, const double* jx,
                          const double* gup, const double* J, double theta, double coriolisF, bool offdiag);
+void launch_face_axpy(hipStream_t st, const LevelDev& L, double* const vel[3], double* const grad[3], double s);
 void launch_mac_correct(hipStream_t st, const LevelDev& L, double* const vel[3], const double* phi, double dtScale);
 void launch_cf_homog(hipStream_t st, const CFCell* cells, int n, double* phi, const double c1[3], const double c2[3],
                      const double fac[3]);

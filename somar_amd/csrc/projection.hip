@@ -119,6 +119,38 @@ void launch_altered_jgup(hipStream_t st, long long n, double* dest, const double
                        coriolisF, offdiag ? 1 : 0);
 }
 
+// vel^a += s * g^a on every a-face of every box (low face at the cell, the last cell of a row also its high face)
+struct FA3 { double* v[3]; const double* g[3]; };
+__global__ __launch_bounds__(512) void k_face_axpy(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ patches,
+                                                   FA3 f, double s)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1]) return;
+    const long long st[3] = {1, (long long)p.pj, p.pk};
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int l[3] = {li0 + q, lj, t.k0 + kk};
+            if (l[0] >= p.n[0]) continue;
+            const long long c = p.off + l[0] + st[1] * l[1] + st[2] * l[2];
+            for (int a = 0; a < 3; ++a) {
+                if (!f.v[a]) continue;
+                f.v[a][c] = f.v[a][c] + s * f.g[a][c];
+                if (l[a] == p.n[a] - 1) f.v[a][c + st[a]] = f.v[a][c + st[a]] + s * f.g[a][c + st[a]];
+            }
+        }
+}
+
+void launch_face_axpy(hipStream_t st, const LevelDev& L, double* const vel[3], double* const grad[3], double s)
+{
+    if (L.ntiles == 0) return;
+    FA3 f;
+    for (int a = 0; a < 3; ++a) { f.v[a] = vel[a]; f.g[a] = grad[a]; }
+    hipLaunchKernelGGL(k_face_axpy, dim3(L.ntiles), dim3(64, L.tile_j, 1), 0, st, L.tiles, L.patches, f, s);
+}
+
 void launch_div_mac(hipStream_t st, const LevelDev& L, double* out, const double* u0, const double* u1,
                     const double* u2, double dt)
 {

@@ -37,6 +37,7 @@ PressureSolver::~PressureSolver()
     drop_graphs();
     for (GhostOp* q : d_diri_ops_) hipFree(q);
     for (double* q : f_flux) Level::free_field(q);
+    hipFree(d_extrapbc_ops_);
     if (st_) hipStreamSynchronize(st_);
     for (double* f : f_res) hipFree(f);
     for (double* f : f_corr) hipFree(f);
@@ -809,7 +810,14 @@ void PressureSolver::mac_correct(double* phi, double dt)
 {
     Level& L = *lev[0];
     L.exchange(phi, st_);  // Copier excp(grids, grids, domain, ghost, true); a_phi.exchange(excp)  (Gradient.cpp:118-121)
-    double* v[3] = {vel(0), vel(1), vel(2)};
+    double* v[3] = {vel(0), vel(1), prm.spaceDim == 3 ? vel(2) : nullptr};
+    if (full_) {
+        // singleBoxMacGrad with a non-diagonal metric (Gradient.cpp:946-1101): extrap from the exchanged phi first, then
+        // the extrapolation BC on phi's own physical ghosts, then MAPPEDMACGRAD == MAPPEDGETFLUX(beta = 1) on every face
+        mac_grad_full(phi);
+        launch_face_axpy(st_, L.dev, v, f_flux, dt == 0.0 ? -1.0 : -dt);
+        return;
+    }
     launch_mac_correct(st_, L.dev, v, phi, dt == 0.0 ? -1.0 : -dt);
 }
 

@@ -116,6 +116,7 @@ public:
     //   on every face of depth 0, for the flux register (reflux, :1615-1707)
     void cf_ev(int d, double* phi);
     double* const* flux_fields(double* phi);
+    void mac_grad_full(double* phi);  // f_flux := MAC gradient of phi, non-diagonal metric (phi exchanged)
     bool has_diri() const { return diri_; }
     bool bc_values_zero() const
     {
@@ -237,6 +238,8 @@ private:
     double bc_value_[3][2] = {{0, 0}, {0, 0}, {0, 0}};
     std::vector<GhostOp*> d_diri_ops_;
     std::vector<int> n_diri_ops_;
+    GhostOp* d_extrapbc_ops_ = nullptr;  // order-2 extrapolation BC on the physical ghosts of depth 0 (gradient BC)
+    int n_extrapbc_ops_ = 0;
     void build_diri_ops(int d);
     void apply_diri(int d, double* phi, bool homogeneous);
     int mini_depth_ = 0;  // > 0 while a mini V-cycle runs: the depth count it is limited to

@@ -262,6 +262,52 @@ double* const* PressureSolver::flux_fields(double* phi)
     return f_flux;
 }
 
+void PressureSolver::mac_grad_full(double* phi)
+{
+    SOMAR_CHECK(full_ && finalized && !hasCF_, "the non-diagonal MAC gradient is implemented for one AMR level");
+    Level& L = *lev[0];
+    if (!d_extrapbc_ops_) {
+        // EllipticExtrapBCGhostClass -> setSideExtrapBC, order 2: the face-adjacent ghost layer of every box side on a
+        // non-periodic domain boundary (BCInterface/EllipticBCUtils.cpp:1011-1050, 224-312)
+        std::vector<GhostOp> ops;
+        for (int pi = 0; pi < L.npatches(); ++pi) {
+            const IBox valid = L.boxes[L.local[pi]];
+            for (int a = 0; a < 3; ++a) {
+                if (!L.active[a] || L.periodic[a]) continue;
+                for (int s = 0; s < 2; ++s) {
+                    if ((s ? valid.hi[a] : valid.lo[a]) != (s ? L.domain.hi[a] : L.domain.lo[a])) continue;
+                    GhostOp op;
+                    std::memset(&op, 0, sizeof(op));
+                    op.patch = pi;
+                    op.type = GHOST_EXTRAP;
+                    for (int q = 0; q < 3; ++q) { op.lo[q] = 0; op.n[q] = valid.size(q); }
+                    op.lo[a] = s ? valid.size(a) : -1;
+                    op.n[a] = 1;
+                    op.dir = a;
+                    op.sgn = s ? 1 : -1;
+                    op.order = 2;
+                    ops.push_back(op);
+                }
+            }
+        }
+        n_extrapbc_ops_ = (int)ops.size();
+        if (!ops.empty()) {
+            SOMAR_HIP(hipMalloc(&d_extrapbc_ops_, ops.size() * sizeof(GhostOp)));
+            SOMAR_HIP(hipMemcpy(d_extrapbc_ops_, ops.data(), ops.size() * sizeof(GhostOp), hipMemcpyHostToDevice));
+            SOMAR_HIP(hipDeviceSynchronize());
+        }
+    }
+    for (int a = 0; a < prm.spaceDim; ++a)
+        if (!f_flux[a]) f_flux[a] = L.alloc_field();
+    launch_copy(st_, f_psi[0], phi, L.field_elems);
+    const FullProgram& P = full_prog_[0][2];
+    for (size_t q = 0; q < P.first.size(); ++q)
+        launch_ghost_ops(st_, L.dev, P.d_ops + P.first[q], P.count[q], phi, f_psi[0]);
+    // one op per (box, side): different sides of a box write different cells and read only valid ones
+    launch_ghost_ops(st_, L.dev, d_extrapbc_ops_, n_extrapbc_ops_, phi, phi);
+    launch_flux_full(st_, L.dev, f_flux, phi, f_psi[0]);
+}
+
 void PressureSolver::set_metric_full(int patch, const double* jg0, const double* jg1, const double* jg2,
                                      const double* jinv)
 {

@@ -102,3 +102,68 @@ def test_level_projection_matches_oracle(oracle, case):
     worst = max(float(np.max(np.abs(f.view(g & inter)))) for g, f in zip(grids, div.fabs))
     assert worst < 1e-4 * amr.history[0] * dt
     gpu.undefine()
+
+
+# ---- non-diagonal metric: MAPPEDMACGRAD with fillExtrap-type extrap and the extrapolation BC on phi's own ghosts ----
+FULL_CASES = [
+    ((16, 16, 8), 8, (False, True, False), (2.0, 1.0, 0.5)),
+    ((24, 16, 8), (12, 8, 8), (False, False, False), (1.5, 1.0, 0.5)),
+]
+
+
+def _full_setup(so, case):
+    from somar_amd import AMRPressureSolver
+    n, bs, per, L = case
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), per)
+    grids = so.split_domain(dom.box, bs)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_full_metric(grids, dx, L, dom)
+    fac = so.Factory(dom, grids, dx, so.BCHolder(), Jgup, Jinv, isDiagonal=False)
+    s = AMRPressureSolver()
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids])
+    for q in range(s.num_local_patches):
+        _, _, gi = s.patch_box(q)
+        s.setMetricFull(q, *[np.asfortranarray(Jgup[gi][d].a) for d in range(3)], np.asfortranarray(Jinv[gi].a[..., 0]))
+    s.finalize()
+    return dom, grids, dx, Jgup, Jinv, fac, s
+
+
+@pytest.mark.parametrize("case", FULL_CASES)
+def test_full_metric_gradient_correction_bit_exact_and_projection(oracle, case):
+    from somar_amd import api as F
+    so = oracle
+    dom, grids, dx, Jgup, Jinv, fac, gpu = _full_setup(so, case)
+    try:
+        amr = so.AMRMultiGrid(fac, so.BiCGStab())
+        vel = _velocity(so, dom, grids)
+        for p in range(gpu.num_local_patches):
+            _, _, gi = gpu.patch_box(p)
+            for d in range(3):
+                gpu.uploadVel(d, p, np.asfortranarray(vel[gi][d].a[..., 0]))
+        dt = 0.37
+        phi = so.random_field(grids, 17, (1, 1, 1), dom.box)
+        upload(gpu, F.F_PHI, phi)
+        corr = so.FluxData(grids, 1, 3)
+        so.level_gradient_mac(corr, phi, grids, dom, Jgup, dx, op=amr.op)
+        ref = [[vel[i][d].a.copy() for d in range(3)] for i in range(len(grids))]
+        for i in range(len(grids)):
+            for d in range(3):
+                ref[i][d] += (-dt) * corr[i][d].a
+        gpu.macCorrect(F.F_PHI, dt)
+        for p in range(gpu.num_local_patches):
+            _, _, gi = gpu.patch_box(p)
+            for d in range(3):
+                np.testing.assert_array_equal(gpu.downloadVel(d, p), ref[gi][d][..., 0])
+        # whole projection
+        gvel = [[np.asfortranarray(vel[gpu.patch_box(p)[2]][d].a[..., 0]).copy(order="F")
+                 for p in range(gpu.num_local_patches)] for d in range(3)]
+        phi2 = so.LevelData(grids, 1, (1, 1, 1))
+        so.mac_level_project(amr, vel, phi2, 0.5)
+        st = gpu.levelProject(gvel, 0.5)
+        assert st["iters"] == amr.iters and st["exitStatus"] == amr.exitStatus
+        np.testing.assert_allclose(st["history"], amr.history, rtol=1e-9, atol=1e-10 * amr.history[0])
+        for d in range(3):
+            want = [vel[gpu.patch_box(p)[2]][d].a[..., 0] for p in range(gpu.num_local_patches)]
+            assert max_rel_diff(gvel[d], want) < 1e-7
+    finally:
+        gpu.undefine()
