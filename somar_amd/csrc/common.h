@@ -102,6 +102,7 @@ struct StencilParams {
     double cf_c1[3], cf_c2[3];  // homogeneous CF interpolation: ghost = c1 * first valid + c2 * second valid
     int bc_homog;               // ghost programs: Dirichlet sides take the value 0 instead of their own
     int pad2_;
+    int diri[3][2];             // 1 = Dirichlet physical face (ghost = 2 value - first cell)
 };
 
 }  // namespace somar

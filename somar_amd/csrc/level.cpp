@@ -688,7 +688,10 @@ void Level::refresh_params()
         P.active[d] = active[d];
         P.periodic[d] = periodic[d] ? 1 : 0;
         P.dx[d] = dx[d];
-        for (int s = 0; s < 2; ++s) P.neum[d][s] = (!periodic[d] && bc_type[d][s] == BC_NEUM) ? 1 : 0;
+        for (int s = 0; s < 2; ++s) {
+            P.neum[d][s] = (!periodic[d] && bc_type[d][s] == BC_NEUM) ? 1 : 0;
+            P.diri[d][s] = (!periodic[d] && bc_type[d][s] == BC_DIRI) ? 1 : 0;
+        }
     }
     P.alpha = alpha;
     P.beta = beta;

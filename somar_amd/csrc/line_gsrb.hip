@@ -48,21 +48,24 @@ __global__ __launch_bounds__(256) void k_line_gsrb_ortho(const Tile* __restrict_
     const double yyScale = P.beta * 1.0 / (P.dx[1] * P.dx[1]);
     const double zzScale = P.beta * 1.0 / (P.dx[2] * P.dx[2]);
     // BC codes of the box: Neumann iff it touches a non-periodic domain face; vertical ends: coeff1 = 0 for
-    // Neumann and for "None" alike (GSRBF.ChF:1804-1817), Dirichlet/CF ends are not offered yet
+    // Neumann and for "None" alike (GSRBF.ChF:1804-1817); Dirichlet ends: see c1lo / c1hi below
     const bool nxl = (gi == P.dom_lo[0]) && P.neum[0][0];
     const bool nxh = (gi == P.dom_hi[0]) && P.neum[0][1];
     const bool nyl = (gj == P.dom_lo[1]) && P.neum[1][0];
     const bool nyh = (gj == P.dom_hi[1]) && P.neum[1][1];
-    const double coeff1 = 0.0;
+    // vertical ends of the column: Neumann and "None" (a box boundary inside the domain) 0, Dirichlet 2 -- the ghost
+    // -phi folded into the diagonal (GSRBF.ChF:1804-1817); CF ends are not offered
+    const double c1lo = (p.lo[2] == P.dom_lo[2] && P.diri[2][0]) ? 2.0 : 0.0;
+    const double c1hi = (p.lo[2] + N - 1 == P.dom_hi[2] && P.diri[2][1]) ? 2.0 : 0.0;
     long long c = p.off + li + sj * lj;  // k = 0
     double d_prev = 0.0, b_prev = 0.0, dl_prev = 0.0;
     for (int k = 0; k < N; ++k, c += sk) {
         const double gzl = jgz[c], gzh = jgz[c + sk];
         double lapDiag;
-        if (k == 0) lapDiag = -zzScale * (gzh + coeff1 * gzl);
-        else if (k == N - 1) lapDiag = -zzScale * (coeff1 * gzh + gzl);
+        if (k == 0) lapDiag = -zzScale * (gzh + c1lo * gzl);
+        else if (k == N - 1) lapDiag = -zzScale * (c1hi * gzh + gzl);
         else lapDiag = -zzScale * (gzl + gzh);
-        if (N == 1) lapDiag = -zzScale * (coeff1 * gzh + coeff1 * gzl);
+        if (N == 1) lapDiag = -zzScale * (c1hi * gzh + c1lo * gzl);
         double JDxx = 0.0, JDyy = 0.0;
         if (!nxl) { JDxx = JDxx + jgx[c] * phi[c - 1];        lapDiag = lapDiag - xxScale * jgx[c]; }
         if (!nxh) { JDxx = JDxx + jgx[c + 1] * phi[c + 1];    lapDiag = lapDiag - xxScale * jgx[c + 1]; }

@@ -195,9 +195,6 @@ void PressureSolver::define(const IBox& domain, const bool periodic[3], const do
     for (int d = 0; d < p.spaceDim; ++d)
         for (int s = 0; s < 2; ++s)
             if (!periodic[d] && bc_type[d][s] == BC_DIRI) diri_ = true;
-    if (diri_)
-        SOMAR_CHECK(prm.relaxMode != RELAX_LINE_GSRB && prm.precondMode != PRECOND_DIAG_LINE_RELAX,
-                    "line relaxation with Dirichlet sides is not implemented");
     std::unique_ptr<Level> L(new Level);
     if (prm.spaceDim == 2) {
         SOMAR_CHECK(domain.size(2) == 1, "space_dim 2 wants a domain (and boxes) one cell thick in z");
@@ -617,6 +614,7 @@ void PressureSolver::line_relax(int d, double* e, const double* res)
     for (int pass = 0; pass < 2; ++pass) {
         L.exchange(e, st_);
         L.cf_homog(e, st_);  // fillGhostsAndExtrapolate: homogeneous CF values in the lateral ghost cells
+        if (diri_) apply_diri(d, e, true);  // ... and the ghosts of lateral Dirichlet sides (the vertical ends are folded in)
         launch_line_gsrb_ortho(st_, L.d_ctiles, L.nctiles, L.ctile_j, L.dev, e, res, f_pp[d], pass);
     }
 }

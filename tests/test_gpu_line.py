@@ -128,3 +128,29 @@ def test_loose_gsrb_sweep_bit_exact_and_solve(oracle, case):
         # the ordered-reduction threshold) wander within that tolerance
         assert st["history"][-1] <= 1e-6 * st["history"][0]
     gpu.undefine()
+
+
+@pytest.mark.parametrize("types", [[(1, 1), (0, 0), (0, 1)], [(0, 1), (1, 0), (1, 1)]])
+def test_line_gsrb_with_dirichlet_sides_bit_exact(oracle, types):
+    """Dirichlet vertical ends are folded into the tridiagonal system (coefficient 2 on the end face), lateral Dirichlet
+    sides arrive through their ghost cells."""
+    from somar_amd import api as F
+    so = oracle
+    n, boxsz, variant, periodic, L = (16, 16, 8), 8, "stretched", (False, False, False), (1.0, 1.0, 0.5)
+    dom, grids, dx, Jgup, Jinv = make_problem(so, n, boxsz, variant, periodic, L)
+    bc = so.BCHolder([list(t) for t in types])
+    fac = so.Factory(dom, grids, dx, bc, Jgup, Jinv, alpha=1.0, beta=-0.05, relaxMode=so.RELAX_LINE_GSRB, maxDepth=0)
+    op = fac.mg_new_op(0, None)
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv, alpha=1.0, beta=-0.05, relaxMode=3, maxDepth=0,
+                          bc_type=[t for pair in types for t in pair])
+    try:
+        phi = so.random_field(grids, 41, (1, 1, 1), dom.box)
+        rhs = so.random_field(grids, 42, (0, 0, 0), dom.box)
+        upload(gpu, F.F_PHI, phi)
+        upload(gpu, F.F_RHS, rhs)
+        op.relax(phi, rhs, 2)
+        gpu.relax(0, F.F_PHI, F.F_RHS, 2)
+        for g, w in zip(download_valid(gpu, F.F_PHI, grids), valid_of(phi)):
+            np.testing.assert_array_equal(g, w)
+    finally:
+        gpu.undefine()

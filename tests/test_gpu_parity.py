@@ -309,10 +309,6 @@ def test_error_paths(F):
     with pytest.raises(SomarError):   # an unknown BC code -> loud failure, no silent fallback
         s.define((0, 0, 0), (7, 7, 7), (0, 0, 0), (1, 1, 1), [((0, 0, 0), (7, 7, 7))], bc_type=[7, 0, 0, 0, 0, 0])
     s = AMRPressureSolver()
-    s.setAMRMGParameters(5, 20, 1e-6, -1, 2, 2, 2, 2, 0, 3, 1, 1e-15, 1e-30, 0)
-    with pytest.raises(SomarError):   # line relaxation with a Dirichlet side is not implemented
-        s.define((0, 0, 0), (7, 7, 7), (0, 0, 0), (1, 1, 1), [((0, 0, 0), (7, 7, 7))], bc_type=[1, 0, 0, 0, 0, 0])
-    s = AMRPressureSolver()
     s.define((0, 0, 0), (7, 7, 7), (0, 0, 0), (1, 1, 1), [((0, 0, 0), (7, 7, 7))])
     with pytest.raises(SomarError):   # field access before finalize
         s.setVal(F.F_PHI, 0.0)
