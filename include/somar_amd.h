@@ -114,8 +114,8 @@ int somar_solver_set_metric_ortho(somar_solver_t* s, int patch, const double* jg
  * EllipticConstDiriBCGhostClass (BCInterface/EllipticBCUtils.H:114-147; ghost = 2 value - first cell, order 1,
  * EllipticBCUtilsF.ChF:71-84).  They enter the residuals of somar_solver_solve unless force_homogeneous is set; the
  * corrections always see zero.  Entries of Neumann / periodic sides are ignored.  A solver with Dirichlet sides runs
- * the two-pass GSRB and direct-load operator kernels (diagonal metric; line relaxation included: Dirichlet vertical ends
- * are folded into the column systems). */
+ * the two-pass GSRB and direct-load operator kernels (line relaxation included: Dirichlet vertical ends are folded into
+ * the column systems); with a non-diagonal metric the Dirichlet ghosts are steps of the ghost programs. */
 int somar_solver_set_bc_values(somar_solver_t* s, const double* values6);
 /* Non-diagonal metric (LevelGeometry::isDiagonal() == false): jgD holds J g^{Db}, b = 0..2, over faces(valid, D),
  * component slowest (the FluxBox layout of LevelGeometry::getFCJgupPtr).  Selects the 19-point kernels

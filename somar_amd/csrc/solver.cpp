@@ -386,7 +386,6 @@ void PressureSolver::finalize()
             build_full_programs(d);
         }
     }
-    SOMAR_CHECK(!(diri_ && full_), "Dirichlet sides with a non-diagonal metric are not implemented");
     d_diri_ops_.assign(D, nullptr);
     n_diri_ops_.assign(D, 0);
     if (diri_)
@@ -578,7 +577,7 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
             for (int pass = 0; pass < 2; ++pass) {
                 L.cf_homog(e, st_);  // homogeneousCFInterp (Relaxer::fillGhostsAndExtrapolate)
                 L.exchange(e, st_);
-                if (diri_) apply_diri(d, e, true);  // ... and its physical ghosts (doBCs)
+                if (diri_ && !full_) apply_diri(d, e, true);  // ... and its physical ghosts (doBCs); non-diagonal: in the program
                 if (full_) run_full_program(d, 1, e);  // psi snapshot + extrapolation (order 1) + Neumann ghosts
                 if (profiling_ && d == 0) prof_begin(0);
                 if (full_) launch_gsrb_full(st_, L.dev, e, f_psi[d], res, pass);
@@ -637,11 +636,11 @@ void PressureSolver::residual_i(int d, double* out, double* phi, const double* r
 {
     Level& L = *lev[d];
     L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
-    if (diri_) apply_diri(d, phi, homogeneous);  // m_bc.setGhosts, :822
+    if (diri_ && !full_) apply_diri(d, phi, homogeneous);  // m_bc.setGhosts, :822 (non-diagonal: inside the program)
     if (profiling_ && d == 0) prof_begin(1);
     if (full_) {
-        // exchangeComplete, fillExtrap (order 2), Neumann ghosts with cross terms, then the 19-point fluxes
-        run_full_program(d, 0, phi);
+        // exchangeComplete, fillExtrap (order 2), physical ghosts (Neumann with cross terms / Dirichlet), then the 19-point fluxes
+        run_full_program(d, 0, phi, homogeneous);
         launch_op_full(st_, L.dev, out, phi, f_psi[d], rhs, 0);
     } else if (L.valid_cells_global >= march_min_cells_ && L.active[2] && !diri_) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, rhs, 0);
     else launch_op_ortho(st_, L.dev, out, phi, rhs, 0);
@@ -652,9 +651,9 @@ void PressureSolver::apply_op_i(int d, double* out, double* phi, bool homogeneou
 {
     Level& L = *lev[d];
     L.exchange(phi, st_);
-    if (diri_) apply_diri(d, phi, homogeneous);
+    if (diri_ && !full_) apply_diri(d, phi, homogeneous);
     if (full_) {
-        run_full_program(d, 0, phi);
+        run_full_program(d, 0, phi, homogeneous);
         launch_op_full(st_, L.dev, out, phi, f_psi[d], nullptr, 1);
     } else if (L.valid_cells_global >= march_min_cells_ && L.active[2] && !diri_) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, nullptr, 1);
     else launch_op_ortho(st_, L.dev, out, phi, nullptr, 1);

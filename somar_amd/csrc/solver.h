@@ -212,7 +212,7 @@ private:
     double* f_flux[3] = {nullptr, nullptr, nullptr};  // face fluxes of depth 0 (refluxing with a non-diagonal metric)
     void alloc_full_metric(Level& L);
     void build_full_programs(int d);
-    void run_full_program(int d, int which, double* phi);
+    void run_full_program(int d, int which, double* phi, bool homogeneous = true);
     std::unique_ptr<PressureSolver> coarse_;   // replicated tail of the hierarchy (agglomeration)
     int agglom_depth_ = -1;
     long long agglom_cells_ = 2097152;  // 128^3: below this a level costs less to replicate (~0.2 ms of sweeps) than to exchange (~8 x 60 us)

@@ -89,7 +89,7 @@ struct Builder {
 // Programs of one level.  which = 0: operator (fillExtrap order 2, then the Neumann ghosts of phi);
 // which = 1: smoother (extrapolation order 1 from the domain box, then the Neumann ghosts of phi).
 // The leading full copy psi := phi is done by the caller with one flat copy.
-static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which)
+static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which, const double bcv[3][2])
 {
     std::vector<std::vector<GhostOp>> perPatch(L.npatches());
     if (which == 3) {
@@ -184,12 +184,18 @@ static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which
         for (int d = 0; d < 3 && which != 2; ++d) {
             if (!L.active[d] || L.periodic[d]) continue;
             for (int side = 0; side < 2; ++side) {
-                if (L.bc_type[d][side] != BC_NEUM) continue;
                 const int vend = side ? valid.hi[d] : valid.lo[d];
                 const int dend = side ? L.domain.hi[d] : L.domain.lo[d];
                 if (vend != dend) continue;
                 const IBox ghostBox = adj_cell(valid, d, side) & B.fab;
                 if (ghostBox.empty()) continue;
+                if (L.bc_type[d][side] == BC_DIRI) {
+                    // setSideDiriBC (order 1) needs no extrap: ghost = 2 value - first cell, value 0 when homogeneous
+                    B.push(GHOST_DIRI, ghostBox, d, side ? 1 : -1, 1, 0, 0);
+                    B.out.back().val = bcv[d][side];
+                    continue;
+                }
+                if (L.bc_type[d][side] != BC_NEUM) continue;
                 B.face_and_copy(1, 0, valid, d, side, 2, L.active);  // ex <- extrapolation of phi, order 2
                 B.push(GHOST_NEUM, ghostBox, d, side ? 1 : -1, 0, 0, 1);
             }
@@ -211,7 +217,7 @@ void PressureSolver::build_full_programs(int d)
         if (which >= 2 && !(hasCF_ || d == 0)) continue;  // [2] serves the flux register (depth 0), [3] needs CF faces
         if (which == 3 && !hasCF_) continue;
         FullProgram& P = full_prog_[d][which];
-        const auto stages = build_program(L, which);
+        const auto stages = build_program(L, which, bc_value_);
         std::vector<GhostOp> flat;
         P.first.clear();
         P.count.clear();
@@ -230,13 +236,13 @@ void PressureSolver::build_full_programs(int d)
     SOMAR_HIP(hipDeviceSynchronize());
 }
 
-void PressureSolver::run_full_program(int d, int which, double* phi)
+void PressureSolver::run_full_program(int d, int which, double* phi, bool homogeneous)
 {
     Level& L = *lev[d];
     launch_copy(st_, f_psi[d], phi, L.field_elems);  // psi := phi (valid cells and exchanged ghosts)
     const FullProgram& P = full_prog_[d][which];
     for (size_t s = 0; s < P.first.size(); ++s)
-        launch_ghost_ops(st_, L.dev, P.d_ops + P.first[s], P.count[s], phi, f_psi[d]);
+        launch_ghost_ops(st_, L.dev, P.d_ops + P.first[s], P.count[s], phi, f_psi[d], homogeneous);
 }
 
 void PressureSolver::cf_ev(int d, double* phi)

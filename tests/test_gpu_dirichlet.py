@@ -96,3 +96,54 @@ def test_inhomogeneous_dirichlet_values(oracle):
         assert max_rel_diff(got, valid_of(x)) < 1e-8
     finally:
         gpu.undefine()
+
+
+def test_dirichlet_sides_with_a_nondiagonal_metric(oracle):
+    """Viscous-type solve on a sheared map: Dirichlet ghosts (order 1) sit in the ghost programs next to the cross-term
+    Neumann ghosts, after fillExtrap as in applyOpI / fillGhostsAndExtrapolate."""
+    from somar_amd import AMRPressureSolver
+    from somar_amd import api as F
+    so = oracle
+    n, bs, per, L = (16, 16, 8), 8, (False, False, False), (2.0, 1.0, 0.5)
+    types = [(D, D), (N, D), (D, N)]
+    vals = [(0.5, -1.0), (0.0, 2.0), (0.25, 0.0)]
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), per)
+    grids = so.split_domain(dom.box, bs)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_full_metric(grids, dx, L, dom)
+    bc = so.BCHolder([list(t) for t in types], [list(v) for v in vals])
+    fac = so.Factory(dom, grids, dx, bc, Jgup, Jinv, alpha=1.0, beta=-0.02, isDiagonal=False)
+    amr = so.AMRMultiGrid(fac, so.BiCGStab())
+    s = AMRPressureSolver()
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids], alpha=1.0, beta=-0.02,
+             bc_type=[t for pair in types for t in pair])
+    s.setBCValues([v for pair in vals for v in pair])
+    for q in range(s.num_local_patches):
+        _, _, gi = s.patch_box(q)
+        s.setMetricFull(q, *[np.asfortranarray(Jgup[gi][d].a) for d in range(3)], np.asfortranarray(Jinv[gi].a[..., 0]))
+    s.finalize()
+    try:
+        op = amr.mg.ops[0]
+        phi = so.random_field(grids, 7, (1, 1, 1), dom.box)
+        rhs = so.random_field(grids, 8, (0, 0, 0), dom.box)
+        upload(s, F.F_PHI, phi)
+        upload(s, F.F_RHS, rhs)
+        res = so.LevelData(grids, 1)
+        op.residual(res, phi, rhs, True)
+        s.residual(0, F.F_RES, F.F_PHI, F.F_RHS)
+        for a, b in zip(download_valid(s, F.F_RES, grids), valid_of(res)):
+            np.testing.assert_array_equal(a, b)
+        op.relax(phi, rhs, 2)
+        s.relax(0, F.F_PHI, F.F_RHS, 2)
+        for a, b in zip(download_valid(s, F.F_PHI, grids), valid_of(phi)):
+            np.testing.assert_array_equal(a, b)
+        # inhomogeneous solve
+        x = so.LevelData(grids, 1, (1, 1, 1))
+        amr.solve(x, rhs, zeroPhi=True, forceHomogeneous=False)
+        gx = [np.zeros(f.a.shape[:3], order="F") for f in x.fabs]
+        gb = [np.asfortranarray(f.a[..., 0]) for f in rhs.fabs]
+        st = s.solve(gx, gb, 0, 0, True, False)
+        assert st["iters"] == amr.iters and st["exitStatus"] == amr.exitStatus
+        np.testing.assert_allclose(st["history"], amr.history, rtol=1e-9, atol=1e-13 * amr.history[0])
+    finally:
+        s.undefine()
