@@ -607,24 +607,26 @@ void AMRSolver::interp_cf(int l, double* phiFine, const double* phiCoarse)
     S[l]->cf_ev(0, phiFine);  // ExtrapolateCFEV: non-diagonal metric only (interpCFGhosts, MappedAMRPoissonOp.cpp:2193-2216)
 }
 
-void AMRSolver::amr_operator(int l, double* LofPhi, double* phiFine, double* phi, const double* phiCoarse)
+void AMRSolver::amr_operator(int l, double* LofPhi, double* phiFine, double* phi, const double* phiCoarse,
+                             bool homogeneous)
 {
     if (phiCoarse) interp_cf(l, phi, phiCoarse);
-    S[l]->apply_op_i(0, LofPhi, phi);
+    S[l]->apply_op_i(0, LofPhi, phi, homogeneous);
     if (phiFine) reflux(l, phiFine, phi, LofPhi);
 }
 
 void AMRSolver::amr_residual(int l, double* res, double* phiFine, double* phi, const double* phiCoarse,
-                             const double* rhs)
+                             const double* rhs, bool homogeneous)
 {
-    amr_operator(l, res, phiFine, phi, phiCoarse);
+    amr_operator(l, res, phiFine, phi, phiCoarse, homogeneous);
     launch_axby(st_, res, res, rhs, -1.0, 1.0, S[l]->level(0).field_elems);  // axby(res, res, rhs, -1, 1)
 }
 
-void AMRSolver::amr_residual_nf(int l, double* res, double* phi, const double* phiCoarse, const double* rhs)
+void AMRSolver::amr_residual_nf(int l, double* res, double* phi, const double* phiCoarse, const double* rhs,
+                                bool homogeneous)
 {
     if (phiCoarse) interp_cf(l, phi, phiCoarse);
-    S[l]->residual_i(0, res, phi, rhs);
+    S[l]->residual_i(0, res, phi, rhs, homogeneous);
 }
 
 void AMRSolver::reflux(int l, double* phiFine, double* phi, double* LofPhi)
@@ -688,14 +690,14 @@ void AMRSolver::zero_covered(int l, double* f)
 void AMRSolver::compute_residual_level(double* const* resid, double* const* phi, double* const* rhs, int l_max,
                                        int l_base, int ilev, bool homogeneous)
 {
-    (void)homogeneous;  // physical BCs are homogeneous Neumann / periodic: nothing to switch
+    // homogeneous switches the PHYSICAL boundary values only (Dirichlet sides); the CF values always come from phi
     if (l_max != l_base) {
-        if (ilev == l_max) amr_residual_nf(l_max, resid[l_max], phi[l_max], phi[l_max - 1], rhs[l_max]);
-        else if (ilev == l_base && l_base == 0) amr_residual(0, resid[0], phi[1], phi[0], nullptr, rhs[0]);
-        else amr_residual(ilev, resid[ilev], phi[ilev + 1], phi[ilev], phi[ilev - 1], rhs[ilev]);
+        if (ilev == l_max) amr_residual_nf(l_max, resid[l_max], phi[l_max], phi[l_max - 1], rhs[l_max], homogeneous);
+        else if (ilev == l_base && l_base == 0) amr_residual(0, resid[0], phi[1], phi[0], nullptr, rhs[0], homogeneous);
+        else amr_residual(ilev, resid[ilev], phi[ilev + 1], phi[ilev], phi[ilev - 1], rhs[ilev], homogeneous);
     } else {
-        if (l_base == 0) S[0]->residual(0, resid[0], phi[0], rhs[0]);
-        else amr_residual_nf(l_max, resid[l_max], phi[l_max], phi[l_max - 1], rhs[l_max]);
+        if (l_base == 0) S[0]->residual(0, resid[0], phi[0], rhs[0], homogeneous);
+        else amr_residual_nf(l_max, resid[l_max], phi[l_max], phi[l_max - 1], rhs[l_max], homogeneous);
     }
 }
 
@@ -762,9 +764,6 @@ void AMRSolver::solve(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous
 {
     SOMAR_CHECK(finalized_, "solve before finalize");
     SOMAR_CHECK(0 <= l_base && l_base <= l_max && l_max < nlevels(), "bad level range");
-    for (auto& q : S)
-        SOMAR_CHECK(forceHomogeneous || !q->has_diri() || q->bc_values_zero(),
-                    "composite solves with non-zero Dirichlet values are not implemented (single-level solves are)");
     const int n = nlevels();
     std::vector<double*> phi(n), rhs(n), uRes(n), uCorr(n), best(n);
     for (int l = 0; l < n; ++l) {

@@ -137,9 +137,13 @@ public:
 
     // pieces (parity tests)
     void interp_cf(int l, double* phiFine, const double* phiCoarse);  // interpCFGhosts(phi, &phiCoarse, false)
-    void amr_operator(int l, double* LofPhi, double* phiFine, double* phi, const double* phiCoarse);
-    void amr_residual(int l, double* res, double* phiFine, double* phi, const double* phiCoarse, const double* rhs);
-    void amr_residual_nf(int l, double* res, double* phi, const double* phiCoarse, const double* rhs);
+    // homogeneous: physical boundary values taken as zero (Dirichlet sides); the CF values always come from phiCoarse
+    void amr_operator(int l, double* LofPhi, double* phiFine, double* phi, const double* phiCoarse,
+                      bool homogeneous = true);
+    void amr_residual(int l, double* res, double* phiFine, double* phi, const double* phiCoarse, const double* rhs,
+                      bool homogeneous = true);
+    void amr_residual_nf(int l, double* res, double* phi, const double* phiCoarse, const double* rhs,
+                         bool homogeneous = true);
     void reflux(int l, double* phiFine, double* phi, double* LofPhi);
     void amr_restrict(int l, double* residual, double* correction, const double* coarseCorrection, double* scratch);
     void assign_coarse_residual(int l, double* coarseResidual);  // assignCopier of link l's resC

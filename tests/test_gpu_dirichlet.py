@@ -147,3 +147,45 @@ def test_dirichlet_sides_with_a_nondiagonal_metric(oracle):
         np.testing.assert_allclose(st["history"], amr.history, rtol=1e-9, atol=1e-13 * amr.history[0])
     finally:
         s.undefine()
+
+
+def test_amr_composite_solve_with_inhomogeneous_dirichlet_values(oracle):
+    """Two levels (refinement (2,2,1)), Dirichlet values on the x sides and the z-high side: they enter the composite
+    outer residuals (force_homogeneous = false), every correction sees zero."""
+    from oracle import somar_amr as am
+    from somar_amd import AMRPressureSolver
+    from somar_amd import api as F
+    from helpers import make_amr_levels
+    so = oracle
+    types = [(D, D), (N, N), (N, D)]
+    vals = [(1.0, -0.5), (0.0, 0.0), (0.0, 2.0)]
+    ratios = [(2, 2, 1)]
+    fb = [[so.Box((8, 8, 0), (23, 23, 7))]]
+    levels = make_amr_levels(so, am, (16, 16, 8), (2.0, 1.0, 0.5), (False, False, False), ratios, fb)
+    bc = so.BCHolder([list(t) for t in types], [list(v) for v in vals])
+    comp = am.AMRComposite(levels, ratios, bc, so.BiCGStab())
+    s = AMRPressureSolver()
+    L0 = levels[0]
+    s.defineAMR(L0.domain.box.lo, L0.domain.box.hi, L0.domain.periodic, L0.dx, ratios,
+                [[(g.lo, g.hi) for g in L.grids] for L in levels], bc_type=[t for pair in types for t in pair])
+    for L, v in zip(levels, s.levels):
+        v.setBCValues([x for pair in vals for x in pair])
+        for p_ in range(v.num_local_patches):
+            _, _, gi = v.patch_box(p_)
+            jg = [np.asfortranarray(L.Jgup[gi][d].a[..., d]) for d in range(3)]
+            v.setMetricOrtho(p_, jg[0], jg[1], jg[2], np.asfortranarray(L.Jinv[gi].a[..., 0]))
+    s.finalize()
+    try:
+        rhs = [so.random_field(L.grids, 50 + l, (0, 0, 0), L.domain.box) for l, L in enumerate(levels)]
+        comp.zero_covered(0, rhs[0])
+        sol = [so.LevelData(L.grids, 1, (1, 1, 1)) for L in levels]
+        comp.solve(sol, rhs, 1, 0, forceHomogeneous=False)
+        for l, v in enumerate(s.levels):
+            upload(v, F.F_RHS, rhs[l])
+        st = s.solveAMR(1, 0, zeroPhi=True, forceHomogeneous=False)
+        assert st["iters"] == comp.iters and st["exitStatus"] == comp.exitStatus
+        np.testing.assert_allclose(st["history"], comp.history, rtol=1e-10, atol=0.0)
+        for l in (0, 1):
+            assert max_rel_diff(download_valid(s.levels[l], F.F_PHI, levels[l].grids), valid_of(sol[l])) < 1e-8
+    finally:
+        s.undefine()
