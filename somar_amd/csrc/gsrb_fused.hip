@@ -116,6 +116,9 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
     const int lane = threadIdx.x, row = threadIdx.y;
     const int ri = 2 * lane;       // region column of the pair's first cell
     const int li = t.i0 - 2 + ri;  // local i of the pair's first cell (even: rows are 16-byte aligned)
+    // output columns of this tile (even, <= FR_I - 4): boxes are split into EQUAL tile columns (a 128-wide box into
+    // 2 x 64, not 124 + 4), so the region beyond wi + 4 columns is neither loaded nor computed
+    const int wi = t.pad_[0] > 0 ? t.pad_[0] : FR_I - 4;
     const int lj = t.j0 - 2 + row;
     // INMODE 3/4: where this pair's coarse parents live (floor division: ghosts map to coarse ghosts)
     long long cbase = 0, cpk = 0;
@@ -149,8 +152,8 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
     // memory predicates: a cell may be touched only inside the patch's 2-cell frame
     const bool fj = (lj >= -FRAME) && (lj < p.n[1] + FRAME);
     const bool fjh = (lj + 1 >= -FRAME) && (lj + 1 < p.n[1] + FRAME);
-    const bool f0 = fj && (li >= -FRAME) && (li < p.n[0] + FRAME);
-    const bool f1 = fj && (li + 1 >= -FRAME) && (li + 1 < p.n[0] + FRAME);
+    const bool f0 = fj && (li >= -FRAME) && (li < p.n[0] + FRAME) && (ri < wi + 4);
+    const bool f1 = fj && (li + 1 >= -FRAME) && (li + 1 < p.n[0] + FRAME) && (ri + 1 < wi + 4);
     // the outermost region rows only supply phi to the red ring: they need no coefficients
     const bool cf = (row >= 1) && (row <= FR_J - 2);
     const bool c0 = f0 && cf, c1 = f1 && cf;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int l = li + s, g = p.lo[0] + l, r = ri + s;
-        bool cmp = (l >= -1) && (l <= p.n[0]) && (r >= 1) && (r <= FR_I - 2) && (lj >= -1) && (lj <= p.n[1]) &&
+        bool cmp = (l >= -1) && (l <= p.n[0]) && (r >= 1) && (r <= wi + 2) && (lj >= -1) && (lj <= p.n[1]) &&
                    (row >= 1) && (row <= FR_J - 2);
         if ((g < P.dom_lo[0] && P.neum[0][0]) || (g > P.dom_hi[0] && P.neum[0][1])) cmp = false;
         if ((gj < P.dom_lo[1] && P.neum[1][0]) || (gj > P.dom_hi[1] && P.neum[1][1])) cmp = false;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         if ((l < 0 && (p.cf & 1)) || (l >= p.n[0] && (p.cf & 2))) cmp = false;
         if ((lj < 0 && (p.cf & 4)) || (lj >= p.n[1] && (p.cf & 8))) cmp = false;
         comp_ij[s] = cmp;
-        out_ij[s] = (l >= 0) && (l < p.n[0]) && (lj >= 0) && (lj < p.n[1]) && (r >= 2) && (r < FR_I - 2) &&
+        out_ij[s] = (l >= 0) && (l < p.n[0]) && (lj >= 0) && (lj < p.n[1]) && (r >= 2) && (r < wi + 2) &&
                     (row >= 2) && (row < FR_J - 2);
     }
     const long long sj = p.pj, sk = p.pk;

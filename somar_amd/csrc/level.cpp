@@ -584,6 +584,15 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     auto march_tiles = [&](int FT_I, int FT_J, double halo) {
         long long cols = 0;
         int maxn2 = 1;
+        // tile columns of equal (even) width per box: 128 cells -> 2 x 64, 512 -> 5 x 104 (104,104,104,104,96), never
+        // a nearly empty last column (a 4-wide remainder tile marches all planes for 3 % of the work)
+        auto tile_w = [&](int n0) {
+            const int ncol = (n0 + FT_I - 1) / FT_I;
+            int w = (n0 + ncol - 1) / ncol;
+            w += w & 1;
+            return std::min(w, FT_I);
+        };
+        static const bool balanced = getenv("SOMAR_NO_BALANCED_TILES") == nullptr;  // A/B switch
         for (const PatchDesc& p : hpatches) {
             cols += (long long)((p.n[0] + FT_I - 1) / FT_I) * ((p.n[1] + FT_J - 1) / FT_J);
             maxn2 = std::max(maxn2, p.n[2]);
@@ -602,13 +611,15 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
             const PatchDesc& p = hpatches[pi];
             int nk = (p.n[2] + best - 1) / best;
             nk += nk & 1;  // even chunks: a chunk never splits the two planes of a coarse cell (fused restriction)
+            const int wstep = balanced ? tile_w(p.n[0]) : FT_I;
             for (int k0 = 0; k0 < p.n[2]; k0 += nk)
                 for (int j0 = 0; j0 < p.n[1]; j0 += FT_J)
-                    for (int i0 = 0; i0 < p.n[0]; i0 += FT_I) {
+                    for (int i0 = 0; i0 < p.n[0]; i0 += wstep) {
                         Tile t;
                         std::memset(&t, 0, sizeof(t));
                         t.patch = pi; t.i0 = i0; t.j0 = j0; t.k0 = k0;
                         t.nk = std::min(nk, p.n[2] - k0);
+                        t.pad_[0] = wstep;
                         fnat.push_back(t);
                     }
         }

@@ -50,20 +50,21 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
     const int lane = threadIdx.x, row = threadIdx.y;
     const int ri = 2 * lane;
     const int li = t.i0 - 2 + ri;  // even: rows are 16-byte aligned
+    const int wi = t.pad_[0] > 0 ? t.pad_[0] : RM_I - 4;  // output columns of this tile (see gsrb_fused.hip)
     const int lj = t.j0 - 1 + row;
     const int gj = p.lo[1] + lj;
     const double sx = 1.0 / P.dx[0], sy = 1.0 / P.dx[1], sz = 1.0 / P.dx[2];
 
     // phi may be touched inside the 1-cell ghost layer, coefficients only at the tile's own cells / faces
     const bool fj = (lj >= -1) && (lj <= p.n[1]);
-    const bool f0 = fj && (li >= -1) && (li <= p.n[0]);
-    const bool f1 = fj && (li + 1 >= -1) && (li + 1 <= p.n[0]);
+    const bool f0 = fj && (li >= -1) && (li <= p.n[0]) && (ri < wi + 4);
+    const bool f1 = fj && (li + 1 >= -1) && (li + 1 <= p.n[0]) && (ri + 1 < wi + 4);
     const bool own_j = (lj >= 0) && (lj < p.n[1]) && (row >= 1) && (row <= RM_J - 2) && (lj < t.j0 + (RM_J - 2));
     bool o[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int l = li + s, r = ri + s;
-        o[s] = own_j && (l >= 0) && (l < p.n[0]) && (r >= 2) && (r < RM_I - 2);
+        o[s] = own_j && (l >= 0) && (l < p.n[0]) && (r >= 2) && (r < wi + 2);
     }
     // Jg^xx is also needed on the face right of the pair's second cell (next lane's first component): load the
     // pair if either of its cells, or the cell left of it, is an output cell
