@@ -52,7 +52,7 @@ void launch_sum_partials(hipStream_t st, const double* partials, int n, double* 
 void launch_combine_sums(hipStream_t st, double* out, const double* a, const double* b, const double* c);
 // one colour of vertical-line GSRB (line_gsrb.hip); ctiles = whole-column tiles (k0 = 0, nk = n2)
 void launch_line_gsrb_ortho(hipStream_t st, const Tile* ctiles, int nctiles, int tile_j, const LevelDev& L,
-                            double* phi, const double* rhs, double* dmod, int color);
+                            double* phi, const double* rhs, double* dmod, int color, const double* psi = nullptr);
 void launch_op_ortho(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* rhs, int mode);
 void launch_lapdiag(hipStream_t st, const LevelDev& L);
 void launch_diag(hipStream_t st, const LevelDev& L, double* phi, const double* r, int mode);

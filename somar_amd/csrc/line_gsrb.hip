@@ -23,6 +23,9 @@
 
 namespace somar {
 
+struct LJ9 { const double* c[3][3]; };  // c[faceDir][component], non-diagonal metric
+
+template <bool FULL>
 __global__ __launch_bounds__(256) void k_line_gsrb_ortho(const Tile* __restrict__ tiles,
                                                          const PatchDesc* __restrict__ patches,
                                                          double* __restrict__ phi,
@@ -31,7 +34,8 @@ __global__ __launch_bounds__(256) void k_line_gsrb_ortho(const Tile* __restrict_
                                                          const double* __restrict__ jgy,
                                                          const double* __restrict__ jgz,
                                                          const double* __restrict__ jinv,
-                                                         double* __restrict__ dmod, StencilParams P, int color)
+                                                         double* __restrict__ dmod, StencilParams P, int color,
+                                                         LJ9 J, const double* __restrict__ E)
 {
     const Tile t = tiles[blockIdx.x];
     const PatchDesc p = patches[t.patch];
@@ -71,7 +75,31 @@ __global__ __launch_bounds__(256) void k_line_gsrb_ortho(const Tile* __restrict_
         if (!nxh) { JDxx = JDxx + jgx[c + 1] * phi[c + 1];    lapDiag = lapDiag - xxScale * jgx[c + 1]; }
         if (!nyl) { JDyy = JDyy + jgy[c] * phi[c - sj];       lapDiag = lapDiag - yyScale * jgy[c]; }
         if (!nyh) { JDyy = JDyy + jgy[c + sj] * phi[c + sj];  lapDiag = lapDiag - yyScale * jgy[c + sj]; }
-        const double lphi = JDxx * xxScale + JDyy * yyScale;
+        double lphi;
+        if (FULL) {
+            // cross terms from the extrapolated copy (explicit, as in LineGSRBIter3D): GSRBF.ChF:1730-2042
+            const double xyScale = P.beta * 0.25 / (P.dx[0] * P.dx[1]);
+            const double yzScale = P.beta * 0.25 / (P.dx[1] * P.dx[2]);
+            const double zxScale = P.beta * 0.25 / (P.dx[2] * P.dx[0]);
+#define EE(di, dj, dk) E[c + (di) + sj * (dj) + sk * (dk)]
+            const double JDxy = J.c[0][1][c + 1] * (EE(1, 1, 0) - EE(1, -1, 0) + EE(0, 1, 0) - EE(0, -1, 0)) -
+                                J.c[0][1][c] * (EE(0, 1, 0) - EE(0, -1, 0) + EE(-1, 1, 0) - EE(-1, -1, 0));
+            const double JDxz = J.c[0][2][c + 1] * (EE(1, 0, 1) - EE(1, 0, -1) + EE(0, 0, 1) - EE(0, 0, -1)) -
+                                J.c[0][2][c] * (EE(0, 0, 1) - EE(0, 0, -1) + EE(-1, 0, 1) - EE(-1, 0, -1));
+            const double JDyx = J.c[1][0][c + sj] * (EE(1, 1, 0) - EE(-1, 1, 0) + EE(1, 0, 0) - EE(-1, 0, 0)) -
+                                J.c[1][0][c] * (EE(1, 0, 0) - EE(-1, 0, 0) + EE(1, -1, 0) - EE(-1, -1, 0));
+            const double JDyz = J.c[1][2][c + sj] * (EE(0, 1, 1) - EE(0, 1, -1) + EE(0, 0, 1) - EE(0, 0, -1)) -
+                                J.c[1][2][c] * (EE(0, 0, 1) - EE(0, 0, -1) + EE(0, -1, 1) - EE(0, -1, -1));
+            const double JDzx = J.c[2][0][c + sk] * (EE(1, 0, 1) - EE(-1, 0, 1) + EE(1, 0, 0) - EE(-1, 0, 0)) -
+                                J.c[2][0][c] * (EE(1, 0, 0) - EE(-1, 0, 0) + EE(1, 0, -1) - EE(-1, 0, -1));
+            const double JDzy = J.c[2][1][c + sk] * (EE(0, 1, 1) - EE(0, -1, 1) + EE(0, 1, 0) - EE(0, -1, 0)) -
+                                J.c[2][1][c] * (EE(0, 1, 0) - EE(0, -1, 0) + EE(0, 1, -1) - EE(0, -1, -1));
+#undef EE
+            lphi = JDxx * xxScale + JDyy * yyScale + (JDyz + JDzy) * yzScale + (JDzx + JDxz) * zxScale +
+                   (JDxy + JDyx) * xyScale;
+        } else {
+            lphi = JDxx * xxScale + JDyy * yyScale;
+        }
         const double Ji = jinv[c];
         double B = -lphi + rhs[c] / Ji;
         double D = P.alpha / Ji + lapDiag;
@@ -99,11 +127,18 @@ __global__ __launch_bounds__(256) void k_line_gsrb_ortho(const Tile* __restrict_
 }
 
 void launch_line_gsrb_ortho(hipStream_t st, const Tile* ctiles, int nctiles, int tile_j, const LevelDev& L,
-                            double* phi, const double* rhs, double* dmod, int color)
+                            double* phi, const double* rhs, double* dmod, int color, const double* psi)
 {
     if (nctiles == 0) return;
-    hipLaunchKernelGGL(k_line_gsrb_ortho, dim3(nctiles), dim3(64, tile_j, 1), 0, st, ctiles, L.patches, phi, rhs,
-                       L.jg[0], L.jg[1], L.jg[2], L.jinv, dmod, L.P, color);
+    LJ9 J;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) J.c[a][b] = L.jgf[a][b];
+    if (psi)
+        hipLaunchKernelGGL(k_line_gsrb_ortho<true>, dim3(nctiles), dim3(64, tile_j, 1), 0, st, ctiles, L.patches, phi, rhs,
+                           L.jg[0], L.jg[1], L.jg[2], L.jinv, dmod, L.P, color, J, psi);
+    else
+        hipLaunchKernelGGL(k_line_gsrb_ortho<false>, dim3(nctiles), dim3(64, tile_j, 1), 0, st, ctiles, L.patches, phi, rhs,
+                           L.jg[0], L.jg[1], L.jg[2], L.jinv, dmod, L.P, color, J, psi);
 }
 
 }  // namespace somar

@@ -376,9 +376,10 @@ void PressureSolver::finalize()
     f_scratch.assign(D, nullptr);
     f_pp.assign(D, nullptr);
     if (full_) {
-        SOMAR_CHECK(prm.relaxMode == RELAX_LEVEL_GSRB || prm.relaxMode == RELAX_JACOBI,
-                    "the non-diagonal metric path offers LevelGSRB and Jacobi");
-        SOMAR_CHECK(prm.precondMode != PRECOND_DIAG_LINE_RELAX, "no line relaxation with a non-diagonal metric");
+        SOMAR_CHECK(prm.relaxMode == RELAX_LEVEL_GSRB || prm.relaxMode == RELAX_JACOBI || prm.relaxMode == RELAX_LINE_GSRB,
+                    "the non-diagonal metric path offers LevelGSRB, LineGSRB and Jacobi");
+        SOMAR_CHECK(prm.spaceDim == 3 || (prm.relaxMode != RELAX_LINE_GSRB && prm.precondMode != PRECOND_DIAG_LINE_RELAX),
+                    "line relaxation is implemented for space_dim 3 only");
         f_psi.assign(D, nullptr);
         full_prog_.resize(D);
         for (int d = 0; d < D; ++d) {
@@ -613,8 +614,9 @@ void PressureSolver::line_relax(int d, double* e, const double* res)
     for (int pass = 0; pass < 2; ++pass) {
         L.exchange(e, st_);
         L.cf_homog(e, st_);  // fillGhostsAndExtrapolate: homogeneous CF values in the lateral ghost cells
-        if (diri_) apply_diri(d, e, true);  // ... and the ghosts of lateral Dirichlet sides (the vertical ends are folded in)
-        launch_line_gsrb_ortho(st_, L.d_ctiles, L.nctiles, L.ctile_j, L.dev, e, res, f_pp[d], pass);
+        if (diri_ && !full_) apply_diri(d, e, true);  // ... and the ghosts of lateral Dirichlet sides (the vertical ends are folded in)
+        if (full_) run_full_program(d, 1, e);  // extrap copy (order 1) + physical ghosts: the cross terms are explicit
+        launch_line_gsrb_ortho(st_, L.d_ctiles, L.nctiles, L.ctile_j, L.dev, e, res, f_pp[d], pass, full_ ? f_psi[d] : nullptr);
     }
 }
 

@@ -154,3 +154,49 @@ def test_line_gsrb_with_dirichlet_sides_bit_exact(oracle, types):
             np.testing.assert_array_equal(g, w)
     finally:
         gpu.undefine()
+
+
+@pytest.mark.parametrize("per", [(False, True, False), (False, False, False)])
+def test_line_gsrb_with_a_nondiagonal_metric_bit_exact_and_solve(oracle, per):
+    """LineGSRBIter3D's explicit cross terms (from the extrapolated copy) next to the implicit column solve."""
+    from somar_amd import AMRPressureSolver
+    from somar_amd import api as F
+    so = oracle
+    n, bs, L = (16, 16, 8), 8, (2.0, 1.0, 0.5)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), per)
+    grids = so.split_domain(dom.box, bs)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_full_metric(grids, dx, L, dom)
+    fac = so.Factory(dom, grids, dx, so.BCHolder(), Jgup, Jinv, isDiagonal=False, relaxMode=so.RELAX_LINE_GSRB)
+    amr = so.AMRMultiGrid(fac, so.BiCGStab())
+    s = AMRPressureSolver()
+    p = s._p
+    s.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 3, p.num_mg, p.hang,
+                         p.norm_thresh, 0)
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids])
+    for q in range(s.num_local_patches):
+        _, _, gi = s.patch_box(q)
+        s.setMetricFull(q, *[np.asfortranarray(Jgup[gi][d].a) for d in range(3)], np.asfortranarray(Jinv[gi].a[..., 0]))
+    s.finalize()
+    try:
+        op = amr.mg.ops[0]
+        phi = so.random_field(grids, 41, (1, 1, 1), dom.box)
+        rhs = so.random_field(grids, 42, (0, 0, 0), dom.box)
+        upload(s, F.F_PHI, phi)
+        upload(s, F.F_RHS, rhs)
+        op.relax(phi, rhs, 2)
+        s.relax(0, F.F_PHI, F.F_RHS, 2)
+        for g, w in zip(download_valid(s, F.F_PHI, grids), valid_of(phi)):
+            np.testing.assert_array_equal(g, w)
+        phi0 = so.random_field(grids, 3, (1, 1, 1), dom.box)
+        b = so.LevelData(grids, 1)
+        amr.op.apply_op(b, phi0, True)
+        x = so.LevelData(grids, 1, (1, 1, 1))
+        amr.solve(x, b)
+        gx = [np.zeros(f.a.shape[:3], order="F") for f in x.fabs]
+        gb = [np.asfortranarray(f.a[..., 0]) for f in b.fabs]
+        st = s.solve(gx, gb, 0, 0, True, False)
+        assert st["iters"] == amr.iters and st["exitStatus"] == amr.exitStatus
+        np.testing.assert_allclose(st["history"], amr.history, rtol=1e-9, atol=1e-12 * amr.history[0])
+    finally:
+        s.undefine()
