@@ -35,23 +35,6 @@ B_RESIDUAL = 56.0              # algorithmic B/cell of the fused residual
 N_FINE = 512
 
 
-def partition(n, ngpus):
-    """one box per GPU; split z then y then x so x rows stay long (coalescing) as long as possible"""
-    # x is never split: the marching kernels' tiles are 124 cells wide, a 512-wide box wastes 3 % of its tile columns,
-    # a 256-wide one 28 % (DESIGN.md 7); the halo surface of 512x256x128 equals that of 256^3
-    split = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (1, 2, 4)}.get(ngpus)
-    if split is None:
-        raise SystemExit("--gpus must be 1, 2, 4 or 8")
-    boxes = []
-    sz = [n // s for s in split]
-    for k in range(split[2]):
-        for j in range(split[1]):
-            for i in range(split[0]):
-                lo = (i * sz[0], j * sz[1], k * sz[2])
-                boxes.append((lo, tuple(l + s - 1 for l, s in zip(lo, sz))))
-    return boxes
-
-
 def cpu_baseline(sample_n=256):
     """oracle V-cycle on a bounded sample, scaled to V-cycles/s at 512^3 (work is linear in cells)."""
     import ctypes as C
@@ -89,11 +72,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
-    from oracle import somar_oracle as so   # only for the synthetic-metric generator and the cpu_baseline leg
-    from somar_amd import api
-    from helpers import make_gpu_solver
+    from somar_amd import api, synthetic   # the measured path never touches oracle/ (only cpu_baseline() below does)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -122,25 +102,23 @@ def main():
     n = args.n
     L = (1.0, 1.0, 1.0)
     dx = tuple(L[d] / n for d in range(3))
-    boxes = partition(n, world)
-    dom = so.Domain(so.Box((0, 0, 0), (n - 1,) * 3))
-    grids = [so.Box(lo, hi) for lo, hi in boxes]
+    boxes = synthetic.slab_partition(n, world)
     owner = list(range(world))
-    # each rank generates the metric of ITS box only (helpers index Jgup/Jinv by global box number)
-    mine = so.make_diagonal_metric([grids[rank]], dx, L, 3, "stretched")
-
-    class _ByGlobal:
-        def __init__(self, x):
-            self.x = x
-
-        def __getitem__(self, gi):
-            assert gi == rank
-            return self.x[0]
-
     t_def = time.perf_counter()
-    gpu = make_gpu_solver(dom, grids, dx, _ByGlobal(mine[0]), _ByGlobal(mine[1]), owner=owner, comm=comm)
+    gpu = api.AMRPressureSolver()
+    p = gpu._p
+    gpu.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg,
+                           p.hang, p.norm_thresh, 0)
+    gpu.define((0, 0, 0), (n - 1,) * 3, (False, False, False), dx, boxes, owner=owner, comm=comm)
+    for q in range(gpu.num_local_patches):
+        lo, hi, gi = gpu.patch_box(q)
+        assert gi == rank
+        # each rank evaluates the metric of ITS box only
+        jg, jinv = synthetic.stretched_diagonal_metric(lo, hi, dx, L)
+        gpu.setMetricOrtho(q, jg[0], jg[1], jg[2], jinv)
+        del jg, jinv
+    gpu.finalize()
     t_def = time.perf_counter() - t_def
-    del mine
     F = api
     depth = gpu.depth()
     cells_total = n ** 3
