@@ -104,7 +104,7 @@ def main():
     dx = tuple(L[d] / n for d in range(3))
     boxes = synthetic.slab_partition(n, world)
     owner = list(range(world))
-    t_def = time.perf_counter()
+    t_def = -time.perf_counter()
     gpu = api.AMRPressureSolver()
     p = gpu._p
     gpu.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg,
@@ -113,12 +113,14 @@ def main():
     for q in range(gpu.num_local_patches):
         lo, hi, gi = gpu.patch_box(q)
         assert gi == rank
-        # each rank evaluates the metric of ITS box only
+        # each rank evaluates the metric of ITS box only (host numpy; not part of define_seconds)
+        t_def += time.perf_counter()
         jg, jinv = synthetic.stretched_diagonal_metric(lo, hi, dx, L)
+        t_def -= time.perf_counter()
         gpu.setMetricOrtho(q, jg[0], jg[1], jg[2], jinv)
         del jg, jinv
     gpu.finalize()
-    t_def = time.perf_counter() - t_def
+    t_def += time.perf_counter()
     F = api
     depth = gpu.depth()
     cells_total = n ** 3
