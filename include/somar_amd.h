@@ -183,6 +183,27 @@ int somar_mac_project(somar_solver_t* s, double dt, int zero_pressure, int force
 int somar_mac_project_host(somar_solver_t* s, double* const* u0, double* const* u1, double* const* u2, double dt,
                            int zero_pressure, int force_homogeneous, somar_stats_t* stats);
 
+/* Cell-centred level projection of a velocity given in flux form (J u at cell centres; ONE host FArrayBox per local
+ * patch with SpaceDim components, component slowest, defined on valid grown by ghost[] >= 1 in every active direction;
+ * the ghost layer is used as the caller filled it -- the reference does not exchange it either):
+ *   rhs = div(CellToEdge(U))/dt with zero normal flux on solid walls ; solve ; U -= dt * EdgeToCell(Jg^{ab} d_b(phi)).
+ *   BaseProjector<FArrayBox>::project, a_velIsFlux = true      projection/BaseProjectorI.H:176-299
+ *   LevelCCProjector::computeDiv/computeGrad/applyCorrection    projection/LevelCCProjector.cpp:163-255
+ *   Divergence::levelDivergenceCC (CellToEdge + levelDivergenceMAC)   calculus/DivCurlGrad/Divergence.cpp:361-396
+ *   Gradient::levelGradientCC (levelGradientMAC + EdgeToCell)         calculus/DivCurlGrad/Gradient.cpp:469-495
+ * wall_bc != 0: the velocity BC of uStarFuncBC with no inflow/outflow side (BCutil/PhysBCUtil.cpp:793-801, 1261-1276):
+ * BasicVelocityBCGhostClass's solid wall = setSideDiriBC(0) on the averaged normal faces of every non-periodic side
+ * (calculus/BCInterface/EllipticBCUtils.cpp:1284-1327, 96-100).  wall_bc == 0: levelDivergenceCC with a_fluxBC = NULL.
+ * Only the valid cells of the host arrays are written back.  Single level (no coarse-fine velocity interpolation). */
+int somar_ccvel_upload(somar_solver_t* s, int patch, const double* host, const int* ghost);
+int somar_ccvel_download(somar_solver_t* s, int patch, double* host, const int* ghost);
+int somar_level_divergence_cc(somar_solver_t* s, int out_field, double dt, int wall_bc);
+int somar_level_cc_correct(somar_solver_t* s, int phi_field, double dt);
+int somar_cc_project(somar_solver_t* s, double dt, int zero_pressure, int force_homogeneous, int wall_bc,
+                     somar_stats_t* stats);
+int somar_cc_project_host(somar_solver_t* s, double* const* vel, const int* ghost, double dt, int zero_pressure,
+                          int force_homogeneous, int wall_bc, somar_stats_t* stats);
+
 /* stream control + HIP-event timing on the solver's own stream */
 int somar_sync(somar_solver_t* s);
 int somar_timer_start(somar_solver_t* s);

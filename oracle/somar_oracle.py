@@ -1507,6 +1507,92 @@ def mac_level_project(amr, vel, phi, dt, zeroPhi=True, ndim=3):
 
 
 # ----------------------------------------------------------------------------
+# Cell-centred level projection (single level; velocity in flux form J*u, SpaceDim comps, >= 1 ghost layer filled by
+# the caller -- the reference does not exchange the velocity either):
+#   BaseProjector<FArrayBox>::project            projection/BaseProjectorI.H:176-299
+#   LevelCCProjector::computeDiv/computeGrad/applyCorrection   projection/LevelCCProjector.cpp:163-255
+#   Divergence::levelDivergenceCC, the branch built by default (USE_SIMPLE_STENCIL is commented out, Divergence.cpp:37):
+#       CellToEdge, then levelDivergenceMAC with the velocity BC        Divergence.cpp:361-396, 44-127
+#   velocity BC on the averaged faces: uStarFuncBC -> basicVelFuncBC -> BasicVelocityBCGhostClass with no inflow /
+#       outflow side (BCutil/PhysBCUtil.cpp:793-801, 1261-1276): every non-periodic side is a solid wall, and both
+#       its viscous and inviscid branches call setSideDiriBC(0) for the wall-normal component
+#       (EllipticBCUtils.cpp:1284-1327), which on a face-centred FAB sets the boundary faces directly (:96-100)
+#       => the normal flux on physical boundary faces is 0.
+#   Gradient::levelGradientCC, default branch: levelGradientMAC, then EdgeToCell    Gradient.cpp:469-495
+#   CellToEdge / EdgeToCell are Chombo 3.1 (EXTERNAL, not under /root/reference); restated from the published source:
+#       edge_d(i) = half*(cell_d(i) + cell_d(i - e_d)) on the d-faces both of whose cells lie in the cell FAB,
+#       cell_d(i) = half*(edge_d(i) + edge_d(i + e_d)) on the valid box.   No reference fixture => parity unpinned.
+# ----------------------------------------------------------------------------
+def cell_to_edge(cc, edge, ndim=3):
+    """edge (1 comp) <- cc (comp d feeds the d-faces)"""
+    for i in range(len(cc.grids)):
+        cf = cc[i]
+        for d in range(ndim):
+            eb = cf.box.faces(d).growDir(d, -1) & edge[i][d].box
+            if eb.isEmpty():
+                continue
+            sh = [0, 0, 0]
+            sh[d] = -1
+            hi_cells = eb                       # face i <-> cell i
+            lo_cells = eb.shift(sh)             # ... and cell i - e_d
+            edge[i][d].view(eb, 0)[...] = 0.5 * (cf.view(hi_cells, d) + cf.view(lo_cells, d))
+
+
+def set_wall_normal_flux(edge, grids, domain, ndim=3):
+    """solid walls: BasicVelocityBCGhostClass -> setSideDiriBC(0) on the FC normal faces"""
+    for i, g in enumerate(grids):
+        for d in range(ndim):
+            if domain.periodic[d]:
+                continue
+            fb = g.faces(d)
+            if g.lo[d] == domain.box.lo[d]:
+                edge[i][d].view(fb.edgeCells(d, 0))[...] = 0.0
+            if g.hi[d] == domain.box.hi[d]:
+                edge[i][d].view(fb.edgeCells(d, 1))[...] = 0.0
+
+
+def edge_to_cell(edge, cc, ndim=3):
+    for i, g in enumerate(cc.grids):
+        for d in range(ndim):
+            sh = [0, 0, 0]
+            sh[d] = 1
+            cc[i].view(g, d)[...] = 0.5 * (edge[i][d].view(g, 0) + edge[i][d].view(g.shift(sh), 0))
+
+
+def level_divergence_cc(div, vel, Jinv, grids, domain, dx, ndim=3, wall=True):
+    edge = FluxData(grids, 1, ndim)
+    cell_to_edge(vel, edge, ndim)
+    if wall:
+        set_wall_normal_flux(edge, grids, domain, ndim)
+    level_divergence_mac(div, edge, Jinv, grids, dx, ndim)
+    return edge
+
+
+def level_gradient_cc(grad, phi, grids, domain, Jgup, dx, ndim=3, op=None):
+    edge = FluxData(grids, 1, ndim)
+    level_gradient_mac(edge, phi, grids, domain, Jgup, dx, ndim, op=op)
+    edge_to_cell(edge, grad, ndim)
+
+
+def cc_level_project(amr, vel, phi, dt, zeroPhi=True, ndim=3, wall=True):
+    """vel: LevelData (ndim comps, >= 1 ghost) holding J*u at cell centres; projected in place (valid cells).
+    Returns the right-hand side of the solve."""
+    op = amr.op
+    rhs = LevelData(op.grids, 1, (0, 0, 0))
+    level_divergence_cc(rhs, vel, op.Jinv, op.grids, op.domain, op.dx, ndim, wall)
+    if dt != 0.0:
+        for f in rhs.fabs:
+            f.a /= dt
+    amr.solve(phi, rhs, zeroPhi=zeroPhi)
+    corr = LevelData(op.grids, ndim, (0, 0, 0))
+    level_gradient_cc(corr, phi, op.grids, op.domain, op.Jgup, op.dx, ndim, op=op)
+    dtScale = -1.0 if dt == 0.0 else -dt
+    for i, g in enumerate(op.grids):
+        vel[i].view(g)[...] += dtScale * corr[i].a   # FArrayBox::plus(src, scale) over the common box
+    return rhs
+
+
+# ----------------------------------------------------------------------------
 # AlteredMetric::fill_Jgup (projection/AlteredMetric.cpp:82-198): the whole-FAB statements after the map has been
 # evaluated, one numpy statement per FArrayBox operation (same roundings).
 # ----------------------------------------------------------------------------

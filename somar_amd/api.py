@@ -104,6 +104,12 @@ _SIGS = {
     "somar_mac_project": [_H, C.c_double, C.c_int, C.c_int, C.POINTER(Stats)],
     "somar_mac_project_host": [_H, C.POINTER(_PD), C.POINTER(_PD), C.POINTER(_PD), C.c_double, C.c_int, C.c_int,
                                C.POINTER(Stats)],
+    "somar_ccvel_upload": [_H, C.c_int, _PD, _PI],
+    "somar_ccvel_download": [_H, C.c_int, _PD, _PI],
+    "somar_level_divergence_cc": [_H, C.c_int, C.c_double, C.c_int],
+    "somar_level_cc_correct": [_H, C.c_int, C.c_double],
+    "somar_cc_project": [_H, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
+    "somar_cc_project_host": [_H, C.POINTER(_PD), _PI, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
     "somar_sync": [_H],
     "somar_timer_start": [_H],
     "somar_timer_stop": [_H, _PD],
@@ -478,6 +484,29 @@ class AMRPressureSolver:
         st = Stats()
         _ck(lib().somar_mac_project_host(self._h, U[0], U[1], U[2], float(dt), int(zeroPressure),
                                          int(forceHomogeneous), C.byref(st)))
+        return self._stats(st)
+
+    # -- cell-centred level projection (LevelCCProjector, velocity in flux form, SpaceDim comps + ghosts) --
+    def uploadCCVel(self, patch, host, ghost):
+        _ck(lib().somar_ccvel_upload(self._h, patch, _dp(host), _ia(ghost)))
+
+    def downloadCCVel(self, patch, host, ghost):
+        """writes the valid cells of `host` (F-ordered (nx+2g, ny+2g, nz+2g, SpaceDim) array) in place"""
+        _ck(lib().somar_ccvel_download(self._h, patch, _dp(host), _ia(ghost)))
+
+    def divergenceCC(self, out_field, dt, wall=True):
+        _ck(lib().somar_level_divergence_cc(self._h, out_field, float(dt), int(wall)))
+
+    def ccCorrect(self, phi_field, dt):
+        _ck(lib().somar_level_cc_correct(self._h, phi_field, float(dt)))
+
+    def levelProjectCC(self, vel, ghost, dt, zeroPressure=True, forceHomogeneous=False, wall=True):
+        """vel: list (per local patch) of F-ordered arrays (valid + ghost, SpaceDim comps last); projected in place."""
+        n = self.num_local_patches
+        U = (_PD * n)(*[_dp(a) for a in vel])
+        st = Stats()
+        _ck(lib().somar_cc_project_host(self._h, U, _ia(ghost), float(dt), int(zeroPressure), int(forceHomogeneous),
+                                        int(wall), C.byref(st)))
         return self._stats(st)
 
     def sync(self):

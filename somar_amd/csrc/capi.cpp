@@ -548,6 +548,67 @@ int somar_mac_project_host(somar_solver_t* s, double* const* u0, double* const* 
     API_END
 }
 
+int somar_ccvel_upload(somar_solver_t* s, int patch, const double* host, const int* ghost)
+{
+    API_BEGIN
+    SOMAR_CHECK(host && ghost, "null pointer");
+    s->ps->upload_cc_vel(patch, host, ghost);
+    API_END
+}
+
+int somar_ccvel_download(somar_solver_t* s, int patch, double* host, const int* ghost)
+{
+    API_BEGIN
+    SOMAR_CHECK(host && ghost, "null pointer");
+    s->ps->download_cc_vel(patch, host, ghost);
+    API_END
+}
+
+int somar_level_divergence_cc(somar_solver_t* s, int out_field, double dt, int wall_bc)
+{
+    API_BEGIN
+    int d0;
+    double* out = field_ptr(s, out_field, &d0);
+    SOMAR_CHECK(d0 == 0, "the divergence lives on depth 0");
+    s->ps->divergence_cc(out, dt, wall_bc != 0);
+    API_END
+}
+
+int somar_level_cc_correct(somar_solver_t* s, int phi_field, double dt)
+{
+    API_BEGIN
+    int d0;
+    double* phi = field_ptr(s, phi_field, &d0);
+    SOMAR_CHECK(d0 == 0, "the correction lives on depth 0");
+    s->ps->cc_correct(phi, dt);
+    API_END
+}
+
+int somar_cc_project(somar_solver_t* s, double dt, int zero_pressure, int force_homogeneous, int wall_bc,
+                     somar_stats_t* stats)
+{
+    API_BEGIN
+    SolveStats st;
+    s->ps->cc_project(dt, zero_pressure != 0, force_homogeneous != 0, wall_bc != 0, st);
+    fill_stats(st, stats);
+    API_END
+}
+
+int somar_cc_project_host(somar_solver_t* s, double* const* vel, const int* ghost, double dt, int zero_pressure,
+                          int force_homogeneous, int wall_bc, somar_stats_t* stats)
+{
+    API_BEGIN
+    SOMAR_CHECK(vel && ghost, "null pointer");
+    PressureSolver& ps = *s->ps;
+    const int np = ps.level(0).npatches();
+    for (int p = 0; p < np; ++p) ps.upload_cc_vel(p, vel[p], ghost);
+    SolveStats st;
+    ps.cc_project(dt, zero_pressure != 0, force_homogeneous != 0, wall_bc != 0, st);
+    for (int p = 0; p < np; ++p) ps.download_cc_vel(p, vel[p], ghost);
+    fill_stats(st, stats);
+    API_END
+}
+
 int somar_sync(somar_solver_t* s)
 {
     API_BEGIN

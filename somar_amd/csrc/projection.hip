@@ -10,6 +10,14 @@
 //                  extrapolation (ELLIPTICEXTRAPBCGHOST, EllipticBCUtilsF.ChF:165-173; BC holder
 //                  PhysBCUtil.cpp:1432-1443) and LevelMACProjector::applyCorrection (LevelMACProjector.cpp:222-241)
 //                  fused: the gradient temporary (3 face arrays written + read) never exists.
+//   k_cell_to_edge U^a on a-faces = half*(u^a_i + u^a_{i-e_a}) from a cell-centred velocity with one ghost layer, and 0
+//                  on physical boundary faces: Chombo CellToEdge (EXTERNAL) as called by Divergence::levelDivergenceCC
+//                  (Divergence.cpp:361-396) + the solid-wall branch of BasicVelocityBCGhostClass, i.e. setSideDiriBC(0)
+//                  on face-centred data (EllipticBCUtils.cpp:1284-1327, 96-100), applied by levelDivergenceMAC (:44-127)
+//   k_cc_correct   u^a_i -= dt * half*(G^a_i + G^a_{i+e_a}),  G = the MAC gradient above: Gradient::levelGradientCC's
+//                  levelGradientMAC + Chombo EdgeToCell (Gradient.cpp:469-495) + LevelCCProjector::applyCorrection
+//                  (LevelCCProjector.cpp:232-255) in one pass; neither the face gradient nor its cell average is stored
+//   k_edge_to_cell_axpy  the same average of a STORED face gradient (non-diagonal metric: singleBoxMacGrad's output)
 // Same operation order as the reference => bit-identical to the oracle.
 #include "common.h"
 #include "kernels.h"
@@ -166,6 +174,124 @@ void launch_mac_correct(hipStream_t st, const LevelDev& L, double* const vel[3],
     hipLaunchKernelGGL(k_mac_correct<0>, g, b, 0, st, L.tiles, L.patches, vel[0], phi, L.jg[0], L.P, dtScale);
     hipLaunchKernelGGL(k_mac_correct<1>, g, b, 0, st, L.tiles, L.patches, vel[1], phi, L.jg[1], L.P, dtScale);
     hipLaunchKernelGGL(k_mac_correct<2>, g, b, 0, st, L.tiles, L.patches, vel[2], phi, L.jg[2], L.P, dtScale);
+}
+
+// One direction per launch; thread = cell (i-pair), it owns the LOW face of each of its cells and, for the last cell of
+// the box in direction DIR, also the HIGH face (the layout of k_mac_correct).  cc carries one filled ghost layer.
+template <int DIR>
+__global__ __launch_bounds__(512) void k_cell_to_edge(const Tile* __restrict__ tiles,
+                                                      const PatchDesc* __restrict__ patches,
+                                                      double* __restrict__ edge, const double* __restrict__ cc,
+                                                      StencilParams P, int wall)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1]) return;
+    const long long s = DIR == 0 ? 1 : (DIR == 1 ? (long long)p.pj : p.pk);
+    const bool walls = wall && !P.periodic[DIR];
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int li = li0 + q;
+            if (li >= p.n[0]) continue;
+            const int lk = t.k0 + kk;
+            const int l = DIR == 0 ? li : (DIR == 1 ? lj : lk);
+            const int g = p.lo[DIR] + l;
+            const long long c = pidx(p, li, lj, lk);
+            const double uc = cc[c];
+            double v = 0.5 * (uc + cc[c - s]);
+            if (walls && g == P.dom_lo[DIR]) v = 0.0;
+            edge[c] = v;
+            if (l == p.n[DIR] - 1) {
+                double w = 0.5 * (cc[c + s] + uc);
+                if (walls && g == P.dom_hi[DIR]) w = 0.0;
+                edge[c + s] = w;
+            }
+        }
+}
+
+struct CC3 { double* u[3]; const double* g[3]; };
+
+// Diagonal metric: both face gradients of a cell from phi (exchanged; physical ghosts by order-2 extrapolation exactly as
+// in k_mac_correct), their average, and the correction, per component.
+__global__ __launch_bounds__(512) void k_cc_correct(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ patches,
+                                                    CC3 f, const double* __restrict__ phi, StencilParams P,
+                                                    double dtScale)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1]) return;
+    const long long st[3] = {1, (long long)p.pj, p.pk};
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int l[3] = {li0 + q, lj, t.k0 + kk};
+            if (l[0] >= p.n[0]) continue;
+            const long long c = p.off + l[0] + st[1] * l[1] + st[2] * l[2];
+            const double pc = phi[c];
+            for (int a = 0; a < 3; ++a) {
+                if (!f.u[a]) continue;
+                const long long s = st[a];
+                const int g = p.lo[a] + l[a];
+                const double dxinv = 1.0 / P.dx[a];
+                double pm = phi[c - s];
+                if (g == P.dom_lo[a] && !P.periodic[a]) pm = 3.0 * (pc - phi[c + s]) + phi[c + 2 * s];
+                double pp = phi[c + s];
+                if (g == P.dom_hi[a] && !P.periodic[a]) pp = 3.0 * (pc - phi[c - s]) + phi[c - 2 * s];
+                const double glo = dxinv * f.g[a][c] * (pc - pm);
+                const double ghi = dxinv * f.g[a][c + s] * (pp - pc);
+                f.u[a][c] = f.u[a][c] + dtScale * (0.5 * (glo + ghi));
+            }
+        }
+}
+
+__global__ __launch_bounds__(512) void k_edge_to_cell_axpy(const Tile* __restrict__ tiles,
+                                                           const PatchDesc* __restrict__ patches, CC3 f, double dtScale)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1]) return;
+    const long long st[3] = {1, (long long)p.pj, p.pk};
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int l0 = li0 + q;
+            if (l0 >= p.n[0]) continue;
+            const long long c = p.off + l0 + st[1] * lj + st[2] * (t.k0 + kk);
+            for (int a = 0; a < 3; ++a) {
+                if (!f.u[a]) continue;
+                f.u[a][c] = f.u[a][c] + dtScale * (0.5 * (f.g[a][c] + f.g[a][c + st[a]]));
+            }
+        }
+}
+
+void launch_cell_to_edge(hipStream_t st, const LevelDev& L, double* const edge[3], double* const cc[3], bool wall)
+{
+    if (L.ntiles == 0) return;
+    const dim3 g(L.ntiles), b(64, L.tile_j, 1);
+    const int w = wall ? 1 : 0;
+    if (cc[0]) hipLaunchKernelGGL(k_cell_to_edge<0>, g, b, 0, st, L.tiles, L.patches, edge[0], cc[0], L.P, w);
+    if (cc[1]) hipLaunchKernelGGL(k_cell_to_edge<1>, g, b, 0, st, L.tiles, L.patches, edge[1], cc[1], L.P, w);
+    if (cc[2]) hipLaunchKernelGGL(k_cell_to_edge<2>, g, b, 0, st, L.tiles, L.patches, edge[2], cc[2], L.P, w);
+}
+
+void launch_cc_correct(hipStream_t st, const LevelDev& L, double* const cc[3], const double* phi, double dtScale)
+{
+    if (L.ntiles == 0) return;
+    CC3 f;
+    for (int a = 0; a < 3; ++a) { f.u[a] = cc[a]; f.g[a] = L.jg[a]; }
+    hipLaunchKernelGGL(k_cc_correct, dim3(L.ntiles), dim3(64, L.tile_j, 1), 0, st, L.tiles, L.patches, f, phi, L.P, dtScale);
+}
+
+void launch_edge_to_cell_axpy(hipStream_t st, const LevelDev& L, double* const cc[3], double* const grad[3], double dtScale)
+{
+    if (L.ntiles == 0) return;
+    CC3 f;
+    for (int a = 0; a < 3; ++a) { f.u[a] = cc[a]; f.g[a] = grad[a]; }
+    hipLaunchKernelGGL(k_edge_to_cell_axpy, dim3(L.ntiles), dim3(64, L.tile_j, 1), 0, st, L.tiles, L.patches, f, dtScale);
 }
 
 }  // namespace somar

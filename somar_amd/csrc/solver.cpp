@@ -37,6 +37,7 @@ PressureSolver::~PressureSolver()
     drop_graphs();
     for (GhostOp* q : d_diri_ops_) hipFree(q);
     for (double* q : f_flux) Level::free_field(q);
+    for (double* q : f_ccvel) Level::free_field(q);
     hipFree(d_extrapbc_ops_);
     if (st_) hipStreamSynchronize(st_);
     for (double* f : f_res) hipFree(f);
@@ -825,6 +826,73 @@ void PressureSolver::mac_project(double dt, bool zeroPressure, bool forceHomogen
     divergence_mac(f_rhs, dt);
     solve(zeroPressure, forceHomogeneous, s);
     mac_correct(f_phi, dt);
+    sync();
+}
+
+// ------------------------------------------------------------------------------------
+// Cell-centred level projection: BaseProjector<FArrayBox>::project (projection/BaseProjectorI.H:176-299) with
+// LevelCCProjector::computeDiv/computeGrad/applyCorrection (LevelCCProjector.cpp:163-255), velocity in flux form.
+// The velocity's ghost layer is the caller's (the reference does not exchange it before CellToEdge either).
+// ------------------------------------------------------------------------------------
+double* PressureSolver::cc_vel(int comp)
+{
+    SOMAR_CHECK(comp >= 0 && comp < prm.spaceDim && finalized, "bad velocity component / solver not finalized");
+    if (!f_ccvel[comp]) f_ccvel[comp] = lev[0]->alloc_field();
+    return f_ccvel[comp];
+}
+
+void PressureSolver::upload_cc_vel(int patch, const double* host, const int ghost[3])
+{
+    Level& L = *lev[0];
+    SOMAR_CHECK(patch >= 0 && patch < L.npatches(), "bad patch index");
+    const IBox valid = L.boxes[L.local[patch]];
+    int one[3] = {0, 0, 0};
+    for (int d = 0; d < prm.spaceDim; ++d) {
+        SOMAR_CHECK(ghost[d] >= 1, "the cell-centred velocity needs one ghost layer (CellToEdge reads it)");
+        one[d] = 1;
+    }
+    const IBox hb = valid.grow(ghost);
+    for (int c = 0; c < prm.spaceDim; ++c) L.upload(cc_vel(c), patch, host + (long long)c * hb.numPts(), hb, valid.grow(one), st_);
+    sync();
+}
+
+void PressureSolver::download_cc_vel(int patch, double* host, const int ghost[3])
+{
+    Level& L = *lev[0];
+    SOMAR_CHECK(patch >= 0 && patch < L.npatches(), "bad patch index");
+    const IBox valid = L.boxes[L.local[patch]];
+    const IBox hb = valid.grow(ghost);
+    for (int c = 0; c < prm.spaceDim; ++c) L.download(cc_vel(c), patch, host + (long long)c * hb.numPts(), hb, valid, st_);
+    sync();
+}
+
+void PressureSolver::divergence_cc(double* out, double dt, bool wall)
+{
+    double* e[3] = {vel(0), vel(1), vel(2)};
+    double* c[3] = {cc_vel(0), cc_vel(1), prm.spaceDim == 3 ? cc_vel(2) : nullptr};
+    launch_cell_to_edge(st_, lev[0]->dev, e, c, wall);  // Divergence::levelDivergenceCC, Divergence.cpp:361-396
+    divergence_mac(out, dt);
+}
+
+void PressureSolver::cc_correct(double* phi, double dt)
+{
+    Level& L = *lev[0];
+    L.exchange(phi, st_);
+    double* c[3] = {cc_vel(0), cc_vel(1), prm.spaceDim == 3 ? cc_vel(2) : nullptr};
+    const double dtScale = dt == 0.0 ? -1.0 : -dt;
+    if (full_) {
+        mac_grad_full(phi);  // singleBoxMacGrad's sequence, as in mac_correct
+        launch_edge_to_cell_axpy(st_, L.dev, c, f_flux, dtScale);
+        return;
+    }
+    launch_cc_correct(st_, L.dev, c, phi, dtScale);
+}
+
+void PressureSolver::cc_project(double dt, bool zeroPressure, bool forceHomogeneous, bool wall, SolveStats& s)
+{
+    divergence_cc(f_rhs, dt, wall);
+    solve(zeroPressure, forceHomogeneous, s);
+    cc_correct(f_phi, dt);
     sync();
 }
 

@@ -149,6 +149,13 @@ public:
     void divergence_mac(double* out, double dt);                 // out = div(vel) [/ dt]
     void mac_correct(double* phi, double dt);                    // vel -= dt * G(phi)
     void mac_project(double dt, bool zeroPressure, bool forceHomogeneous, SolveStats& st);
+    // cell-centred level projection (LevelCCProjector): velocity J*u, SpaceDim comps, resident with one ghost layer
+    double* cc_vel(int comp);
+    void upload_cc_vel(int patch, const double* host, const int ghost[3]);   // host FAB: SpaceDim comps, comp slowest
+    void download_cc_vel(int patch, double* host, const int ghost[3]);       // valid cells only are written
+    void divergence_cc(double* out, double dt, bool wall);                   // CellToEdge [+ wall BC] -> vel(); div [/ dt]
+    void cc_correct(double* phi, double dt);                                 // cc_vel -= dt * EdgeToCell(G(phi))
+    void cc_project(double dt, bool zeroPressure, bool forceHomogeneous, bool wall, SolveStats& st);
     void remove_mean(int d, double* f);
     void sync();
     // per-kernel HIP-event timing of the depth-0 launches (0 = GSRB colour pass, 1 = operator/residual)
@@ -176,6 +183,7 @@ private:
     void fill_metric_ghosts(Level& L);
     void line_relax(int d, double* e, const double* res);
     double* f_vel[3] = {nullptr, nullptr, nullptr};
+    double* f_ccvel[3] = {nullptr, nullptr, nullptr};
     double* f_amr[2] = {nullptr, nullptr};
     bool hasCF_ = false;
     bool own_stream_ = true;

@@ -167,3 +167,102 @@ def test_full_metric_gradient_correction_bit_exact_and_projection(oracle, case):
             assert max_rel_diff(gvel[d], want) < 1e-7
     finally:
         gpu.undefine()
+
+
+# ---- cell-centred level projection (LevelCCProjector): CellToEdge + wall BC + divergence, gradient + EdgeToCell ----
+def _cc_velocity(so, dom, grids, ghost):
+    """a smooth cell field (3 comps) on valid + ghost cells; ghost cells that are another box's (or a periodic image's)
+    valid cells hold that cell's value, physical ghosts hold the same smooth formula continued outside"""
+    vel = so.LevelData(grids, 3, ghost)
+    n = dom.box.size()
+    for f in vel.fabs:
+        I, J, K = np.meshgrid(*[np.arange(f.box.lo[a], f.box.hi[a] + 1) for a in range(3)], indexing="ij")
+        for d in range(3):
+            f.a[..., d] = (np.sin(2 * np.pi * (I + 0.5) / n[0] + 0.1 * d) * np.cos(2 * np.pi * (J + 0.5) / n[1] + 0.3)
+                           * np.cos(2 * np.pi * (K + 0.5) / n[2] + d)) + 0.25 * d
+    return vel
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("ghost", [(1, 1, 1), (2, 1, 2)])
+def test_cc_divergence_and_gradient_correction_bit_exact(oracle, case, ghost):
+    from somar_amd import api as F
+    so = oracle
+    n, boxsz, variant, periodic, L = case
+    dom, grids, dx, Jgup, Jinv = make_problem(so, n, boxsz, variant, periodic, L)
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv)
+    vel = _cc_velocity(so, dom, grids, ghost)
+    for p in range(gpu.num_local_patches):
+        gpu.uploadCCVel(p, vel[gpu.patch_box(p)[2]].a, ghost)
+    dt = 0.37
+    for wall in (True, False):
+        div = so.LevelData(grids, 1)
+        so.level_divergence_cc(div, vel, Jinv, grids, dom, dx, wall=wall)
+        for f in div.fabs:
+            f.a /= dt
+        gpu.divergenceCC(F.F_RHS, dt, wall)
+        for g, w in zip(download_valid(gpu, F.F_RHS, grids), valid_of(div)):
+            np.testing.assert_array_equal(g, w)
+    # gradient + EdgeToCell + correction with a given phi
+    phi = so.random_field(grids, 17, (1, 1, 1), dom.box)
+    upload(gpu, F.F_PHI, phi)
+    corr = so.LevelData(grids, 3)
+    so.level_gradient_cc(corr, phi, grids, dom, Jgup, dx)
+    want = [f.a.copy(order="F") for f in vel.fabs]
+    for i, g in enumerate(grids):
+        vel[i].view(g)[...] += (-dt) * corr[i].a
+    gpu.ccCorrect(F.F_PHI, dt)
+    for p in range(gpu.num_local_patches):
+        gi = gpu.patch_box(p)[2]
+        gpu.downloadCCVel(p, want[gi], ghost)               # valid cells overwritten, ghosts untouched
+        np.testing.assert_array_equal(want[gi], vel[gi].a)
+    gpu.undefine()
+
+
+@pytest.mark.parametrize("case", CASES[:2])
+def test_cc_level_projection_matches_oracle(oracle, case):
+    so = oracle
+    n, boxsz, variant, periodic, L = case
+    dom, grids, dx, Jgup, Jinv = make_problem(so, n, boxsz, variant, periodic, L)
+    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv)
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv)
+    ghost = (1, 1, 1)
+    vel = _cc_velocity(so, dom, grids, ghost)
+    gvel = [vel[gpu.patch_box(p)[2]].a.copy(order="F") for p in range(gpu.num_local_patches)]
+    phi = so.LevelData(grids, 1, (1, 1, 1))
+    dt = 0.5
+    so.cc_level_project(amr, vel, phi, dt)
+    st = gpu.levelProjectCC(gvel, ghost, dt)
+    assert st["iters"] == amr.iters and st["exitStatus"] == amr.exitStatus
+    np.testing.assert_allclose(st["history"], amr.history, rtol=1e-10, atol=1e-10 * amr.history[0])
+    want = [vel[gpu.patch_box(p)[2]].a for p in range(gpu.num_local_patches)]
+    assert max_rel_diff(gvel, want) < 1e-8
+    gpu.undefine()
+
+
+@pytest.mark.parametrize("case", FULL_CASES)
+def test_cc_correction_with_a_non_diagonal_metric_bit_exact(oracle, case):
+    from somar_amd import api as F
+    so = oracle
+    dom, grids, dx, Jgup, Jinv, fac, gpu = _full_setup(so, case)
+    try:
+        amr = so.AMRMultiGrid(fac, so.BiCGStab())
+        ghost = (1, 1, 1)
+        vel = _cc_velocity(so, dom, grids, ghost)
+        for p in range(gpu.num_local_patches):
+            gpu.uploadCCVel(p, vel[gpu.patch_box(p)[2]].a, ghost)
+        dt = 0.37
+        phi = so.random_field(grids, 17, (1, 1, 1), dom.box)
+        upload(gpu, F.F_PHI, phi)
+        corr = so.LevelData(grids, 3)
+        so.level_gradient_cc(corr, phi, grids, dom, Jgup, dx, op=amr.op)
+        got = [f.a.copy(order="F") for f in vel.fabs]
+        for i, g in enumerate(grids):
+            vel[i].view(g)[...] += (-dt) * corr[i].a
+        gpu.ccCorrect(F.F_PHI, dt)
+        for p in range(gpu.num_local_patches):
+            gi = gpu.patch_box(p)[2]
+            gpu.downloadCCVel(p, got[gi], ghost)
+            np.testing.assert_array_equal(got[gi], vel[gi].a)
+    finally:
+        gpu.undefine()
