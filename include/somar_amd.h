@@ -183,6 +183,26 @@ int somar_mac_project(somar_solver_t* s, double dt, int zero_pressure, int force
 int somar_mac_project_host(somar_solver_t* s, double* const* u0, double* const* u1, double* const* u2, double dt,
                            int zero_pressure, int force_homogeneous, somar_stats_t* stats);
 
+/* Viscous / diffusive Helmholtz solves through the same operator (single level).
+ * somar_solver_set_alpha_beta = MappedAMRPoissonOp::setAlphaAndBeta (AMRElliptic/MappedAMRPoissonOp.cpp:582-619) applied to
+ * every op of the hierarchy as MappedBaseLevelHeatSolver::resetSolverAlphaAndBeta does (AMRParabolic/
+ * MappedBaseLevelHeatSolver.cpp:257-270): alpha = a * aCoef, beta = b * bCoef, aCoef / bCoef being the alpha / beta
+ * handed to somar_solver_create (the factory's, MappedAMRPoissonOpFactory.cpp:585-586).  The prolongation strategy
+ * chosen by the null-space probe at finalize is kept, as in the reference.
+ * somar_heat_step = one level time step of d(phi)/dt = L[phi] + src:
+ *   scheme 0  MappedLevelBackwardEuler::updateSoln   (AMRParabolic/MappedLevelBackwardEuler.cpp:52-158)
+ *             (aCoef I - dt bCoef L) phiNew = phiOld          (the reference leaves the source out of this scheme)
+ *   scheme 1  MappedLevelCrankNicolson::updateSoln   (AMRParabolic/MappedLevelCrankNicolson.cpp:52-152)
+ *             (aCoef I - dt/2 bCoef L) phiNew = dt src + (aCoef I + dt/2 bCoef L) phiOld
+ * phiNew is SOMAR_F_PHI (the initial guess unless zero_phi), phiOld SOMAR_F_HEAT_OLD, src SOMAR_F_HEAT_SRC; boundary
+ * conditions are the solver's (viscousSolveFuncBC = constant Dirichlet values on solid walls: bc_type SOMAR_BC_DIRI +
+ * somar_solver_set_bc_values; BCutil/PhysBCUtil.cpp:822-826).  The flux-register increments that follow the solve in the
+ * reference only matter with a finer or coarser level and are not part of this single-level entry point. */
+#define SOMAR_F_HEAT_OLD 8 /* depth 0: phi at the old time */
+#define SOMAR_F_HEAT_SRC 9 /* depth 0: the source term */
+int somar_solver_set_alpha_beta(somar_solver_t* s, double a, double b);
+int somar_heat_step(somar_solver_t* s, int scheme, double dt, int zero_phi, somar_stats_t* stats);
+
 /* Cell-centred level projection of a velocity given in flux form (J u at cell centres; ONE host FArrayBox per local
  * patch with SpaceDim components, component slowest, defined on valid grown by ghost[] >= 1 in every active direction;
  * the ghost layer is used as the caller filled it -- the reference does not exchange it either):

@@ -1593,6 +1593,55 @@ def cc_level_project(amr, vel, phi, dt, zeroPhi=True, ndim=3, wall=True):
 
 
 # ----------------------------------------------------------------------------
+# Viscous / diffusive Helmholtz solves through the same operator, single level:
+#   MappedAMRPoissonOp::setAlphaAndBeta                        AMRElliptic/MappedAMRPoissonOp.cpp:582-619
+#       m_alpha = a*aCoef, m_beta = b*bCoef with aCoef / bCoef the factory's alpha / beta (Factory.cpp:585-586); lapDiag
+#       is refilled with the same values; the prolongation strategy chosen by the factory's null-space probe is kept
+#   MappedBaseLevelHeatSolver::applyHelm / solveHelm / resetSolverAlphaAndBeta    AMRParabolic/MappedBaseLevelHeatSolver.cpp:154-270
+#   MappedLevelBackwardEuler::updateSoln                       AMRParabolic/MappedLevelBackwardEuler.cpp:52-158
+#   MappedLevelCrankNicolson::updateSoln                       AMRParabolic/MappedLevelCrankNicolson.cpp:52-152
+#   (diagonalScale / kappaScale are no-ops for this operator, MappedAMRPoissonOp.H:814-833; the flux-register
+#   increments after the solve only matter with a second level and are not restated)
+# ----------------------------------------------------------------------------
+def reset_solver_alpha_and_beta(amr, a, b):
+    for op in amr.mg.ops:
+        if not hasattr(op, "aCoef"):
+            op.aCoef, op.bCoef = op.alpha, op.beta      # what the factory handed over
+        op.alpha = a * op.aCoef
+        op.beta = b * op.bCoef
+
+
+def level_backward_euler(amr, phiNew, phiOld, src, dt, zeroPhi=True):
+    """(aCoef I - dt bCoef L) phiNew = phiOld.  The source does not enter (the reference comments its term out)."""
+    phit = ld_create(phiNew)
+    rhst = ld_create(src)
+    ld_set(phit, 0.0)
+    ld_set(rhst, 0.0)
+    if zeroPhi:
+        ld_set(phiNew, 0.0)
+    ld_incr(phit, phiOld, 1.0)
+    ld_incr(rhst, phit, 1.0)
+    reset_solver_alpha_and_beta(amr, 1.0, -dt * 1.0)
+    return amr.solve(phiNew, rhst, zeroPhi=zeroPhi)
+
+
+def level_crank_nicolson(amr, phiNew, phiOld, src, dt, zeroPhi=True):
+    """(I - dt/2 L) phiNew = dt src + (I + dt/2 L) phiOld, the explicit half with the inhomogeneous BCs"""
+    phit = ld_create(phiNew)
+    rhst = ld_create(src)
+    ld_set(phit, 0.0)
+    ld_set(rhst, 0.0)
+    if zeroPhi:
+        ld_set(phiNew, 0.0)
+    reset_solver_alpha_and_beta(amr, 1.0, 0.5 * dt)
+    amr.op.apply_op(phit, phiOld, False)
+    ld_incr(rhst, src, dt)
+    ld_incr(rhst, phit, 1.0)
+    reset_solver_alpha_and_beta(amr, 1.0, -dt * 0.5)
+    return amr.solve(phiNew, rhst, zeroPhi=zeroPhi)
+
+
+# ----------------------------------------------------------------------------
 # AlteredMetric::fill_Jgup (projection/AlteredMetric.cpp:82-198): the whole-FAB statements after the map has been
 # evaluated, one numpy statement per FArrayBox operation (same roundings).
 # ----------------------------------------------------------------------------

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 BC_NONE, BC_NEUM, BC_DIRI = -1, 0, 1
-F_PHI, F_RHS, F_RES, F_CORR, F_BEST, F_SCRATCH, F_AMR_CORR, F_AMR_RES = 0, 1, 2, 3, 4, 5, 6, 7
+F_PHI, F_RHS, F_RES, F_CORR, F_BEST, F_SCRATCH, F_AMR_CORR, F_AMR_RES, F_HEAT_OLD, F_HEAT_SRC = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAX_HISTORY = 64
 COMM_ID_BYTES = 128
 
@@ -104,6 +104,8 @@ _SIGS = {
     "somar_mac_project": [_H, C.c_double, C.c_int, C.c_int, C.POINTER(Stats)],
     "somar_mac_project_host": [_H, C.POINTER(_PD), C.POINTER(_PD), C.POINTER(_PD), C.c_double, C.c_int, C.c_int,
                                C.POINTER(Stats)],
+    "somar_solver_set_alpha_beta": [_H, C.c_double, C.c_double],
+    "somar_heat_step": [_H, C.c_int, C.c_double, C.c_int, C.POINTER(Stats)],
     "somar_ccvel_upload": [_H, C.c_int, _PD, _PI],
     "somar_ccvel_download": [_H, C.c_int, _PD, _PI],
     "somar_level_divergence_cc": [_H, C.c_int, C.c_double, C.c_int],
@@ -484,6 +486,16 @@ class AMRPressureSolver:
         st = Stats()
         _ck(lib().somar_mac_project_host(self._h, U[0], U[1], U[2], float(dt), int(zeroPressure),
                                          int(forceHomogeneous), C.byref(st)))
+        return self._stats(st)
+
+    # -- viscous / diffusive Helmholtz solves (MappedBaseLevelHeatSolver and its BE / CN integrators) --
+    def setAlphaAndBeta(self, a, b):
+        _ck(lib().somar_solver_set_alpha_beta(self._h, float(a), float(b)))
+
+    def heatStep(self, scheme, dt, zeroPhi=True):
+        """scheme 0 backward Euler, 1 Crank-Nicolson; phiOld in F_HEAT_OLD, src in F_HEAT_SRC, result in F_PHI"""
+        st = Stats()
+        _ck(lib().somar_heat_step(self._h, int(scheme), float(dt), int(zeroPhi), C.byref(st)))
         return self._stats(st)
 
     # -- cell-centred level projection (LevelCCProjector, velocity in flux form, SpaceDim comps + ghosts) --

@@ -548,6 +548,22 @@ int somar_mac_project_host(somar_solver_t* s, double* const* u0, double* const* 
     API_END
 }
 
+int somar_solver_set_alpha_beta(somar_solver_t* s, double a, double b)
+{
+    API_BEGIN
+    s->ps->set_alpha_beta(a, b);
+    API_END
+}
+
+int somar_heat_step(somar_solver_t* s, int scheme, double dt, int zero_phi, somar_stats_t* stats)
+{
+    API_BEGIN
+    SolveStats st;
+    s->ps->heat_step(scheme, dt, zero_phi != 0, st);
+    fill_stats(st, stats);
+    API_END
+}
+
 int somar_ccvel_upload(somar_solver_t* s, int patch, const double* host, const int* ghost)
 {
     API_BEGIN

@@ -38,6 +38,7 @@ PressureSolver::~PressureSolver()
     for (GhostOp* q : d_diri_ops_) hipFree(q);
     for (double* q : f_flux) Level::free_field(q);
     for (double* q : f_ccvel) Level::free_field(q);
+    for (double* q : f_heat) Level::free_field(q);
     hipFree(d_extrapbc_ops_);
     if (st_) hipStreamSynchronize(st_);
     for (double* f : f_res) hipFree(f);
@@ -164,6 +165,8 @@ double* PressureSolver::field(int depth, int which)
         case 5: return f_scratch[depth];
         case 6: return depth == 0 ? amr_field(0) : nullptr;
         case 7: return depth == 0 ? amr_field(1) : nullptr;
+        case 8: return depth == 0 ? heat_field(0) : nullptr;
+        case 9: return depth == 0 ? heat_field(1) : nullptr;
         default: return nullptr;
     }
 }
@@ -826,6 +829,64 @@ void PressureSolver::mac_project(double dt, bool zeroPressure, bool forceHomogen
     divergence_mac(f_rhs, dt);
     solve(zeroPressure, forceHomogeneous, s);
     mac_correct(f_phi, dt);
+    sync();
+}
+
+// ------------------------------------------------------------------------------------
+// Viscous / diffusive Helmholtz solves (single level).
+//   MappedAMRPoissonOp::setAlphaAndBeta (MappedAMRPoissonOp.cpp:582-619) on every op of the hierarchy, as
+//   MappedBaseLevelHeatSolver::resetSolverAlphaAndBeta does (MappedBaseLevelHeatSolver.cpp:257-270): alpha = a * aCoef,
+//   beta = b * bCoef with aCoef / bCoef the alpha / beta the solver was created with.  The reference refills lapDiag with
+//   the same values (it depends on neither coefficient) and keeps the prolongation strategy the factory's null-space
+//   probe chose at construction; so does this.
+// ------------------------------------------------------------------------------------
+void PressureSolver::set_alpha_beta(double a, double b)
+{
+    SOMAR_CHECK(finalized, "set_alpha_beta before finalize");
+    if (!coefs_saved_) {
+        aCoef_ = lev[0]->alpha;
+        bCoef_ = lev[0]->beta;
+        coefs_saved_ = true;
+    }
+    for (auto& L : lev) {
+        L->alpha = a * aCoef_;
+        L->beta = b * bCoef_;
+        L->refresh_params();
+    }
+    drop_graphs();  // captured launches carry the old coefficients in their kernel arguments
+    if (coarse_) coarse_->set_alpha_beta(a, b);
+}
+
+double* PressureSolver::heat_field(int which)
+{
+    SOMAR_CHECK(which >= 0 && which < 2 && finalized, "bad heat field / solver not finalized");
+    if (!f_heat[which]) f_heat[which] = lev[0]->alloc_field();
+    return f_heat[which];
+}
+
+// MappedLevelBackwardEuler::updateSoln (AMRParabolic/MappedLevelBackwardEuler.cpp:52-158) and
+// MappedLevelCrankNicolson::updateSoln (MappedLevelCrankNicolson.cpp:52-152) on one level, with applyHelm / solveHelm
+// (MappedBaseLevelHeatSolver.cpp:154-255).  phiNew = F_PHI (initial guess unless zeroPhi), phiOld / src = heat fields.
+//   BE: rhs = phiOld (the source term is commented out in the reference);   solve (aCoef I - dt bCoef L) phiNew = rhs
+//   CN: rhs = dt src + (aCoef I + dt/2 bCoef L) phiOld [inhomogeneous BCs]; solve (aCoef I - dt/2 bCoef L) phiNew = rhs
+void PressureSolver::heat_step(int scheme, double dt, bool zeroPhi, SolveStats& s)
+{
+    SOMAR_CHECK(scheme == 0 || scheme == 1, "heat scheme: 0 backward Euler, 1 Crank-Nicolson");
+    SOMAR_CHECK(dt >= 0.0, "negative time step");
+    const long long n = lev[0]->field_elems;
+    double* phiOld = heat_field(0);
+    if (scheme == 0) {
+        launch_copy(st_, f_rhs, phiOld, n);
+        set_alpha_beta(1.0, -dt * 1.0);
+    } else {
+        set_alpha_beta(1.0, 0.5 * dt);
+        apply_op(0, f_scratch[0], phiOld, false);
+        launch_copy(st_, f_rhs, heat_field(1), n);
+        launch_scale(st_, f_rhs, dt, n);
+        launch_incr(st_, f_rhs, f_scratch[0], 1.0, n);
+        set_alpha_beta(1.0, -dt * 0.5);
+    }
+    solve(zeroPhi, false, s);
     sync();
 }
 
