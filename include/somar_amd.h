@@ -154,6 +154,13 @@ int somar_solver_solve_host(somar_solver_t* s, double* const* phi, const int* ph
 int somar_level_relax(somar_solver_t* s, int depth, int phi_field, int rhs_field, int iters);
 int somar_level_residual(somar_solver_t* s, int depth, int out_field, int phi_field, int rhs_field);
 int somar_level_apply_op(somar_solver_t* s, int depth, int out_field, int phi_field);
+/* the same two on depth 0 with the physical BCs' homogeneous flag exposed: applyOp(lhs, phi, a_homogeneous) /
+ * residual(lhs, phi, rhs, a_homogeneous) (MappedAMRPoissonOp.cpp:740-765, 628-677).  With homogeneous = 0 and Dirichlet
+ * sides this is also one component of VelocityAMRPoissonOp::applyOpI with viscous solid walls, where every component's
+ * VelBCHolder entry is a constant Dirichlet value (AMRElliptic/VelocityAMRPoissonOp.cpp:64-166,
+ * BasicVelocityBCGhostClass EllipticBCUtils.cpp:1284-1306): the explicit viscous source is one call per component. */
+int somar_level_apply_op_bc(somar_solver_t* s, int out_field, int phi_field, int homogeneous);
+int somar_level_residual_bc(somar_solver_t* s, int out_field, int phi_field, int rhs_field, int homogeneous);
 int somar_level_restrict_residual(somar_solver_t* s, int depth, int coarse_res_field, int phi_field, int rhs_field);
 int somar_level_prolong_increment(somar_solver_t* s, int depth, int phi_field, int coarse_corr_field);
 int somar_level_precond(somar_solver_t* s, int depth, int phi_field, int rhs_field);
@@ -194,6 +201,9 @@ int somar_mac_project_host(somar_solver_t* s, double* const* u0, double* const* 
  *             (aCoef I - dt bCoef L) phiNew = phiOld          (the reference leaves the source out of this scheme)
  *   scheme 1  MappedLevelCrankNicolson::updateSoln   (AMRParabolic/MappedLevelCrankNicolson.cpp:52-152)
  *             (aCoef I - dt/2 bCoef L) phiNew = dt src + (aCoef I + dt/2 bCoef L) phiOld
+ *   scheme 2  MappedLevelTGA::updateSolnWithTimeIndependentOp (AMRParabolic/MappedLevelTGA.cpp:231-387, coefficients :30-56)
+ *             (I - mu1 dt L)(I - mu2 dt L) phiNew = (I + mu3 dt L) phiOld + (I + mu4 dt L) dt src (source half with
+ *             homogeneous BCs); two solves, both from the caller's initial guess; stats are the second solve's
  * phiNew is SOMAR_F_PHI (the initial guess unless zero_phi), phiOld SOMAR_F_HEAT_OLD, src SOMAR_F_HEAT_SRC; boundary
  * conditions are the solver's (viscousSolveFuncBC = constant Dirichlet values on solid walls: bc_type SOMAR_BC_DIRI +
  * somar_solver_set_bc_values; BCutil/PhysBCUtil.cpp:822-826).  The flux-register increments that follow the solve in the

@@ -1600,6 +1600,7 @@ def cc_level_project(amr, vel, phi, dt, zeroPhi=True, ndim=3, wall=True):
 #   MappedBaseLevelHeatSolver::applyHelm / solveHelm / resetSolverAlphaAndBeta    AMRParabolic/MappedBaseLevelHeatSolver.cpp:154-270
 #   MappedLevelBackwardEuler::updateSoln                       AMRParabolic/MappedLevelBackwardEuler.cpp:52-158
 #   MappedLevelCrankNicolson::updateSoln                       AMRParabolic/MappedLevelCrankNicolson.cpp:52-152
+#   MappedLevelTGA::updateSolnWithTimeIndependentOp            AMRParabolic/MappedLevelTGA.cpp:231-387
 #   (diagonalScale / kappaScale are no-ops for this operator, MappedAMRPoissonOp.H:814-833; the flux-register
 #   increments after the solve only matter with a second level and are not restated)
 # ----------------------------------------------------------------------------
@@ -1639,6 +1640,51 @@ def level_crank_nicolson(amr, phiNew, phiOld, src, dt, zeroPhi=True):
     ld_incr(rhst, phit, 1.0)
     reset_solver_alpha_and_beta(amr, 1.0, -dt * 0.5)
     return amr.solve(phiNew, rhst, zeroPhi=zeroPhi)
+
+
+def tga_coefficients():
+    """MappedLevelTGA's constructor, AMRParabolic/MappedLevelTGA.cpp:30-56 -> (mu1, mu2, mu3, mu4, r1)"""
+    tgaEpsilon = 1.e-12
+    a = 2.0 - np.sqrt(2.0) - tgaEpsilon
+    discr = np.sqrt(a * a - 4.0 * a + 2.0)
+    return (float((a - discr) / 2.0), float((a + discr) / 2.0), float(1.0 - a), float(0.5 - a),
+            float((2.0 * a - 1.0) / (a + discr)))
+
+
+def level_tga(amr, phiNew, phiOld, src, dt, zeroPhi=True):
+    """MappedLevelTGA::updateSolnWithTimeIndependentOp on one level (MappedLevelTGA.cpp:231-387):
+    (I - mu1 dt L)(I - mu2 dt L) phiNew = (I + mu3 dt L) phiOld + (I + mu4 dt L) dt src, the source half with homogeneous
+    BCs.  Returns the iteration counts of the two solves."""
+    mu1, mu2, mu3, mu4, _ = tga_coefficients()
+    op = amr.op
+    rhst = ld_create(src)
+    srct = ld_create(phiNew)
+    phis = ld_create(phiNew)
+    ld_set(srct, 0.0)
+    ld_set(rhst, 0.0)
+    ld_incr(srct, src, dt)
+    if not zeroPhi:
+        ld_set(phis, 0.0)
+        ld_incr(phis, phiNew, 1.0)
+    reset_solver_alpha_and_beta(amr, 1.0, mu4 * dt)                 # applyHelm(rhst, srct, mu4, homogeneous)
+    op.apply_op(rhst, srct, True)
+    reset_solver_alpha_and_beta(amr, 1.0, mu3 * dt)                 # applyHelm(phiNew, phiOld, mu3, inhomogeneous)
+    op.apply_op(phiNew, phiOld, False)
+    ld_incr(rhst, phiNew, 1.0)
+    if not zeroPhi:
+        ld_set(phiNew, 0.0)
+        ld_incr(phiNew, phis, 1.0)
+    reset_solver_alpha_and_beta(amr, 1.0, -dt * mu2)                # solveHelm(mu2)
+    amr.solve(phiNew, rhst, zeroPhi=zeroPhi)
+    it1 = amr.iters
+    for d, f in zip(rhst.fabs, phiNew.fabs):                        # assign(rhst, phiNew)
+        d.copy_from(f)
+    if not zeroPhi:
+        ld_set(phiNew, 0.0)
+        ld_incr(phiNew, phis, 1.0)
+    reset_solver_alpha_and_beta(amr, 1.0, -dt * mu1)                # solveHelm(mu1)
+    amr.solve(phiNew, rhst, zeroPhi=zeroPhi)
+    return it1, amr.iters
 
 
 # ----------------------------------------------------------------------------

@@ -90,6 +90,8 @@ _SIGS = {
     "somar_level_relax": [_H, C.c_int, C.c_int, C.c_int, C.c_int],
     "somar_level_residual": [_H, C.c_int, C.c_int, C.c_int, C.c_int],
     "somar_level_apply_op": [_H, C.c_int, C.c_int, C.c_int],
+    "somar_level_apply_op_bc": [_H, C.c_int, C.c_int, C.c_int],
+    "somar_level_residual_bc": [_H, C.c_int, C.c_int, C.c_int, C.c_int],
     "somar_level_restrict_residual": [_H, C.c_int, C.c_int, C.c_int, C.c_int],
     "somar_level_prolong_increment": [_H, C.c_int, C.c_int, C.c_int],
     "somar_level_precond": [_H, C.c_int, C.c_int, C.c_int],
@@ -436,6 +438,12 @@ class AMRPressureSolver:
 
     def applyOp(self, depth, out_field, phi_field):
         _ck(lib().somar_level_apply_op(self._h, depth, out_field, phi_field))
+
+    def applyOpBC(self, out_field, phi_field, homogeneous):
+        _ck(lib().somar_level_apply_op_bc(self._h, out_field, phi_field, int(homogeneous)))
+
+    def residualBC(self, out_field, phi_field, rhs_field, homogeneous):
+        _ck(lib().somar_level_residual_bc(self._h, out_field, phi_field, rhs_field, int(homogeneous)))
 
     def restrictResidual(self, depth, coarse_res_field, phi_field, rhs_field):
         _ck(lib().somar_level_restrict_residual(self._h, depth, coarse_res_field, phi_field, rhs_field))

@@ -404,6 +404,29 @@ int somar_level_apply_op(somar_solver_t* s, int depth, int out_field, int phi_fi
     API_END
 }
 
+int somar_level_apply_op_bc(somar_solver_t* s, int out_field, int phi_field, int homogeneous)
+{
+    API_BEGIN
+    int d0, d1;
+    double* out = field_ptr(s, out_field, &d0);
+    double* phi = field_ptr(s, phi_field, &d1);
+    SOMAR_CHECK(d0 == 0 && d1 == 0 && out != phi, "depth-0 fields, no aliasing");
+    s->ps->apply_op(0, out, phi, homogeneous != 0);
+    API_END
+}
+
+int somar_level_residual_bc(somar_solver_t* s, int out_field, int phi_field, int rhs_field, int homogeneous)
+{
+    API_BEGIN
+    int d0, d1, d2;
+    double* out = field_ptr(s, out_field, &d0);
+    double* phi = field_ptr(s, phi_field, &d1);
+    double* rhs = field_ptr(s, rhs_field, &d2);
+    SOMAR_CHECK(d0 == 0 && d1 == 0 && d2 == 0 && out != rhs && out != phi, "depth-0 fields, no aliasing");
+    s->ps->residual(0, out, phi, rhs, homogeneous != 0);
+    API_END
+}
+
 int somar_level_restrict_residual(somar_solver_t* s, int depth, int coarse_res_field, int phi_field, int rhs_field)
 {
     API_BEGIN

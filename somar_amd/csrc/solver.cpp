@@ -859,7 +859,7 @@ void PressureSolver::set_alpha_beta(double a, double b)
 
 double* PressureSolver::heat_field(int which)
 {
-    SOMAR_CHECK(which >= 0 && which < 2 && finalized, "bad heat field / solver not finalized");
+    SOMAR_CHECK(which >= 0 && which < 3 && finalized, "bad heat field / solver not finalized");
     if (!f_heat[which]) f_heat[which] = lev[0]->alloc_field();
     return f_heat[which];
 }
@@ -869,22 +869,43 @@ double* PressureSolver::heat_field(int which)
 // (MappedBaseLevelHeatSolver.cpp:154-255).  phiNew = F_PHI (initial guess unless zeroPhi), phiOld / src = heat fields.
 //   BE: rhs = phiOld (the source term is commented out in the reference);   solve (aCoef I - dt bCoef L) phiNew = rhs
 //   CN: rhs = dt src + (aCoef I + dt/2 bCoef L) phiOld [inhomogeneous BCs]; solve (aCoef I - dt/2 bCoef L) phiNew = rhs
+//   TGA: (I - mu1 dt L)(I - mu2 dt L) phiNew = (I + mu3 dt L) phiOld + (I + mu4 dt L) dt src; stats are the last solve's
 void PressureSolver::heat_step(int scheme, double dt, bool zeroPhi, SolveStats& s)
 {
-    SOMAR_CHECK(scheme == 0 || scheme == 1, "heat scheme: 0 backward Euler, 1 Crank-Nicolson");
+    SOMAR_CHECK(scheme >= 0 && scheme <= 2, "heat scheme: 0 backward Euler, 1 Crank-Nicolson, 2 TGA");
     SOMAR_CHECK(dt >= 0.0, "negative time step");
     const long long n = lev[0]->field_elems;
     double* phiOld = heat_field(0);
     if (scheme == 0) {
         launch_copy(st_, f_rhs, phiOld, n);
         set_alpha_beta(1.0, -dt * 1.0);
-    } else {
+    } else if (scheme == 1) {
         set_alpha_beta(1.0, 0.5 * dt);
         apply_op(0, f_scratch[0], phiOld, false);
         launch_copy(st_, f_rhs, heat_field(1), n);
         launch_scale(st_, f_rhs, dt, n);
         launch_incr(st_, f_rhs, f_scratch[0], 1.0, n);
         set_alpha_beta(1.0, -dt * 0.5);
+    } else {
+        // MappedLevelTGA::updateSolnWithTimeIndependentOp, MappedLevelTGA.cpp:231-387; coefficients: its constructor, :30-56
+        const double tgaEpsilon = 1.e-12;
+        const double a = 2.0 - std::sqrt(2.0) - tgaEpsilon;
+        const double discr = std::sqrt(a * a - 4.0 * a + 2.0);
+        const double mu1 = (a - discr) / 2.0, mu2 = (a + discr) / 2.0, mu3 = 1.0 - a, mu4 = 0.5 - a;
+        double* tmp = heat_field(2);              // srct, then phis (the caller's initial guess for both solves)
+        launch_copy(st_, tmp, heat_field(1), n);  // srct = dt * src
+        launch_scale(st_, tmp, dt, n);
+        set_alpha_beta(1.0, mu4 * dt);
+        apply_op(0, f_rhs, tmp, true);            // rhst = (I + mu4 dt L) srct, homogeneous BCs
+        set_alpha_beta(1.0, mu3 * dt);
+        apply_op(0, f_scratch[0], phiOld, false);  // (I + mu3 dt L) phiOld with the inhomogeneous BCs
+        launch_incr(st_, f_rhs, f_scratch[0], 1.0, n);
+        if (!zeroPhi) launch_copy(st_, tmp, f_phi, n);
+        set_alpha_beta(1.0, -dt * mu2);
+        solve(zeroPhi, false, s);                 // (I - mu2 dt L) phi* = rhst
+        launch_copy(st_, f_rhs, f_phi, n);        // assign(rhst, phiNew)
+        if (!zeroPhi) launch_copy(st_, f_phi, tmp, n);
+        set_alpha_beta(1.0, -dt * mu1);           // (I - mu1 dt L) phiNew = phi*
     }
     solve(zeroPhi, false, s);
     sync();

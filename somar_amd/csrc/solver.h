@@ -152,7 +152,7 @@ public:
     // viscous / diffusive Helmholtz solves through the same operator
     void set_alpha_beta(double a, double b);   // MappedAMRPoissonOp::setAlphaAndBeta on every depth: alpha = a*aCoef, beta = b*bCoef
     double* heat_field(int which);             // 0: phiOld, 1: src (depth 0, allocated on first use)
-    void heat_step(int scheme, double dt, bool zeroPhi, SolveStats& st);   // 0 backward Euler, 1 Crank-Nicolson
+    void heat_step(int scheme, double dt, bool zeroPhi, SolveStats& st);   // 0 backward Euler, 1 Crank-Nicolson, 2 TGA
     // cell-centred level projection (LevelCCProjector): velocity J*u, SpaceDim comps, resident with one ghost layer
     double* cc_vel(int comp);
     void upload_cc_vel(int patch, const double* host, const int ghost[3]);   // host FAB: SpaceDim comps, comp slowest
@@ -188,7 +188,7 @@ private:
     void line_relax(int d, double* e, const double* res);
     double* f_vel[3] = {nullptr, nullptr, nullptr};
     double* f_ccvel[3] = {nullptr, nullptr, nullptr};
-    double* f_heat[2] = {nullptr, nullptr};
+    double* f_heat[3] = {nullptr, nullptr, nullptr};
     double aCoef_ = 0.0, bCoef_ = 1.0;  // the factory's alpha / beta (MappedAMRPoissonOpFactory.cpp:585-586)
     bool coefs_saved_ = false;
     double* f_amr[2] = {nullptr, nullptr};

@@ -1,5 +1,6 @@
 """Viscous / diffusive Helmholtz solves on the GPU (somar_solver_set_alpha_beta, somar_heat_step) vs the oracle's
-restatement of MappedAMRPoissonOp::setAlphaAndBeta and the level backward-Euler / Crank-Nicolson integrators."""
+restatement of MappedAMRPoissonOp::setAlphaAndBeta and the level backward-Euler / Crank-Nicolson / TGA integrators
+(for TGA the compared history is the second solve's)."""
 import numpy as np
 import pytest
 
@@ -58,7 +59,7 @@ def test_set_alpha_and_beta_reaches_every_depth_bit_exact(oracle, case):
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("scheme", [0, 1])
+@pytest.mark.parametrize("scheme", [0, 1, 2])
 def test_heat_step_matches_oracle(oracle, case, scheme):
     from somar_amd import api as F
     so = oracle
@@ -70,7 +71,8 @@ def test_heat_step_matches_oracle(oracle, case, scheme):
         upload(gpu, F.F_HEAT_OLD, old)
         upload(gpu, F.F_HEAT_SRC, src)
         new = so.LevelData(grids, 1, (1, 1, 1))
-        (so.level_backward_euler if scheme == 0 else so.level_crank_nicolson)(amr, new, old, src, dt)
+        step = [so.level_backward_euler, so.level_crank_nicolson, so.level_tga][scheme]
+        step(amr, new, old, src, dt)
         st = gpu.heatStep(scheme, dt)
         assert st["iters"] == amr.iters and st["exitStatus"] == amr.exitStatus
         np.testing.assert_allclose(st["history"], amr.history, rtol=1e-10, atol=1e-13 * amr.history[0])
@@ -79,10 +81,57 @@ def test_heat_step_matches_oracle(oracle, case, scheme):
         # a second step from the new state (the coefficients are reset, not compounded)
         upload(gpu, F.F_HEAT_OLD, new)
         new2 = so.LevelData(grids, 1, (1, 1, 1))
-        (so.level_backward_euler if scheme == 0 else so.level_crank_nicolson)(amr, new2, new, src, 0.5 * dt)
+        step(amr, new2, new, src, 0.5 * dt)
         st = gpu.heatStep(scheme, 0.5 * dt)
         assert st["iters"] == amr.iters
         np.testing.assert_allclose(st["history"], amr.history, rtol=1e-10, atol=1e-13 * amr.history[0])
         assert max_rel_diff(download_valid(gpu, F.F_PHI, grids), valid_of(new2)) < 1e-9
+    finally:
+        gpu.undefine()
+
+
+def test_tga_from_an_initial_guess(oracle):
+    """zeroPhi = false: both TGA solves start from the caller's phiNew (the reference saves it in `phis`)"""
+    from somar_amd import api as F
+    so = oracle
+    dom, grids, amr, gpu = _setup(so, CASES[1])
+    try:
+        old = so.random_field(grids, 3, (1, 1, 1), dom.box)
+        src = so.random_field(grids, 4, (0, 0, 0), dom.box)
+        guess = so.random_field(grids, 5, (1, 1, 1), dom.box)
+        upload(gpu, F.F_HEAT_OLD, old)
+        upload(gpu, F.F_HEAT_SRC, src)
+        upload(gpu, F.F_PHI, guess)
+        so.level_tga(amr, guess, old, src, 0.2, zeroPhi=False)
+        st = gpu.heatStep(2, 0.2, zeroPhi=False)
+        assert st["iters"] == amr.iters and st["exitStatus"] == amr.exitStatus
+        np.testing.assert_allclose(st["history"], amr.history, rtol=1e-10, atol=1e-13 * amr.history[0])
+        assert max_rel_diff(download_valid(gpu, F.F_PHI, grids), valid_of(guess)) < 1e-9
+    finally:
+        gpu.undefine()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_inhomogeneous_operator_and_residual_bit_exact(oracle, case):
+    """applyOp / residual with a_homogeneous = false: the Dirichlet values enter through the ghosts (one component of
+    VelocityAMRPoissonOp::applyOpI with viscous walls)"""
+    from somar_amd import api as F
+    so = oracle
+    dom, grids, amr, gpu = _setup(so, case)
+    try:
+        phi = so.random_field(grids, 11, (1, 1, 1), dom.box)
+        rhs = so.random_field(grids, 12, (0, 0, 0), dom.box)
+        upload(gpu, F.F_PHI, phi)
+        upload(gpu, F.F_RHS, rhs)
+        for homog in (False, True):
+            lhs = so.LevelData(grids, 1)
+            amr.op.apply_op(lhs, phi, homog)
+            gpu.applyOpBC(F.F_RES, F.F_PHI, homog)
+            for x, y in zip(download_valid(gpu, F.F_RES, grids), valid_of(lhs)):
+                np.testing.assert_array_equal(x, y)
+            amr.op.residual(lhs, phi, rhs, homog)
+            gpu.residualBC(F.F_RES, F.F_PHI, F.F_RHS, homog)
+            for x, y in zip(download_valid(gpu, F.F_RES, grids), valid_of(lhs)):
+                np.testing.assert_array_equal(x, y)
     finally:
         gpu.undefine()
