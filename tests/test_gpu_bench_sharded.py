@@ -23,7 +23,7 @@ def _run(cmd, env):
 
 def test_two_rank_bench_line():
     env = dict(os.environ)
-    common = ["--steps", "2", "--warmup", "1", "--n", "128", "--no-cpu-baseline"]
+    common = ["--steps", "2", "--warmup", "1", "--size", "128", "--no-cpu-baseline"]  # not "--n": torchrun's parser claims that prefix
     one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, env)
     env2 = dict(env, SOMAR_BENCH_COMM="shm")
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
