@@ -934,3 +934,59 @@ def copy_valid(dst, src):
             reg = db & sb
             if not reg.isEmpty():
                 df.view(reg)[...] = sf.view(reg)
+
+
+# ----------------------------------------------------------------------------
+# Level projection on level l of a hierarchy: BaseProjector<T>::levelProject -> project(lmin = lmax = l)
+# (projection/BaseProjectorI.H:176-366) with the coarser level supplying coarse-fine values.
+#   'mac': LevelMACProjector (LevelMACProjector.cpp:156-241) -- levelDivergenceMAC needs nothing from the coarser level;
+#          computeGrad -> levelGradientMAC(edgeGrad, phi, crsePhi, cfInterp): coarseFineInterp(phi, crsePhi), exchange,
+#          extrapolation BC, MAC gradient (Gradient.cpp:85-206)
+#   'cc' : LevelCCProjector (LevelCCProjector.cpp:163-255) -- levelDivergenceCC first interpolates the velocity's CF
+#          ghosts, m_velCFInterp.coarseFineInterp(u, uCrse) (Divergence.cpp:372-375; MappedQuadCFInterp with SpaceDim
+#          comps = component by component), then CellToEdge etc.; the gradient as above + EdgeToCell
+# The solve in between is AMRPressureSolver::solve(lmin = lmax = l) = the level solve with phi[l-1] as CF data.
+# Diagonal metric (levelGradientMAC adds ExtrapolateCFEV otherwise).
+# ----------------------------------------------------------------------------
+def level_project(comp, l, vel, phi, dt, centring="mac", velCoarse=None, zeroPhi=True, wall=True):
+    op = comp.ops[l]
+    L = comp.levels[l]
+    nd = comp.ndim
+    assert op.isDiagonal
+    rhs = [None] * len(comp.levels)
+    rhs[l] = so.LevelData(L.grids, 1)
+    if centring == "cc":
+        if l > 0:
+            Lc = comp.levels[l - 1]
+            for c in range(nd):
+                f1 = so.LevelData(L.grids, 1, vel.ghost)
+                c1 = so.LevelData(Lc.grids, 1, velCoarse.ghost)
+                for a, b in zip(f1.fabs, vel.fabs):
+                    a.a[..., 0] = b.a[..., c]
+                for a, b in zip(c1.fabs, velCoarse.fabs):
+                    a.a[..., 0] = b.a[..., c]
+                op.quad.coarse_fine_interp(f1, c1)
+                for a, b in zip(f1.fabs, vel.fabs):
+                    b.a[..., c] = a.a[..., 0]
+        so.level_divergence_cc(rhs[l], vel, L.Jinv, L.grids, L.domain, L.dx, nd, wall)
+    else:
+        so.level_divergence_mac(rhs[l], vel, L.Jinv, L.grids, L.dx, nd)
+    if dt != 0.0:
+        for f in rhs[l].fabs:
+            f.a /= dt
+    comp.solve(phi, rhs, l, l, zeroPhi=zeroPhi)
+    if l > 0:
+        op.quad.coarse_fine_interp(phi[l], phi[l - 1])
+    dtScale = -1.0 if dt == 0.0 else -dt
+    if centring == "cc":
+        corr = so.LevelData(L.grids, nd)
+        so.level_gradient_cc(corr, phi[l], L.grids, L.domain, L.Jgup, L.dx, nd)
+        for i, g in enumerate(L.grids):
+            vel[i].view(g)[...] += dtScale * corr[i].a
+    else:
+        corr = so.FluxData(L.grids, 1, nd)
+        so.level_gradient_mac(corr, phi[l], L.grids, L.domain, L.Jgup, L.dx, nd)
+        for i in range(len(L.grids)):
+            for d in range(nd):
+                vel[i][d].a += dtScale * corr[i][d].a
+    return rhs[l]

@@ -127,6 +127,7 @@ _SIGS = {
     "somar_amr_finalize": [_H],
     "somar_amr_solve": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
     "somar_amr_interp_cf": [_H, C.c_int, C.c_int, C.c_int],
+    "somar_amr_level_project": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
     "somar_amr_residual_level": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     "somar_amr_zero_covered": [_H, C.c_int, C.c_int],
     "somar_amr_vcycle": [_H, C.c_int, C.c_int],
@@ -282,6 +283,13 @@ class AMRPressureSolver:
         """MappedAMRMultiGrid::solve on the levels' resident PHI / RHS."""
         st = Stats()
         _ck(lib().somar_amr_solve(self._amr, lmax, lbase, int(zeroPhi), int(forceHomogeneous), C.byref(st)))
+        return self._stats(st)
+
+    def levelProjectAMR(self, level, centring, dt, zeroPressure=True, forceHomogeneous=False, wall=True):
+        """centring 0: the level's uploadVel'ed MAC velocity, 1: its uploadCCVel'ed cell-centred velocity (in place)"""
+        st = Stats()
+        _ck(lib().somar_amr_level_project(self._amr, level, int(centring), float(dt), int(zeroPressure),
+                                          int(forceHomogeneous), int(wall), C.byref(st)))
         return self._stats(st)
 
     def interpCF(self, level, fine_field=F_PHI, coarse_field=F_PHI):

@@ -593,7 +593,7 @@ void AMRSolver::build_reflux_tables(int l)
 // ------------------------------------------------------------------------------------
 // MappedAMRPoissonOp AMR* members
 // ------------------------------------------------------------------------------------
-void AMRSolver::interp_cf(int l, double* phiFine, const double* phiCoarse)
+void AMRSolver::interp_cf(int l, double* phiFine, const double* phiCoarse, bool ev)
 {
     SOMAR_CHECK(l >= 1 && l < nlevels(), "interp_cf: level has no coarser level");
     AMRLink& K = *links_[l];
@@ -604,7 +604,36 @@ void AMRSolver::interp_cf(int l, double* phiFine, const double* phiCoarse)
     K.gather.run(phiCoarse, K.buf, st_);
     launch_cf_slopes(st_, K.d_cc, K.ncc, K.d_pts, K.buf, K.d_der, dxc);
     launch_cf_quad(st_, K.d_fc, K.nfc, K.d_cc, K.d_der, K.buf, phiFine, F.dx, dxc, K.r);
-    S[l]->cf_ev(0, phiFine);  // ExtrapolateCFEV: non-diagonal metric only (interpCFGhosts, MappedAMRPoissonOp.cpp:2193-2216)
+    if (ev) S[l]->cf_ev(0, phiFine);  // ExtrapolateCFEV: non-diagonal metric only (interpCFGhosts, MappedAMRPoissonOp.cpp:2193-2216)
+}
+
+// Level projection on level l with the coarser level's data at the coarse-fine interface.
+//   LevelMACProjector::computeDiv / LevelCCProjector::computeDiv  (LevelMACProjector.cpp:156-186, LevelCCProjector.cpp:163-197):
+//       the cell-centred divergence starts with m_velCFInterp.coarseFineInterp(u, uCrse) (Divergence.cpp:372-375)
+//   AMRPressureSolver::solve(lmin = lmax = l): the level solve, phi[l-1] as CF data
+//   computeGrad -> levelGradientMAC(edgeGrad, phi, crsePhi, cfInterp) (Gradient.cpp:85-206): coarseFineInterp(phi, crsePhi),
+//       exchange, extrapolation BC, MAC gradient [+ EdgeToCell]; applyCorrection
+void AMRSolver::level_project(int l, int centring, double dt, bool zeroPressure, bool forceHomogeneous, bool wall,
+                              SolveStats& st)
+{
+    SOMAR_CHECK(finalized_ && l >= 0 && l < nlevels(), "level_project: bad level / hierarchy not finalized");
+    SOMAR_CHECK(centring == 0 || centring == 1, "centring: 0 MAC, 1 cell-centred");
+    PressureSolver& P = *S[l];
+    SOMAR_CHECK(!P.is_full(), "level projection on an AMR level needs a diagonal metric");
+    double* phi = P.field(0, 0);
+    double* rhs = P.field(0, 1);
+    if (centring == 1) {
+        if (l > 0)
+            for (int c = 0; c < prm.spaceDim; ++c) interp_cf(l, P.cc_vel(c), S[l - 1]->cc_vel(c), false);
+        P.divergence_cc(rhs, dt, wall);
+    } else {
+        P.divergence_mac(rhs, dt);
+    }
+    solve(l, l, zeroPressure, forceHomogeneous, st);
+    if (l > 0) interp_cf(l, phi, S[l - 1]->field(0, 0));
+    if (centring == 1) P.cc_correct(phi, dt);
+    else P.mac_correct(phi, dt);
+    sync();
 }
 
 void AMRSolver::amr_operator(int l, double* LofPhi, double* phiFine, double* phi, const double* phiCoarse,

@@ -135,8 +135,14 @@ public:
     // CF values when l_base > 0)
     void solve(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous, SolveStats& st);
 
+    // BaseProjector<T>::levelProject -> project(lmin = lmax = l) (projection/BaseProjectorI.H:176-366) on the resident
+    // velocity of level l: centring 0 = LevelMACProjector (vel()), 1 = LevelCCProjector (cc_vel(), level l-1's supplies the
+    // velocity's coarse-fine values); phi of level l-1 supplies the pressure's.  Diagonal metric.
+    void level_project(int l, int centring, double dt, bool zeroPressure, bool forceHomogeneous, bool wall, SolveStats& st);
+
     // pieces (parity tests)
-    void interp_cf(int l, double* phiFine, const double* phiCoarse);  // interpCFGhosts(phi, &phiCoarse, false)
+    // interpCFGhosts(phi, &phiCoarse, false); ev = false: MappedQuadCFInterp::coarseFineInterp alone (no ExtrapolateCFEV)
+    void interp_cf(int l, double* phiFine, const double* phiCoarse, bool ev = true);
     // homogeneous: physical boundary values taken as zero (Dirichlet sides); the CF values always come from phiCoarse
     void amr_operator(int l, double* LofPhi, double* phiFine, double* phi, const double* phiCoarse,
                       bool homogeneous = true);

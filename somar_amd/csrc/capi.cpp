@@ -816,6 +816,16 @@ int somar_amr_solve(somar_amr_t* a, int l_max, int l_base, int zero_phi, int for
     API_END
 }
 
+int somar_amr_level_project(somar_amr_t* a, int level, int centring, double dt, int zero_pressure, int force_homogeneous,
+                            int wall_bc, somar_stats_t* stats)
+{
+    API_BEGIN
+    SolveStats st;
+    a->amr->level_project(level, centring, dt, zero_pressure != 0, force_homogeneous != 0, wall_bc != 0, st);
+    fill_stats(st, stats);
+    API_END
+}
+
 static double* amr_field(somar_amr* a, int level, int field)
 {
     SOMAR_CHECK(level >= 0 && level < (int)a->levels.size(), "bad AMR level");

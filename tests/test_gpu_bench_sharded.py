@@ -36,6 +36,8 @@ def test_two_rank_bench_line():
         assert line["value"] > 0 and line["ms_per_step"] > 0
         assert line["config"]["cells"] == 128 ** 3
     assert "2 box(es) 128x128x64" in two["config"]["workload"]
-    # same problem, same V-cycle: the contraction differs only by the association of the large-level sums
-    assert two["vcycle_contraction"] == pytest.approx(one["vcycle_contraction"], rel=1e-6)
+    # same problem; the two-box layout stops coarsening one depth earlier (its boxes are 64 cells in z: the reference's
+    # coarsenable test works per box), so the cycles differ slightly -- but both contract alike
+    assert two["config"]["mg_depth"] == one["config"]["mg_depth"] - 1
+    assert two["vcycle_contraction"] == pytest.approx(one["vcycle_contraction"], rel=1e-2)
     assert 0.0 < one["vcycle_contraction"] < 1.0
