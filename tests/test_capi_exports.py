@@ -52,3 +52,12 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: include/somar_amd.h must compile as C99 on its own (no C++-isms, no torch/HIP types)"""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "somar_amd.h"\nint main(void) { int (*f)(void) = somar_abi_version; return f == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only",
+                           "-I", os.path.join(ROOT, "include"), str(src)])
