@@ -648,7 +648,7 @@ void PressureSolver::residual_i(int d, double* out, double* phi, const double* r
         // exchangeComplete, fillExtrap (order 2), physical ghosts (Neumann with cross terms / Dirichlet), then the 19-point fluxes
         run_full_program(d, 0, phi, homogeneous);
         launch_op_full(st_, L.dev, out, phi, f_psi[d], rhs, 0);
-    } else if (L.valid_cells_global >= march_min_cells_ && L.active[2] && !diri_) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, rhs, 0);
+    } else if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, rhs, 0);  // Dirichlet sides: their ghosts were just written, the kernel only zeroes NEUMANN fluxes
     else launch_op_ortho(st_, L.dev, out, phi, rhs, 0);
     if (profiling_ && d == 0) prof_end(1);
 }
@@ -661,7 +661,7 @@ void PressureSolver::apply_op_i(int d, double* out, double* phi, bool homogeneou
     if (full_) {
         run_full_program(d, 0, phi, homogeneous);
         launch_op_full(st_, L.dev, out, phi, f_psi[d], nullptr, 1);
-    } else if (L.valid_cells_global >= march_min_cells_ && L.active[2] && !diri_) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, nullptr, 1);
+    } else if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, nullptr, 1);
     else launch_op_ortho(st_, L.dev, out, phi, nullptr, 1);
 }
 
@@ -687,10 +687,11 @@ void PressureSolver::restrict_residual(int d, double* resCoarse, double* phiFine
 {
     // restrictResidual, MappedAMRPoissonOp.cpp:1281-1304
     Level& F = *lev[d];
-    if (F.valid_cells_global >= march_min_cells_ && F.active[2] && !full_ && !diri_) {
+    if (F.valid_cells_global >= march_min_cells_ && F.active[2] && !full_) {
         // large level: residual and J-weighted average in one marching pass, the fine residual is never stored
         F.cf_homog(phiFine, st_);
         F.exchange(phiFine, st_);
+        if (diri_) apply_diri(d, phiFine, true);  // homogeneous Dirichlet ghosts, as residual() fills them
         if (profiling_ && d == 0) prof_begin(1);
         const bool want = F.zeroAvg && !ordered(d);  // the fine half of the folded prolongation's mean
         launch_resid_restrict(st_, F.d_rtiles, F.nrtiles, F.dev, lev[d + 1]->dev, resCoarse, phiFine, rhsFine,

@@ -16,6 +16,14 @@ CASES = [
 ]
 
 
+@pytest.fixture(autouse=True, params=["direct", "march"])
+def _residual_path(request, monkeypatch):
+    """every test twice: levels this small run the direct-load residual; SOMAR_MARCH_MIN_CELLS = 0 sends them through
+    the LDS-marching residual and the fused residual + restriction that large Dirichlet levels (viscous solves) use"""
+    if request.param == "march":
+        monkeypatch.setenv("SOMAR_MARCH_MIN_CELLS", "0")
+
+
 def _setup(so, case, values=None, **kw):
     n, bs, per, types, alpha, beta = case
     dom, grids, dx, Jgup, Jinv = make_problem(so, n, bs, "stretched", per, (1.0, 1.0, 0.5))
@@ -54,6 +62,13 @@ def test_dirichlet_pieces_bit_exact(oracle, case):
             gpu.relax(d, fc, fr, 2)
             for a, b in zip(download_valid(gpu, fc, g, d), valid_of(phi)):
                 np.testing.assert_array_equal(a, b)
+            if d + 1 < amr.mg.depth:
+                cg = [b.coarsen(op.mgCrseRefRatio) for b in g]
+                crse = op.create_coarser(rhs)
+                op.restrict_residual(crse, phi, rhs)
+                gpu.restrictResidual(d, F.FIELD(d + 1, F.F_RES), fc, fr)
+                for a, b in zip(download_valid(gpu, F.FIELD(d + 1, F.F_RES), cg, d + 1), valid_of(crse)):
+                    np.testing.assert_array_equal(a, b)
     finally:
         gpu.undefine()
 
