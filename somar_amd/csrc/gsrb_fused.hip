@@ -47,11 +47,12 @@ __device__ __forceinline__ double2 ld2(const double* __restrict__ a, long long i
 }
 
 // One GSRB point update of cell (gi,gj,gk): interior form = GSRBITER3DORTHO, cells touching a domain
-// face = GSRBBOUNDARYITER3DORTHO (a Neumann face contributes neither flux nor diagonal).
+// face = GSRBBOUNDARYITER3DORTHO (a Neumann face contributes neither flux nor diagonal; a Dirichlet face contributes
+// both, its ghost being -own).  own = the cell's value before this update.
 __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS, double yyS, double zzS, int gi,
                                              int gj, int gk, double pxl, double pxh, double pyl, double pyh,
                                              double pzl, double pzh, double gxl, double gxh, double gyl, double gyh,
-                                             double gzl, double gzh, double Ji, double rhs)
+                                             double gzl, double gzh, double Ji, double rhs, double own)
 {
     // a ring cell may be the periodic image of a cell on the far side: classify the REAL cell
     if (P.periodic[0]) { const int n = P.dom_hi[0] - P.dom_lo[0] + 1; gi = gi < P.dom_lo[0] ? gi + n : (gi > P.dom_hi[0] ? gi - n : gi); }
@@ -74,6 +75,15 @@ __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS,
     const bool nyh = (gj == P.dom_hi[1]) && P.neum[1][1];
     const bool nzl = (gk == P.dom_lo[2]) && P.neum[2][0];
     const bool nzh = (gk == P.dom_hi[2]) && P.neum[2][1];
+    // A Dirichlet face: the neighbour beyond it is the ghost ELLIPTICCONSTDIRIBCGHOST (order 1, homogeneous inside the
+    // smoother) derives from this very cell, -phi(cell).  The cell keeps its value through the other colour's pass, so
+    // the ghost LevelGSRB refills before each pass is -own in both; it never has to exist in memory.
+    if ((gi == P.dom_lo[0]) && P.diri[0][0]) pxl = -own;
+    if ((gi == P.dom_hi[0]) && P.diri[0][1]) pxh = -own;
+    if ((gj == P.dom_lo[1]) && P.diri[1][0]) pyl = -own;
+    if ((gj == P.dom_hi[1]) && P.diri[1][1]) pyh = -own;
+    if ((gk == P.dom_lo[2]) && P.diri[2][0]) pzl = -own;
+    if ((gk == P.dom_hi[2]) && P.diri[2][1]) pzh = -own;
     double JDloX = 0, JDhiX = 0, JDloY = 0, JDhiY = 0, JDloZ = 0, JDhiZ = 0, ld = 0.0;
     if (!nxl) { JDloX = gxl * pxl; ld = ld - xxS * gxl; }
     if (!nyl) { JDloY = gyl * pyl; ld = ld - yyS * gyl; }
@@ -166,8 +176,8 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         const int l = li + s, g = p.lo[0] + l, r = ri + s;
         bool cmp = (l >= -1) && (l <= p.n[0]) && (r >= 1) && (r <= wi + 2) && (lj >= -1) && (lj <= p.n[1]) &&
                    (row >= 1) && (row <= FR_J - 2);
-        if ((g < P.dom_lo[0] && P.neum[0][0]) || (g > P.dom_hi[0] && P.neum[0][1])) cmp = false;
-        if ((gj < P.dom_lo[1] && P.neum[1][0]) || (gj > P.dom_hi[1] && P.neum[1][1])) cmp = false;
+        if ((g < P.dom_lo[0] && (P.neum[0][0] || P.diri[0][0])) || (g > P.dom_hi[0] && (P.neum[0][1] || P.diri[0][1]))) cmp = false;
+        if ((gj < P.dom_lo[1] && (P.neum[1][0] || P.diri[1][0])) || (gj > P.dom_hi[1] && (P.neum[1][1] || P.diri[1][1]))) cmp = false;
         // beyond a coarse-fine face of this box there is no cell of this level either: the ghost there is an
         // interpolated value (filled before the sweep for the red phase, recomputed below for the black one)
         if ((l < 0 && (p.cf & 1)) || (l >= p.n[0] && (p.cf & 2))) cmp = false;
@@ -219,14 +229,14 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         double red = pick(Pc, c);  // cells not computed here keep their old value
         {
             bool comp = comp_ij[c] && (k >= -1) && (k <= p.n[2]);
-            if ((gk < P.dom_lo[2] && P.neum[2][0]) || (gk > P.dom_hi[2] && P.neum[2][1])) comp = false;
+            if ((gk < P.dom_lo[2] && (P.neum[2][0] || P.diri[2][0])) || (gk > P.dom_hi[2] && (P.neum[2][1] || P.diri[2][1]))) comp = false;
             if ((k < 0 && (p.cf & 16)) || (k >= p.n[2] && (p.cf & 32))) comp = false;
             if (comp) {
                 const double pxl = S[slot][row][rc - 1], pxh = S[slot][row][rc + 1];
                 const double pyl = S[slot][row - 1][rc], pyh = S[slot][row + 1][rc];
                 red = gsrb_point(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, gk, pxl, pxh, pyl, pyh, pick(Pm, c),
                                  pick(Pp, c), c ? Gx.y : Gx.x, c ? gx_next : Gx.y, pick(Gy, c), pick(Gyh, c),
-                                 pick(Gzc, c), pick(Gzp, c), pick(Ji, c), pick(Rh, c));
+                                 pick(Gzc, c), pick(Gzp, c), pick(Ji, c), pick(Rh, c), red);
                 S[slot][row][rc] = red;  // visible to the black phase of the NEXT step (after its barrier)
             }
         }
@@ -257,7 +267,8 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
                         if ((p.cf & 32) && kb == p.n[2] - 1) pzh = P.cf_c1[2] * own + P.cf_c2[2] * zl;
                     }
                     black = gsrb_point(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, p.lo[2] + kb, pxl, pxh, pyl, pyh,
-                                       pzl, pzh, b_gxl, b_gxh, b_gyl, b_gyh, b_gzl, pick(Gzc, c), b_ji, b_rhs);
+                                       pzl, pzh, b_gxl, b_gxh, b_gyl, b_gyh, b_gzl, pick(Gzc, c), b_ji, b_rhs,
+                                       S[sb][row][rc]);
                 }
                 // plane k-1: column c is the new black, column c^1 is red(k-1) (= redPrev1)
                 double* dst = phi_out + base + sk * kb;

@@ -535,7 +535,7 @@ bool PressureSolver::fused_relax(int d, int iters) const
     const Level& L = *lev[d];
     // levels with coarse-fine boundaries qualify when their layout allows it (Level::cf_fusable)
     return prm.relaxMode == RELAX_LEVEL_GSRB && L.valid_cells_global >= fused_min_cells_ && iters > 0 &&
-           (L.ncf == 0 || L.cf_fusable) && L.active[2] && !no_cf_fused_(L) && !full_ && !diri_;
+           (L.ncf == 0 || L.cf_fusable) && L.active[2] && !no_cf_fused_(L) && !full_;  // Dirichlet sides: ghosts synthesized in the kernel
 }
 
 void PressureSolver::relax(int d, double* e, const double* res, int iters, bool e_zero, const double* e_shift,

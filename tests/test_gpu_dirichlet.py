@@ -16,12 +16,16 @@ CASES = [
 ]
 
 
-@pytest.fixture(autouse=True, params=["direct", "march"])
-def _residual_path(request, monkeypatch):
-    """every test twice: levels this small run the direct-load residual; SOMAR_MARCH_MIN_CELLS = 0 sends them through
-    the LDS-marching residual and the fused residual + restriction that large Dirichlet levels (viscous solves) use"""
+@pytest.fixture(autouse=True, params=["direct", "march", "fused"])
+def _kernel_path(request, monkeypatch):
+    """every test three times: levels this small run the direct-load residual and the two-pass smoother;
+    SOMAR_MARCH_MIN_CELLS = 0 sends them through the LDS-marching residual and the fused residual + restriction,
+    SOMAR_FUSED_MIN_CELLS = 0 also through the fused red+black sweep (Dirichlet ghosts synthesized in the kernel) --
+    the kernels large Dirichlet levels (viscous solves) use"""
     if request.param == "march":
         monkeypatch.setenv("SOMAR_MARCH_MIN_CELLS", "0")
+    elif request.param == "fused":
+        monkeypatch.setenv("SOMAR_FUSED_MIN_CELLS", "0")
 
 
 def _setup(so, case, values=None, **kw):

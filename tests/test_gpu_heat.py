@@ -16,6 +16,13 @@ CASES = [
 ]
 
 
+@pytest.fixture(autouse=True, params=["small", "large"])
+def _kernel_path(request, monkeypatch):
+    """'large': the kernels levels above 64^3 cells run -- fused red+black sweep, marching residual, fused restriction"""
+    if request.param == "large":
+        monkeypatch.setenv("SOMAR_FUSED_MIN_CELLS", "0")
+
+
 def _setup(so, case):
     n, bs, per, types, values, nu = case
     dom, grids, dx, Jgup, Jinv = make_problem(so, n, bs, "stretched", per, (1.0, 1.0, 0.5))
