@@ -267,7 +267,7 @@ void Level::define_cf(const double dxCrse[3])
     if (!cf_fusable) hcfx = hcf;
     for (int d = 0; d < 3; ++d) {
         cf_faces[d].reset();
-        if (cf_fusable && ncf > 0 && active[d]) {
+        if (active[d] && ((cf_fusable && ncf > 0) || (!periodic[d] && bc_type[d][1] == BC_DIRI))) {
             int gh[3];
             for (int e = 0; e < 3; ++e) gh[e] = active[e] ? FRAME : 0;
             cf_faces[d].reset(new Copier);
@@ -684,6 +684,18 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     dev.ntiles = N;
     dev.patches = d_patches;
     dev.npatches = (int)hpatches.size();
+    // A Dirichlet wall on the HIGH side of direction d: the fused sweep's recomputed red ring needs, in a neighbouring
+    // box's frame, the coefficient of that box's top face -- a face no box owns as a low face, so the cell-shaped
+    // exchange never carries it (with a Neumann wall the face's flux is dropped and the value is never read).
+    for (int d = 0; d < 3; ++d) {
+        cf_faces[d].reset();
+        if (active[d] && !periodic[d] && bc_type[d][1] == BC_DIRI) {
+            int gh[3];
+            for (int e = 0; e < 3; ++e) gh[e] = active[e] ? FRAME : 0;
+            cf_faces[d].reset(new Copier);
+            cf_faces[d]->define_faces(domain, periodic, *this, d, gh, comm);
+        }
+    }
     refresh_params();
     // the tables above went up with plain hipMemcpy (null stream); the solver's stream is non-blocking and
     // would not wait for them

@@ -141,7 +141,7 @@ public:
     CFCell* d_cfx = nullptr;
     int ncfx = 0;
     bool cf_fusable = true;
-    std::unique_ptr<class Copier> cf_faces[3];  // high-face coefficients of neighbouring boxes (Copier::define_faces)
+    std::unique_ptr<class Copier> cf_faces[3];  // high-face coefficients of neighbouring boxes (Copier::define_faces): CF levels, Dirichlet hi walls
     void cf_homog_ext(double* phi, hipStream_t st) const
     {
         launch_cf_homog(st, d_cfx, ncfx, phi, cf_c1, cf_c2, cf_fac);
