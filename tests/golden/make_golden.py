@@ -102,6 +102,33 @@ def compute():
     out["leptic_res_norms"] = np.array(lep.resNorms)
     out["leptic_status_horiz_full"] = np.array([status, lep.horizSolves, int(lep.usedFullSolver)])
     out["leptic_phi_box0"] = phi[0].view(grids[0])[..., 0].copy()
+    # 7. cell-centred level projection: divergence (CellToEdge + wall faces) / dt, gradient + EdgeToCell + correction
+    from helpers import smooth_cc_velocity
+    dom, grids, dx, Jgup, Jinv = make_problem(so, (16, 16, 8), 8, "stretched", (False, True, False), (2.0, 1.0, 0.5))
+    vel = smooth_cc_velocity(so, dom, grids, (1, 1, 1))
+    div = so.LevelData(grids, 1)
+    so.level_divergence_cc(div, vel, Jinv, grids, dom, dx)
+    out["cc_div_over_dt_box0"] = div[0].a[..., 0] / 0.37
+    phi = so.random_field(grids, 17, (1, 1, 1), dom.box)
+    corr = so.LevelData(grids, 3)
+    so.level_gradient_cc(corr, phi, grids, dom, Jgup, dx)
+    out["cc_corrected_vel_box1"] = vel[1].view(grids[1]) + (-0.37) * corr[1].a
+    # 8. Helmholtz operator with Dirichlet walls after setAlphaAndBeta(1, -0.37): two GSRB sweeps; one TGA step
+    bc = so.BCHolder([[1, 1], [0, 0], [1, 0]], [[0.3, -0.2], [0.0, 0.0], [0.1, 0.0]])
+    dom, grids, dx, Jgup, Jinv = make_problem(so, (16, 16, 8), 8, "stretched", (False, True, False), (1.0, 1.0, 0.5))
+    amr = so.AMRMultiGrid(so.Factory(dom, grids, dx, bc, Jgup, Jinv, alpha=1.0, beta=5e-2), so.BiCGStab())
+    so.reset_solver_alpha_and_beta(amr, 1.0, -0.37)
+    phi = so.random_field(grids, 7, (1, 1, 1), dom.box)
+    rhs = so.random_field(grids, 8, (0, 0, 0), dom.box)
+    amr.op.relax(phi, rhs, 2)
+    out["helm_gsrb2_box0"] = phi[0].view(grids[0])[..., 0].copy()
+    old = so.random_field(grids, 3, (1, 1, 1), dom.box)
+    src = so.random_field(grids, 4, (0, 0, 0), dom.box)
+    new = so.LevelData(grids, 1, (1, 1, 1))
+    so.level_tga(amr, new, old, src, 0.2)
+    out["tga_history"] = np.array(amr.history)
+    out["tga_iters_exit"] = np.array([amr.iters, amr.exitStatus])
+    out["tga_phi_box0"] = new[0].view(grids[0])[..., 0].copy()
     return out
 
 

@@ -125,3 +125,15 @@ def make_gpu_amr(levels, ratios, alpha=0.0, beta=1.0, pre=2, post=2, bottom=2, m
             v.setMetricOrtho(p_, jg[0], jg[1], jg[2], np.asfortranarray(L.Jinv[gi].a[..., 0]))
     s.finalize()
     return s
+
+
+def smooth_cc_velocity(so, dom, grids, ghost, ncomp=3):
+    """a smooth cell field (ncomp comps) on valid + ghost cells, the same formula continued into every ghost cell"""
+    vel = so.LevelData(grids, ncomp, ghost)
+    n = dom.box.size()
+    for f in vel.fabs:
+        I, J, K = np.meshgrid(*[np.arange(f.box.lo[a], f.box.hi[a] + 1) for a in range(3)], indexing="ij")
+        for d in range(ncomp):
+            f.a[..., d] = (np.sin(2 * np.pi * (I + 0.5) / n[0] + 0.1 * d) * np.cos(2 * np.pi * (J + 0.5) / n[1] + 0.3)
+                           * np.cos(2 * np.pi * (K + 0.5) / n[2] + d)) + 0.25 * d
+    return vel

@@ -154,3 +154,44 @@ def test_ratio4_vcycle_and_leptic_match_golden(oracle):
         scale = float(np.max(np.abs(GOLD["leptic_phi_box0"])))
         np.testing.assert_allclose(download_valid(s.level, F.F_PHI, grids)[0], GOLD["leptic_phi_box0"], rtol=0,
                                    atol=1e-11 * scale)
+
+
+def test_cc_projection_and_helmholtz_match_golden(oracle):
+    from somar_amd import api as F
+    from helpers import smooth_cc_velocity
+    so = oracle
+    dom, grids, dx, Jgup, Jinv = make_problem(so, (16, 16, 8), 8, "stretched", (False, True, False), (2.0, 1.0, 0.5))
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv)
+    try:
+        ghost = (1, 1, 1)
+        vel = smooth_cc_velocity(so, dom, grids, ghost)
+        for p in range(gpu.num_local_patches):
+            gpu.uploadCCVel(p, vel[gpu.patch_box(p)[2]].a, ghost)
+        gpu.divergenceCC(F.F_RHS, 0.37)
+        np.testing.assert_array_equal(download_valid(gpu, F.F_RHS, grids)[0], GOLD["cc_div_over_dt_box0"])
+        upload(gpu, F.F_PHI, so.random_field(grids, 17, (1, 1, 1), dom.box))
+        gpu.ccCorrect(F.F_PHI, 0.37)
+        for p in range(gpu.num_local_patches):
+            if gpu.patch_box(p)[2] == 1:
+                buf = vel[1].a.copy(order="F")
+                gpu.downloadCCVel(p, buf, ghost)
+                np.testing.assert_array_equal(buf[1:-1, 1:-1, 1:-1], GOLD["cc_corrected_vel_box1"])
+    finally:
+        gpu.undefine()
+    dom, grids, dx, Jgup, Jinv = make_problem(so, (16, 16, 8), 8, "stretched", (False, True, False), (1.0, 1.0, 0.5))
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv, alpha=1.0, beta=5e-2, bc_type=[1, 1, 0, 0, 1, 0],
+                          bc_values=[0.3, -0.2, 0.0, 0.0, 0.1, 0.0])
+    try:
+        gpu.setAlphaAndBeta(1.0, -0.37)
+        upload(gpu, F.F_PHI, so.random_field(grids, 7, (1, 1, 1), dom.box))
+        upload(gpu, F.F_RHS, so.random_field(grids, 8, (0, 0, 0), dom.box))
+        gpu.relax(0, F.F_PHI, F.F_RHS, 2)
+        np.testing.assert_array_equal(download_valid(gpu, F.F_PHI, grids)[0], GOLD["helm_gsrb2_box0"])
+        upload(gpu, F.F_HEAT_OLD, so.random_field(grids, 3, (1, 1, 1), dom.box))
+        upload(gpu, F.F_HEAT_SRC, so.random_field(grids, 4, (0, 0, 0), dom.box))
+        st = gpu.heatStep(2, 0.2)
+        assert [st["iters"], st["exitStatus"]] == list(GOLD["tga_iters_exit"])
+        np.testing.assert_allclose(st["history"], GOLD["tga_history"], rtol=1e-10)
+        np.testing.assert_allclose(download_valid(gpu, F.F_PHI, grids)[0], GOLD["tga_phi_box0"], rtol=0, atol=1e-9)
+    finally:
+        gpu.undefine()

@@ -171,16 +171,8 @@ def test_full_metric_gradient_correction_bit_exact_and_projection(oracle, case):
 
 # ---- cell-centred level projection (LevelCCProjector): CellToEdge + wall BC + divergence, gradient + EdgeToCell ----
 def _cc_velocity(so, dom, grids, ghost):
-    """a smooth cell field (3 comps) on valid + ghost cells; ghost cells that are another box's (or a periodic image's)
-    valid cells hold that cell's value, physical ghosts hold the same smooth formula continued outside"""
-    vel = so.LevelData(grids, 3, ghost)
-    n = dom.box.size()
-    for f in vel.fabs:
-        I, J, K = np.meshgrid(*[np.arange(f.box.lo[a], f.box.hi[a] + 1) for a in range(3)], indexing="ij")
-        for d in range(3):
-            f.a[..., d] = (np.sin(2 * np.pi * (I + 0.5) / n[0] + 0.1 * d) * np.cos(2 * np.pi * (J + 0.5) / n[1] + 0.3)
-                           * np.cos(2 * np.pi * (K + 0.5) / n[2] + d)) + 0.25 * d
-    return vel
+    from helpers import smooth_cc_velocity
+    return smooth_cc_velocity(so, dom, grids, ghost)
 
 
 @pytest.mark.parametrize("case", CASES)
