@@ -87,6 +87,7 @@ void AMRSolver::define(const IBox& domain0, const bool periodic[3], const double
         }
         std::unique_ptr<PressureSolver> ps(new PressureSolver(comm_, st_));
         ps->define(dom, periodic, dx, bc_type, boxes[l], owners[l], alpha, beta, p, l > 0 ? dxc : nullptr);
+        ps->set_amr_member();
         if (l > 0) {
             // the mini V-cycle's coarsening pattern, MappedAMRMultiGrid.H:1455-1482 (anisotropic coarsening first)
             int r[3] = {ratios[l - 1][0], ratios[l - 1][1], ratios[l - 1][2]};

@@ -844,6 +844,7 @@ void PressureSolver::mac_project(double dt, bool zeroPressure, bool forceHomogen
 void PressureSolver::set_alpha_beta(double a, double b)
 {
     SOMAR_CHECK(finalized, "set_alpha_beta before finalize");
+    SOMAR_CHECK(!amr_member_, "set_alpha_beta on a level of an AMR hierarchy is not implemented (its flux-register scales carry beta)");
     if (!coefs_saved_) {
         aCoef_ = lev[0]->alpha;
         bCoef_ = lev[0]->beta;

@@ -57,6 +57,7 @@ public:
     // (LevelGeometry::getFCJgup's FluxBox layout).  Switches the solver to the 19-point kernels (full19.hip).
     void set_metric_full(int patch, const double* jg0, const double* jg1, const double* jg2, const double* jinv);
     bool is_full() const { return full_; }
+    void set_amr_member() { amr_member_ = true; }  // a level of an AMRSolver hierarchy (whose reflux tables carry beta)
     void finalize();  // builds the semicoarsened hierarchy, coarse metrics, lapDiag, null-space probes
 
     // ---- data movement across the boundary (host FABs, caller-owned) ---------------------
@@ -191,6 +192,7 @@ private:
     double* f_heat[3] = {nullptr, nullptr, nullptr};
     double aCoef_ = 0.0, bCoef_ = 1.0;  // the factory's alpha / beta (MappedAMRPoissonOpFactory.cpp:585-586)
     bool coefs_saved_ = false;
+    bool amr_member_ = false;
     double* f_amr[2] = {nullptr, nullptr};
     bool hasCF_ = false;
     bool own_stream_ = true;

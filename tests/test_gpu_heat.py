@@ -142,3 +142,23 @@ def test_inhomogeneous_operator_and_residual_bit_exact(oracle, case):
                 np.testing.assert_array_equal(x, y)
     finally:
         gpu.undefine()
+
+
+def test_set_alpha_and_beta_on_a_level_of_a_hierarchy_fails_loudly(oracle):
+    """the flux-register scales of an AMR hierarchy carry beta: changing it behind their back must be an error, not a
+    silently inconsistent composite operator"""
+    from oracle import somar_amr as am
+    from somar_amd import SomarError
+    from helpers import make_amr_levels, make_gpu_amr
+    so = oracle
+    fb = [[so.Box((8, 8, 4), (23, 23, 11))]]
+    levels = make_amr_levels(so, am, (16, 16, 8), (2.0, 1.0, 0.5), (False, False, False), [(2, 2, 2)], fb)
+    gpu = make_gpu_amr(levels, [(2, 2, 2)])
+    try:
+        for v in gpu.levels:
+            with pytest.raises(SomarError):
+                v.setAlphaAndBeta(1.0, -0.1)
+            with pytest.raises(SomarError):
+                v.heatStep(0, 0.1)
+    finally:
+        gpu.undefine()
