@@ -50,7 +50,7 @@ def cpu_baseline(sample_n=256):
     corr = so.LevelData(grids, 1, (1, 1, 1))
     amr.mg.init(corr, res)
     amr.mg.one_cycle(corr, res)  # warm-up
-    reps = 2
+    reps = 12   # ~0.6 s each on one core: with set-up and warm-up about 10-15 s of CPU work
     t0 = time.perf_counter()
     for _ in range(reps):
         so.ld_set(corr, 0.0)
