@@ -181,7 +181,11 @@ int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* ite
  *   LevelMACProjector::computeDiv/computeGrad/applyCorrection  projection/LevelMACProjector.cpp:156-241
  *   Divergence::levelDivergenceMAC                              calculus/DivCurlGrad/Divergence.cpp:44-127
  *   Gradient::levelGradientMAC (order-2 extrapolated ghosts)    calculus/DivCurlGrad/Gradient.cpp:85-206
- * Boundary-face velocities are taken as given (the caller's uStarFuncBC has already been applied). */
+ * Boundary-face velocities are taken as given; somar_vel_wall_bc applies what levelDivergenceMAC applies through its
+ * a_fluxBC = uStarFuncBC when no side is an inflow / outflow side (BCutil/PhysBCUtil.cpp:793-801, 1261-1276): solid walls,
+ * BasicVelocityBCGhostClass -> setSideDiriBC(0) on the wall-normal faces of the resident velocity, in place as in the
+ * reference (Divergence.cpp:73-100, EllipticBCUtils.cpp:1284-1327, 96-100).  Call it between upload and projection. */
+int somar_vel_wall_bc(somar_solver_t* s);
 int somar_vel_upload(somar_solver_t* s, int dir, int patch, const double* host);
 int somar_vel_download(somar_solver_t* s, int dir, int patch, double* host);
 int somar_level_divergence_mac(somar_solver_t* s, int out_field, double dt);

@@ -970,6 +970,9 @@ def level_project(comp, l, vel, phi, dt, centring="mac", velCoarse=None, zeroPhi
                     b.a[..., c] = a.a[..., 0]
         so.level_divergence_cc(rhs[l], vel, L.Jinv, L.grids, L.domain, L.dx, nd, wall)
     else:
+        if wall:
+            # levelDivergenceMAC's a_fluxBC = m_divBC overwrites the caller's wall-normal faces (Divergence.cpp:73-100)
+            so.set_wall_normal_flux(vel, L.grids, L.domain, nd)
         so.level_divergence_mac(rhs[l], vel, L.Jinv, L.grids, L.dx, nd)
     if dt != 0.0:
         for f in rhs[l].fabs:

@@ -101,6 +101,7 @@ _SIGS = {
     "somar_bottom_solve": [_H, C.c_int, C.c_int, _PI, _PI],
     "somar_vel_upload": [_H, C.c_int, C.c_int, _PD],
     "somar_vel_download": [_H, C.c_int, C.c_int, _PD],
+    "somar_vel_wall_bc": [_H],
     "somar_level_divergence_mac": [_H, C.c_int, C.c_double],
     "somar_level_mac_correct": [_H, C.c_int, C.c_double],
     "somar_mac_project": [_H, C.c_double, C.c_int, C.c_int, C.POINTER(Stats)],
@@ -488,6 +489,10 @@ class AMRPressureSolver:
         out = np.zeros(shape, dtype=np.float64, order="F")
         _ck(lib().somar_vel_download(self._h, d, patch, _dp(out)))
         return out
+
+    def velWallBC(self):
+        """zero wall-normal faces of the resident MAC velocity (uStarFuncBC, solid walls)"""
+        _ck(lib().somar_vel_wall_bc(self._h))
 
     def divergenceMAC(self, out_field, dt):
         _ck(lib().somar_level_divergence_mac(self._h, out_field, float(dt)))

@@ -628,6 +628,7 @@ void AMRSolver::level_project(int l, int centring, double dt, bool zeroPressure,
             for (int c = 0; c < prm.spaceDim; ++c) interp_cf(l, P.cc_vel(c), S[l - 1]->cc_vel(c), false);
         P.divergence_cc(rhs, dt, wall);
     } else {
+        if (wall) P.vel_wall_bc();
         P.divergence_mac(rhs, dt);
     }
     solve(l, l, zeroPressure, forceHomogeneous, st);

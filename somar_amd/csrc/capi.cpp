@@ -524,6 +524,13 @@ int somar_vel_download(somar_solver_t* s, int dir, int patch, double* host)
     API_END
 }
 
+int somar_vel_wall_bc(somar_solver_t* s)
+{
+    API_BEGIN
+    s->ps->vel_wall_bc();
+    API_END
+}
+
 int somar_level_divergence_mac(somar_solver_t* s, int out_field, double dt)
 {
     API_BEGIN

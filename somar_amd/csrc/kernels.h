@@ -89,6 +89,7 @@ void launch_altered_jgup(hipStream_t st, long long n, double* dest, const double
 void launch_face_axpy(hipStream_t st, const LevelDev& L, double* const vel[3], double* const grad[3], double s);
 void launch_mac_correct(hipStream_t st, const LevelDev& L, double* const vel[3], const double* phi, double dtScale);
 // cell-centred level projection: CellToEdge (+ zero normal flux on walls), EdgeToCell + correction (null cc[a] = skip a)
+void launch_face_wall(hipStream_t st, const LevelDev& L, double* const edge[3]);  // zero normal flux on solid walls (null = skip)
 void launch_cell_to_edge(hipStream_t st, const LevelDev& L, double* const edge[3], double* const cc[3], bool wall);
 void launch_cc_correct(hipStream_t st, const LevelDev& L, double* const cc[3], const double* phi, double dtScale);
 void launch_edge_to_cell_axpy(hipStream_t st, const LevelDev& L, double* const cc[3], double* const grad[3], double dtScale);

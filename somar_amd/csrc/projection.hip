@@ -211,6 +211,40 @@ __global__ __launch_bounds__(512) void k_cell_to_edge(const Tile* __restrict__ t
         }
 }
 
+// BasicVelocityBCGhostClass on face-centred data, solid walls: setSideDiriBC(0) sets the wall-normal faces directly
+// (EllipticBCUtils.cpp:1284-1327, 96-100) -- what levelDivergenceMAC does to the caller's velocity through a_fluxBC
+template <int DIR>
+__global__ __launch_bounds__(512) void k_face_wall(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ patches,
+                                                   double* __restrict__ edge, StencilParams P)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1] || P.periodic[DIR]) return;
+    const long long s = DIR == 0 ? 1 : (DIR == 1 ? (long long)p.pj : p.pk);
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int li = li0 + q;
+            if (li >= p.n[0]) continue;
+            const int lk = t.k0 + kk;
+            const int l = DIR == 0 ? li : (DIR == 1 ? lj : lk);
+            const int g = p.lo[DIR] + l;
+            const long long c = pidx(p, li, lj, lk);
+            if (g == P.dom_lo[DIR]) edge[c] = 0.0;
+            if (g == P.dom_hi[DIR]) edge[c + s] = 0.0;
+        }
+}
+
+void launch_face_wall(hipStream_t st, const LevelDev& L, double* const edge[3])
+{
+    if (L.ntiles == 0) return;
+    const dim3 g(L.ntiles), b(64, L.tile_j, 1);
+    if (edge[0]) hipLaunchKernelGGL(k_face_wall<0>, g, b, 0, st, L.tiles, L.patches, edge[0], L.P);
+    if (edge[1]) hipLaunchKernelGGL(k_face_wall<1>, g, b, 0, st, L.tiles, L.patches, edge[1], L.P);
+    if (edge[2]) hipLaunchKernelGGL(k_face_wall<2>, g, b, 0, st, L.tiles, L.patches, edge[2], L.P);
+}
+
 struct CC3 { double* u[3]; const double* g[3]; };
 
 // Diagonal metric: both face gradients of a cell from phi (exchanged; physical ghosts by order-2 extrapolation exactly as

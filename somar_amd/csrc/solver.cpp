@@ -825,6 +825,14 @@ void PressureSolver::mac_correct(double* phi, double dt)
     launch_mac_correct(st_, L.dev, v, phi, dt == 0.0 ? -1.0 : -dt);
 }
 
+// uStarFuncBC without inflow / outflow sides on the face-centred velocity (LevelMACProjector::computeDiv hands &m_divBC to
+// levelDivergenceMAC, Divergence.cpp:73-100, which overwrites the caller's boundary faces): solid walls, zero normal flux
+void PressureSolver::vel_wall_bc()
+{
+    double* e[3] = {vel(0), vel(1), prm.spaceDim == 3 ? vel(2) : nullptr};
+    launch_face_wall(st_, lev[0]->dev, e);
+}
+
 void PressureSolver::mac_project(double dt, bool zeroPressure, bool forceHomogeneous, SolveStats& s)
 {
     divergence_mac(f_rhs, dt);

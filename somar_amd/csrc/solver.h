@@ -150,6 +150,7 @@ public:
     void divergence_mac(double* out, double dt);                 // out = div(vel) [/ dt]
     void mac_correct(double* phi, double dt);                    // vel -= dt * G(phi)
     void mac_project(double dt, bool zeroPressure, bool forceHomogeneous, SolveStats& st);
+    void vel_wall_bc();   // the velocity BC levelDivergenceMAC applies through a_fluxBC, solid walls: zero wall-normal faces of vel()
     // viscous / diffusive Helmholtz solves through the same operator
     void set_alpha_beta(double a, double b);   // MappedAMRPoissonOp::setAlphaAndBeta on every depth: alpha = a*aCoef, beta = b*bCoef
     double* heat_field(int which);             // 0: phiOld, 1: src (depth 0, allocated on first use)

@@ -258,3 +258,35 @@ def test_cc_correction_with_a_non_diagonal_metric_bit_exact(oracle, case):
             np.testing.assert_array_equal(got[gi], vel[gi].a)
     finally:
         gpu.undefine()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_mac_velocity_wall_bc_bit_exact(oracle, case):
+    """somar_vel_wall_bc = the solid-wall velocity BC levelDivergenceMAC applies in place: wall-normal faces zero, all
+    other faces untouched, periodic directions skipped"""
+    so = oracle
+    n, boxsz, variant, periodic, L = case
+    dom, grids, dx, Jgup, Jinv = make_problem(so, n, boxsz, variant, periodic, L)
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv)
+    try:
+        vel = so.FluxData(grids, 1, 3)
+        rng = np.random.default_rng(5)
+        for i in range(len(grids)):
+            for d in range(3):
+                vel[i][d].a[...] = rng.uniform(0.5, 1.5, vel[i][d].a.shape)
+        for p in range(gpu.num_local_patches):
+            gi = gpu.patch_box(p)[2]
+            for d in range(3):
+                gpu.uploadVel(d, p, np.asfortranarray(vel[gi][d].a[..., 0]))
+        so.set_wall_normal_flux(vel, grids, dom)
+        gpu.velWallBC()
+        nz = 0
+        for p in range(gpu.num_local_patches):
+            gi = gpu.patch_box(p)[2]
+            for d in range(3):
+                got = gpu.downloadVel(d, p)
+                np.testing.assert_array_equal(got, vel[gi][d].a[..., 0])
+                nz += int((got == 0.0).sum())
+        assert (nz > 0) == (not all(periodic))
+    finally:
+        gpu.undefine()
