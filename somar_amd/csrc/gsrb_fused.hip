@@ -49,6 +49,7 @@ __device__ __forceinline__ double2 ld2(const double* __restrict__ a, long long i
 // One GSRB point update of cell (gi,gj,gk): interior form = GSRBITER3DORTHO, cells touching a domain
 // face = GSRBBOUNDARYITER3DORTHO (a Neumann face contributes neither flux nor diagonal; a Dirichlet face contributes
 // both, its ghost being -own).  own = the cell's value before this update.
+template <bool DIRI>
 __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS, double yyS, double zzS, int gi,
                                              int gj, int gk, double pxl, double pxh, double pyl, double pyh,
                                              double pzl, double pzh, double gxl, double gxh, double gyl, double gyh,
@@ -78,12 +79,15 @@ __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS,
     // A Dirichlet face: the neighbour beyond it is the ghost ELLIPTICCONSTDIRIBCGHOST (order 1, homogeneous inside the
     // smoother) derives from this very cell, -phi(cell).  The cell keeps its value through the other colour's pass, so
     // the ghost LevelGSRB refills before each pass is -own in both; it never has to exist in memory.
-    if ((gi == P.dom_lo[0]) && P.diri[0][0]) pxl = -own;
-    if ((gi == P.dom_hi[0]) && P.diri[0][1]) pxh = -own;
-    if ((gj == P.dom_lo[1]) && P.diri[1][0]) pyl = -own;
-    if ((gj == P.dom_hi[1]) && P.diri[1][1]) pyh = -own;
-    if ((gk == P.dom_lo[2]) && P.diri[2][0]) pzl = -own;
-    if ((gk == P.dom_hi[2]) && P.diri[2][1]) pzh = -own;
+    // (DIRI is a template parameter: the Neumann / periodic instantiations carry none of this.)
+    if (DIRI) {
+        if ((gi == P.dom_lo[0]) && P.diri[0][0]) pxl = -own;
+        if ((gi == P.dom_hi[0]) && P.diri[0][1]) pxh = -own;
+        if ((gj == P.dom_lo[1]) && P.diri[1][0]) pyl = -own;
+        if ((gj == P.dom_hi[1]) && P.diri[1][1]) pyh = -own;
+        if ((gk == P.dom_lo[2]) && P.diri[2][0]) pzl = -own;
+        if ((gk == P.dom_hi[2]) && P.diri[2][1]) pzh = -own;
+    }
     double JDloX = 0, JDhiX = 0, JDloY = 0, JDhiY = 0, JDloZ = 0, JDhiZ = 0, ld = 0.0;
     if (!nxl) { JDloX = gxl * pxl; ld = ld - xxS * gxl; }
     if (!nyl) { JDloY = gyl * pyl; ld = ld - yyS * gyl; }
@@ -105,7 +109,7 @@ __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS,
 //    post-smoothing sweep instead of a separate 16 B/cell pass.
 // 3: phi_in is read as value + crse(i / r): the prolongation (CONSTINTERPPS) folded into the first post-smoothing
 //    sweep -- ghosts included, which needs crse exchanged one cell deep.  4: as 3, minus sums[0]/sums[1].
-template <int FR_J, int INMODE>
+template <int FR_J, int INMODE, bool DIRI = false>
 __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict__ tiles,
                                                      const PatchDesc* __restrict__ patches,
                                                      double* __restrict__ phi_out,
@@ -176,8 +180,12 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         const int l = li + s, g = p.lo[0] + l, r = ri + s;
         bool cmp = (l >= -1) && (l <= p.n[0]) && (r >= 1) && (r <= wi + 2) && (lj >= -1) && (lj <= p.n[1]) &&
                    (row >= 1) && (row <= FR_J - 2);
-        if ((g < P.dom_lo[0] && (P.neum[0][0] || P.diri[0][0])) || (g > P.dom_hi[0] && (P.neum[0][1] || P.diri[0][1]))) cmp = false;
-        if ((gj < P.dom_lo[1] && (P.neum[1][0] || P.diri[1][0])) || (gj > P.dom_hi[1] && (P.neum[1][1] || P.diri[1][1]))) cmp = false;
+        if ((g < P.dom_lo[0] && (P.neum[0][0] || (DIRI && P.diri[0][0]))) ||
+            (g > P.dom_hi[0] && (P.neum[0][1] || (DIRI && P.diri[0][1]))))
+            cmp = false;
+        if ((gj < P.dom_lo[1] && (P.neum[1][0] || (DIRI && P.diri[1][0]))) ||
+            (gj > P.dom_hi[1] && (P.neum[1][1] || (DIRI && P.diri[1][1]))))
+            cmp = false;
         // beyond a coarse-fine face of this box there is no cell of this level either: the ghost there is an
         // interpolated value (filled before the sweep for the red phase, recomputed below for the black one)
         if ((l < 0 && (p.cf & 1)) || (l >= p.n[0] && (p.cf & 2))) cmp = false;
@@ -229,12 +237,14 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         double red = pick(Pc, c);  // cells not computed here keep their old value
         {
             bool comp = comp_ij[c] && (k >= -1) && (k <= p.n[2]);
-            if ((gk < P.dom_lo[2] && (P.neum[2][0] || P.diri[2][0])) || (gk > P.dom_hi[2] && (P.neum[2][1] || P.diri[2][1]))) comp = false;
+            if ((gk < P.dom_lo[2] && (P.neum[2][0] || (DIRI && P.diri[2][0]))) ||
+                (gk > P.dom_hi[2] && (P.neum[2][1] || (DIRI && P.diri[2][1]))))
+                comp = false;
             if ((k < 0 && (p.cf & 16)) || (k >= p.n[2] && (p.cf & 32))) comp = false;
             if (comp) {
                 const double pxl = S[slot][row][rc - 1], pxh = S[slot][row][rc + 1];
                 const double pyl = S[slot][row - 1][rc], pyh = S[slot][row + 1][rc];
-                red = gsrb_point(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, gk, pxl, pxh, pyl, pyh, pick(Pm, c),
+                red = gsrb_point<DIRI>(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, gk, pxl, pxh, pyl, pyh, pick(Pm, c),
                                  pick(Pp, c), c ? Gx.y : Gx.x, c ? gx_next : Gx.y, pick(Gy, c), pick(Gyh, c),
                                  pick(Gzc, c), pick(Gzp, c), pick(Ji, c), pick(Rh, c), red);
                 S[slot][row][rc] = red;  // visible to the black phase of the NEXT step (after its barrier)
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
                         if ((p.cf & 16) && kb == 0) pzl = P.cf_c1[2] * own + P.cf_c2[2] * zh;
                         if ((p.cf & 32) && kb == p.n[2] - 1) pzh = P.cf_c1[2] * own + P.cf_c2[2] * zl;
                     }
-                    black = gsrb_point(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, p.lo[2] + kb, pxl, pxh, pyl, pyh,
+                    black = gsrb_point<DIRI>(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, p.lo[2] + kb, pxl, pxh, pyl, pyh,
                                        pzl, pzh, b_gxl, b_gxh, b_gyl, b_gyh, b_gzl, pick(Gzc, c), b_ji, b_rhs,
                                        S[sb][row][rc]);
                 }
@@ -315,6 +325,22 @@ void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const Leve
         case 3: SOMAR_LAUNCH_FUSED(ROWS, 3); break;    \
         case 4: SOMAR_LAUNCH_FUSED(ROWS, 4); break;    \
         default: SOMAR_LAUNCH_FUSED(ROWS, 0);          \
+    }
+    bool diri = false;
+    for (int d = 0; d < 3; ++d) diri = diri || L.P.diri[d][0] || L.P.diri[d][1];
+    if (diri) {
+        // Dirichlet sides: no null space, hence never a mean removal (modes 2 / 4)
+#define SOMAR_LAUNCH_FUSED_D(ROWS, M)                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gsrb_fused<ROWS, M, true>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
+                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2)
+        SOMAR_CHECK(in_mode == 0 || in_mode == 1 || in_mode == 3, "internal: mean removal on a level with Dirichlet sides");
+        if (fused_rows() == 8) {
+            if (in_mode == 1) SOMAR_LAUNCH_FUSED_D(8, 1); else if (in_mode == 3) SOMAR_LAUNCH_FUSED_D(8, 3); else SOMAR_LAUNCH_FUSED_D(8, 0);
+        } else {
+            if (in_mode == 1) SOMAR_LAUNCH_FUSED_D(16, 1); else if (in_mode == 3) SOMAR_LAUNCH_FUSED_D(16, 3); else SOMAR_LAUNCH_FUSED_D(16, 0);
+        }
+#undef SOMAR_LAUNCH_FUSED_D
+        return;
     }
     if (fused_rows() == 8) { SOMAR_LAUNCH_FUSED_MODES(8) }
     else { SOMAR_LAUNCH_FUSED_MODES(16) }
