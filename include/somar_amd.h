@@ -43,7 +43,9 @@
 extern "C" {
 #endif
 
-#define SOMAR_AMD_ABI_VERSION 3
+/* 4: + cell-centred level projection, level projections on hierarchy levels, Helmholtz coefficients and heat
+ *    integrators, operator / residual with the BC flag, MAC wall BC (additions only: version-3 callers are unaffected) */
+#define SOMAR_AMD_ABI_VERSION 4
 
 /* BCType codes, calculus/BCInterface/BCDescriptor.H:34-39 */
 #define SOMAR_BC_NONE (-1)
