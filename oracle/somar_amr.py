@@ -946,13 +946,13 @@ def copy_valid(dst, src):
 #          ghosts, m_velCFInterp.coarseFineInterp(u, uCrse) (Divergence.cpp:372-375; MappedQuadCFInterp with SpaceDim
 #          comps = component by component), then CellToEdge etc.; the gradient as above + EdgeToCell
 # The solve in between is AMRPressureSolver::solve(lmin = lmax = l) = the level solve with phi[l-1] as CF data.
-# Diagonal metric (levelGradientMAC adds ExtrapolateCFEV otherwise).
+# With a non-diagonal metric levelGradientMAC adds ExtrapolateCFEV after the interpolation and the gradient is
+# singleBoxMacGrad's full sequence (so.level_gradient_mac with the level operator).
 # ----------------------------------------------------------------------------
 def level_project(comp, l, vel, phi, dt, centring="mac", velCoarse=None, zeroPhi=True, wall=True):
     op = comp.ops[l]
     L = comp.levels[l]
     nd = comp.ndim
-    assert op.isDiagonal
     rhs = [None] * len(comp.levels)
     rhs[l] = so.LevelData(L.grids, 1)
     if centring == "cc":
@@ -980,15 +980,17 @@ def level_project(comp, l, vel, phi, dt, centring="mac", velCoarse=None, zeroPhi
     comp.solve(phi, rhs, l, l, zeroPhi=zeroPhi)
     if l > 0:
         op.quad.coarse_fine_interp(phi[l], phi[l - 1])
+        if not op.isDiagonal:
+            op.cf.extrapolate_cf_ev(phi[l], 2, op.activeDirs)       # levelGradientMAC, Gradient.cpp:110-113
     dtScale = -1.0 if dt == 0.0 else -dt
     if centring == "cc":
         corr = so.LevelData(L.grids, nd)
-        so.level_gradient_cc(corr, phi[l], L.grids, L.domain, L.Jgup, L.dx, nd)
+        so.level_gradient_cc(corr, phi[l], L.grids, L.domain, L.Jgup, L.dx, nd, op=op)
         for i, g in enumerate(L.grids):
             vel[i].view(g)[...] += dtScale * corr[i].a
     else:
         corr = so.FluxData(L.grids, 1, nd)
-        so.level_gradient_mac(corr, phi[l], L.grids, L.domain, L.Jgup, L.dx, nd)
+        so.level_gradient_mac(corr, phi[l], L.grids, L.domain, L.Jgup, L.dx, nd, op=op)
         for i in range(len(L.grids)):
             for d in range(nd):
                 vel[i][d].a += dtScale * corr[i][d].a
