@@ -293,8 +293,8 @@ int somar_amr_interp_cf(somar_amr_t* a, int level, int fine_field, int coarse_fi
  *   centring 1  LevelCCProjector  (projection/LevelCCProjector.cpp:163-255): the level's somar_ccvel_upload'ed velocity; level-1's
  *               cell-centred velocity feeds m_velCFInterp.coarseFineInterp (calculus/DivCurlGrad/Divergence.cpp:372-375)
  * SOMAR_F_PHI of level-1 feeds the level solve (AMRPressureSolver::levelSolve's a_crsePhiPtr, AMRPressureSolver.cpp:567-594)
- * and levelGradientMAC's coarseFineInterp (+ ExtrapolateCFEV with a non-diagonal metric, Gradient.cpp:106-113).
- * Velocities in flux form. */
+ * and levelGradientMAC's coarseFineInterp (Gradient.cpp:106-113).  Velocities in flux form.  On a refined level the
+ * metric must be diagonal (error otherwise; level 0 takes either). */
 int somar_amr_level_project(somar_amr_t* a, int level, int centring, double dt, int zero_pressure, int force_homogeneous,
                             int wall_bc, somar_stats_t* stats);
 int somar_amr_residual_level(somar_amr_t* a, int l_max, int l_base, int ilev, int res_field, int phi_field,

@@ -620,6 +620,8 @@ void AMRSolver::level_project(int l, int centring, double dt, bool zeroPressure,
     SOMAR_CHECK(finalized_ && l >= 0 && l < nlevels(), "level_project: bad level / hierarchy not finalized");
     SOMAR_CHECK(centring == 0 || centring == 1, "centring: 0 MAC, 1 cell-centred");
     PressureSolver& P = *S[l];
+    SOMAR_CHECK(!(P.is_full() && l > 0),
+                "level projection on a REFINED level with a non-diagonal metric is not implemented (singleBoxMacGrad next to coarse-fine faces)");
     double* phi = P.field(0, 0);
     double* rhs = P.field(0, 1);
     if (centring == 1) {

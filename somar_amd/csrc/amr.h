@@ -137,7 +137,7 @@ public:
 
     // BaseProjector<T>::levelProject -> project(lmin = lmax = l) (projection/BaseProjectorI.H:176-366) on the resident
     // velocity of level l: centring 0 = LevelMACProjector (vel()), 1 = LevelCCProjector (cc_vel(), level l-1's supplies the
-    // velocity's coarse-fine values); phi of level l-1 supplies the pressure's (non-diagonal metric: + ExtrapolateCFEV).
+    // velocity's coarse-fine values); phi of level l-1 supplies the pressure's.  Refined levels: diagonal metric.
     void level_project(int l, int centring, double dt, bool zeroPressure, bool forceHomogeneous, bool wall, SolveStats& st);
 
     // pieces (parity tests)
