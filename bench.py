@@ -4,20 +4,32 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload): BASELINE config C2 -- single-level 512^3 Poisson (alpha=0, beta=1), homogeneous
+Headline workload (config.workload): BASELINE config C2 -- single-level 512^3 Poisson (alpha=0, beta=1), homogeneous
 Neumann on all faces, "mapped-Cartesian" = separable stretched DIAGONAL metric stored as full coefficient
-arrays, LevelGSRB smoother, pre/post/bottom = 2/2/2 (utils/ProblemContext.cpp:1153-1163),
+arrays (SURVEY.md 8d variant ii), LevelGSRB smoother, pre/post/bottom = 2/2/2 (utils/ProblemContext.cpp:1153-1163),
 BiCGStab bottom solver.  A step = one MappedMultiGrid V-cycle (cycle(0)) from a zero correction on a fixed
 compatible residual, with every input already resident in HBM.  N > 1: the SAME 512^3 problem, its box
 layout sharded over N GPUs (one box per GPU, one process per GPU, halo exchange + scalar reductions over
-RCCL/xGMI) => strong scaling.
+RCCL/xGMI) => strong scaling.  The timed loop runs the shipped code path (HIP-graph replay of the coarse depths,
+no per-kernel events); the per-kernel HIP-event numbers of the `roofline` block come from a separate, untimed,
+profiled pass of the same V-cycle.
 
 One JSON line on rank 0.  Besides the contract keys it carries
-  roofline     -- dominant kernel (k_gsrb_fused, depth 0; k_gsrb_ortho below the fused threshold): algorithmic bytes (32 B/cell per colour pass =
-                  half of the 64 B/cell red+black sweep of SURVEY.md 8d) / HIP-event launch duration measured
-                  in the timed region on the solver's stream, against the 8 TB/s HBM3E peak
-  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's Fortran+C++ path; the reference itself
-                  cannot be built here) timed on a bounded 256^3 sample of the same workload, 1 core
+  roofline      dominant kernel (k_gsrb_fused, depth 0): algorithmic bytes (64 B/cell per red+black sweep)
+                / HIP-event launch duration on the solver's stream, against the 8 TB/s HBM3E peak; `measured_copy_GBs`
+                = device-to-device copy bandwidth measured in this run (read + written bytes / time)
+  cpu_baseline  the reference's V-cycle call sequence orchestrated in C over the restated Fortran kernels
+                (oracle/cpu_vcycle.c; the reference itself cannot be built here), OpenMP over k-slabs, timed on the
+                REAL 512^3 problem on all host cores given to this process and on 1 core, with the measured STREAM triad
+  c2_cartesian  SURVEY.md 8d variant (i): the same V-cycle with the all-ones (true Cartesian) metric -- the variant on
+                which point-GSRB multigrid converges at 0.07-0.1 per cycle (on the stretched metric the cycle stalls at
+                512^3, in the oracle too: DESIGN.md)
+  c4_amr        BASELINE config C4, the workload the north star's >= 6x 1->8-GPU scaling is quoted on: 3-level
+                1024x1024x128 LockExchange hierarchy ((2,2,1) refinements, 128^3 boxes, 940 M cells), every level's boxes
+                sharded in y-slabs over the N GPUs, ms per AMR V-cycle (MappedAMRMultiGrid::AMRVCycle, 4/4/2), measured in
+                the same run at every N
+The run FAILS (non-zero exit) when a timed operator does not contract, or when the N > 1 contraction departs from the
+recorded single-GPU value of the same problem: a broken exchange must not produce a plausible throughput line.
 """
 import argparse
 import json
@@ -27,40 +39,217 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 B_GSRB_COLOR = 32.0            # algorithmic B/cell of ONE colour pass (64 B/cell per red+black sweep)
 B_RESIDUAL = 56.0              # algorithmic B/cell of the fused residual
 N_FINE = 512
+# single-GPU first-cycle contraction |r1|/|r0| of the timed problems (driver BENCH_r01 / profiles/): the N > 1 runs
+# must reproduce them (same arithmetic; only the large-level mean sums associate differently)
+SINGLE_RANK_CONTRACTION = {("stretched", 512): 0.46093832950371805}
 
 
-def cpu_baseline(sample_n=256):
-    """oracle V-cycle on a bounded sample, scaled to V-cycles/s at 512^3 (work is linear in cells)."""
-    import ctypes as C
-    import subprocess
-    from oracle import somar_oracle as so
-    from helpers import make_oracle_solver, make_problem
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle_fast.so"])
-    so._LIB = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_fast.so"))  # -O3 -march=native build of the same source
-    dom, grids, dx, Jgup, Jinv = make_problem(so, sample_n, sample_n, "stretched")
-    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv)
-    res = so.random_field(grids, 12345, (0, 0, 0), dom.box)
-    so.remove_weighted_mean(res, Jinv)
-    corr = so.LevelData(grids, 1, (1, 1, 1))
-    amr.mg.init(corr, res)
-    amr.mg.one_cycle(corr, res)  # warm-up
-    reps = 12   # ~0.6 s each on one core: with set-up and warm-up about 10-15 s of CPU work
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n=N_FINE):
+    """The reference's V-cycle on the host: C orchestration + restated Fortran kernels + OpenMP (oracle/cpu_vcycle.c),
+    the real n^3 problem.  Bounded: 1 timed cycle on one core, 3 on all cores (~20-40 s of CPU work at 512^3)."""
+    import numpy as np
+    from oracle import cpu_vcycle as cv
+    from somar_amd import synthetic
+    cores = host_cores()
+    dx = (1.0 / n,) * 3
+    jg, jinv = synthetic.stretched_diagonal_metric((0, 0, 0), (n - 1,) * 3, dx, (1.0, 1.0, 1.0))
+    rng = np.random.default_rng(12345)
+    res = np.asfortranarray(rng.uniform(-1.0, 1.0, (n,) * 3))
+    res -= float((res / jinv).sum() / (1.0 / jinv).sum())
+    corr = np.zeros((n + 2,) * 3, order="F")
+    h = cv.CpuVCycle((n,) * 3, dx, jg, jinv, pre=2, post=2, bottom=2, nthreads=cores)
+    h.vcycle(corr, res)   # warm-up on all cores (first touch of every array)
+    reps = 3
     t0 = time.perf_counter()
     for _ in range(reps):
-        so.ld_set(corr, 0.0)
-        amr.mg.one_cycle(corr, res)
-    dt = (time.perf_counter() - t0) / reps
-    scale = (N_FINE / sample_n) ** 3
-    return {"value": 1.0 / (dt * scale), "unit": "V-cycles/s", "cores": 1, "kind": "port",
-            "sample": "%d^3 single-box V-cycle (2/2/2, same metric/BCs), %d reps, %.2f s each, scaled by (512/%d)^3; "
-                      "oracle = C restatement of the reference Fortran kernels (gcc -O3 -march=native) driven by "
-                      "numpy orchestration" % (sample_n, reps, dt, sample_n)}
+        h.vcycle(corr, res)
+    t_all = (time.perf_counter() - t0) / reps
+    # per-kernel rates on all cores: one red+black sweep, one residual
+    phi = np.zeros((n + 2,) * 3, order="F")
+    out = np.zeros((n,) * 3, order="F")
+    t0 = time.perf_counter()
+    h.relax(phi, res, 1)
+    t_sweep = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    h.residual(out, phi, res)
+    t_resid = time.perf_counter() - t0
+    h.set_threads(1)
+    t0 = time.perf_counter()
+    h.vcycle(corr, res)
+    t_one = time.perf_counter() - t0
+    h.close()
+    triad_all = cv.triad_gbs(cores)
+    triad_one = cv.triad_gbs(1)
+    return {"value": 1.0 / t_all, "unit": "V-cycles/s", "cores": cores, "kind": "port",
+            "one_core_value": 1.0 / t_one, "cpu_model": cpu_model(),
+            "stream_triad_GBs": {"all_cores": triad_all, "one_core": triad_one},
+            "gsrb_cell_updates_per_s": n ** 3 / t_sweep, "residual_cells_per_s": n ** 3 / t_resid,
+            "sample": "the full %d^3 C2 V-cycle (2/2/2, same stretched metric / Neumann BCs / hierarchy depth): %d timed "
+                      "cycles on %d cores (%.2f s each) after one warm-up, 1 timed cycle on 1 core (%.2f s); reference call "
+                      "sequence orchestrated in C (oracle/cpu_vcycle.c: flux temporaries, ghost fill per colour pass, 26 "
+                      "boundary sub-box calls, BiCGStab bottom) over the restated Fortran kernels, gcc -O3 -march=native, "
+                      "OpenMP over k-slabs standing in for one MPI rank per core" % (n, reps, cores, t_all, t_one)}
+
+
+def measured_copy_gbs(torch, nbytes=1 << 30, reps=10):
+    """device-to-device copy bandwidth (bytes read + bytes written per second) -- the streaming ceiling of this GPU"""
+    a = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda")
+    b = torch.ones(nbytes // 8, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        a.copy_(b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        a.copy_(b)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    torch.cuda.empty_cache()
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
+def build_c2(api, synthetic, n, world, rank, comm, variant):
+    import numpy as np
+    L = (1.0, 1.0, 1.0)
+    dx = tuple(L[d] / n for d in range(3))
+    boxes = synthetic.slab_partition(n, world)
+    t_def = -time.perf_counter()
+    gpu = api.AMRPressureSolver()
+    p = gpu._p
+    gpu.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg,
+                           p.hang, p.norm_thresh, 0)
+    gpu.define((0, 0, 0), (n - 1,) * 3, (False, False, False), dx, boxes, owner=list(range(world)), comm=comm)
+    for q in range(gpu.num_local_patches):
+        lo, hi, gi = gpu.patch_box(q)
+        assert gi == rank
+        t_def += time.perf_counter()    # host-side metric evaluation (numpy) is the caller's, not define's
+        if variant == "stretched":
+            jg, jinv = synthetic.stretched_diagonal_metric(lo, hi, dx, L)
+        else:
+            shp = [h - a + 1 for a, h in zip(lo, hi)]
+            jg = [np.ones((shp[0] + (d == 0), shp[1] + (d == 1), shp[2] + (d == 2)), order="F") for d in range(3)]
+            jinv = np.ones(shp, order="F")
+        t_def -= time.perf_counter()
+        gpu.setMetricOrtho(q, jg[0], jg[1], jg[2], jinv)
+        del jg, jinv
+    gpu.finalize()
+    t_def += time.perf_counter()
+    return gpu, boxes, t_def
+
+
+def time_c2(gpu, F, torch, dist, steps, warmup):
+    """-> (seconds for `steps` V-cycles, max over ranks)"""
+    def barrier():
+        gpu.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(warmup):
+        gpu.vcycleFromZero(F.F_CORR, F.F_RES)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        # one V-cycle from a zero correction, as every iteration of MappedAMRMultiGrid::solveNoInitResid runs it
+        gpu.vcycleFromZero(F.F_CORR, F.F_RES)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    return dt
+
+
+def contraction_c2(gpu, F):
+    """|rhs - L[corr]| / |rhs| after ONE V-cycle from zero (not timed)"""
+    r0 = gpu.norm(F.F_RES, 0)
+    gpu.setVal(F.F_PHI, 0.0)
+    gpu.setVal(F.F_CORR, 0.0)
+    gpu.vcycle(F.F_CORR, F.F_RES)
+    gpu.residual(0, F.F_SCRATCH, F.F_CORR, F.F_RES)
+    return gpu.norm(F.F_SCRATCH, 0) / r0
+
+
+def bench_c4(api, torch, dist, comm, world, steps, warmup, scale):
+    """BASELINE C4: ms per AMR V-cycle on the 3-level 1024x1024x128 hierarchy, levels sharded in y-slabs"""
+    from bench_amr import build_hierarchy
+    F = api
+    gpu, levels, cells_local, t_def, dx0, ratios = build_hierarchy("c4", scale, 128, comm=comm, nranks=world)
+    nlev = len(levels)
+    try:
+        for l, v in enumerate(gpu.levels):
+            v.fillHash(F.F_RES, 12345 + l)
+        for l in range(nlev - 1):
+            gpu.zeroCovered(l, F.F_RES)
+
+        def step():
+            for v in gpu.levels:
+                v.setVal(F.F_CORR, 0.0)
+            gpu.vcycleAMR(nlev - 1, 0)
+
+        def barrier():
+            gpu.levels[0].sync()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        # composite residual after the last cycle (CORR holds its correction): max over levels, covered cells zeroed
+        r0 = max(v.norm(F.F_RES, 0) for v in gpu.levels)
+        for ilev in range(nlev):
+            gpu.residualLevel(nlev - 1, 0, ilev, res_field=F.F_SCRATCH, phi_field=F.F_CORR, rhs_field=F.F_RES)
+        for l in range(nlev - 1):
+            gpu.zeroCovered(l, F.F_SCRATCH)
+        r1 = max(v.norm(F.F_SCRATCH, 0) for v in gpu.levels)
+        s = scale
+        cells = [1024 * 1024 * 128 // s ** 3, 1024 * 2048 * 128 // s ** 3, 1024 * 4096 * 128 // s ** 3]
+        ms = 1e3 * dt / steps
+        return {"workload": "C4 LockExchange-shaped 3-level %dx%dx%d, (2,2,1) refinements of the central half / quarter in x, "
+                            "Cartesian metric, y periodic, 128^3 boxes, AMR V-cycle 4/4/2; every level's boxes in y-slabs over "
+                            "%d GPU(s)" % (1024 // s, 1024 // s, 128 // s, world),
+                "ms_per_amr_vcycle": ms, "amr_vcycles_per_s": 1e3 / ms, "steps": steps, "warmup": warmup,
+                "cells_per_level": cells, "boxes_per_level": [len(b) for b in levels], "define_seconds": t_def,
+                "mg_depth_per_level": [v.depth() for v in gpu.levels],
+                "gsrb_cell_updates_per_s": sum(cells) * 8 / (ms * 1e-3),   # 4 pre + 4 post sweeps per level per cycle
+                "amr_vcycle_contraction": r1 / r0}
+    finally:
+        gpu.undefine()
 
 
 def main():
@@ -70,10 +259,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", "--size", dest="n", type=int, default=N_FINE, help="fine grid size per direction (512 = BASELINE C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip the c4_amr sub-record")
+    ap.add_argument("--no-cartesian", action="store_true", help="skip the c2_cartesian sub-record")
+    ap.add_argument("--c4-steps", type=int, default=5)
+    ap.add_argument("--c4-warmup", type=int, default=1)
+    ap.add_argument("--c4-scale", type=int, default=1, help="divide every C4 extent (rehearsals on small boxes)")
     args = ap.parse_args()
 
     import torch
-    from somar_amd import api, synthetic   # the measured path never touches oracle/ (only cpu_baseline() below does)
+    from somar_amd import api, synthetic   # the measured path never touches oracle/ (only cpu_baseline() above does)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,84 +292,51 @@ def main():
             ids = [api.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             comm = api.comm_create(ids[0], rank, world, local_rank)
+        api.comm_selftest(comm)   # all-reduce + ring exchange checked on the host before anything is timed
 
-    n = args.n
-    L = (1.0, 1.0, 1.0)
-    dx = tuple(L[d] / n for d in range(3))
-    boxes = synthetic.slab_partition(n, world)
-    owner = list(range(world))
-    t_def = -time.perf_counter()
-    gpu = api.AMRPressureSolver()
-    p = gpu._p
-    gpu.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg,
-                           p.hang, p.norm_thresh, 0)
-    gpu.define((0, 0, 0), (n - 1,) * 3, (False, False, False), dx, boxes, owner=owner, comm=comm)
-    for q in range(gpu.num_local_patches):
-        lo, hi, gi = gpu.patch_box(q)
-        assert gi == rank
-        # each rank evaluates the metric of ITS box only (host numpy; not part of define_seconds)
-        t_def += time.perf_counter()
-        jg, jinv = synthetic.stretched_diagonal_metric(lo, hi, dx, L)
-        t_def -= time.perf_counter()
-        gpu.setMetricOrtho(q, jg[0], jg[1], jg[2], jinv)
-        del jg, jinv
-    gpu.finalize()
-    t_def += time.perf_counter()
     F = api
+    n = args.n
+    failures = []
+    copy_gbs = measured_copy_gbs(torch) if rank == 0 else None
+
+    # ---------------- headline: C2, stretched diagonal metric ----------------
+    gpu, boxes, t_def = build_c2(api, synthetic, n, world, rank, comm, "stretched")
     depth = gpu.depth()
+    ratios = [list(r) for r in gpu.mgRefRatios()]
     cells_total = n ** 3
     cells_local = cells_total // world
-
     # the residual of a solve from phi = 0: uniform(-1,1) (seed 12345) minus its J-weighted mean
     gpu.fillHash(F.F_RES, 12345)
     gpu.removeMean(F.F_RES)
+    dt = time_c2(gpu, F, torch, dist, args.steps, args.warmup)
+    ms_per_step = 1e3 * dt / args.steps
+    value = args.steps / dt
 
-    def barrier():
-        gpu.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    def step():
-        # one V-cycle from a zero correction, as every iteration of MappedAMRMultiGrid::solveNoInitResid runs it
-        gpu.vcycleFromZero(F.F_CORR, F.F_RES)
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
+    # per-kernel HIP events: a separate profiled pass (launch by launch, events around the depth-0 kernels), NOT timed above
     gpu.profileEnable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for _ in range(5):
+        gpu.vcycleFromZero(F.F_CORR, F.F_RES)
     gpu.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
     n_gsrb, ms_gsrb = gpu.profileGet(0)
     n_rr, ms_rr = gpu.profileGet(1)   # depth-0 residual launches of the V-cycle = fused residual + restriction
-    # the plain residual (north-star unit "one residual + one red+black sweep"), timed outside the V-cycle timing
+    gpu.profileEnable(False)
+    gpu.profileEnable(True)
+    # the plain residual (north-star unit "one residual + one red+black sweep")
     for _ in range(5):
         gpu.residual(0, F.F_SCRATCH, F.F_CORR, F.F_RES)
+    gpu.sync()
     n_op, ms_op = gpu.profileGet(1)
     gpu.profileEnable(False)
 
-    # contraction check of the timed operator (not timed): one more cycle must reduce the residual
-    r0 = gpu.norm(F.F_RES, 0)
-    gpu.setVal(F.F_PHI, 0.0)
-    gpu.setVal(F.F_CORR, 0.0)
-    gpu.vcycle(F.F_CORR, F.F_RES)
-    gpu.residual(0, F.F_SCRATCH, F.F_CORR, F.F_RES)
-    r1 = gpu.norm(F.F_SCRATCH, 0)
+    contraction = contraction_c2(gpu, F)
+    if not (0.0 < contraction < 1.0):
+        failures.append("C2 V-cycle does not contract: |r1|/|r0| = %r" % contraction)
+    want = SINGLE_RANK_CONTRACTION.get(("stretched", n))
+    if want is not None and abs(contraction - want) > 1e-2 * want:
+        failures.append("C2 contraction %.6f departs from the recorded single-GPU value %.6f" % (contraction, want))
+    gpu.undefine()
+    del gpu
 
-    ms_per_step = 1e3 * dt / args.steps
-    value = args.steps / dt
-    # depth 0 runs the fused red+black sweep (one launch = one sweep = 64 B/cell algorithmic) unless the
-    # level is below SOMAR_FUSED_MIN_CELLS, in which case one launch = one colour pass = 32 B/cell
     fused = cells_total >= int(os.environ.get("SOMAR_FUSED_MIN_CELLS", "262144"))
     kname = "k_gsrb_fused (red+black sweep, depth 0)" if fused else "k_gsrb_ortho (one colour pass, depth 0)"
     b_launch = (2.0 if fused else 1.0) * B_GSRB_COLOR
@@ -195,12 +356,14 @@ def main():
         "config": {"workload": "C2 single-level %d^3 Poisson, diagonal stretched metric, Neumann, LevelGSRB V-cycle "
                                "2/2/2 + BiCGStab bottom; layout = %d box(es) %s, one per GPU"
                                % (n, world, "x".join(str(h - l + 1) for l, h in zip(*boxes[0]))),
-                   "mg_depth": depth, "mg_ref_ratios": [list(r) for r in gpu.mgRefRatios()],
-                   "cells": cells_total, "define_seconds": t_def},
+                   "mg_depth": depth, "mg_ref_ratios": ratios, "cells": cells_total, "define_seconds": t_def},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": b_launch * cells_local, "launches": n_gsrb,
-                     "avg_launch_ms": t_gsrb * 1e3},
+                     "avg_launch_ms": t_gsrb * 1e3, "measured_copy_GBs": copy_gbs,
+                     "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
+                     "note": "per-launch HIP events from a separate profiled pass of the same V-cycle (5 cycles); the timed "
+                             "loop runs without events"},
         "gsrb_cell_updates_per_s": cells_local / t_sweep * world,
         "residual_kernel": {"avg_launch_ms": t_op * 1e3, "achieved_GBs": B_RESIDUAL * cells_local / t_op / 1e9,
                             "frac": B_RESIDUAL * cells_local / t_op / 1e9 / HBM_PEAK_GBS},
@@ -210,20 +373,47 @@ def main():
                                      "achieved_GBs": 49.0 * cells_local / (ms_rr / max(n_rr, 1) * 1e-3) / 1e9},
         "residual_plus_smooth_unit": {"ms": unit_t * 1e3, "algorithmic_GBs": 120.0 * cells_local / unit_t / 1e9,
                                       "frac_of_hbm_peak": 120.0 * cells_local / unit_t / 1e9 / HBM_PEAK_GBS},
-        "vcycle_contraction": r1 / r0,
+        "vcycle_contraction": contraction,
     }
+
+    # ---------------- SURVEY 8d variant (i): true Cartesian metric, the converging case ----------------
+    if not args.no_cartesian:
+        g2, _, t_def2 = build_c2(api, synthetic, n, world, rank, comm, "cartesian")
+        g2.fillHash(F.F_RES, 12345)
+        g2.removeMean(F.F_RES)
+        dt2 = time_c2(g2, F, torch, dist, args.steps, args.warmup)
+        c2 = contraction_c2(g2, F)
+        if not (0.0 < c2 < 1.0):
+            failures.append("Cartesian C2 V-cycle does not contract: %r" % c2)
+        out["c2_cartesian"] = {"workload": "C2 variant (i): %d^3, all-ones metric (stored as arrays), same V-cycle" % n,
+                               "value": args.steps / dt2, "unit": "V-cycles/s", "ms_per_step": 1e3 * dt2 / args.steps,
+                               "vcycle_contraction": c2, "define_seconds": t_def2}
+        g2.undefine()
+        del g2
+
+    # ---------------- C4: the workload of the north star's scaling target ----------------
+    if not args.no_c4:
+        c4 = bench_c4(api, torch, dist, comm, world, args.c4_steps, args.c4_warmup, args.c4_scale)
+        if not (0.0 < c4["amr_vcycle_contraction"] < 1.0):
+            failures.append("C4 AMR V-cycle does not contract: %r" % c4["amr_vcycle_contraction"])
+        out["c4_amr"] = c4
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(n)
     elif rank == 0:
         out["cpu_baseline"] = None
-    gpu.undefine()
     if comm is not None:
         api.comm_destroy(comm)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if failures:
+        out["failures"] = failures
     if rank == 0:
         print(json.dumps(out))
+    if failures:
+        sys.stderr.write("bench.py: FAILED: " + "; ".join(failures) + "\n")
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -44,8 +44,9 @@ extern "C" {
 #endif
 
 /* 4: + cell-centred level projection, level projections on hierarchy levels, Helmholtz coefficients and heat
- *    integrators, operator / residual with the BC flag, MAC wall BC (additions only: version-3 callers are unaffected) */
-#define SOMAR_AMD_ABI_VERSION 4
+ *    integrators, operator / residual with the BC flag, MAC wall BC (additions only: version-3 callers are unaffected)
+ * 5: + somar_amr_solve_host (multi-level host boundary), somar_k_gsrbiter3dortho (box-by-box kernel hook); additions only */
+#define SOMAR_AMD_ABI_VERSION 5
 
 /* BCType codes, calculus/BCInterface/BCDescriptor.H:34-39 */
 #define SOMAR_BC_NONE (-1)
@@ -84,7 +85,9 @@ typedef struct somar_stats {
     int bottom_iters, bottom_exit;
     int nhistory;
     double initial_rnorm, final_rnorm;
-    double history[SOMAR_MAX_HISTORY]; /* max-norm residual: [0] initial, [k] after V-cycle k */
+    double history[SOMAR_MAX_HISTORY]; /* max-norm residual: [0] initial, [k] after V-cycle k; TRUNCATED at SOMAR_MAX_HISTORY
+                                        * entries (nhistory = min(iters + 1, SOMAR_MAX_HISTORY)): iters, initial_rnorm and
+                                        * final_rnorm are exact whatever imax is */
 } somar_stats_t;
 
 /* resident field handles: which | (depth << 8) */
@@ -240,6 +243,30 @@ int somar_cc_project(somar_solver_t* s, double dt, int zero_pressure, int force_
 int somar_cc_project_host(somar_solver_t* s, double* const* vel, const int* ghost, double dt, int zero_pressure,
                           int force_homogeneous, int wall_bc, somar_stats_t* stats);
 
+/* Kernel-level, box-by-box hook with the argument shapes the reference's Fortran exports: one colour
+ * pass of GSRBITER3DORTHO (RelaxationMethods/GSRBF.ChF:545-701; prototype RelaxationMethods/GSRBF_F.H:216-232) on HOST FABs.
+ * Chombo's FORT_PROTO expansion: every argument by pointer; CHFp_FRA(a) = Real* a, const int* ialo0, ialo1, ialo2, iahi0,
+ * iahi1, iahi2, const int* nacomp; CHFp_CONST_FRA1(a) the same without the component count; CHFp_BOX(b) = six const int*;
+ * CHFp_CONST_REALVECT = const Real* (3 values); CHFp_CONST_REAL / _INT = const Real* / const int*.  Arrays column-major,
+ * inclusive bounds, component slowest.  phi is updated in place on `region` (cells of the colour only); it must be
+ * defined one cell around the region, rhs / Jinv / lapDiag on the region, Jg^{aa} on its a-faces.  This is a parity-test
+ * hook (it moves the box to the GPU and back per call), not a production path: production keeps levels resident. */
+int somar_k_gsrbiter3dortho(double* phi, const int* iphilo0, const int* iphilo1, const int* iphilo2, const int* iphihi0,
+                            const int* iphihi1, const int* iphihi2, const int* nphicomp, const double* rhs,
+                            const int* irhslo0, const int* irhslo1, const int* irhslo2, const int* irhshi0,
+                            const int* irhshi1, const int* irhshi2, const int* nrhscomp, const double* Jgxx,
+                            const int* iJgxxlo0, const int* iJgxxlo1, const int* iJgxxlo2, const int* iJgxxhi0,
+                            const int* iJgxxhi1, const int* iJgxxhi2, const double* Jgyy, const int* iJgyylo0,
+                            const int* iJgyylo1, const int* iJgyylo2, const int* iJgyyhi0, const int* iJgyyhi1,
+                            const int* iJgyyhi2, const double* Jgzz, const int* iJgzzlo0, const int* iJgzzlo1,
+                            const int* iJgzzlo2, const int* iJgzzhi0, const int* iJgzzhi1, const int* iJgzzhi2,
+                            const double* Jinv, const int* iJinvlo0, const int* iJinvlo1, const int* iJinvlo2,
+                            const int* iJinvhi0, const int* iJinvhi1, const int* iJinvhi2, const double* lapDiag,
+                            const int* ilapDiaglo0, const int* ilapDiaglo1, const int* ilapDiaglo2, const int* ilapDiaghi0,
+                            const int* ilapDiaghi1, const int* ilapDiaghi2, const int* iregionlo0, const int* iregionlo1,
+                            const int* iregionlo2, const int* iregionhi0, const int* iregionhi1, const int* iregionhi2,
+                            const double* dx, const double* alpha, const double* beta, const int* redBlack);
+
 /* stream control + HIP-event timing on the solver's own stream */
 int somar_sync(somar_solver_t* s);
 int somar_timer_start(somar_solver_t* s);
@@ -286,6 +313,19 @@ int somar_amr_destroy(somar_amr_t* a);
 int somar_amr_level(somar_amr_t* a, int level, somar_solver_t** out);
 int somar_amr_finalize(somar_amr_t* a);
 int somar_amr_solve(somar_amr_t* a, int l_max, int l_base, int zero_phi, int force_homogeneous, somar_stats_t* stats);
+/* The same solve on CALLER-OWNED host data of several levels: the primary boundary for AMR hierarchies,
+ *   AMREllipticSolver<LevelData<FArrayBox>>::solve(Vector<T*>& phi, const Vector<T*>& rhs, l_max, l_base, zeroPhi,
+ *   forceHomogeneous)  (calculus/AMRElliptic/AMREllipticSolver.H:33-48), reached from AMRPressureSolver::solve
+ *   (projection/AMRPressureSolver.cpp:494-561; note its call order solve(phi, rhs, a_lmax, a_lmin, ...) :529-534) and
+ *   levelSolve (:567-594).
+ * phi[l] / rhs[l]: one pointer per LOCAL patch of level l (host FABs over valid.grow(ghost)); entries of levels outside
+ * [l_base, l_max] may be NULL, except phi[l_base-1] when l_base > 0 (it supplies the coarse-fine boundary values, as
+ * the reference's a_phi[l_base-1] does).  Uploads rhs (and phi unless zero_phi; phi[l_base-1] always), runs
+ * somar_amr_solve, writes phi of l_base..l_max back (valid cells and the ghost layer the solver leaves).  Same stats,
+ * exit status and best-phi semantics as somar_amr_solve. */
+int somar_amr_solve_host(somar_amr_t* a, double* const* const* phi, const int* phi_ghost, const double* const* const* rhs,
+                         const int* rhs_ghost, int l_max, int l_base, int zero_phi, int force_homogeneous,
+                         somar_stats_t* stats);
 int somar_amr_interp_cf(somar_amr_t* a, int level, int fine_field, int coarse_field);
 /* Level projection on level `level` of the hierarchy, the coarser level supplying the coarse-fine values:
  * BaseProjector<T>::levelProject -> project(lmin = lmax = level) (projection/BaseProjectorI.H:176-366).

@@ -115,6 +115,9 @@ _SIGS = {
     "somar_level_cc_correct": [_H, C.c_int, C.c_double],
     "somar_cc_project": [_H, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
     "somar_cc_project_host": [_H, C.POINTER(_PD), _PI, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
+    # FORT_PROTO shapes: FRA = data, 3 lo, 3 hi, ncomp; FRA1 = data, 3 lo, 3 hi; BOX = 3 lo, 3 hi; then dx, alpha, beta, redBlack
+    "somar_k_gsrbiter3dortho": ([_PD] + [_PI] * 7 + [_PD] + [_PI] * 7 + ([_PD] + [_PI] * 6) * 5 + [_PI] * 6
+                                + [_PD, _PD, _PD, _PI]),
     "somar_sync": [_H],
     "somar_timer_start": [_H],
     "somar_timer_stop": [_H, _PD],
@@ -127,6 +130,8 @@ _SIGS = {
     "somar_amr_level": [_H, C.c_int, C.POINTER(_H)],
     "somar_amr_finalize": [_H],
     "somar_amr_solve": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
+    "somar_amr_solve_host": [_H, C.POINTER(C.POINTER(_PD)), _PI, C.POINTER(C.POINTER(_PD)), _PI, C.c_int, C.c_int, C.c_int,
+                             C.c_int, C.POINTER(Stats)],
     "somar_amr_interp_cf": [_H, C.c_int, C.c_int, C.c_int],
     "somar_amr_level_project": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
     "somar_amr_residual_level": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
@@ -284,6 +289,32 @@ class AMRPressureSolver:
         """MappedAMRMultiGrid::solve on the levels' resident PHI / RHS."""
         st = Stats()
         _ck(lib().somar_amr_solve(self._amr, lmax, lbase, int(zeroPhi), int(forceHomogeneous), C.byref(st)))
+        return self._stats(st)
+
+    def solveAMRHost(self, phi, rhs, lmin, lmax, zeroPhi=True, forceHomogeneous=False, phi_ghost=(1, 1, 1),
+                     rhs_ghost=(0, 0, 0)):
+        """AMRPressureSolver::solve(Vector<LevelData*> phi, rhs, lmin, lmax) (AMRPressureSolver.cpp:494-561) on host data:
+        phi[l] / rhs[l] = list (one per local patch of level l) of Fortran-ordered arrays, or None for levels outside
+        [lmin-1, lmax]; phi is updated in place."""
+        nl = len(self.levels)
+        keep = []
+
+        def table(v):
+            rows = (C.POINTER(_PD) * nl)()
+            for l in range(nl):
+                if v[l] is None:
+                    rows[l] = None
+                    continue
+                assert len(v[l]) == self.levels[l].num_local_patches
+                row = (_PD * max(len(v[l]), 1))(*[_dp(a) for a in v[l]])
+                keep.append(row)
+                rows[l] = row
+            return rows
+
+        st = Stats()
+        # the reference's call order: solve(phi, rhs, a_lmax, a_lmin, ...) (AMRPressureSolver.cpp:529-534)
+        _ck(lib().somar_amr_solve_host(self._amr, table(phi), _ia(phi_ghost), table(rhs), _ia(rhs_ghost), lmax, lmin,
+                                       int(zeroPhi), int(forceHomogeneous), C.byref(st)))
         return self._stats(st)
 
     def levelProjectAMR(self, level, centring, dt, zeroPressure=True, forceHomogeneous=False, wall=True):
@@ -560,6 +591,30 @@ class AMRPressureSolver:
         ms = C.c_double()
         _ck(lib().somar_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+
+def k_gsrbiter3dortho(phi, phi_lo, rhs, rhs_lo, jg, jg_lo, jinv, jinv_lo, lapdiag, lapdiag_lo, region, dx, alpha, beta,
+                      redBlack):
+    """GSRBITER3DORTHO through the Fortran-shaped C entry (RelaxationMethods/GSRBF_F.H:216-232): arrays are Fortran-ordered
+    numpy arrays (phi / rhs may carry a trailing component axis), *_lo their low corners, region = (lo, hi); phi in place."""
+    def ip(v):
+        return [C.byref(C.c_int(int(x))) for x in v]
+
+    def fab(a, lo, ncomp):
+        shp = a.shape[:3]
+        hi = [l + n - 1 for l, n in zip(lo, shp)]
+        out = [_dp(a)] + ip(lo) + ip(hi)
+        if ncomp:
+            out.append(C.byref(C.c_int(a.shape[3] if a.ndim == 4 else 1)))
+        return out
+
+    args = fab(phi, phi_lo, True) + fab(rhs, rhs_lo, True)
+    for d in range(3):
+        args += fab(jg[d], jg_lo[d], False)
+    args += fab(jinv, jinv_lo, False) + fab(lapdiag, lapdiag_lo, False)
+    args += ip(region[0]) + ip(region[1])
+    args += [_da(dx), C.byref(C.c_double(alpha)), C.byref(C.c_double(beta)), C.byref(C.c_int(redBlack))]
+    _ck(lib().somar_k_gsrbiter3dortho(*args))
 
 
 def altered_jgup(nsq_fc, dximu_dz, dxinu_dz, gup, J, dt_theta, coriolis_f, hjac=None):

@@ -355,7 +355,7 @@ int somar_solver_solve_host(somar_solver_t* s, double* const* phi, const int* ph
                             int zero_phi, int force_homogeneous, somar_stats_t* stats)
 {
     API_BEGIN
-    SOMAR_CHECK(l_max == 0 && l_base == 0, "multi-level AMR solves are not implemented yet (l_max = l_base = 0 only)");
+    SOMAR_CHECK(l_max == 0 && l_base == 0, "a somar_solver_t is ONE level (l_max = l_base = 0); hierarchies go through somar_amr_solve_host");
     SOMAR_CHECK(phi && rhs && phi_ghost && rhs_ghost, "null pointer");
     PressureSolver& ps = *s->ps;
     const int np = ps.level(0).npatches();
@@ -820,6 +820,127 @@ int somar_amr_solve(somar_amr_t* a, int l_max, int l_base, int zero_phi, int for
     SolveStats st;
     a->amr->solve(l_max, l_base, zero_phi != 0, force_homogeneous != 0, st);
     fill_stats(st, stats);
+    API_END
+}
+
+// AMREllipticSolver<LevelData<FArrayBox>>::solve on caller-owned host data of SEVERAL levels
+// (AMREllipticSolver.H:33-48, as AMRPressureSolver::solve / levelSolve call it, AMRPressureSolver.cpp:494-594)
+int somar_amr_solve_host(somar_amr_t* a, double* const* const* phi, const int* phi_ghost, const double* const* const* rhs,
+                         const int* rhs_ghost, int l_max, int l_base, int zero_phi, int force_homogeneous,
+                         somar_stats_t* stats)
+{
+    API_BEGIN
+    AMRSolver& A = *a->amr;
+    SOMAR_CHECK(phi && rhs && phi_ghost && rhs_ghost, "null pointer");
+    SOMAR_CHECK(0 <= l_base && l_base <= l_max && l_max < A.nlevels(), "bad level range");
+    for (int l = l_base; l <= l_max; ++l) SOMAR_CHECK(phi[l] && rhs[l], "phi / rhs of a solved level is null");
+    if (l_base > 0) SOMAR_CHECK(phi[l_base - 1], "phi of level l_base - 1 supplies the coarse-fine values and must be given");
+    for (int l = (l_base > 0 ? l_base - 1 : 0); l <= l_max; ++l) {
+        PressureSolver& ps = A.level(l);
+        const int np = ps.level(0).npatches();
+        for (int p = 0; p < np; ++p) {
+            if (l >= l_base) ps.upload_rhs(p, rhs[l][p], rhs_ghost);
+            if (l < l_base || !zero_phi) ps.upload_phi(p, phi[l][p], phi_ghost);
+        }
+    }
+    SolveStats st;
+    A.solve(l_max, l_base, zero_phi != 0, force_homogeneous != 0, st);
+    for (int l = l_base; l <= l_max; ++l) {
+        PressureSolver& ps = A.level(l);
+        const int np = ps.level(0).npatches();
+        for (int p = 0; p < np; ++p) ps.download_phi(p, phi[l][p], phi_ghost);
+    }
+    fill_stats(st, stats);
+    API_END
+}
+
+// ---- kernel-level box-by-box hook: one colour pass of GSRBITER3DORTHO on host FABs, Fortran argument shapes ---------
+extern "C++" {
+namespace {
+struct HostFab {
+    const double* p;
+    IBox box;
+    int ncomp;
+};
+HostFab mkfab(const double* p, const int* l0, const int* l1, const int* l2, const int* h0, const int* h1, const int* h2,
+              const int* nc)
+{
+    HostFab f;
+    f.p = p;
+    const int lo[3] = {*l0, *l1, *l2}, hi[3] = {*h0, *h1, *h2};
+    f.box = IBox(lo, hi);
+    f.ncomp = nc ? *nc : 1;
+    return f;
+}
+}  // namespace
+}  // extern "C++"
+
+int somar_k_gsrbiter3dortho(double* phi, const int* iphilo0, const int* iphilo1, const int* iphilo2, const int* iphihi0,
+                            const int* iphihi1, const int* iphihi2, const int* nphicomp, const double* rhs,
+                            const int* irhslo0, const int* irhslo1, const int* irhslo2, const int* irhshi0,
+                            const int* irhshi1, const int* irhshi2, const int* nrhscomp, const double* Jgxx,
+                            const int* iJgxxlo0, const int* iJgxxlo1, const int* iJgxxlo2, const int* iJgxxhi0,
+                            const int* iJgxxhi1, const int* iJgxxhi2, const double* Jgyy, const int* iJgyylo0,
+                            const int* iJgyylo1, const int* iJgyylo2, const int* iJgyyhi0, const int* iJgyyhi1,
+                            const int* iJgyyhi2, const double* Jgzz, const int* iJgzzlo0, const int* iJgzzlo1,
+                            const int* iJgzzlo2, const int* iJgzzhi0, const int* iJgzzhi1, const int* iJgzzhi2,
+                            const double* Jinv, const int* iJinvlo0, const int* iJinvlo1, const int* iJinvlo2,
+                            const int* iJinvhi0, const int* iJinvhi1, const int* iJinvhi2, const double* lapDiag,
+                            const int* ilapDiaglo0, const int* ilapDiaglo1, const int* ilapDiaglo2, const int* ilapDiaghi0,
+                            const int* ilapDiaghi1, const int* ilapDiaghi2, const int* iregionlo0, const int* iregionlo1,
+                            const int* iregionlo2, const int* iregionhi0, const int* iregionhi1, const int* iregionhi2,
+                            const double* dx, const double* alpha, const double* beta, const int* redBlack)
+{
+    API_BEGIN
+    HostFab fphi = mkfab(phi, iphilo0, iphilo1, iphilo2, iphihi0, iphihi1, iphihi2, nphicomp);
+    HostFab frhs = mkfab(rhs, irhslo0, irhslo1, irhslo2, irhshi0, irhshi1, irhshi2, nrhscomp);
+    HostFab fjg[3] = {mkfab(Jgxx, iJgxxlo0, iJgxxlo1, iJgxxlo2, iJgxxhi0, iJgxxhi1, iJgxxhi2, nullptr),
+                      mkfab(Jgyy, iJgyylo0, iJgyylo1, iJgyylo2, iJgyyhi0, iJgyyhi1, iJgyyhi2, nullptr),
+                      mkfab(Jgzz, iJgzzlo0, iJgzzlo1, iJgzzlo2, iJgzzhi0, iJgzzhi1, iJgzzhi2, nullptr)};
+    HostFab fji = mkfab(Jinv, iJinvlo0, iJinvlo1, iJinvlo2, iJinvhi0, iJinvhi1, iJinvhi2, nullptr);
+    HostFab fld = mkfab(lapDiag, ilapDiaglo0, ilapDiaglo1, ilapDiaglo2, ilapDiaghi0, ilapDiaghi1, ilapDiaghi2, nullptr);
+    const int rlo[3] = {*iregionlo0, *iregionlo1, *iregionlo2}, rhi[3] = {*iregionhi0, *iregionhi1, *iregionhi2};
+    const IBox region(rlo, rhi);
+    if (region.empty()) return 0;
+    SOMAR_CHECK(fphi.ncomp == frhs.ncomp && fphi.ncomp >= 1, "phi and rhs must carry the same number of components");
+    const int one[3] = {1, 1, 1};
+    const IBox halo = region.grow(one);
+    for (int d = 0; d < 3; ++d)
+        SOMAR_CHECK(halo.lo[d] >= fphi.box.lo[d] && halo.hi[d] <= fphi.box.hi[d],
+                    "GSRBITER3DORTHO reads phi one cell around the region: the phi FAB must contain it");
+    // a one-box level whose domain lies well outside the region, so every cell takes the interior (full-stencil) form
+    const int four[3] = {4, 4, 4};
+    const IBox dom = region.grow(four);
+    const bool per[3] = {false, false, false};
+    const int bct[3][2] = {{BC_NEUM, BC_NEUM}, {BC_NEUM, BC_NEUM}, {BC_NEUM, BC_NEUM}};
+    Level L;
+    Comm self;
+    L.define(dom, per, dx, bct, std::vector<IBox>{region}, std::vector<int>{0}, &self);
+    L.alloc_metric();
+    L.alpha = *alpha;
+    L.beta = *beta;
+    L.refresh_params();
+    hipStream_t st = nullptr;
+    double* dphi = L.alloc_field();
+    double* drhs = L.alloc_field();
+    for (int d = 0; d < 3; ++d) {
+        IBox fr = region;
+        fr.hi[d] += 1;  // faces(region, d)
+        L.upload(L.dev.jg[d], 0, fjg[d].p, fjg[d].box, fr, st);
+    }
+    L.upload(L.dev.jinv, 0, fji.p, fji.box, region, st);
+    L.upload(L.dev.lapdiag, 0, fld.p, fld.box, region, st);
+    for (int n = 0; n < fphi.ncomp; ++n) {
+        double* hp = phi + (size_t)n * fphi.box.numPts();
+        const double* hr = rhs + (size_t)n * frhs.box.numPts();
+        L.upload(dphi, 0, hp, fphi.box, halo, st);
+        L.upload(drhs, 0, hr, frhs.box, region, st);
+        launch_gsrb_ortho(st, L.dev, dphi, drhs, *redBlack);
+        L.download(dphi, 0, hp, fphi.box, region, st);
+    }
+    SOMAR_HIP(hipStreamSynchronize(st));
+    Level::free_field(dphi);
+    Level::free_field(drhs);
     API_END
 }
 

@@ -9,6 +9,7 @@
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -26,6 +27,7 @@ struct ShmHeader {
     std::atomic<int> generation;
     int nranks;
     int pad_;
+    long long epoch;  // creation time (seconds): an attaching rank refuses a segment older than a few minutes (a stale one of the same name)
     // directory: where in src's outbox the message for dst starts, and its length (doubles)
     long long off[16][16];
     long long cnt[16][16];
@@ -44,8 +46,21 @@ struct ShmComm : Comm {
     int fd = -1;
     bool creator = false;
 
+    static constexpr size_t RED_DOUBLES = 16384;  // per-rank slot of the vector all-reduce (ordered sums of small levels)
     double* outbox(int r) const { return reinterpret_cast<double*>(base + sizeof(ShmHeader) + (size_t)r * box_bytes); }
+    double* redbox(int r) const
+    {
+        return reinterpret_cast<double*>(base + sizeof(ShmHeader) + (size_t)size * box_bytes) + (size_t)r * RED_DOUBLES;
+    }
 
+    static double now_s()
+    {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec + 1e-9 * ts.tv_nsec;
+    }
+
+    // a rank that never arrives (crashed peer, stale segment) must end in an error, not in a hang
     void barrier()
     {
         const int gen = hdr->generation.load(std::memory_order_acquire);
@@ -53,7 +68,12 @@ struct ShmComm : Comm {
             hdr->arrive.store(0, std::memory_order_relaxed);
             hdr->generation.store(gen + 1, std::memory_order_release);
         } else {
-            while (hdr->generation.load(std::memory_order_acquire) == gen) sched_yield();
+            const double t0 = now_s();
+            long spins = 0;
+            while (hdr->generation.load(std::memory_order_acquire) == gen) {
+                sched_yield();
+                if ((++spins & 0xfff) == 0) SOMAR_CHECK(now_s() - t0 < 300.0, "shm barrier timed out (a peer rank is gone?)");
+            }
         }
     }
 
@@ -67,7 +87,22 @@ struct ShmComm : Comm {
     void allreduce(double* dbuf, int n, int op, hipStream_t st) override
     {
         if (size == 1) return;
-        SOMAR_CHECK(n <= 64, "shm allreduce: too many values");
+        if (n > 64) {
+            // vector form: each rank publishes its vector in its slot, every rank adds the slots in rank order
+            SOMAR_CHECK((size_t)n <= RED_DOUBLES, "shm allreduce: too many values");
+            SOMAR_HIP(hipMemcpyAsync(redbox(rank), dbuf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+            SOMAR_HIP(hipStreamSynchronize(st));
+            barrier();
+            std::vector<double> acc(redbox(0), redbox(0) + n);
+            for (int r = 1; r < size; ++r) {
+                const double* v = redbox(r);
+                for (int i = 0; i < n; ++i) acc[i] = op ? (acc[i] > v[i] ? acc[i] : v[i]) : acc[i] + v[i];
+            }
+            SOMAR_HIP(hipMemcpyAsync(dbuf, acc.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+            SOMAR_HIP(hipStreamSynchronize(st));
+            barrier();
+            return;
+        }
         // every copy goes through the caller's stream: a plain hipMemcpy runs on the null stream, which the
         // solver's non-blocking stream does not wait for (and an H2D copy from pageable memory may return before
         // its DMA has landed)
@@ -133,7 +168,7 @@ Comm* shm_create(const char* name, int rank, int nranks, size_t outbox_bytes)
     c->size = nranks;
     c->name = name;
     c->box_bytes = outbox_bytes;
-    c->total = sizeof(ShmHeader) + (size_t)nranks * outbox_bytes;
+    c->total = sizeof(ShmHeader) + (size_t)nranks * outbox_bytes + (size_t)nranks * ShmComm::RED_DOUBLES * sizeof(double);
     try {
         if (rank == 0) {
             shm_unlink(name);
@@ -141,30 +176,37 @@ Comm* shm_create(const char* name, int rank, int nranks, size_t outbox_bytes)
             SOMAR_CHECK(c->fd >= 0, "shm_open(create) failed");
             c->creator = true;
             SOMAR_CHECK(ftruncate(c->fd, (off_t)c->total) == 0, "ftruncate failed");
-        } else {
-            for (int tries = 0; tries < 20000 && c->fd < 0; ++tries) {
-                c->fd = shm_open(name, O_RDWR, 0600);
-                if (c->fd < 0) usleep(1000);
-            }
-            SOMAR_CHECK(c->fd >= 0, "shm_open(attach) timed out");
-            // wait until rank 0 has sized the segment
-            for (int tries = 0; tries < 20000; ++tries) {
-                off_t sz = lseek(c->fd, 0, SEEK_END);
-                if (sz >= (off_t)c->total) break;
-                usleep(1000);
-            }
-        }
-        void* m = mmap(nullptr, c->total, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0);
-        SOMAR_CHECK(m != MAP_FAILED, "mmap failed");
-        c->base = static_cast<char*>(m);
-        c->hdr = reinterpret_cast<ShmHeader*>(m);
-        if (rank == 0) {
+            void* m = mmap(nullptr, c->total, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0);
+            SOMAR_CHECK(m != MAP_FAILED, "mmap failed");
+            c->base = static_cast<char*>(m);
+            c->hdr = reinterpret_cast<ShmHeader*>(m);
             std::memset(static_cast<void*>(c->hdr), 0, sizeof(ShmHeader));
             c->hdr->nranks = nranks;
+            c->hdr->epoch = (long long)time(nullptr);
             std::atomic_thread_fence(std::memory_order_release);
             c->hdr->generation.store(1, std::memory_order_release);  // "initialised"
         } else {
-            while (c->hdr->generation.load(std::memory_order_acquire) == 0) usleep(1000);
+            // Attach: the segment must exist, have its full size, be initialised, be made for this many ranks and be
+            // FRESH -- a segment of the same name left by an earlier run (opened before rank 0 unlinks it) is dead
+            // memory on which the barrier below would never complete.  Anything else: drop it and look again.
+            const double t0 = ShmComm::now_s();
+            bool ok = false;
+            while (!ok) {
+                SOMAR_CHECK(ShmComm::now_s() - t0 < 60.0, "shm attach timed out (no fresh, fully sized segment of that name appeared)");
+                if (c->base) { munmap(c->base, c->total); c->base = nullptr; c->hdr = nullptr; }
+                if (c->fd >= 0) { close(c->fd); c->fd = -1; }
+                c->fd = shm_open(name, O_RDWR, 0600);
+                if (c->fd < 0) { usleep(1000); continue; }
+                if (lseek(c->fd, 0, SEEK_END) < (off_t)c->total) { usleep(1000); continue; }
+                void* m = mmap(nullptr, c->total, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0);
+                SOMAR_CHECK(m != MAP_FAILED, "mmap failed");
+                c->base = static_cast<char*>(m);
+                c->hdr = reinterpret_cast<ShmHeader*>(m);
+                if (c->hdr->generation.load(std::memory_order_acquire) == 0) { usleep(1000); continue; }
+                const long long age = (long long)time(nullptr) - c->hdr->epoch;
+                if (c->hdr->nranks != nranks || age < -5 || age > 120) { usleep(20000); continue; }
+                ok = true;
+            }
         }
         c->barrier();
     } catch (...) {

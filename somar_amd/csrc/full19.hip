@@ -31,6 +31,9 @@ struct JgFull { const double* c[3][3]; };  // c[faceDir][component]
 // ------------------------------------------------------------------------------------
 // ghost programs
 // ------------------------------------------------------------------------------------
+// REDIRECT: psi is kept in the boxes' frames only (its copy inside the valid region is never made): a read of psi at a
+// cell INSIDE the box's valid region returns phi there -- the value the full copy psi := phi would have put.
+template <bool REDIRECT>
 __global__ void k_ghost_ops(const GhostOp* __restrict__ ops, const PatchDesc* __restrict__ patches,
                             double* __restrict__ phi, double* __restrict__ psi, JgFull J, StencilParams P)
 {
@@ -46,14 +49,26 @@ __global__ void k_ghost_ops(const GhostOp* __restrict__ ops, const PatchDesc* __
         const int k = (int)(idx / n01);
         const int r = (int)(idx - (long long)k * n01);
         const int j = r / n0, i = r - j * n0;
-        const long long c = fidx(p, op.lo[0] + i, op.lo[1] + j, op.lo[2] + k);
+        const int l0 = op.lo[0] + i, l1 = op.lo[1] + j, l2 = op.lo[2] + k;
+        const long long c = fidx(p, l0, l1, l2);
+        // value of field `f` (1 = psi) at this cell moved by m steps along direction dd (and mt steps along dt)
+        auto rd = [&](const double* f, bool is_psi, int dd, int m, int dt = 0, int mt = 0) {
+            int q[3] = {l0, l1, l2};
+            q[dd] += m;
+            q[dt] += mt;
+            const long long cc = c + m * st[dd] + mt * st[dt];
+            if (REDIRECT && is_psi && q[0] >= 0 && q[0] < p.n[0] && q[1] >= 0 && q[1] < p.n[1] && q[2] >= 0 && q[2] < p.n[2])
+                return phi[cc];
+            return f[cc];
+        };
         if (op.type == GHOST_COPY) {
-            dst[c] = src[c];
+            dst[c] = rd(src, op.srcf != 0, 0, 0);
         } else if (op.type == GHOST_EXTRAP) {
-            const long long s = op.sgn * st[op.dir];  // towards the ghost; values come from c - s, c - 2s, ...
-            if (op.order == 0) dst[c] = src[c - s];
-            else if (op.order == 1) dst[c] = 2.0 * src[c - s] - src[c - 2 * s];
-            else dst[c] = 3.0 * (src[c - s] - src[c - 2 * s]) + src[c - 3 * s];
+            const int s = -op.sgn;  // values come from 1, 2, 3 steps back along dir
+            const bool ps = op.srcf != 0;
+            if (op.order == 0) dst[c] = rd(src, ps, op.dir, s);
+            else if (op.order == 1) dst[c] = 2.0 * rd(src, ps, op.dir, s) - rd(src, ps, op.dir, 2 * s);
+            else dst[c] = 3.0 * (rd(src, ps, op.dir, s) - rd(src, ps, op.dir, 2 * s)) + rd(src, ps, op.dir, 3 * s);
         } else if (op.type == GHOST_DIRI) {
             // ELLIPTICCONSTDIRIBCGHOST, order 1 (EllipticBCUtilsF.ChF:71-84): the value sits on the face
             const long long s = op.sgn * st[op.dir];
@@ -67,8 +82,11 @@ __global__ void k_ghost_ops(const GhostOp* __restrict__ ops, const PatchDesc* __
             const long long v = c - op.sgn * sa;                    // first valid cell
             const long long f = (op.sgn < 0) ? c + sa : c;          // boundary face (index of the cell it is the low face of)
             const double idxb = -0.25 / P.dx[b], idxc = -0.25 / P.dx[cc];
-            const double cross = (psi[g + sb] - psi[g - sb] + psi[v + sb] - psi[v - sb]) * J.c[a][b][f] * idxb +
-                                 (psi[g + sc] - psi[g - sc] + psi[v + sc] - psi[v - sc]) * J.c[a][cc][f] * idxc;
+            (void)sb; (void)sc;
+            // g = this cell, v = this cell moved one step back along a
+            const int bk = -op.sgn;
+            const double cross = (rd(psi, true, b, 1) - rd(psi, true, b, -1) + rd(psi, true, a, bk, b, 1) - rd(psi, true, a, bk, b, -1)) * J.c[a][b][f] * idxb +
+                                 (rd(psi, true, cc, 1) - rd(psi, true, cc, -1) + rd(psi, true, a, bk, cc, 1) - rd(psi, true, a, bk, cc, -1)) * J.c[a][cc][f] * idxc;
             phi[g] = phi[v] + (0.0 - cross) * P.dx[a] / J.c[a][a][f];
         }
     }
@@ -294,12 +312,13 @@ static JgFull jgfull(const LevelDev& L)
 }
 
 void launch_ghost_ops(hipStream_t st, const LevelDev& L, const GhostOp* ops, int nops, double* phi, double* psi,
-                      bool bc_homog)
+                      bool bc_homog, bool redirect)
 {
     if (nops == 0) return;
     StencilParams P = L.P;
     P.bc_homog = bc_homog ? 1 : 0;
-    hipLaunchKernelGGL(k_ghost_ops, dim3(nops, 4), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
+    if (redirect) hipLaunchKernelGGL(k_ghost_ops<true>, dim3(nops, 4), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
+    else hipLaunchKernelGGL(k_ghost_ops<false>, dim3(nops, 4), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
 }
 
 void launch_flux_full(hipStream_t st, const LevelDev& L, double* const out[3], const double* phi, const double* psi)

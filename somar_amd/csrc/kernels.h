@@ -20,8 +20,17 @@ struct LevelDev {
 };
 
 // 19-point path (full19.hip)
+// redirect: a read of psi that lands INSIDE the box's valid region takes phi instead (psi is then maintained in the
+// boxes' frames only -- the frame-only programs of the marching 19-point kernels, full19_march.hip)
 void launch_ghost_ops(hipStream_t st, const LevelDev& L, const GhostOp* ops, int nops, double* phi, double* psi,
-                      bool bc_homog = true);
+                      bool bc_homog = true, bool redirect = false);
+// k-marching 19-point operator / residual (mode 0: out = rhs - L[phi], 1: out = L[phi]) and one GSRB colour pass
+// (out = phi with the colour's cells relaxed; out != phi); psi valid in the one-cell frames only (full19_march.hip)
+void launch_full_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out, const double* phi,
+                       const double* psi, const double* rhs, int mode);
+void launch_gsrb_full_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out,
+                            const double* phi, const double* psi, const double* rhs, int color);
+int full_march_rows();
 void launch_flux_full(hipStream_t st, const LevelDev& L, double* const out[3], const double* phi, const double* psi);
 void launch_op_full(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* psi,
                     const double* rhs, int mode);
@@ -81,6 +90,12 @@ void launch_axby(hipStream_t st, double* z, const double* x, const double* y, do
 // ordered: reference-ordered serial sum (modes 0 and 2; meant for small levels, see k_reduce_ordered)
 void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const double* b, int mode, double* partials,
                    double* out, bool ordered = false);
+// sharded small level: the rank's per-cell terms into their slot of the serial sequence (mode 0: a*b, 2: |a|, 6: X = dxProduct/b*a,
+// Y = dxProduct/b), then -- after a sum-allreduce of X (and Y) -- the walk in the reference's order (k_reduce_ordered_flat)
+void launch_ord_fill(hipStream_t st, const LevelDev& L, const long long* start, const double* a, const double* b,
+                     int mode, double dxProduct, double* X, double* Y);
+void launch_reduce_ordered_flat(hipStream_t st, int nboxes, const long long* box_start, const double* X, const double* Y,
+                                int mode, double* out);
 void launch_div_mac(hipStream_t st, const LevelDev& L, double* out, const double* u0, const double* u1,
                     const double* u2, double dt);
 void launch_altered_jgup(hipStream_t st, long long n, double* dest, const double* nsq, const double* dmu,

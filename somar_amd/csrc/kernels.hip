@@ -664,6 +664,63 @@ __global__ __launch_bounds__(64) void k_reduce_ordered(const PatchDesc* __restri
     }
 }
 
+// ---- the same serial sums on a SHARDED small level -------------------------------------------------------------
+// Every rank writes the per-cell terms of ITS boxes at their position in the serial (box after box, Fortran order)
+// sequence, zeros elsewhere; a sum-allreduce of that vector (x + 0 is exact) hands every rank the whole sequence,
+// which one wavefront then walks exactly as k_reduce_ordered does.  <= 4096 cells: a 32-64 KB message.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ord_fill(const PatchDesc* __restrict__ patches, const long long* __restrict__ start,
+                                                  const double* __restrict__ a, const double* __restrict__ b,
+                                                  double dxProduct, double* __restrict__ X, double* __restrict__ Y)
+{
+    const PatchDesc p = patches[blockIdx.x];
+    const long long n = (long long)p.n[0] * p.n[1] * p.n[2], s0 = start[blockIdx.x];
+    for (long long idx = threadIdx.x; idx < n; idx += 256) {
+        const int i = (int)(idx % p.n[0]);
+        const long long r = idx / p.n[0];
+        const int j = (int)(r % p.n[1]), k = (int)(r / p.n[1]);
+        const long long c = cidx(p, i, j, k);
+        if (MODE == 0) X[s0 + idx] = a[c] * b[c];
+        else if (MODE == 2) X[s0 + idx] = fabs(a[c]);
+        else { const double y = dxProduct / b[c]; Y[s0 + idx] = y; X[s0 + idx] = y * a[c]; }
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(64) void k_reduce_ordered_flat(int nboxes, const long long* __restrict__ box_start,
+                                                            const double* __restrict__ Xg, const double* __restrict__ Yg,
+                                                            double* __restrict__ out)
+{
+    constexpr int CH = 512;
+    __shared__ double X[CH], Y[MODE == 6 ? CH : 1];
+    const int lane = threadIdx.x;
+    double tot = 0.0, run_s = 0.0, run_v = 0.0;
+    for (int pi = 0; pi < nboxes; ++pi) {
+        const long long s0 = box_start[pi], n = box_start[pi + 1] - s0;
+        double sbox = 0.0;
+        for (long long base = 0; base < n; base += CH) {
+            const int cnt = (int)((n - base) < CH ? (n - base) : CH);
+            __syncthreads();
+            for (int q = lane; q < cnt; q += 64) {
+                X[q] = Xg[s0 + base + q];
+                if (MODE == 6) Y[q] = Yg[s0 + base + q];
+            }
+            __syncthreads();
+            if (MODE == 6) {
+                for (int q = 0; q < cnt; ++q) { run_s = run_s + X[q]; run_v = run_v + Y[q]; }
+            } else {
+                int q = 0;
+                if (base == 0) { sbox = X[0]; q = 1; }
+                for (; q < cnt; ++q) sbox = sbox + X[q];
+            }
+        }
+        if (MODE != 6) tot = tot + sbox;
+    }
+    if (lane == 0) {
+        if (MODE == 6) { out[0] = run_s; out[1] = run_v; }
+        else out[0] = tot;
+    }
+}
+
 // splitmix64(cell index, seed) -> uniform(-1,1): same integer recipe as
 // oracle/somar_oracle.py::hash_uniform; used by bench/tests for device-side synthetic fills.
 __global__ __launch_bounds__(512) void k_fill_hash(const Tile* __restrict__ tiles,
@@ -871,6 +928,21 @@ void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const dou
         hipLaunchKernelGGL(k_reduce_valid<5>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, L.ntiles, 1,
                        mode == 1 ? 1 : (mode == 3 ? 2 : 0), out);
+}
+void launch_ord_fill(hipStream_t st, const LevelDev& L, const long long* start, const double* a, const double* b,
+                     int mode, double dxProduct, double* X, double* Y)
+{
+    if (L.npatches == 0) return;
+    if (mode == 0) hipLaunchKernelGGL(k_ord_fill<0>, dim3(L.npatches), dim3(256), 0, st, L.patches, start, a, b, dxProduct, X, Y);
+    else if (mode == 2) hipLaunchKernelGGL(k_ord_fill<2>, dim3(L.npatches), dim3(256), 0, st, L.patches, start, a, b, dxProduct, X, Y);
+    else hipLaunchKernelGGL(k_ord_fill<6>, dim3(L.npatches), dim3(256), 0, st, L.patches, start, a, b, dxProduct, X, Y);
+}
+void launch_reduce_ordered_flat(hipStream_t st, int nboxes, const long long* box_start, const double* X, const double* Y,
+                                int mode, double* out)
+{
+    if (mode == 0) hipLaunchKernelGGL(k_reduce_ordered_flat<0>, dim3(1), dim3(64), 0, st, nboxes, box_start, X, Y, out);
+    else if (mode == 2) hipLaunchKernelGGL(k_reduce_ordered_flat<2>, dim3(1), dim3(64), 0, st, nboxes, box_start, X, Y, out);
+    else hipLaunchKernelGGL(k_reduce_ordered_flat<6>, dim3(1), dim3(64), 0, st, nboxes, box_start, X, Y, out);
 }
 void launch_fill_hash(hipStream_t st, const LevelDev& L, double* f, unsigned long long seed)
 {

@@ -487,6 +487,7 @@ Level::~Level()
     hipFree(d_tiles);
     hipFree(d_ftiles);
     hipFree(d_rtiles);
+    hipFree(d_qtiles);
     hipFree(d_ctiles);
     hipFree(d_local_items);
     hipFree(d_send_items);
@@ -638,6 +639,9 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     hrtiles = march_tiles(124, 14, 2.0);
     d_rtiles = to_device(hrtiles);
     nrtiles = (int)hrtiles.size();
+    hqtiles = march_tiles(124, full_march_rows() - 2, 2.0);
+    d_qtiles = to_device(hqtiles);
+    nqtiles = (int)hqtiles.size();
 
     // ---- whole-column tiles for line relaxation (one lane per (i-pair, j) column) ---------------
     {

@@ -100,6 +100,9 @@ public:
     std::vector<Tile> hrtiles;   // tiles of the k-marching operator/residual (resid_march.hip): 124 x 14 columns
     Tile* d_rtiles = nullptr;
     int nrtiles = 0;
+    std::vector<Tile> hqtiles;   // tiles of the k-marching 19-point kernels (full19_march.hip): 124 x (rows - 2) columns
+    Tile* d_qtiles = nullptr;
+    int nqtiles = 0;
     std::vector<Tile> hctiles;   // whole-column tiles (line relaxation): 128 x ctile_j columns, all of k
     Tile* d_ctiles = nullptr;
     int nctiles = 0, ctile_j = 2;

@@ -574,6 +574,25 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
         if (cur != e) launch_copy(st_, e, cur, L.field_elems);
         return;
     }
+    if (prm.relaxMode == RELAX_LEVEL_GSRB && full_march(d)) {
+        // LevelGSRB::relax with a non-diagonal metric on a large level: per colour the same exchange / CF fill / ghost
+        // program, then ONE marching pass (full19_march.hip) that reads the pre-pass values everywhere (the snapshot
+        // semantics of the reference's `extrap`) and writes the other buffer.
+        double* cur = e;
+        double* alt = f_pp[d];
+        for (int it = 0; it < iters; ++it)
+            for (int pass = 0; pass < 2; ++pass) {
+                L.cf_homog(cur, st_);
+                L.exchange(cur, st_);
+                run_full_program_frames(d, 1, cur);
+                if (profiling_ && d == 0) prof_begin(0);
+                launch_gsrb_full_march(st_, L.d_qtiles, L.nqtiles, L.dev, alt, cur, f_psi[d], res, pass);
+                if (profiling_ && d == 0) prof_end(0);
+                std::swap(cur, alt);
+            }
+        // an even number of passes: the result is back in e
+        return;
+    }
     for (int it = 0; it < iters; ++it) {
         if (prm.relaxMode == RELAX_LEVEL_GSRB) {
             // LevelGSRB::relax, GSRB.cpp:58-98.  The Neumann ghost fill of
@@ -644,7 +663,10 @@ void PressureSolver::residual_i(int d, double* out, double* phi, const double* r
     L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
     if (diri_ && !full_) apply_diri(d, phi, homogeneous);  // m_bc.setGhosts, :822 (non-diagonal: inside the program)
     if (profiling_ && d == 0) prof_begin(1);
-    if (full_) {
+    if (full_march(d)) {
+        run_full_program_frames(d, 0, phi, homogeneous);
+        launch_full_march(st_, L.d_qtiles, L.nqtiles, L.dev, out, phi, f_psi[d], rhs, 0);
+    } else if (full_) {
         // exchangeComplete, fillExtrap (order 2), physical ghosts (Neumann with cross terms / Dirichlet), then the 19-point fluxes
         run_full_program(d, 0, phi, homogeneous);
         launch_op_full(st_, L.dev, out, phi, f_psi[d], rhs, 0);
@@ -658,7 +680,10 @@ void PressureSolver::apply_op_i(int d, double* out, double* phi, bool homogeneou
     Level& L = *lev[d];
     L.exchange(phi, st_);
     if (diri_ && !full_) apply_diri(d, phi, homogeneous);
-    if (full_) {
+    if (full_march(d)) {
+        run_full_program_frames(d, 0, phi, homogeneous);
+        launch_full_march(st_, L.d_qtiles, L.nqtiles, L.dev, out, phi, f_psi[d], nullptr, 1);
+    } else if (full_) {
         run_full_program(d, 0, phi, homogeneous);
         launch_op_full(st_, L.dev, out, phi, f_psi[d], nullptr, 1);
     } else if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, nullptr, 1);
@@ -668,10 +693,12 @@ void PressureSolver::apply_op_i(int d, double* out, double* phi, bool homogeneou
 void PressureSolver::prolong_from(const LevelDev& C, const double* crse, const int r[3], double* fine)
 {
     Level& F = *lev[0];
-    launch_prolong(st_, F.dev, C, fine, crse, r, F.zeroAvg, F.dxProduct, d_partials, d_scalars + SLOT_SUMS,
+    const bool os = F.zeroAvg && ord_sharded(0);
+    launch_prolong(st_, F.dev, C, fine, crse, r, F.zeroAvg && !os, F.dxProduct, d_partials, d_scalars + SLOT_SUMS,
                    F.field_elems, ordered(0));
     if (F.zeroAvg) {
-        comm_->allreduce(d_scalars + SLOT_SUMS, 2, 0, st_);
+        if (os) ordered_sums(0, fine, F.dev.jinv, 6, F.dxProduct, d_scalars + SLOT_SUMS);
+        else comm_->allreduce(d_scalars + SLOT_SUMS, 2, 0, st_);
         launch_sub_mean(st_, fine, F.field_elems, d_scalars + SLOT_SUMS);
     }
 }
@@ -710,10 +737,12 @@ const double* PressureSolver::prolong_increment(int d, double* phiFine, const do
     // ConstInterpPS / ZeroAvgConstInterpPS, ProlongationStrategy.cpp:49-164.  The two scalar
     // MPI_Allreduce calls of the reference become one 2-element device-side reduction.
     Level& F = *lev[d];
-    launch_prolong(st_, F.dev, lev[d + 1]->dev, phiFine, corrCoarse, F.mgCrseRefRatio, F.zeroAvg, F.dxProduct,
+    const bool os = F.zeroAvg && ord_sharded(d);
+    launch_prolong(st_, F.dev, lev[d + 1]->dev, phiFine, corrCoarse, F.mgCrseRefRatio, F.zeroAvg && !os, F.dxProduct,
                    d_partials, d_scalars + SLOT_SUMS, F.field_elems, ordered(d));
     if (F.zeroAvg) {
-        comm_->allreduce(d_scalars + SLOT_SUMS, 2, 0, st_);
+        if (os) ordered_sums(d, phiFine, F.dev.jinv, 6, F.dxProduct, d_scalars + SLOT_SUMS);
+        else comm_->allreduce(d_scalars + SLOT_SUMS, 2, 0, st_);
         if (defer_mean) return d_scalars + SLOT_SUMS;
         launch_sub_mean(st_, phiFine, F.field_elems, d_scalars + SLOT_SUMS);
     }
@@ -745,21 +774,52 @@ double PressureSolver::norm(int d, const double* a, int ord)
         return fetch_scalar(SLOT_TMP);
     }
     if (ord == 1) {
-        launch_reduce(st_, L.dev, a, nullptr, 2, d_partials, d_scalars + SLOT_TMP, ordered(d));
-        comm_->allreduce(d_scalars + SLOT_TMP, 1, 0, st_);
+        reduce_sum(d, a, nullptr, 2, d_scalars + SLOT_TMP);
         return fetch_scalar(SLOT_TMP);
     }
     SOMAR_CHECK(ord == 2, "norm order must be 0, 1 or 2");
-    launch_reduce(st_, L.dev, a, a, 0, d_partials, d_scalars + SLOT_TMP, ordered(d));
-    comm_->allreduce(d_scalars + SLOT_TMP, 1, 0, st_);
+    reduce_sum(d, a, a, 0, d_scalars + SLOT_TMP);
     return std::sqrt(fetch_scalar(SLOT_TMP));
 }
 
 double PressureSolver::dot(int d, const double* a, const double* b)
 {
-    launch_reduce(st_, lev[d]->dev, a, b, 0, d_partials, d_scalars + SLOT_TMP, ordered(d));
-    comm_->allreduce(d_scalars + SLOT_TMP, 1, 0, st_);
+    reduce_sum(d, a, b, 0, d_scalars + SLOT_TMP);
     return fetch_scalar(SLOT_TMP);
+}
+
+void PressureSolver::reduce_sum(int d, const double* a, const double* b, int mode, double* out)
+{
+    if (ord_sharded(d)) {
+        ordered_sums(d, a, b, mode, 0.0, out);
+        return;
+    }
+    launch_reduce(st_, lev[d]->dev, a, b, mode, d_partials, out, ordered(d));
+    comm_->allreduce(out, 1, 0, st_);
+}
+
+void PressureSolver::ordered_sums(int d, const double* a, const double* b, int mode, double dxProduct, double* out)
+{
+    Level& L = *lev[d];
+    const int nb = (int)L.boxes.size();
+    if ((int)d_ord_start_.size() <= d) { d_ord_start_.resize(lev.size(), nullptr); d_box_start_.resize(lev.size(), nullptr); }
+    if (!d_box_start_[d]) {
+        std::vector<long long> bs(nb + 1, 0), ls(std::max<size_t>(L.local.size(), 1), 0);
+        for (int i = 0; i < nb; ++i) bs[i + 1] = bs[i] + L.boxes[i].numPts();
+        for (size_t q = 0; q < L.local.size(); ++q) ls[q] = bs[L.local[q]];
+        SOMAR_HIP(hipMalloc(&d_box_start_[d], bs.size() * sizeof(long long)));
+        SOMAR_HIP(hipMalloc(&d_ord_start_[d], ls.size() * sizeof(long long)));
+        SOMAR_HIP(hipMemcpy(d_box_start_[d], bs.data(), bs.size() * sizeof(long long), hipMemcpyHostToDevice));
+        SOMAR_HIP(hipMemcpy(d_ord_start_[d], ls.data(), ls.size() * sizeof(long long), hipMemcpyHostToDevice));
+    }
+    const long long n = L.valid_cells_global;
+    if (!d_ordbuf_) SOMAR_HIP(hipMalloc(&d_ordbuf_, (size_t)2 * ordered_max_cells_ * sizeof(double)));
+    const int nvec = mode == 6 ? 2 : 1;
+    double *X = d_ordbuf_, *Y = d_ordbuf_ + n;
+    launch_set(st_, X, nvec * n, 0.0);
+    launch_ord_fill(st_, L.dev, d_ord_start_[d], a, b, mode, dxProduct, X, Y);
+    comm_->allreduce(X, (int)(nvec * n), 0, st_);
+    launch_reduce_ordered_flat(st_, nb, d_box_start_[d], X, Y, mode, out);
 }
 
 // f -= sum(f*J)/sum(J): the J-weighted mean removal the callers apply to make an all-Neumann/periodic
@@ -1270,9 +1330,14 @@ void PressureSolver::bottom_solve(double* phi, const double* rhs)
             pre_cond(d, s_tilde, r);
             apply_op(d, t, s_tilde);
             // (t,r) and (t,t) in one host round trip
-            launch_reduce(st_, lev[d]->dev, t, r, 0, d_partials, d_scalars + SLOT_TMP, ordered(d));
-            launch_reduce(st_, lev[d]->dev, t, t, 0, d_partials, d_scalars + SLOT_TMP + 1, ordered(d));
-            comm_->allreduce(d_scalars + SLOT_TMP, 2, 0, st_);
+            if (ord_sharded(d)) {
+                ordered_sums(d, t, r, 0, 0.0, d_scalars + SLOT_TMP);
+                ordered_sums(d, t, t, 0, 0.0, d_scalars + SLOT_TMP + 1);
+            } else {
+                launch_reduce(st_, lev[d]->dev, t, r, 0, d_partials, d_scalars + SLOT_TMP, ordered(d));
+                launch_reduce(st_, lev[d]->dev, t, t, 0, d_partials, d_scalars + SLOT_TMP + 1, ordered(d));
+                comm_->allreduce(d_scalars + SLOT_TMP, 2, 0, st_);
+            }
             fetch_scalars(SLOT_TMP, 2);
             const double tr = h_scalars[SLOT_TMP], tt = h_scalars[SLOT_TMP + 1];
             omega[0] = tr / tt;

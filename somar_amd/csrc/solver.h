@@ -203,6 +203,15 @@ private:
     long long march_min_cells_ = 262144;  // levels at least this big use the k-marching operator/residual
     long long ordered_max_cells_ = 4096;
     bool ordered(int d) const { return lev[d]->valid_cells_global <= ordered_max_cells_; }
+    // A small level that is SHARDED keeps the serial order too: every rank contributes the per-cell terms of its boxes to
+    // one vector in the serial (box after box) sequence, a sum-allreduce completes it, one wavefront walks it
+    // (k_ord_fill / k_reduce_ordered_flat) -- so a sharded solve adds the same numbers in the same order as one rank.
+    bool ord_sharded(int d) const { return ordered(d) && comm_->size > 1; }
+    double* d_ordbuf_ = nullptr;                    // 2 * ordered_max_cells_ doubles
+    std::vector<long long*> d_ord_start_, d_box_start_;  // per depth: serial start of each LOCAL patch / of every box (+ end)
+    void ordered_sums(int d, const double* a, const double* b, int mode, double dxProduct, double* out);
+    // out[0] = sum over the level (mode 0: a*b, 2: |a|), every rank: serial order on small levels, tree order on large ones
+    void reduce_sum(int d, const double* a, const double* b, int mode, double* out);
 
     Comm* comm_;
     Comm self_;
@@ -226,11 +235,18 @@ private:
     bool full_ = false;
     std::vector<double*> f_psi;                            // per depth: the extrapolated copy of phi
     // per depth: [0] operator, [1] smoother, [2] fillExtrap alone (getFlux of the flux register), [3] ExtrapolateCFEV
-    std::vector<std::array<FullProgram, 4>> full_prog_;
+    std::vector<std::array<FullProgram, 6>> full_prog_;   // + [4] / [5]: [0] / [1] writing psi in the boxes' frames only (marching kernels)
     double* f_flux[3] = {nullptr, nullptr, nullptr};  // face fluxes of depth 0 (refluxing with a non-diagonal metric)
     void alloc_full_metric(Level& L);
     void build_full_programs(int d);
     void run_full_program(int d, int which, double* phi, bool homogeneous = true);
+    void run_full_program_frames(int d, int which, double* phi, bool homogeneous = true);
+    // large 3-D levels of the non-diagonal path run the k-marching 19-point kernels (full19_march.hip)
+    bool full_march(int d) const
+    {
+        const Level& L = *lev[d];
+        return full_ && L.active[2] && L.valid_cells_global >= march_min_cells_;
+    }
     std::unique_ptr<PressureSolver> coarse_;   // replicated tail of the hierarchy (agglomeration)
     int agglom_depth_ = -1;
     long long agglom_cells_ = 2097152;  // 128^3: below this a level costs less to replicate (~0.2 ms of sweeps) than to exchange (~8 x 60 us)

@@ -210,14 +210,46 @@ static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which
     return stages;
 }
 
+// Stage 0 of a frame-only program: psi := phi in the one-cell frame of every box (all six slabs of all boxes in ONE
+// launch: they overlap only in edge / corner cells, where they write the same values).
+static std::vector<GhostOp> frame_copy_stage(const Level& L)
+{
+    std::vector<GhostOp> out;
+    for (int pi = 0; pi < L.npatches(); ++pi) {
+        const IBox valid = L.boxes[L.local[pi]];
+        int g1[3];
+        for (int d = 0; d < 3; ++d) g1[d] = L.active[d] ? 1 : 0;
+        const IBox fab = valid.grow(g1);
+        for (int a = 0; a < 3; ++a) {
+            if (!L.active[a]) continue;
+            for (int side = 0; side < 2; ++side) {
+                IBox slab = fab;
+                if (side == 0) slab.hi[a] = slab.lo[a];
+                else slab.lo[a] = slab.hi[a];
+                GhostOp op;
+                std::memset(&op, 0, sizeof(op));
+                op.patch = pi;
+                op.type = GHOST_COPY;
+                for (int q = 0; q < 3; ++q) { op.lo[q] = slab.lo[q] - valid.lo[q]; op.n[q] = slab.size(q); }
+                op.dstf = 1;
+                op.srcf = 0;
+                out.push_back(op);
+            }
+        }
+    }
+    return out;
+}
+
 void PressureSolver::build_full_programs(int d)
 {
     Level& L = *lev[d];
-    for (int which = 0; which < 4; ++which) {
-        if (which >= 2 && !(hasCF_ || d == 0)) continue;  // [2] serves the flux register (depth 0), [3] needs CF faces
+    for (int which = 0; which < 6; ++which) {
+        if ((which == 2 || which == 3) && !(hasCF_ || d == 0)) continue;  // [2] serves the flux register (depth 0), [3] needs CF faces
         if (which == 3 && !hasCF_) continue;
+        if (which >= 4 && !full_march(d)) continue;   // [4] / [5]: [0] / [1] for the marching kernels (psi in frames only)
         FullProgram& P = full_prog_[d][which];
-        const auto stages = build_program(L, which, bc_value_);
+        auto stages = build_program(L, which >= 4 ? which - 4 : which, bc_value_);
+        if (which >= 4) stages.insert(stages.begin(), frame_copy_stage(L));
         std::vector<GhostOp> flat;
         P.first.clear();
         P.count.clear();
@@ -243,6 +275,17 @@ void PressureSolver::run_full_program(int d, int which, double* phi, bool homoge
     const FullProgram& P = full_prog_[d][which];
     for (size_t s = 0; s < P.first.size(); ++s)
         launch_ghost_ops(st_, L.dev, P.d_ops + P.first[s], P.count[s], phi, f_psi[d], homogeneous);
+}
+
+// The same call sequences for the marching kernels (full19_march.hip): psi is written in the boxes' one-cell frames
+// only -- stage 0 copies phi's frame, the ops read "psi" inside a box's valid region from phi (k_ghost_ops<true>) --
+// so the whole-field copy psi := phi (16 B/cell per application) is gone.  which: 0 operator, 1 smoother.
+void PressureSolver::run_full_program_frames(int d, int which, double* phi, bool homogeneous)
+{
+    Level& L = *lev[d];
+    const FullProgram& P = full_prog_[d][which + 4];
+    for (size_t s = 0; s < P.first.size(); ++s)
+        launch_ghost_ops(st_, L.dev, P.d_ops + P.first[s], P.count[s], phi, f_psi[d], homogeneous, true);
 }
 
 void PressureSolver::cf_ev(int d, double* phi)

@@ -59,3 +59,67 @@ def slab_partition(n, nparts):
                 lo = (i * sz[0], j * sz[1], k * sz[2])
                 boxes.append((lo, tuple(a + b - 1 for a, b in zip(lo, sz))))
     return boxes
+
+
+def boxes_of(lo, hi, bs):
+    """[lo, hi] cut into boxes of bs cells, k slowest / i fastest (the order Chombo's domainSplit produces)"""
+    out = []
+    for k in range(lo[2], hi[2] + 1, bs[2]):
+        for j in range(lo[1], hi[1] + 1, bs[1]):
+            for i in range(lo[0], hi[0] + 1, bs[0]):
+                out.append(((i, j, k), (min(i + bs[0], hi[0] + 1) - 1, min(j + bs[1], hi[1] + 1) - 1,
+                                        min(k + bs[2], hi[2] + 1) - 1)))
+    return out
+
+
+def y_slab_owners(boxes, nranks):
+    """Horizontal-only sharding of one level: boxes sorted by their y start are dealt to the ranks
+    in contiguous, equally sized groups, so every rank owns one y-slab of EVERY level -- vertical columns stay
+    whole, x rows stay long, and a fine box mostly sits over coarse cells of the same rank."""
+    if nranks == 1:
+        return [0] * len(boxes)
+    ys = sorted({b[0][1] for b in boxes})
+    rank_of_y = {y: min(q * nranks // len(ys), nranks - 1) for q, y in enumerate(ys)}
+    return [rank_of_y[b[0][1]] for b in boxes]
+
+
+def lockexchange_hierarchy(config="c3", scale=1, box=128, mult=4, nranks=1):
+    """Box layouts of the LockExchange-shaped BASELINE configs (the refined regions are this
+    repository's choice, recorded in BASELINE.md):
+      c3   512x512x64 base, L = (15,3,2), y periodic, level 1 = (2,2,1) refinement of the central half in x
+      c4   1024x1024x128 base + two (2,2,1) levels (central half, central quarter in x)
+      le3d exec/inputs.LockExchange_Cartesian3D.machine: 64x96x64 times mult, one level refined by (4,1,1)
+      le2d exec/inputs.LockExchange_Cartesian2D.machine: 2-D, 128x64 times mult, L = (15,2), one level (4,1)
+    scale divides every extent.  -> dict(n0, L, periodic, ratios, levels, owners, flat)"""
+    s = scale
+    if config == "c3":
+        n0, nlev = (512 // s, 512 // s, 64 // s), 2
+    elif config == "le3d":
+        n0, nlev = (64 * mult // s, 96 * mult // s, 64 * mult // s), 2
+    elif config == "le2d":
+        n0, nlev = (128 * mult // s, 64 * mult // s, 1), 2
+    elif config == "c4":
+        n0, nlev = (1024 // s, 1024 // s, 128 // s), 3
+    else:
+        raise ValueError(config)
+    L = (15.0, 3.0, 2.0)
+    le = config in ("le3d", "le2d")
+    ratios = [(4, 1, 1)] * (nlev - 1) if le else [(2, 2, 1)] * (nlev - 1)
+    flat = config == "le2d"
+    if flat:
+        L = (15.0, 2.0, 1.0)
+    bs = (max(box // s, 8), max(box // s, 8), n0[2])
+    levels = [boxes_of((0, 0, 0), tuple(a - 1 for a in n0), bs)]
+    n = list(n0)
+    frac = 2
+    for l in range(1, nlev):
+        r = ratios[l - 1]
+        n = [n[0] * r[0], n[1] * r[1], n[2] * r[2]]
+        w = n[0] // frac          # central half, then central quarter (of the refined index space)
+        lo_x = (n[0] - w) // 2
+        lo_x -= lo_x % ((1 if le else 2) * bs[0])
+        levels.append(boxes_of((lo_x, 0, 0), (lo_x + w - 1, n[1] - 1, n[2] - 1), bs))
+        frac *= 2
+    return {"n0": n0, "L": L, "periodic": (False, False, False) if flat else (False, True, False), "ratios": ratios,
+            "levels": levels, "owners": [y_slab_owners(b, nranks) for b in levels], "flat": flat,
+            "dx0": tuple(L[d] / n0[d] for d in range(3))}

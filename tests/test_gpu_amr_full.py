@@ -9,6 +9,14 @@ from helpers import download_valid, make_full_amr_levels, make_gpu_amr, max_rel_
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["direct", "march"])
+def kernel_path(request, monkeypatch):
+    """direct: k_op_full / k_gsrb_full (small levels); march: the k-marching LDS kernels of large levels
+    (full19_march.hip, psi kept in the boxes' frames only), forced onto these small cases.  Same bits either way."""
+    monkeypatch.setenv("SOMAR_MARCH_MIN_CELLS", "0" if request.param == "march" else "1000000000000")
+    return request.param
+
 LAYOUTS = [
     # ndim, n, L, cbox, periodic, ratios, fine boxes
     (2, (32, 16, 1), (2.0, 1.0, 1.0), (32, 16, 1), (False, False, False), [(2, 2, 1)], [[((16, 8, 0), (47, 23, 0))]]),

@@ -1,5 +1,6 @@
-"""BASELINE config C3 at FULL size (512x512x64 base + a (2,2,1)-refined central half in x, 50 M cells, Cartesian,
-y periodic) -- too big for the oracle, so checked through size-independent properties:
+"""BASELINE configs C3 and C4 at FULL size (C3: 512x512x64 base + a (2,2,1)-refined central half in x, 50 M cells; C4:
+1024x1024x128 base + two (2,2,1) levels, 940 M cells, here on ONE GPU; Cartesian, y periodic) -- too big for the oracle,
+so checked through size-independent properties:
   * the refluxed composite operator is conservative: its volume integral over the closed/periodic domain vanishes;
   * a composite solve of a compatible right-hand side converges with the reference's stopping logic, monotonically."""
 import os
@@ -12,12 +13,17 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-def test_c3_composite_operator_conserves_and_solve_converges():
+@pytest.mark.parametrize("config", ["c3", "c4"])
+def test_composite_operator_conserves_and_solve_converges(config):
+    """c3: 512x512x64 + one level (50 M cells); c4: BASELINE C4 on ONE GPU -- 1024x1024x128 + two (2,2,1) levels, 940 M cells"""
     from bench_amr import build_hierarchy
     from somar_amd import api as F
-    gpu, levels, cells, _, dx0, ratios = build_hierarchy("c3", 1)
+    gpu, levels, cells, _, dx0, ratios = build_hierarchy(config, 1)
     try:
-        assert cells == [512 * 512 * 64, 512 * 1024 * 64]
+        if config == "c3":
+            assert cells == [512 * 512 * 64, 512 * 1024 * 64]
+        else:
+            assert cells == [1024 * 1024 * 128, 1024 * 2048 * 128, 1024 * 4096 * 128]
         nlev = len(levels)
         for l, v in enumerate(gpu.levels):
             v.fillHash(F.F_PHI, 5 + l)
@@ -25,7 +31,8 @@ def test_c3_composite_operator_conserves_and_solve_converges():
         # RES = 0 - L_composite[phi] on every level, covered coarse cells zeroed
         for ilev in range(nlev):
             gpu.residualLevel(nlev - 1, 0, ilev)
-        gpu.zeroCovered(0, F.F_RES)
+        for l in range(nlev - 1):
+            gpu.zeroCovered(l, F.F_RES)
         total, mag = 0.0, 0.0
         dx = list(dx0)
         for l, v in enumerate(gpu.levels):

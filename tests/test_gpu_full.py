@@ -8,6 +8,14 @@ from helpers import download_valid, max_rel_diff, upload, valid_of
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["direct", "march"])
+def kernel_path(request, monkeypatch):
+    """direct: k_op_full / k_gsrb_full (small levels); march: the k-marching LDS kernels of large levels
+    (full19_march.hip, psi kept in the boxes' frames only), forced onto these small cases.  Same bits either way."""
+    monkeypatch.setenv("SOMAR_MARCH_MIN_CELLS", "0" if request.param == "march" else "1000000000000")
+    return request.param
+
 CASES = [
     ((16, 16, 16), 8, (True, True, True), (1.0, 1.0, 1.0)),
     ((16, 16, 8), 8, (False, True, False), (2.0, 1.0, 0.5)),

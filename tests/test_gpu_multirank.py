@@ -3,9 +3,11 @@ transport (csrc/comm_shm.cpp; RCCL refuses two ranks on one device).  Same plans
 reductions as the RCCL path -- only the wire differs.  Every rank checks ITS patches against the oracle, which
 computes the whole problem serially:
   * LevelGSRB (fused and two-pass), residual, fused residual+restriction, prolongation: bit-exact;
-  * full solve: same iteration count, history to 1e-6 (the rank-wise association of the scalar sums differs
-    from the serial box order, and BiCGStab amplifies that, see DESIGN.md 4);
-  * two AMR levels, both sharded: CF interpolation + refluxed composite residual bit-exact, AMR V-cycle 1e-6."""
+  * full solve: same iteration count, history to 1e-10 -- the north star's tolerance.  Small levels (where BiCGStab runs
+    and amplifies last-bit differences) add their scalar sums in the serial box order on every rank: per-cell terms go
+    into one vector in serial sequence, a sum-allreduce completes it, one wavefront walks it (PressureSolver::ordered_sums);
+    only the mean of large levels is a tree sum whose association depends on the sharding (as it does on one rank);
+  * two AMR levels, both sharded: CF interpolation + refluxed composite residual bit-exact, AMR V-cycle 1e-10."""
 import multiprocessing as mp
 import os
 import traceback
@@ -90,7 +92,7 @@ def _worker(rank, nranks, name, mode, q):
         except Exception:
             raise AssertionError("solve failed: %r vs oracle %r" % (gpu.stats, amr.history))
         assert st["iters"] == amr.iters and st["exitStatus"] == amr.exitStatus
-        np.testing.assert_allclose(st["history"], amr.history, rtol=1e-6, atol=1e-9 * amr.history[0])
+        np.testing.assert_allclose(st["history"], amr.history, rtol=1e-10, atol=1e-10 * amr.history[0])
         gpu.undefine()
 
         if nranks != 2:
@@ -150,7 +152,7 @@ def _worker(rank, nranks, name, mode, q):
             got = download_valid(s.levels[l], F.F_CORR, levels[l].grids)
             for g, w in zip(got, valid_of(corr[l])):
                 if g is not None:
-                    np.testing.assert_allclose(g, w, rtol=0, atol=1e-6 * float(np.max(np.abs(w))))
+                    np.testing.assert_allclose(g, w, rtol=0, atol=1e-10 * float(np.max(np.abs(w))))
         s.undefine()
         F.comm_destroy(comm)
         q.put((rank, "ok"))

@@ -25,46 +25,12 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def boxes_of(lo, hi, bs):
-    out = []
-    for k in range(lo[2], hi[2] + 1, bs[2]):
-        for j in range(lo[1], hi[1] + 1, bs[1]):
-            for i in range(lo[0], hi[0] + 1, bs[0]):
-                out.append(((i, j, k), (min(i + bs[0], hi[0] + 1) - 1, min(j + bs[1], hi[1] + 1) - 1,
-                                        min(k + bs[2], hi[2] + 1) - 1)))
-    return out
-
-
-def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult=4):
-    """-> (AMRPressureSolver (finalized), levels' boxes, cells per level, define seconds)"""
+def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult=4, comm=None, nranks=1):
+    """-> (AMRPressureSolver (finalized), levels' boxes, LOCAL cells per level, define seconds, dx0, ratios)"""
     from somar_amd import api as F
-    s = scale
-    if config == "c3":
-        n0, nlev = (512 // s, 512 // s, 64 // s), 2
-    elif config == "le3d":
-        n0, nlev = (64 * mult // s, 96 * mult // s, 64 * mult // s), 2
-    elif config == "le2d":
-        n0, nlev = (128 * mult // s, 64 * mult // s, 1), 2
-    else:
-        n0, nlev = (1024 // s, 1024 // s, 128 // s), 3
-    L = (15.0, 3.0, 2.0)
-    ratios = [(4, 1, 1)] * (nlev - 1) if config in ("le3d", "le2d") else [(2, 2, 1)] * (nlev - 1)
-    flat = config == "le2d"
-    if flat:
-        L = (15.0, 2.0, 1.0)
-    dx0 = tuple(L[d] / n0[d] for d in range(3))
-    bs = (max(box // s, 8), max(box // s, 8), n0[2])
-    levels = [boxes_of((0, 0, 0), tuple(a - 1 for a in n0), bs)]
-    n = list(n0)
-    frac = 2
-    for l in range(1, nlev):
-        r = ratios[l - 1]
-        n = [n[0] * r[0], n[1] * r[1], n[2] * r[2]]
-        w = n[0] // frac          # central half, then central quarter (of the refined index space)
-        lo_x = (n[0] - w) // 2
-        lo_x -= lo_x % ((2 if config not in ("le3d", "le2d") else 1) * bs[0])
-        levels.append(boxes_of((lo_x, 0, 0), (lo_x + w - 1, n[1] - 1, n[2] - 1), bs))
-        frac *= 2
+    from somar_amd import synthetic
+    H = synthetic.lockexchange_hierarchy(config, scale, box, mult, nranks)
+    levels, ratios, dx0, flat, n0 = H["levels"], H["ratios"], H["dx0"], H["flat"], H["n0"]
     gpu = F.AMRPressureSolver()
     if flat:
         gpu.setSpaceDim(2)
@@ -72,8 +38,8 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
     gpu.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, pre, post, bottom, p.precond_mode, 1, p.num_mg,
                            p.hang, p.norm_thresh, 0)
     t0 = time.perf_counter()
-    gpu.defineAMR((0, 0, 0), tuple(a - 1 for a in n0), (False, False, False) if flat else (False, True, False), dx0, ratios,
-                  levels)
+    gpu.defineAMR((0, 0, 0), tuple(a - 1 for a in n0), H["periodic"], dx0, ratios, levels,
+                  owners_per_level=H["owners"], comm=comm)
     cells = []
     for l, v in enumerate(gpu.levels):
         tot = 0
