@@ -1264,3 +1264,63 @@ int orc_ellipticconstdiribcghost(double *st_, const int *slo, const int *shi, in
                 }
     return 0;
 }
+
+/* ------------------------------------------------------------------------
+ * CRSEONESIDEGRAD   calculus/DivCurlGrad/DivCurlGradF.ChF:626-697
+ * One-sided face gradients on the coarse side of a coarse-fine interface: the face between a coarse cell and the
+ * region covered by the finer level takes the linear extrapolation of the two faces behind it (or a copy of the
+ * one behind it), judged by the mask (MASKCOPY = 0: a cell of this level not covered by the finer one,
+ * calculus/DivCurlGrad/Mask.cpp, MASKVAL.H:21).  edgeGrad is face-centred in `dir` (index i = low face of cell i).
+ * ---------------------------------------------------------------------- */
+void orc_crseonesidegrad(double *eg_, const int *elo, const int *ehi,
+                         const int *mask_, const int *mlo, const int *mhi,
+                         const int *lolo, const int *lohi, const int *hilo, const int *hihi,
+                         int dir, int doLo, int doHi)
+{
+    fra_t eg = mk(eg_, elo, ehi);
+    const long ms1 = (long)(mhi[0] - mlo[0] + 1), ms2 = ms1 * (long)(mhi[1] - mlo[1] + 1);
+#define MASK(i, j, k) mask_[((long)(i) - mlo[0]) + ms1 * ((long)(j) - mlo[1]) + ms2 * ((long)(k) - mlo[2])]
+    const int ii = dir == 0, jj = dir == 1, kk = dir == 2;
+    if (doLo == 1)
+        for (int k = lolo[2]; k <= lohi[2]; ++k)
+            for (int j = lolo[1]; j <= lohi[1]; ++j)
+                for (int i = lolo[0]; i <= lohi[0]; ++i) {
+                    if (MASK(i - 2 * ii, j - 2 * jj, k - 2 * kk) == 0)
+                        AT(eg, i, j, k, 0) = 2.0 * AT(eg, i - ii, j - jj, k - kk, 0) - AT(eg, i - 2 * ii, j - 2 * jj, k - 2 * kk, 0);
+                    else if (MASK(i - ii, j - jj, k - kk) == 0)
+                        AT(eg, i, j, k, 0) = AT(eg, i - ii, j - jj, k - kk, 0);
+                }
+    if (doHi == 1)
+        for (int k = hilo[2]; k <= hihi[2]; ++k)
+            for (int j = hilo[1]; j <= hihi[1]; ++j)
+                for (int i = hilo[0]; i <= hihi[0]; ++i) {
+                    if (MASK(i + ii, j + jj, k + kk) == 0)
+                        AT(eg, i, j, k, 0) = 2.0 * AT(eg, i + ii, j + jj, k + kk, 0) - AT(eg, i + 2 * ii, j + 2 * jj, k + 2 * kk, 0);
+                    else if (MASK(i, j, k) == 0)
+                        AT(eg, i, j, k, 0) = AT(eg, i + ii, j + jj, k + kk, 0);
+                }
+#undef MASK
+}
+
+/* ------------------------------------------------------------------------
+ * UNMAPPEDAVERAGE   MappedChombo/MappedCoarseAverageF.ChF:7-41  (bref loop = ii2 outer .. ii0 inner)
+ * ---------------------------------------------------------------------- */
+void orc_unmappedaverage(double *crse_, const int *clo, const int *chi, int ncomp,
+                         const double *fine_, const int *flo, const int *fhi,
+                         const int *boxlo, const int *boxhi, const int *refRatio)
+{
+    fra_t coarse = mk(crse_, clo, chi), fine = mk((double *)fine_, flo, fhi);
+    const double refScale = 1.0 / (double)(refRatio[0] * refRatio[1] * refRatio[2]);
+    for (int var = 0; var < ncomp; ++var)
+        for (int ic2 = boxlo[2]; ic2 <= boxhi[2]; ++ic2)
+            for (int ic1 = boxlo[1]; ic1 <= boxhi[1]; ++ic1)
+                for (int ic0 = boxlo[0]; ic0 <= boxhi[0]; ++ic0) {
+                    const int ip0 = ic0 * refRatio[0], ip1 = ic1 * refRatio[1], ip2 = ic2 * refRatio[2];
+                    double coarseSum = 0.0;
+                    for (int ii2 = 0; ii2 < refRatio[2]; ++ii2)
+                        for (int ii1 = 0; ii1 < refRatio[1]; ++ii1)
+                            for (int ii0 = 0; ii0 < refRatio[0]; ++ii0)
+                                coarseSum = coarseSum + AT(fine, ip0 + ii0, ip1 + ii1, ip2 + ii2, var);
+                    AT(coarse, ic0, ic1, ic2, var) = coarseSum * refScale;
+                }
+}
