@@ -51,10 +51,27 @@ SINGLE_RANK_CONTRACTION = {("stretched", 512): 0.46093832950371805}
 
 
 def host_cores():
+    """the CPU threads this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands one
+    GPU's share of the host -- 16 of 256 hardware threads -- through cpu.max, not through the affinity mask)"""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get("SOMAR_CPU_THREADS")
+    return max(1, int(env)) if env else n
 
 
 def cpu_model():
@@ -202,8 +219,13 @@ def bench_c4(api, torch, dist, comm, world, steps, warmup, scale):
     gpu, levels, cells_local, t_def, dx0, ratios = build_hierarchy("c4", scale, 128, comm=comm, nranks=world)
     nlev = len(levels)
     try:
+        # a COMPATIBLE composite residual (the hierarchy is all-Neumann / periodic: L has the constants in its null space):
+        # RES := 0 - L_composite[hash-random phi], covered coarse cells zeroed -- what a solve from phi = 0 would hand the cycle
         for l, v in enumerate(gpu.levels):
-            v.fillHash(F.F_RES, 12345 + l)
+            v.fillHash(F.F_PHI, 12345 + l)
+            v.setVal(F.F_RHS, 0.0)
+        for ilev in range(nlev):
+            gpu.residualLevel(nlev - 1, 0, ilev)
         for l in range(nlev - 1):
             gpu.zeroCovered(l, F.F_RES)
 

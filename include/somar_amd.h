@@ -199,6 +199,20 @@ int somar_mac_project(somar_solver_t* s, double dt, int zero_pressure, int force
 int somar_mac_project_host(somar_solver_t* s, double* const* u0, double* const* u1, double* const* u2, double dt,
                            int zero_pressure, int force_homogeneous, somar_stats_t* stats);
 
+/* Velocities that are NOT in flux form: BaseProjector::project(..., a_velIsFlux = false) multiplies the velocity by J before
+ * the projection and divides it by J afterwards (projection/BaseProjectorI.H:235-241, 291-297) with
+ * LevelGeometry::multByJ / divByJ (geometry/LevelGeometryUtil.cpp:287-339, 372-420, 456-...): data *= J, resp. data *= Jinv
+ * (a multiplication by the cached 1/J, not a division).  Here the scale arrays become resident once --
+ *   somar_solver_set_cc_j   J and Jinv at cell centres over valid.grow(ghost), ghost >= 1 (getCCJ / getCCJinv)
+ *   somar_solver_set_face_j J and Jinv on faces(valid, dir) (what fill_J / fill_Jinv put on the face box)
+ * -- and somar_vel_mult_by_j / somar_vel_div_by_j scale the resident velocity on the device (centring 0: the MAC velocity,
+ * every direction; 1: the cell-centred velocity, every component, ghost layer included), so a non-flux velocity costs
+ * two launches around the projection instead of a round trip through the host.  After finalize. */
+int somar_solver_set_cc_j(somar_solver_t* s, int patch, const double* J, const double* Jinv, const int* ghost);
+int somar_solver_set_face_j(somar_solver_t* s, int dir, int patch, const double* J, const double* Jinv);
+int somar_vel_mult_by_j(somar_solver_t* s, int centring);
+int somar_vel_div_by_j(somar_solver_t* s, int centring);
+
 /* Viscous / diffusive Helmholtz solves through the same operator (single level).
  * somar_solver_set_alpha_beta = MappedAMRPoissonOp::setAlphaAndBeta (AMRElliptic/MappedAMRPoissonOp.cpp:582-619) applied to
  * every op of the hierarchy as MappedBaseLevelHeatSolver::resetSolverAlphaAndBeta does (AMRParabolic/
@@ -337,6 +351,27 @@ int somar_amr_interp_cf(somar_amr_t* a, int level, int fine_field, int coarse_fi
  * metric must be diagonal (error otherwise; level 0 takes either). */
 int somar_amr_level_project(somar_amr_t* a, int level, int centring, double dt, int zero_pressure, int force_homogeneous,
                             int wall_bc, somar_stats_t* stats);
+/* The COMPOSITE cell-centred projection over levels l_min..l_max -- SOMAR's sync / initialisation / post-regrid projection
+ * (NavierStokes/AMRNavierStokesSync.cpp:280-295), velocities in flux form (J u at cell centres, the levels'
+ * somar_ccvel_upload'ed fields; level l_min-1's velocity and pressure, if that level exists, supply coarse-fine values):
+ *   BaseProjector<FArrayBox>::project(lmin, lmax)                  projection/BaseProjectorI.H:176-299
+ *   AMRCCProjector::computeDiv / computeGrad / applyCorrection     projection/AMRCCProjector.cpp:204-377
+ *   Divergence::compDivergenceCC: CF interpolation of the velocity, CellToEdge, wall BC, level divergence, and the
+ *       coarse-fine mismatch refluxed through MappedLevelFluxRegister      calculus/DivCurlGrad/Divergence.cpp:697-838
+ *   Gradient::compGradientCC: levelGradientMAC, one-sided faces next to the finer level (CRSEONESIDEGRAD,
+ *       DivCurlGradF.ChF:626-697, mask of calculus/DivCurlGrad/Mask.cpp), EdgeToCell     Gradient.cpp:707-842
+ *   correction from the finest level down, each level then averaged onto the next coarser one
+ *       (MappedCoarseAverage::averageToCoarse, unweighted: UNMAPPEDAVERAGE)  AMRCCProjector.cpp:334-377
+ * rhs = compDiv / dt (not divided when dt == 0) goes to SOMAR_F_RHS, the pressure is left in SOMAR_F_PHI of each level.
+ * The pieces are exposed for parity tests: somar_amr_comp_divergence_cc writes compDivergenceCC of one level (NOT divided
+ * by dt) to out_field; somar_amr_comp_grad_correct_cc does ccvel(level) += (dt == 0 ? -1 : -dt) * compGradientCC(phi_field
+ * of that level; PHI of level-1 / level+1 as coarse / fine data); somar_amr_average_down_ccvel overwrites the cells of
+ * `level` under level+1 with the plain average of level+1's velocity.  The pressure operator must have beta = 1. */
+int somar_amr_cc_project(somar_amr_t* a, int l_min, int l_max, double dt, int zero_pressure, int force_homogeneous,
+                         int wall_bc, somar_stats_t* stats);
+int somar_amr_comp_divergence_cc(somar_amr_t* a, int level, int l_max, int out_field, int wall_bc);
+int somar_amr_comp_grad_correct_cc(somar_amr_t* a, int level, int l_max, int phi_field, double dt);
+int somar_amr_average_down_ccvel(somar_amr_t* a, int level);
 int somar_amr_residual_level(somar_amr_t* a, int l_max, int l_base, int ilev, int res_field, int phi_field,
                              int rhs_field);
 int somar_amr_zero_covered(somar_amr_t* a, int level, int field);

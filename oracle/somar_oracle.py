@@ -1143,7 +1143,23 @@ class MultiGrid:
                 self.bottomSolver.solve(correction, residual)
         else:
             cycles = self.cycle_type
-            assert cycles > 0, "F-cycle branch (:577-619) not restated"
+            if cycles < 0:
+                # F-cycle (:577-619): a recursive F-cycle first, pre-smoothing, then |m_cycle| V-cycles, post-smoothing
+                cycles = -cycles
+                op.restrict_residual(self.residual[depth + 1], correction, residual)
+                ld_set(self.correction[depth + 1], 0.0)
+                self.cycle(depth + 1, self.correction[depth + 1], self.residual[depth + 1])
+                op.prolong_increment(correction, self.correction[depth + 1])
+                op.relax(correction, residual, self.pre)
+                for _ in range(cycles):
+                    op.restrict_residual(self.residual[depth + 1], correction, residual)
+                    ld_set(self.correction[depth + 1], 0.0)
+                    self.cycle_type = 1            # "hack to get a V-cycle"
+                    self.cycle(depth + 1, self.correction[depth + 1], self.residual[depth + 1])
+                    self.cycle_type = -cycles
+                    op.prolong_increment(correction, self.correction[depth + 1])
+                op.relax(correction, residual, self.post)
+                return
             op.relax(correction, residual, self.pre)
             op.restrict_residual(self.residual[depth + 1], correction, residual)
             ld_set(self.correction[depth + 1], 0.0)
@@ -1348,6 +1364,49 @@ def make_full_metric(grids, dx, L, domain, amp=(0.25, 0.2, 0.15), variant="shear
             for b in range(3):
                 Jgup[i][d].a[..., b] = G[..., d, b]
         Jinv[i].a[..., 0] = 1.0 / np.linalg.det(jac(coords(g, -1)))
+    return Jgup, Jinv
+
+
+def make_terrain_metric(grids, dx, L, domain):
+    """BASELINE config C5's terrain-following (bathymetric) map, SURVEY.md 8d: x = xi, y = eta,
+    z = d + (1 - d/H) zeta (geometry/BathymetricBaseMapF.ChF:85-110) over the depth H s(x, y),
+    s = 0.5 + 0.3 exp(-r^2/w^2), r measured from the domain centre, w = min(L0, L1)/4, H = L2:
+    J = s, J g = [[s, 0, -z_xi], [0, s, -z_eta], [-z_xi, -z_eta, (1 + z_xi^2 + z_eta^2)/s]] with z_xi = s_x (zeta - H).
+    Non-periodic directions only (a bump is not periodic).  The product-side generator somar_amd/synthetic.py::terrain_metric
+    evaluates the same expressions; tests/test_synthetic.py compares them bit for bit."""
+    assert not any(domain.periodic)
+    Jgup = FluxData(grids, 3, 3)
+    Jinv = LevelData(grids, 1, (0, 0, 0), 1.0)
+    H = L[2]
+    w = min(L[0], L[1]) / 4.0
+
+    def coords(box, faceDir):
+        xs = []
+        for d in range(3):
+            idx = np.arange(box.lo[d], box.hi[d] + 1, dtype=np.float64)
+            xs.append((idx if d == faceDir else idx + 0.5) * dx[d])
+        return np.meshgrid(*xs, indexing="ij")
+
+    def fields(X):
+        ex = np.exp(-((X[0] - 0.5 * L[0]) ** 2 + (X[1] - 0.5 * L[1]) ** 2) / (w * w))
+        s = 0.5 + 0.3 * ex
+        sx = -0.3 * ex * (2.0 * (X[0] - 0.5 * L[0]) / (w * w))
+        sy = -0.3 * ex * (2.0 * (X[1] - 0.5 * L[1]) / (w * w))
+        return s, sx * (X[2] - H), sy * (X[2] - H)
+
+    for i, g in enumerate(grids):
+        for d in range(3):
+            s, zx, zy = fields(coords(Jgup[i][d].box, d))
+            a = Jgup[i][d].a
+            a[...] = 0.0
+            if d == 0:
+                a[..., 0], a[..., 2] = s, -zx
+            elif d == 1:
+                a[..., 1], a[..., 2] = s, -zy
+            else:
+                a[..., 0], a[..., 1], a[..., 2] = -zx, -zy, (1.0 + zx * zx + zy * zy) / s
+        s, _, _ = fields(coords(g, -1))
+        Jinv[i].a[..., 0] = 1.0 / s
     return Jgup, Jinv
 
 

@@ -107,6 +107,10 @@ _SIGS = {
     "somar_mac_project": [_H, C.c_double, C.c_int, C.c_int, C.POINTER(Stats)],
     "somar_mac_project_host": [_H, C.POINTER(_PD), C.POINTER(_PD), C.POINTER(_PD), C.c_double, C.c_int, C.c_int,
                                C.POINTER(Stats)],
+    "somar_solver_set_cc_j": [_H, C.c_int, _PD, _PD, _PI],
+    "somar_solver_set_face_j": [_H, C.c_int, C.c_int, _PD, _PD],
+    "somar_vel_mult_by_j": [_H, C.c_int],
+    "somar_vel_div_by_j": [_H, C.c_int],
     "somar_solver_set_alpha_beta": [_H, C.c_double, C.c_double],
     "somar_heat_step": [_H, C.c_int, C.c_double, C.c_int, C.POINTER(Stats)],
     "somar_ccvel_upload": [_H, C.c_int, _PD, _PI],
@@ -134,6 +138,10 @@ _SIGS = {
                              C.c_int, C.POINTER(Stats)],
     "somar_amr_interp_cf": [_H, C.c_int, C.c_int, C.c_int],
     "somar_amr_level_project": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
+    "somar_amr_cc_project": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
+    "somar_amr_comp_divergence_cc": [_H, C.c_int, C.c_int, C.c_int, C.c_int],
+    "somar_amr_comp_grad_correct_cc": [_H, C.c_int, C.c_int, C.c_int, C.c_double],
+    "somar_amr_average_down_ccvel": [_H, C.c_int],
     "somar_amr_residual_level": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     "somar_amr_zero_covered": [_H, C.c_int, C.c_int],
     "somar_amr_vcycle": [_H, C.c_int, C.c_int],
@@ -323,6 +331,22 @@ class AMRPressureSolver:
         _ck(lib().somar_amr_level_project(self._amr, level, int(centring), float(dt), int(zeroPressure),
                                           int(forceHomogeneous), int(wall), C.byref(st)))
         return self._stats(st)
+
+    def projectAMRCC(self, lmin, lmax, dt, zeroPressure=False, forceHomogeneous=False, wall=True):
+        """AMRCCProjector / BaseProjector<FArrayBox>::project(lmin, lmax) on the levels' uploadCCVel'ed velocities (in place)"""
+        st = Stats()
+        _ck(lib().somar_amr_cc_project(self._amr, lmin, lmax, float(dt), int(zeroPressure), int(forceHomogeneous), int(wall),
+                                       C.byref(st)))
+        return self._stats(st)
+
+    def compDivergenceCC(self, level, lmax, out_field=F_RHS, wall=True):
+        _ck(lib().somar_amr_comp_divergence_cc(self._amr, level, lmax, out_field, int(wall)))
+
+    def compGradCorrectCC(self, level, lmax, phi_field, dt):
+        _ck(lib().somar_amr_comp_grad_correct_cc(self._amr, level, lmax, phi_field, float(dt)))
+
+    def averageDownCCVel(self, level):
+        _ck(lib().somar_amr_average_down_ccvel(self._amr, level))
 
     def interpCF(self, level, fine_field=F_PHI, coarse_field=F_PHI):
         _ck(lib().somar_amr_interp_cf(self._amr, level, fine_field, coarse_field))
@@ -541,6 +565,19 @@ class AMRPressureSolver:
         return self._stats(st)
 
     # -- viscous / diffusive Helmholtz solves (MappedBaseLevelHeatSolver and its BE / CN integrators) --
+    # -- LevelGeometry::multByJ / divByJ on the resident velocities (a_velIsFlux = false, BaseProjectorI.H:235-241, 291-297)
+    def setCCJ(self, patch, J, Jinv, ghost):
+        _ck(lib().somar_solver_set_cc_j(self._h, patch, _dp(J), _dp(Jinv), _ia(ghost)))
+
+    def setFaceJ(self, d, patch, J, Jinv):
+        _ck(lib().somar_solver_set_face_j(self._h, d, patch, _dp(J), _dp(Jinv)))
+
+    def multByJ(self, centring):
+        _ck(lib().somar_vel_mult_by_j(self._h, centring))
+
+    def divByJ(self, centring):
+        _ck(lib().somar_vel_div_by_j(self._h, centring))
+
     def setAlphaAndBeta(self, a, b):
         _ck(lib().somar_solver_set_alpha_beta(self._h, float(a), float(b)))
 

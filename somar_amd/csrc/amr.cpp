@@ -37,7 +37,7 @@ AMRLink::~AMRLink()
     Level::free_field(buf);
     Level::free_field(resC);
     hipFree(d_cc); hipFree(d_pts); hipFree(d_fc); hipFree(d_der); hipFree(d_cover); hipFree(d_reg); hipFree(d_regvals);
-    hipFree(d_reflux); hipFree(d_A); hipFree(d_B); hipFree(d_sendidx); hipFree(d_sendbuf);
+    hipFree(d_reflux); hipFree(d_A); hipFree(d_B); hipFree(d_sendidx); hipFree(d_sendbuf); hipFree(d_osg);
 }
 
 // ------------------------------------------------------------------------------------
@@ -620,8 +620,6 @@ void AMRSolver::level_project(int l, int centring, double dt, bool zeroPressure,
     SOMAR_CHECK(finalized_ && l >= 0 && l < nlevels(), "level_project: bad level / hierarchy not finalized");
     SOMAR_CHECK(centring == 0 || centring == 1, "centring: 0 MAC, 1 cell-centred");
     PressureSolver& P = *S[l];
-    SOMAR_CHECK(!(P.is_full() && l > 0),
-                "level projection on a REFINED level with a non-diagonal metric is not implemented (singleBoxMacGrad next to coarse-fine faces)");
     double* phi = P.field(0, 0);
     double* rhs = P.field(0, 1);
     if (centring == 1) {
@@ -636,6 +634,180 @@ void AMRSolver::level_project(int l, int centring, double dt, bool zeroPressure,
     if (l > 0) interp_cf(l, phi, S[l - 1]->field(0, 0));
     if (centring == 1) P.cc_correct(phi, dt);
     else P.mac_correct(phi, dt);
+    sync();
+}
+
+// ------------------------------------------------------------------------------------
+// The COMPOSITE cell-centred projector (sync / initialisation / post-regrid projection)
+// ------------------------------------------------------------------------------------
+// compGradientCC's one-sided faces (Gradient.cpp:740-833) on level l-1 next to level l, as a face list: per coarse box,
+// per coarsened fine box, per direction the loops of the reference, the mask of Mask::buildMask (Mask.cpp:16-59)
+// evaluated on the host (MASKCOPY = a cell of a box of this level, unshifted, that no coarsened fine box covers).
+// do_lo / do_hi keep every face that is read inside the faces of the box itself, so no exchange of the face gradient is
+// needed.  Entries are staged in the reference's order: an entry that reads or rewrites a face an earlier entry wrote
+// (fine boxes one or two coarse cells apart) goes to a later stage.
+void AMRSolver::build_one_sided_tables(int l)
+{
+    AMRLink& K = *links_[l];
+    if (K.osg_built) return;
+    Level& C = S[l - 1]->level(0);
+    Level& F = S[l]->level(0);
+    std::vector<IBox> cfb;
+    for (const IBox& b : F.boxes) cfb.push_back(b.coarsen(K.r));
+    auto is_copy = [&](const int iv[3]) {
+        bool in = false;
+        for (const IBox& b : C.boxes)
+            if (contains(b, iv)) { in = true; break; }
+        if (!in) return false;
+        for (const IBox& b : cfb)
+            if (contains(b, iv)) return false;
+        return true;
+    };
+    struct E { OneSided o; int stage; };
+    std::vector<E> ents;
+    std::map<std::pair<int, long long>, int> wrote;   // (dir, face) -> stage of its last writer
+    for (int pi = 0; pi < C.npatches(); ++pi) {
+        const IBox box = C.boxes[C.local[pi]];
+        const PatchDesc& p = C.hpatches[pi];
+        const long long st[3] = {1, (long long)p.pj, p.pk};
+        const int one[3] = {1, 1, 1};
+        for (const IBox& fb : cfb) {
+            const IBox overlap = box & fb.grow(one);
+            if (overlap.empty()) continue;
+            for (int dir = 0; dir < 3; ++dir) {
+                if (!C.active[dir]) continue;
+                for (int side = 0; side < 2; ++side) {
+                    // the coarse cells just outside the fine box on that side, inside this box
+                    IBox adj = fb;
+                    if (side == 0) { adj.lo[dir] = fb.lo[dir] - 1; adj.hi[dir] = fb.lo[dir] - 1; }
+                    else { adj.lo[dir] = fb.hi[dir] + 1; adj.hi[dir] = fb.hi[dir] + 1; }
+                    adj = adj & box;
+                    if (adj.empty()) continue;
+                    if (side == 0 && overlap.lo[dir] <= box.lo[dir]) continue;   // do_lo = 0
+                    if (side == 1 && overlap.hi[dir] >= box.hi[dir]) continue;   // do_hi = 0
+                    int iv[3];
+                    for (iv[2] = adj.lo[2]; iv[2] <= adj.hi[2]; ++iv[2])
+                        for (iv[1] = adj.lo[1]; iv[1] <= adj.hi[1]; ++iv[1])
+                            for (iv[0] = adj.lo[0]; iv[0] <= adj.hi[0]; ++iv[0]) {
+                                // lo side: the face is the HIGH face of cell iv (index iv + e); the mask is read at the cells
+                                // face - 2e = iv - e and face - e = iv.  hi side: the face is the LOW face of iv (index iv); the
+                                // mask is read at face + e = iv + e and face = iv.
+                                int far[3] = {iv[0], iv[1], iv[2]}, near[3] = {iv[0], iv[1], iv[2]};
+                                far[dir] += side == 0 ? -1 : 1;
+                                int mode = 0;
+                                if (is_copy(far)) mode = 2;
+                                else if (is_copy(near)) mode = 1;
+                                if (!mode) continue;
+                                int fl[3] = {iv[0] - box.lo[0], iv[1] - box.lo[1], iv[2] - box.lo[2]};
+                                if (side == 0) fl[dir] += 1;
+                                OneSided o;
+                                o.face = p.off + fl[0] + st[1] * fl[1] + st[2] * fl[2];
+                                o.stride = (int)(side == 0 ? -st[dir] : st[dir]);
+                                o.dirmode = dir | (mode << 2);
+                                int stage = 0;
+                                const long long rd[3] = {o.face, o.face + o.stride, o.face + 2LL * o.stride};
+                                for (int q = 0; q < (mode == 2 ? 3 : 2); ++q) {
+                                    auto it = wrote.find({dir, rd[q]});
+                                    if (it != wrote.end()) stage = std::max(stage, it->second + 1);
+                                }
+                                wrote[{dir, o.face}] = stage;
+                                ents.push_back({o, stage});
+                            }
+                }
+            }
+        }
+    }
+    int nst = 0;
+    for (const E& e : ents) nst = std::max(nst, e.stage + 1);
+    std::vector<OneSided> flat;
+    K.osg_first.clear();
+    K.osg_count.clear();
+    for (int sgi = 0; sgi < nst; ++sgi) {
+        K.osg_first.push_back((int)flat.size());
+        for (const E& e : ents)
+            if (e.stage == sgi) flat.push_back(e.o);
+        K.osg_count.push_back((int)flat.size() - K.osg_first.back());
+    }
+    K.d_osg = to_device(flat);
+    K.osg_built = true;
+}
+
+void AMRSolver::comp_divergence_cc(int l, int l_max, double* out, bool wall)
+{
+    SOMAR_CHECK(finalized_ && l >= 0 && l <= l_max && l_max < nlevels(), "comp_divergence_cc: bad level range");
+    PressureSolver& P = *S[l];
+    Level& L = P.level(0);
+    const int nd = prm.spaceDim;
+    for (int c = 0; c < nd; ++c) L.exchange(P.cc_vel(c), st_);   // "Just in case...", AMRCCProjector.cpp:241-243
+    if (l > 0)
+        for (int c = 0; c < nd; ++c) interp_cf(l, P.cc_vel(c), S[l - 1]->cc_vel(c), false);
+    P.divergence_cc(out, 0.0, wall);   // CellToEdge (+ wall BC, in place on the face field) and the level divergence
+    if (l == l_max) return;
+    // coarse-fine mismatch: reflux the face velocities of level l+1 (Divergence.cpp:770-836)
+    AMRLink& K = *links_[l + 1];
+    PressureSolver& Q = *S[l + 1];
+    Level& F = Q.level(0);
+    for (int c = 0; c < nd; ++c) interp_cf(l + 1, Q.cc_vel(c), P.cc_vel(c), false);
+    if (!K.fluxDefined) return;
+    // the register's scales carry the operator's beta / dx_coarse; the divergence wants 1 / dx_coarse
+    SOMAR_CHECK(L.beta == 1.0, "the composite projector needs the pressure operator's beta = 1 (AMRPressureSolver's)");
+    double* fe[3] = {Q.vel(0), Q.vel(1), Q.vel(2)};
+    double* fc[3] = {Q.cc_vel(0), Q.cc_vel(1), nd == 3 ? Q.cc_vel(2) : nullptr};
+    launch_cell_to_edge(st_, F.dev, fe, fc, false);   // only the box-side faces are used: cells astride a CF face
+    double* ce[3] = {P.vel(0), P.vel(1), P.vel(2)};
+    launch_fine_register(st_, K.d_reg, K.nreg_local, F.dev.patches, nullptr, F.dev.jg, F.dx, K.sc_fine, K.r, K.d_regvals, fe);
+    if (!K.peers.empty()) {
+        launch_gather(st_, K.d_sendidx, K.nsend, K.d_regvals, K.d_sendbuf);
+        comm_->neighbor_exchange(K.d_sendbuf, K.d_regvals + K.nreg_local, K.peers, K.soff, K.scount, K.roff, K.rcount, st_);
+    }
+    launch_reflux(st_, K.d_reflux, K.nreflux, K.d_A, K.d_B, L.dev.patches, nullptr, L.dev.jg, L.dev.jinv, L.dx, K.d_regvals,
+                  out, ce);
+}
+
+void AMRSolver::comp_grad_correct_cc(int l, int l_max, double* phi, double dt)
+{
+    SOMAR_CHECK(finalized_ && l >= 0 && l <= l_max && l_max < nlevels(), "comp_grad_correct_cc: bad level range");
+    PressureSolver& P = *S[l];
+    Level& L = P.level(0);
+    const int nd = prm.spaceDim;
+    L.exchange(phi, st_);                                         // Copier + CornerCopier, AMRCCProjector.cpp:303-313
+    if (l > 0) interp_cf(l, phi, S[l - 1]->field(0, 0));          // levelGradientMAC, Gradient.cpp:104-114
+    double* const* g = P.mac_grad(phi);                           // the face gradient, stored
+    if (l < l_max) {
+        build_one_sided_tables(l + 1);
+        AMRLink& K = *links_[l + 1];
+        for (size_t q = 0; q < K.osg_first.size(); ++q) launch_one_sided(st_, K.d_osg + K.osg_first[q], K.osg_count[q], g);
+    }
+    double* c[3] = {P.cc_vel(0), P.cc_vel(1), nd == 3 ? P.cc_vel(2) : nullptr};
+    double* gg[3] = {g[0], g[1], g[2]};
+    launch_edge_to_cell_axpy(st_, L.dev, c, gg, dt == 0.0 ? -1.0 : -dt);   // EdgeToCell + JVelFAB.plus(corrFAB, dtScale)
+}
+
+void AMRSolver::average_down_ccvel(int l)
+{
+    SOMAR_CHECK(finalized_ && l >= 0 && l + 1 < nlevels(), "average_down_ccvel: level has no finer level");
+    AMRLink& K = *links_[l + 1];
+    for (int c = 0; c < prm.spaceDim; ++c) {
+        launch_avg_unweighted(st_, K.cfl->dev, S[l + 1]->level(0).dev, K.resC, S[l + 1]->cc_vel(c), K.r);
+        K.scatter.run(K.resC, S[l]->cc_vel(c), st_);
+    }
+}
+
+void AMRSolver::cc_project(int l_min, int l_max, double dt, bool zeroPressure, bool forceHomogeneous, bool wall,
+                           SolveStats& st)
+{
+    SOMAR_CHECK(finalized_ && 0 <= l_min && l_min <= l_max && l_max < nlevels(), "cc_project: bad level range");
+    for (int l = l_min; l <= l_max; ++l) comp_divergence_cc(l, l_max, S[l]->field(0, 1), wall);
+    if (dt != 0.0)
+        for (int l = l_min; l <= l_max; ++l) launch_divide(st_, S[l]->field(0, 1), dt, S[l]->level(0).field_elems);
+    solve(l_max, l_min, zeroPressure, forceHomogeneous, st);
+    // computeGrad on every level first (each level's gradient sees the UNcorrected pressure of its neighbours only), then
+    // applyCorrection from the finest level down with the averaging (AMRCCProjector.cpp:334-377); the face gradient of a
+    // level does not depend on any velocity, so gradient + correction per level, finest first, is the same arithmetic
+    for (int l = l_max; l >= l_min; --l) {
+        comp_grad_correct_cc(l, l_max, S[l]->field(0, 0), dt);
+        if (l < l_max) average_down_ccvel(l);
+    }
     sync();
 }
 

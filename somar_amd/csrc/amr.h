@@ -61,6 +61,11 @@ struct RefluxCell {   // one coarse cell next to the fine level
     int b0, nb;       // register-value index range (into the rank's register array)
     int pad_;
 };
+struct OneSided {     // one face of CRSEONESIDEGRAD: g[face] = 2 g[face + stride] - g[face + 2 stride]  (mode 2) or g[face + stride] (mode 1)
+    long long face;   // offset (coarse field) of the cell whose LOW face it is
+    int stride;       // signed element stride pointing AWAY from the finer level
+    int dirmode;      // dir | mode << 2
+};
 struct FillItem {     // a region of one patch
     int patch;
     int lo[3];        // local start
@@ -68,6 +73,10 @@ struct FillItem {     // a region of one patch
     int pad_;
 };
 
+void launch_one_sided(hipStream_t st, const OneSided* e, int n, double* const grad[3]);
+// crse(ic) = (sum over the children of ic of fine) * (1 / prod r): UNMAPPEDAVERAGE (MappedCoarseAverageF.ChF:7-41)
+void launch_avg_unweighted(hipStream_t st, const LevelDev& C, const LevelDev& F, double* crse, const double* fine, const int r[3]);
+void launch_divide(hipStream_t st, double* a, double d, long long n);   // a[i] = a[i] / d
 void launch_fill_items(hipStream_t st, const PatchDesc* patches, const FillItem* items, int nitems, double* f, double v);
 void launch_cf_slopes(hipStream_t st, const QCoarse* cc, int ncc, const QPoint* pts, const double* buf, double* der,
                       const double dxc[3]);
@@ -115,6 +124,11 @@ struct AMRLink {
     long long nsend = 0;
     double* d_sendbuf = nullptr;
     double sc_fine[3][2];
+    // compGradientCC's one-sided faces on the COARSE level next to this (fine) level, in stages (entries of one stage are
+    // independent; normally there is one stage)
+    bool osg_built = false;
+    OneSided* d_osg = nullptr;
+    std::vector<int> osg_first, osg_count;
     ~AMRLink();
 };
 
@@ -139,6 +153,19 @@ public:
     // velocity of level l: centring 0 = LevelMACProjector (vel()), 1 = LevelCCProjector (cc_vel(), level l-1's supplies the
     // velocity's coarse-fine values); phi of level l-1 supplies the pressure's.  Refined levels: diagonal metric.
     void level_project(int l, int centring, double dt, bool zeroPressure, bool forceHomogeneous, bool wall, SolveStats& st);
+
+    // ---- the COMPOSITE cell-centred projector (sync / init / regrid projection) on the levels' resident cc velocities ----
+    //   BaseProjector<FArrayBox>::project over l_min..l_max   projection/BaseProjectorI.H:176-299
+    //   AMRCCProjector::computeDiv/computeGrad/applyCorrection projection/AMRCCProjector.cpp:204-377
+    //   Divergence::compDivergenceCC (refluxed)                calculus/DivCurlGrad/Divergence.cpp:697-838
+    //   Gradient::compGradientCC (one-sided CF faces)          calculus/DivCurlGrad/Gradient.cpp:707-842
+    void cc_project(int l_min, int l_max, double dt, bool zeroPressure, bool forceHomogeneous, bool wall, SolveStats& st);
+    // pieces: out = compDivergenceCC of level l (finer level l+1 refluxed in when l < l_max; NOT divided by dt);
+    // cc_vel(l) += dtScale * compGradientCC(phi) with phi = field `phi` of level l (PHI of l-1 / l+1 as coarse / fine data);
+    // the valid cells of level l under level l+1 := plain average of level l+1's cc velocity
+    void comp_divergence_cc(int l, int l_max, double* out, bool wall);
+    void comp_grad_correct_cc(int l, int l_max, double* phi, double dt);
+    void average_down_ccvel(int l);
 
     // pieces (parity tests)
     // interpCFGhosts(phi, &phiCoarse, false); ev = false: MappedQuadCFInterp::coarseFineInterp alone (no ExtrapolateCFEV)
@@ -174,6 +201,7 @@ private:
     void build_link(int l);
     void build_quad_tables(int l);
     void build_reflux_tables(int l);
+    void build_one_sided_tables(int l);   // link l: the one-sided faces on level l-1
     Comm* comm_;
     Comm self_;
     hipStream_t st_ = nullptr;

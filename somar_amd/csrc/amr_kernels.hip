@@ -266,6 +266,67 @@ void launch_fine_register(hipStream_t st, const FRegCell* cells, int n, const Pa
     hipLaunchKernelGGL(k_fine_register, dim3(grid1(n)), dim3(256), 0, st, cells, n, fpatches, phi, J, FL, d3(dxf), S, i3(r),
                        out);
 }
+// CRSEONESIDEGRAD (calculus/DivCurlGrad/DivCurlGradF.ChF:626-697) over a precomputed face list
+struct G3 { double* v[3]; };
+__global__ void k_one_sided(const OneSided* __restrict__ e, int n, G3 g)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const OneSided o = e[i];
+    double* f = g.v[o.dirmode & 3];
+    const long long s = o.stride;
+    if ((o.dirmode >> 2) == 2) f[o.face] = 2.0 * f[o.face + s] - f[o.face + 2 * s];
+    else f[o.face] = f[o.face + s];
+}
+void launch_one_sided(hipStream_t st, const OneSided* e, int n, double* const grad[3])
+{
+    if (n == 0) return;
+    G3 g;
+    for (int d = 0; d < 3; ++d) g.v[d] = grad[d];
+    hipLaunchKernelGGL(k_one_sided, dim3(grid1(n)), dim3(256), 0, st, e, n, g);
+}
+
+// UNMAPPEDAVERAGE: one thread per coarse cell of the coarsened-fine layout, children summed in the Fortran's ii2, ii1, ii0 order
+__global__ void k_avg_unweighted(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ cpatches,
+                                 const PatchDesc* __restrict__ fpatches, double* __restrict__ crse,
+                                 const double* __restrict__ fine, int r0, int r1, int r2)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc cp = cpatches[t.patch];
+    const PatchDesc fp = fpatches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    if (lj >= cp.n[1]) return;
+    const double refScale = 1.0 / (double)(r0 * r1 * r2);
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int li = t.i0 + 2 * threadIdx.x + q;
+            if (li >= cp.n[0]) continue;
+            const int lk = t.k0 + kk;
+            double sum = 0.0;
+            for (int o2 = 0; o2 < r2; ++o2)
+                for (int o1 = 0; o1 < r1; ++o1)
+                    for (int o0 = 0; o0 < r0; ++o0) sum = sum + fine[pidx(fp, li * r0 + o0, lj * r1 + o1, lk * r2 + o2)];
+            crse[pidx(cp, li, lj, lk)] = sum * refScale;
+        }
+}
+void launch_avg_unweighted(hipStream_t st, const LevelDev& C, const LevelDev& F, double* crse, const double* fine, const int r[3])
+{
+    if (C.ntiles == 0) return;
+    hipLaunchKernelGGL(k_avg_unweighted, dim3(C.ntiles), dim3(64, C.tile_j, 1), 0, st, C.tiles, C.patches, F.patches, crse,
+                       fine, r[0], r[1], r[2]);
+}
+
+__global__ void k_divide(double* __restrict__ a, double d, long long n)
+{
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i < n) a[i] = a[i] / d;
+}
+void launch_divide(hipStream_t st, double* a, double d, long long n)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_divide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, d, n);
+}
+
 void launch_gather(hipStream_t st, const int* idx, long long n, const double* src, double* dst)
 {
     if (n == 0) return;

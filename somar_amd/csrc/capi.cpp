@@ -944,6 +944,80 @@ int somar_k_gsrbiter3dortho(double* phi, const int* iphilo0, const int* iphilo1,
     API_END
 }
 
+int somar_solver_set_cc_j(somar_solver_t* s, int patch, const double* J, const double* Jinv, const int* ghost)
+{
+    API_BEGIN
+    SOMAR_CHECK(J && Jinv && ghost, "null pointer");
+    s->ps->set_scale_cc(0, patch, J, ghost);
+    s->ps->set_scale_cc(1, patch, Jinv, ghost);
+    API_END
+}
+
+int somar_solver_set_face_j(somar_solver_t* s, int dir, int patch, const double* J, const double* Jinv)
+{
+    API_BEGIN
+    SOMAR_CHECK(J && Jinv, "null pointer");
+    s->ps->set_scale_face(0, dir, patch, J);
+    s->ps->set_scale_face(1, dir, patch, Jinv);
+    API_END
+}
+
+int somar_vel_mult_by_j(somar_solver_t* s, int centring)
+{
+    API_BEGIN
+    s->ps->scale_vel(centring, 0);
+    API_END
+}
+
+int somar_vel_div_by_j(somar_solver_t* s, int centring)
+{
+    API_BEGIN
+    s->ps->scale_vel(centring, 1);
+    API_END
+}
+
+int somar_amr_cc_project(somar_amr_t* a, int l_min, int l_max, double dt, int zero_pressure, int force_homogeneous,
+                         int wall_bc, somar_stats_t* stats)
+{
+    API_BEGIN
+    SolveStats st;
+    a->amr->cc_project(l_min, l_max, dt, zero_pressure != 0, force_homogeneous != 0, wall_bc != 0, st);
+    fill_stats(st, stats);
+    API_END
+}
+
+int somar_amr_comp_divergence_cc(somar_amr_t* a, int level, int l_max, int out_field, int wall_bc)
+{
+    API_BEGIN
+    SOMAR_CHECK(level >= 0 && level < a->amr->nlevels(), "bad level");
+    int d0;
+    double* out = field_ptr(a->levels[level], out_field, &d0);
+    SOMAR_CHECK(d0 == 0, "the divergence is a depth-0 field");
+    a->amr->comp_divergence_cc(level, l_max, out, wall_bc != 0);
+    a->amr->sync();
+    API_END
+}
+
+int somar_amr_comp_grad_correct_cc(somar_amr_t* a, int level, int l_max, int phi_field, double dt)
+{
+    API_BEGIN
+    SOMAR_CHECK(level >= 0 && level < a->amr->nlevels(), "bad level");
+    int d0;
+    double* phi = field_ptr(a->levels[level], phi_field, &d0);
+    SOMAR_CHECK(d0 == 0, "phi is a depth-0 field");
+    a->amr->comp_grad_correct_cc(level, l_max, phi, dt);
+    a->amr->sync();
+    API_END
+}
+
+int somar_amr_average_down_ccvel(somar_amr_t* a, int level)
+{
+    API_BEGIN
+    a->amr->average_down_ccvel(level);
+    a->amr->sync();
+    API_END
+}
+
 int somar_amr_level_project(somar_amr_t* a, int level, int centring, double dt, int zero_pressure, int force_homogeneous,
                             int wall_bc, somar_stats_t* stats)
 {

@@ -317,8 +317,8 @@ void launch_ghost_ops(hipStream_t st, const LevelDev& L, const GhostOp* ops, int
     if (nops == 0) return;
     StencilParams P = L.P;
     P.bc_homog = bc_homog ? 1 : 0;
-    if (redirect) hipLaunchKernelGGL(k_ghost_ops<true>, dim3(nops, 4), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
-    else hipLaunchKernelGGL(k_ghost_ops<false>, dim3(nops, 4), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
+    if (redirect) hipLaunchKernelGGL(k_ghost_ops<true>, dim3(nops, 16), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
+    else hipLaunchKernelGGL(k_ghost_ops<false>, dim3(nops, 16), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
 }
 
 void launch_flux_full(hipStream_t st, const LevelDev& L, double* const out[3], const double* phi, const double* psi)

@@ -85,6 +85,7 @@ void launch_publish(hipStream_t st, const double* src, int n, double* host_dst, 
 void launch_copy(hipStream_t st, double* d, const double* s, long long n);
 void launch_incr(hipStream_t st, double* y, const double* x, double a, long long n);
 void launch_scale(hipStream_t st, double* y, double a, long long n);
+void launch_mul(hipStream_t st, double* y, const double* x, long long n);   // y *= x elementwise
 void launch_axby(hipStream_t st, double* z, const double* x, const double* y, double a, double b, long long n);
 // mode 0: sum a*b, 1: max|a|, 2: sum|a|, 3: signed max a  -> out[0] (device)
 // ordered: reference-ordered serial sum (modes 0 and 2; meant for small levels, see k_reduce_ordered)

@@ -556,6 +556,12 @@ __global__ void k_scale(double* __restrict__ y, double a, long long n)
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         y[i] = y[i] * a;
 }
+// y = y * x elementwise (FArrayBox::mult)
+__global__ void k_mul(double* __restrict__ y, const double* __restrict__ x, long long n)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = y[i] * x[i];
+}
 // z = a*x + b*y
 __global__ void k_axby(double* __restrict__ z, const double* __restrict__ x, const double* __restrict__ y,
                        double a, double b, long long n)
@@ -895,6 +901,10 @@ void launch_incr(hipStream_t st, double* y, const double* x, double a, long long
 void launch_scale(hipStream_t st, double* y, double a, long long n)
 {
     hipLaunchKernelGGL(k_scale, dim3(flat_grid(n)), dim3(256), 0, st, y, a, n);
+}
+void launch_mul(hipStream_t st, double* y, const double* x, long long n)
+{
+    hipLaunchKernelGGL(k_mul, dim3(flat_grid(n)), dim3(256), 0, st, y, x, n);
 }
 void launch_axby(hipStream_t st, double* z, const double* x, const double* y, double a, double b, long long n)
 {

@@ -171,9 +171,9 @@ void launch_mac_correct(hipStream_t st, const LevelDev& L, double* const vel[3],
 {
     if (L.ntiles == 0) return;
     const dim3 g(L.ntiles), b(64, L.tile_j, 1);
-    hipLaunchKernelGGL(k_mac_correct<0>, g, b, 0, st, L.tiles, L.patches, vel[0], phi, L.jg[0], L.P, dtScale);
-    hipLaunchKernelGGL(k_mac_correct<1>, g, b, 0, st, L.tiles, L.patches, vel[1], phi, L.jg[1], L.P, dtScale);
-    hipLaunchKernelGGL(k_mac_correct<2>, g, b, 0, st, L.tiles, L.patches, vel[2], phi, L.jg[2], L.P, dtScale);
+    if (vel[0]) hipLaunchKernelGGL(k_mac_correct<0>, g, b, 0, st, L.tiles, L.patches, vel[0], phi, L.jg[0], L.P, dtScale);
+    if (vel[1]) hipLaunchKernelGGL(k_mac_correct<1>, g, b, 0, st, L.tiles, L.patches, vel[1], phi, L.jg[1], L.P, dtScale);
+    if (vel[2]) hipLaunchKernelGGL(k_mac_correct<2>, g, b, 0, st, L.tiles, L.patches, vel[2], phi, L.jg[2], L.P, dtScale);
 }
 
 // One direction per launch; thread = cell (i-pair), it owns the LOW face of each of its cells and, for the last cell of

@@ -41,6 +41,7 @@ PressureSolver::~PressureSolver()
     for (double* q : f_heat) Level::free_field(q);
     hipFree(d_extrapbc_ops_);
     if (st_) hipStreamSynchronize(st_);
+    for (int w = 0; w < 2; ++w) { hipFree(f_sc_cc[w]); for (int d = 0; d < 3; ++d) hipFree(f_sc_face[w][d]); }
     for (double* f : f_res) hipFree(f);
     for (double* f : f_corr) hipFree(f);
     for (double* f : f_scratch) hipFree(f);
@@ -488,7 +489,9 @@ void PressureSolver::agglom_cycle(double* corr, const double* res, bool corr_zer
     C.prm.num_smooth_up = prm.num_smooth_up;
     C.prm.num_smooth_bottom = prm.num_smooth_bottom;
     C.prm.numMG = prm.numMG;
+    C.cycle_override_ = cycle_override_;   // inside an F-cycle's inner V-cycle the replicated tail runs a V-cycle too
     C.cycle(0, cC, rC, corr_zero);
+    C.cycle_override_ = 0;
     bottom_iters = C.bottom_iters;
     bottom_exit = C.bottom_exit;
     launch_copy_items2(st_, C.lev[0]->dev.patches, T.dev.patches, d_agglom_back_, n_agglom_back_, cC, corr);
@@ -585,6 +588,9 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
                 L.cf_homog(cur, st_);
                 L.exchange(cur, st_);
                 run_full_program_frames(d, 1, cur);
+                // the pass rewrites the valid cells only; the ghost frame travels with them (edge / vertex ghosts at
+                // coarse-fine corners keep whatever the last ExtrapolateCFEV left there, as in the reference's in-place sweep)
+                copy_frames(d, cur, alt);
                 if (profiling_ && d == 0) prof_begin(0);
                 launch_gsrb_full_march(st_, L.d_qtiles, L.nqtiles, L.dev, alt, cur, f_psi[d], res, pass);
                 if (profiling_ && d == 0) prof_end(0);
@@ -885,6 +891,64 @@ void PressureSolver::mac_correct(double* phi, double dt)
     launch_mac_correct(st_, L.dev, v, phi, dt == 0.0 ? -1.0 : -dt);
 }
 
+void PressureSolver::set_scale_cc(int which, int patch, const double* host, const int ghost[3])
+{
+    Level& L = *lev[0];
+    SOMAR_CHECK(finalized && (which == 0 || which == 1) && patch >= 0 && patch < L.npatches(), "set_scale_cc: bad argument");
+    if (!f_sc_cc[which]) f_sc_cc[which] = L.alloc_field();
+    const IBox valid = L.boxes[L.local[patch]];
+    int one[3] = {0, 0, 0};
+    for (int d = 0; d < prm.spaceDim; ++d) {
+        SOMAR_CHECK(ghost[d] >= 1, "the cell-centred scale needs the velocity's ghost layer");
+        one[d] = 1;
+    }
+    L.upload(f_sc_cc[which], patch, host, valid.grow(ghost), valid.grow(one), st_);
+    sync();
+}
+
+void PressureSolver::set_scale_face(int which, int dir, int patch, const double* host)
+{
+    Level& L = *lev[0];
+    SOMAR_CHECK(finalized && (which == 0 || which == 1) && dir >= 0 && dir < prm.spaceDim && patch >= 0 && patch < L.npatches(),
+                "set_scale_face: bad argument");
+    if (!f_sc_face[which][dir]) f_sc_face[which][dir] = L.alloc_field();
+    IBox fb = L.boxes[L.local[patch]];
+    fb.hi[dir] += 1;
+    L.upload(f_sc_face[which][dir], patch, host, fb, fb, st_);
+    sync();
+}
+
+void PressureSolver::scale_vel(int centring, int which)
+{
+    Level& L = *lev[0];
+    SOMAR_CHECK(which == 0 || which == 1, "which: 0 = J, 1 = Jinv");
+    if (centring == 1) {
+        SOMAR_CHECK(f_sc_cc[which], "the cell-centred J / Jinv has not been set (somar_solver_set_cc_j)");
+        for (int c = 0; c < prm.spaceDim; ++c) launch_mul(st_, cc_vel(c), f_sc_cc[which], L.field_elems);
+    } else {
+        for (int d = 0; d < prm.spaceDim; ++d) {
+            SOMAR_CHECK(f_sc_face[which][d], "the face-centred J / Jinv has not been set (somar_solver_set_face_j)");
+            launch_mul(st_, vel(d), f_sc_face[which][d], L.field_elems);
+        }
+    }
+}
+
+double* const* PressureSolver::mac_grad(double* phi)
+{
+    Level& L = *lev[0];
+    if (full_) {
+        mac_grad_full(phi);
+        return f_flux;
+    }
+    for (int a = 0; a < 3; ++a)
+        if (!f_flux[a]) f_flux[a] = L.alloc_field();
+    // G = 0 + 1.0 * (dxinv * Jg * dphi): k_mac_correct's own expression, stored instead of subtracted (exact)
+    double* g[3] = {f_flux[0], f_flux[1], prm.spaceDim == 3 ? f_flux[2] : nullptr};
+    for (int a = 0; a < prm.spaceDim; ++a) launch_set(st_, f_flux[a], L.field_elems, 0.0);
+    launch_mac_correct(st_, L.dev, g, phi, 1.0);
+    return f_flux;
+}
+
 // uStarFuncBC without inflow / outflow sides on the face-centred velocity (LevelMACProjector::computeDiv hands &m_divBC to
 // levelDivergenceMAC, Divergence.cpp:73-100, which overwrites the caller's boundary faces): solid walls, zero normal flux
 void PressureSolver::vel_wall_bc()
@@ -1126,10 +1190,37 @@ void PressureSolver::cycle(int d, double* corr, const double* res, bool corr_zer
         if (lev[d]->domain.numPts() != 1) bottom_solve(corr, res);
         return;
     }
-    SOMAR_CHECK(prm.numMG > 0, "F-cycles (numMG < 0) are not implemented");
+    const int ncyc = cycle_override_ ? cycle_override_ : prm.numMG;
+    SOMAR_CHECK(ncyc != 0, "numMG must not be 0");
+    if (ncyc < 0) {
+        // F-cycle (MappedMultiGrid.H:577-619): a recursive F-cycle first, pre-smoothing, then |numMG| V-cycles ("hack to
+        // get a V-cycle": m_cycle = 1 around the inner call), post-smoothing.  No folding, no graphs: plain passes.
+        const int cycles = -ncyc;
+        Level& L = *lev[d];
+        if (corr_zero) launch_set(st_, corr, L.field_elems, 0.0);
+        restrict_residual(d, f_res[d + 1], corr, res);
+        cycle(d + 1, f_corr[d + 1], f_res[d + 1], true);
+        prolong_increment(d, corr, f_corr[d + 1]);
+        relax(d, corr, res, prm.num_smooth_down);
+        for (int img = 0; img < cycles; ++img) {
+            restrict_residual(d, f_res[d + 1], corr, res);
+            const int saved = cycle_override_;
+            cycle_override_ = 1;
+            try {
+                cycle(d + 1, f_corr[d + 1], f_res[d + 1], true);
+            } catch (...) {
+                cycle_override_ = saved;
+                throw;
+            }
+            cycle_override_ = saved;
+            prolong_increment(d, corr, f_corr[d + 1]);
+        }
+        relax(d, corr, res, prm.num_smooth_up);
+        return;
+    }
     if (mini_depth_ == 0 && graph_cycle(d, corr, res, corr_zero)) return;
     cycle_down(d, corr, res, corr_zero);
-    for (int img = 0; img < prm.numMG; ++img) cycle(d + 1, f_corr[d + 1], f_res[d + 1], img == 0);
+    for (int img = 0; img < ncyc; ++img) cycle(d + 1, f_corr[d + 1], f_res[d + 1], img == 0);
     cycle_up(d, corr, res);
 }
 

@@ -118,6 +118,9 @@ public:
     void cf_ev(int d, double* phi);
     double* const* flux_fields(double* phi);
     void mac_grad_full(double* phi);  // f_flux := MAC gradient of phi, non-diagonal metric (phi exchanged)
+    // the MAC gradient G^a = J g^{ab} d_b(phi) on every a-face of depth 0, STORED (either metric; phi exchanged, CF ghosts
+    // filled by the caller): levelGradientMAC's per-box part (Gradient.cpp:124-160)
+    double* const* mac_grad(double* phi);
     bool has_diri() const { return diri_; }
     bool bc_values_zero() const
     {
@@ -162,6 +165,12 @@ public:
     void divergence_cc(double* out, double dt, bool wall);                   // CellToEdge [+ wall BC] -> vel(); div [/ dt]
     void cc_correct(double* phi, double dt);                                 // cc_vel -= dt * EdgeToCell(G(phi))
     void cc_project(double dt, bool zeroPressure, bool forceHomogeneous, bool wall, SolveStats& st);
+    // LevelGeometry::multByJ / divByJ on the resident velocities (geometry/LevelGeometryUtil.cpp:287-339, 372-420, 456-...):
+    // data *= J resp. data *= Jinv, the scale arrays being the caller's (getCCJ / getCCJinv over valid.grow(ghost), fill_J /
+    // fill_Jinv on the face boxes).  which: 0 = J, 1 = Jinv.  centring 0: the MAC velocity (set per direction), 1: cell-centred.
+    void set_scale_cc(int which, int patch, const double* host, const int ghost[3]);
+    void set_scale_face(int which, int dir, int patch, const double* host);
+    void scale_vel(int centring, int which);
     void remove_mean(int d, double* f);
     void sync();
     // per-kernel HIP-event timing of the depth-0 launches (0 = GSRB colour pass, 1 = operator/residual)
@@ -191,6 +200,8 @@ private:
     double* f_vel[3] = {nullptr, nullptr, nullptr};
     double* f_ccvel[3] = {nullptr, nullptr, nullptr};
     double* f_heat[3] = {nullptr, nullptr, nullptr};
+    double* f_sc_cc[2] = {nullptr, nullptr};
+    double* f_sc_face[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     double aCoef_ = 0.0, bCoef_ = 1.0;  // the factory's alpha / beta (MappedAMRPoissonOpFactory.cpp:585-586)
     bool coefs_saved_ = false;
     bool amr_member_ = false;
@@ -241,6 +252,7 @@ private:
     void build_full_programs(int d);
     void run_full_program(int d, int which, double* phi, bool homogeneous = true);
     void run_full_program_frames(int d, int which, double* phi, bool homogeneous = true);
+    void copy_frames(int d, const double* src, double* dst);   // dst := src in the one-cell frame of every box
     // large 3-D levels of the non-diagonal path run the k-marching 19-point kernels (full19_march.hip)
     bool full_march(int d) const
     {
@@ -277,6 +289,7 @@ private:
     void build_diri_ops(int d);
     void apply_diri(int d, double* phi, bool homogeneous);
     int mini_depth_ = 0;  // > 0 while a mini V-cycle runs: the depth count it is limited to
+    int cycle_override_ = 0;  // != 0 inside an F-cycle's inner V-cycles: the effective numMG ("m_cycle = 1" hack, MappedMultiGrid.H:603-605)
     void cycle_down(int d, double* corr, const double* res, bool corr_zero);  // pre-smoothing + restriction
     void cycle_up(int d, double* corr, const double* res);                    // prolongation + post-smoothing
     void cycle_bottom_relax(double* corr, const double* res, bool corr_zero);

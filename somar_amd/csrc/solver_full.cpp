@@ -86,6 +86,63 @@ struct Builder {
 
 }  // namespace
 
+// The ops of one box must take effect in the order the reference issues them -- but only where they touch the same
+// cells.  Each op gets the earliest stage after every earlier op of its box it conflicts with (read-after-write,
+// write-after-read, write-after-write on the same field); ops of one stage then go up in ONE launch.  The reference's
+// ~130 sequential calls per box and application collapse to about a dozen launches.
+static std::vector<std::vector<GhostOp>> schedule_stages(const std::vector<std::vector<GhostOp>>& perPatch)
+{
+    struct Acc { IBox box; int field; };
+    auto reads_of = [](const GhostOp& op, std::vector<Acc>& rd) {
+        IBox r;
+        for (int d = 0; d < 3; ++d) { r.lo[d] = op.lo[d]; r.hi[d] = op.lo[d] + op.n[d] - 1; }
+        if (op.type == GHOST_COPY) rd.push_back({r, op.srcf});
+        else if (op.type == GHOST_EXTRAP || op.type == GHOST_DIRI) {
+            IBox b = r;   // 1 .. 3 steps back along dir
+            const int far = op.type == GHOST_DIRI ? 1 : (op.order == 2 ? 3 : (op.order == 1 ? 2 : 1));
+            if (op.sgn > 0) { b.lo[op.dir] = r.lo[op.dir] - far; b.hi[op.dir] = r.hi[op.dir] - 1; }
+            else { b.lo[op.dir] = r.lo[op.dir] + 1; b.hi[op.dir] = r.hi[op.dir] + far; }
+            rd.push_back({b, op.srcf});
+        } else {  // GHOST_NEUM: psi on the ghost layer and the first valid layer, one cell wider tangentially; phi on the valid layer
+            IBox b = r;
+            if (op.sgn > 0) b.lo[op.dir] -= 1; else b.hi[op.dir] += 1;
+            IBox v = b;
+            for (int d = 0; d < 3; ++d)
+                if (d != op.dir) { b.lo[d] -= 1; b.hi[d] += 1; }
+            rd.push_back({b, 1});
+            rd.push_back({v, 0});
+        }
+    };
+    size_t ns = 0;
+    std::vector<std::vector<int>> stageOf(perPatch.size());
+    for (size_t pi = 0; pi < perPatch.size(); ++pi) {
+        const auto& ops = perPatch[pi];
+        std::vector<std::vector<Acc>> rds(ops.size());
+        std::vector<Acc> wrs(ops.size());
+        stageOf[pi].assign(ops.size(), 0);
+        for (size_t q = 0; q < ops.size(); ++q) {
+            const GhostOp& op = ops[q];
+            IBox w;
+            for (int d = 0; d < 3; ++d) { w.lo[d] = op.lo[d]; w.hi[d] = op.lo[d] + op.n[d] - 1; }
+            wrs[q] = {w, (op.type == GHOST_NEUM || op.type == GHOST_DIRI) ? 0 : op.dstf};
+            reads_of(op, rds[q]);
+            int st = 0;
+            for (size_t e = 0; e < q; ++e) {
+                bool dep = wrs[e].field == wrs[q].field && !(wrs[e].box & wrs[q].box).empty();            // WAW
+                for (const Acc& r : rds[q]) dep = dep || (r.field == wrs[e].field && !(r.box & wrs[e].box).empty());   // RAW
+                for (const Acc& r : rds[e]) dep = dep || (r.field == wrs[q].field && !(r.box & wrs[q].box).empty());   // WAR
+                if (dep) st = std::max(st, stageOf[pi][e] + 1);
+            }
+            stageOf[pi][q] = st;
+            ns = std::max(ns, (size_t)st + 1);
+        }
+    }
+    std::vector<std::vector<GhostOp>> stages(ns);
+    for (size_t pi = 0; pi < perPatch.size(); ++pi)
+        for (size_t q = 0; q < perPatch[pi].size(); ++q) stages[stageOf[pi][q]].push_back(perPatch[pi][q]);
+    return stages;
+}
+
 // Programs of one level.  which = 0: operator (fillExtrap order 2, then the Neumann ghosts of phi);
 // which = 1: smoother (extrapolation order 1 from the domain box, then the Neumann ghosts of phi).
 // The leading full copy psi := phi is done by the caller with one flat copy.
@@ -148,12 +205,7 @@ static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which
                 }
             }
         }
-        size_t nse = 0;
-        for (auto& v : perPatch) nse = std::max(nse, v.size());
-        std::vector<std::vector<GhostOp>> stagesE(nse);
-        for (auto& v : perPatch)
-            for (size_t q = 0; q < v.size(); ++q) stagesE[q].push_back(v[q]);
-        return stagesE;
+        return schedule_stages(perPatch);
     }
     int g1[3];
     for (int d = 0; d < 3; ++d) g1[d] = L.active[d] ? 1 : 0;
@@ -201,13 +253,7 @@ static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which
             }
         }
     }
-    // transpose into stages
-    size_t ns = 0;
-    for (auto& v : perPatch) ns = std::max(ns, v.size());
-    std::vector<std::vector<GhostOp>> stages(ns);
-    for (auto& v : perPatch)
-        for (size_t s = 0; s < v.size(); ++s) stages[s].push_back(v[s]);
-    return stages;
+    return schedule_stages(perPatch);
 }
 
 // Stage 0 of a frame-only program: psi := phi in the one-cell frame of every box (all six slabs of all boxes in ONE
@@ -288,6 +334,15 @@ void PressureSolver::run_full_program_frames(int d, int which, double* phi, bool
         launch_ghost_ops(st_, L.dev, P.d_ops + P.first[s], P.count[s], phi, f_psi[d], homogeneous, true);
 }
 
+// stage 0 of the frame-only programs with (src, dst) in the roles of (phi, psi)
+void PressureSolver::copy_frames(int d, const double* src, double* dst)
+{
+    Level& L = *lev[d];
+    const FullProgram& P = full_prog_[d][5];
+    if (P.first.empty()) return;
+    launch_ghost_ops(st_, L.dev, P.d_ops + P.first[0], P.count[0], const_cast<double*>(src), dst, true, false);
+}
+
 void PressureSolver::cf_ev(int d, double* phi)
 {
     if (!full_ || !hasCF_) return;
@@ -313,7 +368,9 @@ double* const* PressureSolver::flux_fields(double* phi)
 
 void PressureSolver::mac_grad_full(double* phi)
 {
-    SOMAR_CHECK(full_ && finalized && !hasCF_, "the non-diagonal MAC gradient is implemented for one AMR level");
+    SOMAR_CHECK(full_ && finalized, "mac_grad_full is the non-diagonal path");
+    // On a refined level the caller has filled the coarse-fine ghosts (quadratic interpolation + ExtrapolateCFEV,
+    // Gradient.cpp:104-114); they lie inside the domain, so fillExtrap copies them like any exchanged ghost.
     Level& L = *lev[0];
     if (!d_extrapbc_ops_) {
         // EllipticExtrapBCGhostClass -> setSideExtrapBC, order 2: the face-adjacent ghost layer of every box side on a

@@ -123,3 +123,71 @@ def lockexchange_hierarchy(config="c3", scale=1, box=128, mult=4, nranks=1):
     return {"n0": n0, "L": L, "periodic": (False, False, False) if flat else (False, True, False), "ratios": ratios,
             "levels": levels, "owners": [y_slab_owners(b, nranks) for b in levels], "flat": flat,
             "dx0": tuple(L[d] / n0[d] for d in range(3))}
+
+
+def terrain_metric(lo, hi, dx, L):
+    """BASELINE config C5's terrain-following map, the form of geometry/BathymetricBaseMapF.ChF:85-110:
+    x = xi, y = eta, z = d(xi, eta) + (1 - d/H) zeta over the depth h = H - d = H s,  s = 0.5 + 0.3 exp(-r^2 / w^2),
+    r^2 = (x - L0/2)^2 + (y - L1/2)^2, w = min(L0, L1) / 4, H = L2  =>  J = z_zeta = s, z_xi = s_x (zeta - H), z_eta = s_y (zeta - H),
+        J g^{xi b}   = (s, 0, -z_xi)            on xi-faces
+        J g^{eta b}  = (0, s, -z_eta)           on eta-faces
+        J g^{zeta b} = (-z_xi, -z_eta, (1 + z_xi^2 + z_eta^2) / s)   on zeta-faces,      Jinv = 1 / s at cell centres.
+    Box [lo, hi] (cell indices, inclusive).  -> ([jg0, jg1, jg2] each (faces shape) + (3,) Fortran-ordered = component
+    slowest, the FluxBox layout of LevelGeometry::getFCJgupPtr; Jinv)"""
+    H = L[2]
+    w = min(L[0], L[1]) / 4.0
+
+    def coords(face_dir):
+        xs = []
+        for d in range(3):
+            n = hi[d] - lo[d] + 1 + (1 if d == face_dir else 0)
+            idx = np.arange(lo[d], lo[d] + n, dtype=np.float64)
+            xs.append((idx if d == face_dir else idx + 0.5) * dx[d])
+        return np.meshgrid(*xs, indexing="ij")
+
+    def fields(X):
+        ex = np.exp(-((X[0] - 0.5 * L[0]) ** 2 + (X[1] - 0.5 * L[1]) ** 2) / (w * w))
+        s = 0.5 + 0.3 * ex
+        sx = -0.3 * ex * (2.0 * (X[0] - 0.5 * L[0]) / (w * w))
+        sy = -0.3 * ex * (2.0 * (X[1] - 0.5 * L[1]) / (w * w))
+        zx = sx * (X[2] - H)
+        zy = sy * (X[2] - H)
+        return s, zx, zy
+
+    jg = []
+    for d in range(3):
+        s, zx, zy = fields(coords(d))
+        a = np.zeros(s.shape + (3,), order="F")
+        if d == 0:
+            a[..., 0], a[..., 2] = s, -zx
+        elif d == 1:
+            a[..., 1], a[..., 2] = s, -zy
+        else:
+            a[..., 0], a[..., 1], a[..., 2] = -zx, -zy, (1.0 + zx * zx + zy * zy) / s
+        jg.append(a)
+    s, _, _ = fields(coords(-1))
+    return jg, np.asfortranarray(1.0 / s)
+
+
+def c5_hierarchy(scale=1, box=64, nranks=1, nlev=4):
+    """BASELINE config C5's shape: terrain-following NON-diagonal metric (terrain_metric), 4 levels each
+    refined by (2,2,1), nested around the topographic bump at the domain centre: level l covers the central 2^-l of the
+    horizontal extent in x and y.  Base 512x512x64 / scale over L = (8, 8, 1), no periodic direction, boxes of
+    box x box x nz cells (columns stay whole), every level's boxes in y-slabs over the ranks.  Each level has
+    (512/scale)^2 x 64/scale cells.  -> the dict lockexchange_hierarchy returns, plus "metric": "terrain"."""
+    s = scale
+    n0 = (512 // s, 512 // s, 64 // s)
+    L = (8.0, 8.0, 1.0)
+    ratios = [(2, 2, 1)] * (nlev - 1)
+    bs = (max(box // s, 8), max(box // s, 8), n0[2])
+    levels = [boxes_of((0, 0, 0), tuple(a - 1 for a in n0), bs)]
+    n = list(n0)
+    for l in range(1, nlev):
+        n = [n[0] * 2, n[1] * 2, n[2]]
+        w = [n[0] // (2 ** l), n[1] // (2 ** l)]          # the central 2^-l of the level-l index space
+        lo = [(n[0] - w[0]) // 2, (n[1] - w[1]) // 2]
+        lo = [a - a % (2 * bs[0]) for a in lo]
+        levels.append(boxes_of((lo[0], lo[1], 0), (lo[0] + w[0] - 1, lo[1] + w[1] - 1, n[2] - 1), bs))
+    return {"n0": n0, "L": L, "periodic": (False, False, False), "ratios": ratios, "levels": levels,
+            "owners": [y_slab_owners(b, nranks) for b in levels], "flat": False, "metric": "terrain",
+            "dx0": tuple(L[d] / n0[d] for d in range(3))}

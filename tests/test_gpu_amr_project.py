@@ -114,18 +114,65 @@ def test_mac_level_projection_on_the_fine_level(oracle, am, layout):
         gpu.undefine()
 
 
-# ---- non-diagonal metric on a REFINED level: not implemented on the GPU (the oracle's level_project restates it:
-#      ExtrapolateCFEV after the pressure's CF interpolation, singleBoxMacGrad's full sequence); the call must fail loudly ----
-def test_level_projection_on_a_refined_level_with_a_non_diagonal_metric_fails_loudly(oracle, am):
-    from somar_amd import SomarError
+# ---- non-diagonal metric on a REFINED level: ExtrapolateCFEV after the pressure's CF interpolation, then singleBoxMacGrad's
+#      full sequence (Gradient.cpp:104-114, 946-1101) next to coarse-fine faces ----
+@pytest.mark.parametrize("centring", ["cc", "mac"])
+def test_level_projection_on_a_refined_level_with_a_non_diagonal_metric(oracle, am, centring):
+    from somar_amd import api as F
     from helpers import make_full_amr_levels
     so = oracle
     fb = [[so.Box((8, 8, 4), (23, 23, 11))]]
     levels = make_full_amr_levels(so, am, (16, 16, 8), (2.0, 1.0, 0.5), (False, False, False), [(2, 2, 2)], fb, cbox=8, ndim=3)
+    comp = am.AMRComposite(levels, [(2, 2, 2)], so.BCHolder(), so.BiCGStab(), isDiagonal=False)
     gpu = make_gpu_amr(levels, [(2, 2, 2)], ndim=3, full=True)
     try:
-        for centring in (0, 1):
-            with pytest.raises(SomarError):
-                gpu.levelProjectAMR(1, centring, 0.5)
+        ghost = (1, 1, 1)
+        phi = [so.random_field(L.grids, 5 + l, (1, 1, 1), L.domain.box) for l, L in enumerate(levels)]
+        for l, v in enumerate(gpu.levels):
+            upload(v, F.F_PHI, phi[l])
+        v = gpu.levels[1]
+        dt = 0.5
+        if centring == "cc":
+            vc = _smooth(so, levels[0], 3, ghost, 0.0)
+            vf = _smooth(so, levels[1], 3, ghost, 0.0)
+            for l, w in enumerate(gpu.levels):
+                src = vc if l == 0 else vf
+                for p in range(w.num_local_patches):
+                    w.uploadCCVel(p, src[w.patch_box(p)[2]].a, ghost)
+            am.level_project(comp, 1, vf, phi, dt, "cc", vc)
+            st = gpu.levelProjectAMR(1, 1, dt)
+        else:
+            L1 = levels[1]
+            n = L1.domain.box.size()
+            vel = so.FluxData(L1.grids, 1, 3)
+            for i in range(len(L1.grids)):
+                for d in range(3):
+                    fbx = vel[i][d].box
+                    I, J, K = np.meshgrid(*[np.arange(fbx.lo[a], fbx.hi[a] + 1) for a in range(3)], indexing="ij")
+                    vel[i][d].a[..., 0] = (np.sin(2 * np.pi * I / n[0] + 0.1 * d) * np.cos(2 * np.pi * J / n[1])
+                                           * np.cos(2 * np.pi * K / n[2] + d))
+            for p in range(v.num_local_patches):
+                gi = v.patch_box(p)[2]
+                for d in range(3):
+                    v.uploadVel(d, p, np.asfortranarray(vel[gi][d].a[..., 0]))
+            am.level_project(comp, 1, vel, phi, dt, "mac")
+            st = gpu.levelProjectAMR(1, 0, dt)
+        assert st["iters"] == comp.iters and st["exitStatus"] == comp.exitStatus
+        np.testing.assert_allclose(st["history"], comp.history, rtol=1e-10, atol=1e-10 * comp.history[0])
+        if centring == "cc":
+            got, want = [], []
+            for p in range(v.num_local_patches):
+                gi = v.patch_box(p)[2]
+                buf = np.zeros(vf[gi].a.shape, order="F")
+                v.downloadCCVel(p, buf, ghost)
+                sl = levels[1].grids[gi].slices(vf[gi].box.lo)
+                got.append(buf[sl])
+                want.append(vf[gi].a[sl])
+            assert max_rel_diff(got, want) < 1e-8
+        else:
+            for d in range(3):
+                got = [v.downloadVel(d, p) for p in range(v.num_local_patches)]
+                want = [vel[v.patch_box(p)[2]][d].a[..., 0] for p in range(v.num_local_patches)]
+                assert max_rel_diff(got, want) < 1e-8
     finally:
         gpu.undefine()

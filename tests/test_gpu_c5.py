@@ -1,0 +1,154 @@
+"""BASELINE config C5's shape: terrain-following NON-diagonal metric (geometry/BathymetricBaseMapF.ChF's form, SURVEY.md
+8d), 4 AMR levels each refined by (2,2,1) and nested around the topographic bump (somar_amd/synthetic.py::c5_hierarchy),
+19-point kernels on every level, multigrid composite solve (the reference's default: its leptic solver is switched off
+at compile time, projection/AMRPressureSolver.cpp:39-40).
+  * small size (scale 16: 32x32x4 per level, 16 boxes per level): parity with the oracle -- refluxed composite residual bit
+    for bit on every level, AMR V-cycle bit for bit, composite solve: same iterations / exit status, history to 1e-8
+    (both kernel paths: direct-load and k-marching);
+  * full size (512x512x64 per level, 67 M cells, 19-point k-marching kernels on every level): the composite operator is
+    conservative to round-off on the one-box-column layout's... no: on this multi-box layout the non-diagonal Neumann ghost
+    carries the reference's layout quirk, so conservation is checked to the quirk's size (1e-6 of the
+    operator's magnitude), and the composite solve reduces the residual monotonically."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import download_valid, make_gpu_amr, upload, valid_of
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.fixture(scope="module")
+def am(oracle):
+    from oracle import somar_amr
+    return somar_amr
+
+
+def _c5_levels(so, am, scale):
+    from somar_amd import synthetic
+    H = synthetic.c5_hierarchy(scale)
+    levels = []
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in H["n0"])), H["periodic"])
+    dx = H["dx0"]
+    for l, boxes in enumerate(H["levels"]):
+        if l > 0:
+            dom = dom.refine(H["ratios"][l - 1])
+            dx = tuple(a / b for a, b in zip(dx, H["ratios"][l - 1]))
+        grids = [so.Box(lo, hi) for lo, hi in boxes]
+        Jgup, Jinv = so.make_terrain_metric(grids, dx, H["L"], dom)
+        levels.append(am.AMRLevel(dom, grids, dx, Jgup, Jinv))
+    return H, levels
+
+
+@pytest.mark.parametrize("path", ["direct", "march"])
+def test_c5_small_parity_with_the_oracle(oracle, am, path, monkeypatch):
+    from somar_amd import api as F
+    monkeypatch.setenv("SOMAR_MARCH_MIN_CELLS", "0" if path == "march" else "1000000000000")
+    so = oracle
+    H, levels = _c5_levels(so, am, 16)
+    ratios = H["ratios"]
+    comp = am.AMRComposite(levels, ratios, so.BCHolder(), so.BiCGStab(), isDiagonal=False)
+    gpu = make_gpu_amr(levels, ratios, full=True)
+    G = (1, 1, 1)
+    lmax = len(levels) - 1
+    try:
+        phi = [so.random_field(L.grids, 5 + l, G, L.domain.box) for l, L in enumerate(levels)]
+        rhs = [so.random_field(L.grids, 50 + l, (0, 0, 0), L.domain.box) for l, L in enumerate(levels)]
+        res = [so.LevelData(L.grids, 1) for L in levels]
+        for l, v in enumerate(gpu.levels):
+            upload(v, F.F_PHI, phi[l])
+            upload(v, F.F_RHS, rhs[l])
+        comp.init(phi, rhs, lmax, 0)
+        comp.compute_amr_residual(res, phi, rhs, lmax, 0, True)
+        for ilev in range(lmax + 1):
+            gpu.residualLevel(lmax, 0, ilev)
+            if ilev < lmax:
+                gpu.zeroCovered(ilev, F.F_RES)
+            for g_, w_ in zip(download_valid(gpu.levels[ilev], F.F_RES, levels[ilev].grids), valid_of(res[ilev])):
+                np.testing.assert_array_equal(g_, w_, err_msg="composite residual level %d" % ilev)
+        # one AMR V-cycle over all four levels
+        zero = [so.LevelData(L.grids, 1, G) for L in levels]
+        r2 = [so.random_field(L.grids, 70 + l, (0, 0, 0), L.domain.box) for l, L in enumerate(levels)]
+        for l in range(lmax):
+            comp.zero_covered(l, r2[l])
+        comp.init(zero, r2, lmax, 0)
+        comp.set_bottom_solver(lmax, 0)
+        corr = [so.LevelData(L.grids, 1, G) for L in levels]
+        for l, v in enumerate(gpu.levels):
+            upload(v, F.F_RES, r2[l])
+            v.setVal(F.F_CORR, 0.0)
+        comp.amr_vcycle(corr, r2, lmax, lmax, 0)
+        gpu.vcycleAMR(lmax, 0)
+        for l in range(lmax + 1):
+            for g_, w_ in zip(download_valid(gpu.levels[l], F.F_CORR, levels[l].grids), valid_of(corr[l])):
+                np.testing.assert_array_equal(g_, w_, err_msg="AMR V-cycle level %d" % l)
+        # composite solve of a compatible right-hand side
+        z0 = [so.LevelData(L.grids, 1) for L in levels]
+        b = [so.LevelData(L.grids, 1) for L in levels]
+        comp.init(phi, z0, lmax, 0)
+        comp.compute_amr_residual(b, phi, z0, lmax, 0, True)
+        for r in b:
+            so.ld_scale(r, -1.0)
+        sol = [so.LevelData(L.grids, 1, G) for L in levels]
+        try:
+            comp.solve(sol, b, lmax, 0)
+        except RuntimeError:
+            pass
+        for l, v in enumerate(gpu.levels):
+            upload(v, F.F_RHS, b[l])
+        try:
+            st = gpu.solveAMR(lmax, 0)
+        except Exception:
+            st = gpu.stats
+        assert st["iters"] == comp.iters and st["exitStatus"] == comp.exitStatus
+        np.testing.assert_allclose(st["history"], comp.history, rtol=1e-8, atol=0.0)
+    finally:
+        gpu.undefine()
+
+
+def test_c5_full_size_properties():
+    """512x512x64 per level x 4 levels, 19-point k-marching kernels everywhere"""
+    from bench_amr import build_hierarchy
+    from somar_amd import api as F
+    gpu, levels, cells, _, dx0, ratios = build_hierarchy("c5", 1, 64)
+    try:
+        assert cells == [512 * 512 * 64] * 4
+        nlev = len(levels)
+        for l, v in enumerate(gpu.levels):
+            v.fillHash(F.F_PHI, 5 + l)
+            v.setVal(F.F_RHS, 0.0)
+        for ilev in range(nlev):
+            gpu.residualLevel(nlev - 1, 0, ilev)
+        for l in range(nlev - 1):
+            gpu.zeroCovered(l, F.F_RES)
+        # J-weighted integral of the composite operator: sum over valid cells of L * J * dV; J = 1 / Jinv is not a resident
+        # field, but Jinv * L / Jinv ... use the level dot products with the J field built on the fly in SCRATCH
+        total, mag = 0.0, 0.0
+        dx = list(dx0)
+        from somar_amd import synthetic
+        for l, v in enumerate(gpu.levels):
+            if l > 0:
+                dx = [a / b for a, b in zip(dx, ratios[l - 1])]
+            for q in range(v.num_local_patches):
+                lo, hi, _ = v.patch_box(q)
+                _, jinv = synthetic.terrain_metric(lo, hi, dx, (8.0, 8.0, 1.0))
+                v.upload(F.F_SCRATCH, q, np.asfortranarray(1.0 / jinv), (0, 0, 0))
+            total += v.dotProduct(F.F_RES, F.F_SCRATCH) * float(np.prod(dx))
+            mag = max(mag, v.norm(F.F_RES, 0))
+        volume = 8.0 * 8.0 * 1.0
+        assert abs(total) < 1e-6 * mag * volume
+        for v in gpu.levels:
+            for q in range(v.num_local_patches):
+                v.upload(F.F_RHS, q, v.download(F.F_RES, q, (0, 0, 0)), (0, 0, 0))
+        try:
+            st = gpu.solveAMR(nlev - 1, 0)
+        except Exception:
+            st = gpu.stats
+        h = st["history"]
+        assert len(h) >= 3 and h[-1] < 1e-2 * h[0]
+        assert all(b < a for a, b in zip(h, h[1:]))
+    finally:
+        gpu.undefine()

@@ -290,3 +290,57 @@ def test_mac_velocity_wall_bc_bit_exact(oracle, case):
         assert (nz > 0) == (not all(periodic))
     finally:
         gpu.undefine()
+
+
+def test_mult_and_div_by_j_on_the_resident_velocities(oracle):
+    """LevelGeometry::multByJ / divByJ (geometry/LevelGeometryUtil.cpp:287-339, 372-420, 456-...): data *= J, data *= Jinv on
+    the device, for the cell-centred velocity (ghost layer included) and the MAC velocity -- the same products, bit for bit."""
+    from somar_amd import api as F
+    from helpers import make_gpu_solver, make_problem, smooth_cc_velocity
+    so = oracle
+    dom, grids, dx, Jgup, Jinv = make_problem(so, (16, 16, 8), 8, "stretched", (False, True, False), (2.0, 1.0, 0.5))
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv)
+    try:
+        rng = np.random.default_rng(9)
+        ghost = (1, 1, 1)
+        vel = smooth_cc_velocity(so, dom, grids, ghost)
+        Js = {}
+        for p in range(gpu.num_local_patches):
+            _, _, gi = gpu.patch_box(p)
+            J = np.asfortranarray(rng.uniform(0.5, 2.0, vel[gi].a.shape[:3]))
+            Js[gi] = (J, np.asfortranarray(1.0 / J), vel[gi].a * J[..., None])
+            gpu.uploadCCVel(p, vel[gi].a, ghost)
+            gpu.setCCJ(p, Js[gi][0], Js[gi][1], ghost)
+        gpu.multByJ(1)
+        for p in range(gpu.num_local_patches):
+            _, _, gi = gpu.patch_box(p)
+            buf = np.zeros(vel[gi].a.shape, order="F")
+            gpu.downloadCCVel(p, buf, ghost)
+            sl = grids[gi].slices(vel[gi].box.lo)
+            np.testing.assert_array_equal(buf[sl], Js[gi][2][sl])
+        gpu.divByJ(1)
+        for p in range(gpu.num_local_patches):
+            _, _, gi = gpu.patch_box(p)
+            buf = np.zeros(vel[gi].a.shape, order="F")
+            gpu.downloadCCVel(p, buf, ghost)
+            sl = grids[gi].slices(vel[gi].box.lo)
+            np.testing.assert_array_equal(buf[sl], (Js[gi][2] * Js[gi][1][..., None])[sl])
+        # MAC velocity
+        faces = {}
+        for p in range(gpu.num_local_patches):
+            _, _, gi = gpu.patch_box(p)
+            for d in range(3):
+                shp = tuple(n + (1 if a == d else 0) for a, n in enumerate(grids[gi].size()))
+                u = np.asfortranarray(rng.uniform(-1, 1, shp))
+                J = np.asfortranarray(rng.uniform(0.5, 2.0, shp))
+                gpu.uploadVel(d, p, u)
+                gpu.setFaceJ(d, p, J, np.asfortranarray(1.0 / J))
+                faces[(p, d)] = (u, J)
+        gpu.multByJ(0)
+        for (p, d), (u, J) in faces.items():
+            np.testing.assert_array_equal(gpu.downloadVel(d, p), u * J)
+        gpu.divByJ(0)
+        for (p, d), (u, J) in faces.items():
+            np.testing.assert_array_equal(gpu.downloadVel(d, p), (u * J) * (1.0 / J))
+    finally:
+        gpu.undefine()

@@ -25,6 +25,23 @@ def test_stretched_metric_equals_the_oracles_generator(oracle):
         np.testing.assert_array_equal(jinv, Jinv[gi].a[..., 0])
 
 
+def test_terrain_metric_equals_the_oracles_generator(oracle):
+    so = oracle
+    from somar_amd import synthetic
+    n = (16, 12, 8)
+    L = (4.0, 3.0, 0.5)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, (8, 4, 8))
+    Jgup, Jinv = so.make_terrain_metric(grids, dx, L, dom)
+    for gi, g in enumerate(grids):
+        jg, jinv = synthetic.terrain_metric(g.lo, g.hi, dx, L)
+        for d in range(3):
+            np.testing.assert_array_equal(jg[d], Jgup[gi][d].a)
+        np.testing.assert_array_equal(jinv, Jinv[gi].a[..., 0])
+        assert np.all(jinv > 0) and float(np.abs(jg[2][..., 0]).max()) > 0.0   # positive Jacobian, genuinely non-diagonal
+
+
 def test_slab_partition_tiles_the_domain():
     from somar_amd import synthetic
     for parts in (1, 2, 4, 8):

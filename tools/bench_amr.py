@@ -5,6 +5,8 @@
 
 C3: 512x512x64 base, L = (15,3,2), y periodic, level 1 = (2,2,1) refinement of the central half in x.
 C4: 1024x1024x128 base + two (2,2,1) levels (central half, central quarter in x).
+c5: BASELINE C5's shape -- terrain-following NON-diagonal metric (19-point kernels), 512x512x64 base + three (2,2,1) levels
+    nested around the topographic bump, boxes 64x64x64 (somar_amd/synthetic.py::c5_hierarchy).
 le3d: the reference's own exec/inputs.LockExchange_Cartesian3D.machine shape -- base nx = 64 x 96 x 64 times
       --mult (default 4: 256x384x256), one level refined by (4,1,1) (amr.refratio_lev0) over the central half in x:
       forced (2,1,1) MG depth + mini V-cycles on the fine level.
@@ -29,7 +31,7 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
     """-> (AMRPressureSolver (finalized), levels' boxes, LOCAL cells per level, define seconds, dx0, ratios)"""
     from somar_amd import api as F
     from somar_amd import synthetic
-    H = synthetic.lockexchange_hierarchy(config, scale, box, mult, nranks)
+    H = synthetic.c5_hierarchy(scale, min(box, 64), nranks) if config == "c5" else synthetic.lockexchange_hierarchy(config, scale, box, mult, nranks)
     levels, ratios, dx0, flat, n0 = H["levels"], H["ratios"], H["dx0"], H["flat"], H["n0"]
     gpu = F.AMRPressureSolver()
     if flat:
@@ -41,12 +43,19 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
     gpu.defineAMR((0, 0, 0), tuple(a - 1 for a in n0), H["periodic"], dx0, ratios, levels,
                   owners_per_level=H["owners"], comm=comm)
     cells = []
+    dxl = list(dx0)
     for l, v in enumerate(gpu.levels):
         tot = 0
+        if l > 0:
+            dxl = [a / b for a, b in zip(dxl, ratios[l - 1])]
         for q in range(v.num_local_patches):
             lo, hi, _ = v.patch_box(q)
             shp = [h - a + 1 for a, h in zip(lo, hi)]
             tot += shp[0] * shp[1] * shp[2]
+            if H.get("metric") == "terrain":
+                jg, jinv = synthetic.terrain_metric(lo, hi, dxl, H["L"])   # non-diagonal: the 19-point kernels
+                v.setMetricFull(q, jg[0], jg[1], jg[2], jinv)
+                continue
             ones = [np.ones((shp[0] + (d == 0), shp[1] + (d == 1), shp[2] + (d == 2)), order="F") for d in range(3)]
             v.setMetricOrtho(q, ones[0], ones[1], None if flat else ones[2], np.ones(shp, order="F"))   # Cartesian: J = 1, Jg^aa = 1
         cells.append(tot)
@@ -67,8 +76,12 @@ def main():
     s = args.scale
     gpu, levels, cells, t_def, dx0, ratios = build_hierarchy(args.config, s, args.box, mult=args.mult)
     nlev = len(levels)
+    # a compatible composite residual: RES := 0 - L_composite[hash-random phi], covered coarse cells zeroed
     for l, v in enumerate(gpu.levels):
-        v.fillHash(F.F_RES, 12345 + l)
+        v.fillHash(F.F_PHI, 12345 + l)
+        v.setVal(F.F_RHS, 0.0)
+    for ilev in range(nlev):
+        gpu.residualLevel(nlev - 1, 0, ilev)
     for l in range(nlev - 1):
         gpu.zeroCovered(l, F.F_RES)
 
@@ -85,7 +98,13 @@ def main():
         step()
     gpu.levels[0].sync()
     dt = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"config": args.config, "scale": s, "levels": nlev, "cells_per_level": cells,
+    r0 = max(v.norm(F.F_RES, 0) for v in gpu.levels)
+    for ilev in range(nlev):
+        gpu.residualLevel(nlev - 1, 0, ilev, res_field=F.F_SCRATCH, phi_field=F.F_CORR, rhs_field=F.F_RES)
+    for l in range(nlev - 1):
+        gpu.zeroCovered(l, F.F_SCRATCH)
+    r1 = max(v.norm(F.F_SCRATCH, 0) for v in gpu.levels)
+    print(json.dumps({"config": args.config, "amr_vcycle_contraction": r1 / r0, "scale": s, "levels": nlev, "cells_per_level": cells,
                       "boxes_per_level": [len(b) for b in levels], "define_seconds": t_def, "ms_per_amr_vcycle": dt * 1e3,
                       "amr_vcycles_per_s": 1.0 / dt, "mg_depth_per_level": [v.depth() for v in gpu.levels],
                       "cell_updates_per_s": sum(cells) * 8 / dt}))
