@@ -351,6 +351,16 @@ int somar_amr_interp_cf(somar_amr_t* a, int level, int fine_field, int coarse_fi
  * metric must be diagonal (error otherwise; level 0 takes either). */
 int somar_amr_level_project(somar_amr_t* a, int level, int centring, double dt, int zero_pressure, int force_homogeneous,
                             int wall_bc, somar_stats_t* stats);
+/* Solver inspector: MappedAMRMultiGridInspector<T>::recordResiduals / recordCorrections (calculus/AMRElliptic/
+ * MappedAMRMultiGrid.H:260-298, called at :1064-1065 and :1083-1084).  somar_amr_solve[_host] calls fn(user, kind, iter,
+ * l_min, l_max) with every stream drained: kind 0 before V-cycle `iter` -- each level's SOMAR_F_RES holds uberResidual --
+ * and kind 1 after it -- SOMAR_F_CORR holds uberCorrection.  Inside the callback the fields can be read through the level
+ * handles (somar_amr_level + somar_field_download): that is what OutputMappedAMRMultiGridInspector (:305-362) hands to
+ * outputAMR / HDF5, so a reference build can write the same "name.residual.iter.N.hdf5" files from this solver's data, and
+ * tools/inspect_solve.py dumps them as .npz for diffing against such files.  fn = NULL removes the inspector. */
+typedef void (*somar_inspector_fn)(void* user, int kind, int iter, int l_min, int l_max);
+int somar_amr_set_inspector(somar_amr_t* a, somar_inspector_fn fn, void* user);
+
 /* The COMPOSITE cell-centred projection over levels l_min..l_max -- SOMAR's sync / initialisation / post-regrid projection
  * (NavierStokes/AMRNavierStokesSync.cpp:280-295), velocities in flux form (J u at cell centres, the levels'
  * somar_ccvel_upload'ed fields; level l_min-1's velocity and pressure, if that level exists, supply coarse-fine values):

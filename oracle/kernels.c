@@ -1324,3 +1324,28 @@ void orc_unmappedaverage(double *crse_, const int *clo, const int *chi, int ncom
                     AT(coarse, ic0, ic1, ic2, var) = coarseSum * refScale;
                 }
 }
+
+/* ------------------------------------------------------------------------
+ * LEPTICVERTHORIZGRAD   calculus/LepticSolver/LevelLepticSolverF.ChF:59-99 (SpaceDim 3)
+ * bcVals(i,j) on the vertical boundary face (index k = face): scale * J g^{z m} d(phi)/dx^m, m = x, y, averaged over
+ * the ghost and the first valid layer.  isign = -1: bottom face (ghost cell k-1, valid cell k); +1: top face (ghost
+ * cell k, valid cell k-1).  bcVals is a flat array over [lo0..hi0] x [lo1..hi1]; extrap = phi with ghosts filled.
+ * ---------------------------------------------------------------------- */
+void orc_lepticverthorizgrad(double *bc_, const int *blo, const int *bhi,
+                             const double *ex_, const int *elo, const int *ehi,
+                             const double *jgz_, const int *zlo, const int *zhi,
+                             const int *flo, const int *fhi, int isign, const double *dx, double scale)
+{
+    fra_t ex = mk((double *)ex_, elo, ehi), Jgz = mk((double *)jgz_, zlo, zhi);
+    const long bs1 = (long)(bhi[0] - blo[0] + 1);
+    const int g = -(1 - isign) / 2, v = -(1 + isign) / 2;
+    const double dxinv0 = scale * 0.25 / dx[0], dxinv1 = scale * 0.25 / dx[1];
+    for (int k = flo[2]; k <= fhi[2]; ++k)
+        for (int j = flo[1]; j <= fhi[1]; ++j)
+            for (int i = flo[0]; i <= fhi[0]; ++i)
+                bc_[(i - blo[0]) + bs1 * (j - blo[1])] =
+                    AT(Jgz, i, j, k, 0) * dxinv0 *
+                        (AT(ex, i + 1, j, k + g, 0) - AT(ex, i - 1, j, k + g, 0) + AT(ex, i + 1, j, k + v, 0) - AT(ex, i - 1, j, k + v, 0)) +
+                    AT(Jgz, i, j, k, 1) * dxinv1 *
+                        (AT(ex, i, j + 1, k + g, 0) - AT(ex, i, j - 1, k + g, 0) + AT(ex, i, j + 1, k + v, 0) - AT(ex, i, j - 1, k + v, 0));
+}

@@ -4,7 +4,8 @@ Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import 
 
   LevelLepticSolver::define / solve      calculus/LepticSolver/LevelLepticSolver.cpp:147-437, 646-956
   computeHorizRHS                        :981-1097
-  levelVertHorizGradient                 :1107-1176      (diagonal metric: boundary data := 0)
+  levelVertHorizGradient                 :1107-1176      (diagonal metric: boundary data := 0; else LEPTICVERTHORIZGRAD,
+                                                          LevelLepticSolverF.ChF:59-99, after ExtrapolateFaceAndCopy in z)
   computeVerticalExcess                  :1183-1240
   verticalLineSolver                     :1248-1421      (Neumann-Neumann columns: TriDiagPoissonNN1DFAB)
   horizontalSolver, add*Correction       :1427-1517
@@ -15,7 +16,9 @@ Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import 
 
 Scope (the same as the HIP path, csrc/leptic.cpp): one level whose boxes are vertically complete columns
 (the layout LepticBoxUtils::createVerticalSolverGrids produces), so the reference's orig <-> vertical and
-flat <-> horizontal re-layouts are identities; diagonal metric; Neumann (or any non-periodic) physical
+flat <-> horizontal re-layouts are identities; diagonal OR non-diagonal metric (the latter: MAPPEDMACGRAD with its cross
+terms in computeHorizRHS after extrapAllGhosts + exchanges, the vertical boundary data of levelVertHorizGradient, the
+vertically averaged horizontal block J g^{ab}, a, b < 2, as a 9-point flat problem solved at EVERY order); Neumann (or any non-periodic) physical
 boundaries in the vertical and non-periodic horizontal directions (the reference never fills the face gradient on
 a periodic horizontal boundary, LevelLepticSolver.cpp:997-1001 + :1056-1061); no coarse-fine boundary.
 Parity unpinned w.r.t. reference tests: the reference ships none; pinned by the
@@ -35,20 +38,24 @@ def flatten_box(b, pos):
     return so.Box((b.lo[0], b.lo[1], pos), (b.hi[0], b.hi[1], pos))
 
 
-def vert_avg_metric(grids, Jgup, domBox):
-    """The horizontal problem's metric: vertical average of the horizontal J g^{aa} (diagonal metric), J^{-1} := 1.
-    createVertAvgFCJgupPtr: levelSum += func * (1/Nz), k ascending."""
+def vert_avg_metric(grids, Jgup, domBox, isDiagonal=True):
+    """The horizontal problem's metric: vertical average of the horizontal block J g^{ab}, a, b < 2 (diagonal metric:
+    only a == b is non-zero), J^{-1} := 1.  createVertAvgFCJgupPtr (geometry/LevelGeometryBasics.cpp:500-569):
+    UNMAPPEDVERTINTEGRAL, levelSum += func * (1/Nz), k ascending."""
     pos = domBox.lo[2]
     flat = [flatten_box(g, pos) for g in grids]
     hJg = so.FluxData(flat, 2, ndim=2)
     for i, g in enumerate(grids):
         scale = 1.0 / float(g.size()[2])
         for d in range(2):
-            src = Jgup[i][d].a[..., d]
-            acc = np.zeros(src.shape[:2])
-            for k in range(src.shape[2]):
-                acc = acc + src[:, :, k] * scale
-            hJg[i][d].a[:, :, 0, d] = acc
+            for b in range(2):
+                if isDiagonal and b != d:
+                    continue
+                src = Jgup[i][d].a[..., b]
+                acc = np.zeros(src.shape[:2])
+                for k in range(src.shape[2]):
+                    acc = acc + src[:, :, k] * scale
+                hJg[i][d].a[:, :, 0, b] = acc
     hJinv = so.LevelData(flat, 1, (0, 0, 0), fill=1.0)
     return flat, hJg, hJinv
 
@@ -67,7 +74,8 @@ class LevelLepticSolver:
         assert normType == 0, "only the max norm (the reference's default) is restated"
         self.maxOrder, self.hang, self.normType, self.horizRhsTol = maxOrder, hang, normType, horizRhsTol
         op = self.origOp = origOp
-        assert op.isDiagonal and op.cf is None and op.ndim == 3
+        assert op.cf is None and op.ndim == 3
+        self.isDiagonal = op.isDiagonal
         dom, grids, dx = op.domain, op.grids, op.dx
         self.domain, self.grids, self.dx = dom, grids, dx
         domBox = dom.box
@@ -79,7 +87,7 @@ class LevelLepticSolver:
         self.Jgup = op.Jgup
         self.Jinv1 = so.LevelData(grids, 1, (0, 0, 0), fill=1.0)
         # full 3-D MG solver (also supplies m_opPtr: alpha 0, beta 1)            :254-300
-        fac = so.Factory(dom, grids, dx, op.bc, self.Jgup, self.Jinv1, alpha=0.0, beta=1.0, isDiagonal=True, ndim=3,
+        fac = so.Factory(dom, grids, dx, op.bc, self.Jgup, self.Jinv1, alpha=0.0, beta=1.0, isDiagonal=op.isDiagonal, ndim=3,
                          maxDepth=fl["maxDepth"], precondIters=fl["precond"], relaxMode=fl["relaxMode"])
         bot = so.BiCGStab(imax=flb["imax"], numRestarts=flb["numRestarts"], normType=normType, hang=1e-8)
         self.mgSolver = so.AMRMultiGrid(fac, bot, fl["maxDepth"])
@@ -90,10 +98,10 @@ class LevelLepticSolver:
         # gatherVerticalBCTypes: physical Neumann at both ends => horizontal solves                 :1523-1640
         self.doHorizSolve = True
         # horizontal structures                                                   :304-432
-        self.flatGrids, hJg, hJinv = vert_avg_metric(grids, self.Jgup, domBox)
+        self.flatGrids, hJg, hJinv = vert_avg_metric(grids, self.Jgup, domBox, op.isDiagonal)
         self.horizDomain = so.Domain(flatten_box(domBox, domBox.lo[2]), dom.periodic)
         hfac = so.Factory(self.horizDomain, self.flatGrids, dx, so.BCHolder(), hJg, hJinv, alpha=0.0, beta=1.0,
-                          isDiagonal=True, ndim=2, maxDepth=hz["maxDepth"], precondIters=hz["precond"],
+                          isDiagonal=op.isDiagonal, ndim=2, maxDepth=hz["maxDepth"], precondIters=hz["precond"],
                           relaxMode=hz["relaxMode"])
         hbot = so.BiCGStab(imax=hzb["imax"], eps=hzb["eps"], numRestarts=hzb["numRestarts"], hang=hzb["hang"],
                            normType=normType)
@@ -144,6 +152,9 @@ class LevelLepticSolver:
     def compute_horiz_rhs(self, flatRhs, phi):
         """-d_m bar(Jg^{mm} d_m phi), diagonal metric; boundary faces carry the (zero) boundary data   :981-1097"""
         dom = self.domain
+        if not self.isDiagonal:
+            self.compute_horiz_rhs_full(flatRhs, phi)
+            return
         # extrapAllGhosts(phi, 2) only matters on faces whose gradient is then overwritten by boundary data or
         # which the exchange refills; the exchange supplies the neighbour values
         so.exchange(phi, dom, phi.ghost)
@@ -178,6 +189,66 @@ class LevelLepticSolver:
                 else:
                     acc_rhs = acc_rhs + (avg[:, 1:] - avg[:, :-1]) * dxScale
             flatRhs[i][...] = acc_rhs
+
+    def compute_horiz_rhs_full(self, flatRhs, phi):
+        """computeHorizRHS with a non-diagonal metric (:981-1097): extrapAllGhosts(phi, 2) (every ghost layer of every box
+        by order-2 extrapolation from the BOX's valid cells, x sides, then y with the box grown in x, then z;
+        ExtrapolationUtils.cpp:388-420), exchange (+ corner exchange), MAPPEDMACGRAD with phi as its own extrap on the
+        faces inside the domain, zero on the domain's side faces (the boundary data), vertical average, -divergence."""
+        dom = self.domain
+        for i, g in enumerate(self.grids):
+            valid = g
+            for d in range(3):
+                for side in (0, 1):
+                    so.extrapolate_face_no_ev(phi[i], phi[i], valid, d, side, 2)
+                valid = valid.growDir(d, 1)
+        so.exchange(phi, dom, phi.ghost)
+        for i, g in enumerate(self.grids):
+            Nz = g.size()[2]
+            dzScale = 1.0 / float(Nz)
+            acc_rhs = np.zeros(g.size()[:2])
+            pF = phi[i]
+            for d in range(2):
+                fb = g.faces(d)
+                # interior faces: faceBox & grow(surroundingNodes(domBox, d), d, -1)
+                lo, hi = list(fb.lo), list(fb.hi)
+                lo[d] = max(lo[d], dom.box.lo[d] + 1)
+                hi[d] = min(hi[d], dom.box.hi[d])
+                grad = so.Fab(fb, 1, 0.0)    # boundary faces: gradPhiFAB.copy(bcFAB) = 0
+                inner = so.Box(lo, hi)
+                if not inner.isEmpty():
+                    blo, bhi = so._b(inner)
+                    so.lib().orc_mappedgetflux(*grad.fra(), *pF.fran(), *pF.fran(), *self.Jgup[i][d].fran(), blo, bhi,
+                                               C.c_double(1.0), so._rv(self.dx), d)
+                gv = grad.a[..., 0]
+                avg = np.zeros(gv.shape[:2])
+                for k in range(Nz):
+                    avg = avg + gv[:, :, k] * dzScale
+                dxScale = -1.0 / self.dx[d]
+                if d == 0:
+                    acc_rhs = acc_rhs + (avg[1:, :] - avg[:-1, :]) * dxScale
+                else:
+                    acc_rhs = acc_rhs + (avg[:, 1:] - avg[:, :-1]) * dxScale
+            flatRhs[i][...] = acc_rhs
+
+    def level_vert_horiz_gradient(self, bcLo, bcHi, phi, scale):
+        """levelVertHorizGradient (:1107-1176), non-diagonal metric: per box and vertical side, ExtrapolateFaceAndCopy of phi
+        in z (order 2, from the box's FAB clipped to the domain, in place), then LEPTICVERTHORIZGRAD on the boundary face."""
+        dom = self.domain
+        for side, bcs in ((0, bcLo), (1, bcHi)):
+            isign = 1 if side else -1
+            for i, g in enumerate(self.grids):
+                pF = phi[i]
+                domValid = pF.box & dom.box
+                so.extrapolate_face_and_copy(pF, pF, domValid, 2, side, 2)
+                kface = g.lo[2] if side == 0 else g.hi[2] + 1
+                fb = so.Box((g.lo[0], g.lo[1], kface), (g.hi[0], g.hi[1], kface))
+                out = np.zeros(g.size()[:2], order="F")
+                JgzF = self.Jgup[i][2]
+                flo, fhi = so._b(fb)
+                so.lib().orc_lepticverthorizgrad(out.ctypes.data_as(C.POINTER(C.c_double)), flo, fhi, *pF.fra1(0),
+                                                 *JgzF.fran(), flo, fhi, isign, so._rv(self.dx), C.c_double(scale))
+                bcs[i][...] = out
 
     @staticmethod
     def set_zero_avg(phi):
@@ -224,6 +295,8 @@ class LevelLepticSolver:
                 if order >= 1:   # levelVertHorizGradient: zero for a diagonal metric
                     for a in bcLo + bcHi:
                         a[...] = 0.0
+                    if not self.isDiagonal:
+                        self.level_vert_horiz_gradient(bcLo, bcHi, vertPhi, -1.0)
                 if order >= 1 and useExcess:
                     for i in range(len(grids)):
                         bcHi[i][...] = bcHi[i] + excess[i] * 1.0
@@ -282,7 +355,8 @@ class LevelLepticSolver:
             else:
                 self.exitStatus = EXIT_KABOOM if order == 0 else EXIT_HANG
                 break
-            useHorizPhi = False   # LevelGeometry::isDiagonal()
+            if self.isDiagonal:
+                useHorizPhi = False   # LevelGeometry::isDiagonal()
 
         self.last = {"vertPhi": vertPhi, "horizPhi": horizPhi, "horizRhs": horizRhs, "phiTotal": phiTotal}
         if self.exitStatus != EXIT_KABOOM:

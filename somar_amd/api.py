@@ -138,6 +138,7 @@ _SIGS = {
                              C.c_int, C.POINTER(Stats)],
     "somar_amr_interp_cf": [_H, C.c_int, C.c_int, C.c_int],
     "somar_amr_level_project": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
+    "somar_amr_set_inspector": [_H, C.c_void_p, C.c_void_p],
     "somar_amr_cc_project": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
     "somar_amr_comp_divergence_cc": [_H, C.c_int, C.c_int, C.c_int, C.c_int],
     "somar_amr_comp_grad_correct_cc": [_H, C.c_int, C.c_int, C.c_int, C.c_double],
@@ -331,6 +332,17 @@ class AMRPressureSolver:
         _ck(lib().somar_amr_level_project(self._amr, level, int(centring), float(dt), int(zeroPressure),
                                           int(forceHomogeneous), int(wall), C.byref(st)))
         return self._stats(st)
+
+    def setInspector(self, fn):
+        """fn(kind, iter, lmin, lmax) -- kind 0: every level's F_RES holds uberResidual (before V-cycle iter), kind 1: F_CORR
+        holds uberCorrection (after it).  MappedAMRMultiGridInspector, MappedAMRMultiGrid.H:260-298.  None removes it."""
+        if fn is None:
+            self._inspector = None
+            _ck(lib().somar_amr_set_inspector(self._amr, None, None))
+            return
+        proto = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)
+        self._inspector = proto(lambda user, kind, it, l0, l1: fn(kind, it, l0, l1))   # keep the thunk alive
+        _ck(lib().somar_amr_set_inspector(self._amr, C.cast(self._inspector, C.c_void_p), None))
 
     def projectAMRCC(self, lmin, lmax, dt, zeroPressure=False, forceHomogeneous=False, wall=True):
         """AMRCCProjector / BaseProjector<FArrayBox>::project(lmin, lmax) on the levels' uploadCCVel'ed velocities (in place)"""

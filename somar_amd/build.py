@@ -19,6 +19,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-I/opt/rocm/include"]
 
 
+EXTRA = os.environ.get("SOMAR_EXTRA_FLAGS", "").split()   # A/B experiments, e.g. -DSOMAR_NT_LOADS
+
+
 def _stale():
     if not os.path.exists(OUT):
         return True
@@ -33,7 +36,7 @@ def build(force=False, verbose=False):
     for f in SOURCES:
         src = os.path.join(CSRC, f)
         obj = os.path.join(CSRC, os.path.splitext(f)[0] + ".o")
-        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if f.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA + (["-x", "hip"] if f.endswith(".cpp") else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

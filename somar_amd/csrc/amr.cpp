@@ -1005,8 +1005,10 @@ void AMRSolver::solve(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous
     bool goIter = iter < prm.imax;
     bool goHang = iter < prm.imin || rnorm < (1 - prm.hang) * norm_last;
     while (goIter && goRedu && goHang && goNorm) {
+        if (inspector_) { sync(); inspector_(inspector_user_, 0, iter, l_base, l_max); }   // recordResiduals, :1064-1065
         norm_last = rnorm;
         vcycle(uCorr.data(), uRes.data(), l_max, l_max, l_base);
+        if (inspector_) { sync(); inspector_(inspector_user_, 1, iter, l_base, l_max); }   // recordCorrections, :1083-1084
         for (int l = l_base; l <= l_max; ++l) {  // postVCycleOps
             const long long ne = S[l]->level(0).field_elems;
             launch_incr(st_, phi[l], uCorr[l], 1.0, ne);

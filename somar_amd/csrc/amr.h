@@ -196,8 +196,14 @@ public:
     void sync() { SOMAR_HIP(hipStreamSynchronize(st_)); }
 
     SolverParams prm;
+    // MappedAMRMultiGridInspector (MappedAMRMultiGrid.H:260-298): called from solve() with the solver's stream synchronized,
+    // kind 0 = recordResiduals (uberResidual, before every V-cycle), 1 = recordCorrections (uberCorrection, after it)
+    typedef void (*Inspector)(void* user, int kind, int iter, int l_min, int l_max);
+    void set_inspector(Inspector f, void* user) { inspector_ = f; inspector_user_ = user; }
 
 private:
+    Inspector inspector_ = nullptr;
+    void* inspector_user_ = nullptr;
     void build_link(int l);
     void build_quad_tables(int l);
     void build_reflux_tables(int l);

@@ -976,6 +976,13 @@ int somar_vel_div_by_j(somar_solver_t* s, int centring)
     API_END
 }
 
+int somar_amr_set_inspector(somar_amr_t* a, somar_inspector_fn fn, void* user)
+{
+    API_BEGIN
+    a->amr->set_inspector(fn, user);
+    API_END
+}
+
 int somar_amr_cc_project(somar_amr_t* a, int l_min, int l_max, double dt, int zero_pressure, int force_homogeneous,
                          int wall_bc, somar_stats_t* stats)
 {

@@ -91,18 +91,29 @@ void LepticSolver::define(const IBox& domain, const bool periodic[3], const doub
 void LepticSolver::finalize()
 {
     SOMAR_CHECK(orig_ && !finalized_, "finalize before define / twice");
-    SOMAR_CHECK(!orig_->is_full(), "the leptic solver is implemented for a diagonal metric");
+    full_ = orig_->is_full();
+    if (full_) {
+        // the J-scaled operator and the flat problem inherit LevelGeometry::isDiagonal() == false: 19-point / 9-point kernels
+        vert_->make_full();
+        horiz_->make_full();
+    }
     orig_->finalize();
     Level& O = orig_->level(0);
     Level& V = vert_->level(0);
     Level& F = horiz_->level(0);
     SOMAR_CHECK(O.field_elems == V.field_elems && O.npatches() == V.npatches() && V.npatches() == F.npatches(),
                 "internal: layouts differ");
-    // metric of the J-scaled operator: the level's J g^{aa}, J^{-1} := 1
-    for (int d = 0; d < 3; ++d) launch_copy(st_, V.dev.jg[d], O.dev.jg[d], V.field_elems);
+    // metric of the J-scaled operator: the level's J g^{ab}, J^{-1} := 1
+    if (full_) {
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) launch_copy(st_, V.dev.jgf[a][b], O.dev.jgf[a][b], V.field_elems);
+    } else {
+        for (int d = 0; d < 3; ++d) launch_copy(st_, V.dev.jg[d], O.dev.jg[d], V.field_elems);
+    }
     launch_set(st_, V.dev.jinv, V.field_elems, 1.0);
     // metric of the flat problem: vertical average of the horizontal components, J^{-1} := 1
-    launch_lep_avg_metric(st_, V.d_ctiles, V.nctiles, V.ctile_j, V.dev, F.dev);
+    if (full_) launch_lep_avg_metric_full(st_, V.d_ctiles, V.nctiles, V.ctile_j, V.dev, F.dev);
+    else launch_lep_avg_metric(st_, V.d_ctiles, V.nctiles, V.ctile_j, V.dev, F.dev);
     launch_set(st_, F.dev.jinv, F.field_elems, 1.0);
     sync();
     vert_->finalize();
@@ -165,6 +176,10 @@ void LepticSolver::solve(bool homogeneous, LepticStats& S)
         if (order >= 1) {  // levelVertHorizGradient: zero for a diagonal metric                   :1107-1176
             launch_set(st_, h_bcLo, hn, 0.0);
             launch_set(st_, h_bcHi, hn, 0.0);
+            if (full_) {
+                Vs.run_aux_program(1, vertPhi);   // ExtrapolateFaceAndCopy in z, lo then hi, order 2, in place
+                launch_lep_vhgrad(st_, ct, nct, tj, V.dev, F.dev, vertPhi, h_bcLo, h_bcHi, -1.0);
+            }
         }
         if (order >= 1 && useExcess) launch_incr(st_, h_bcHi, h_excess, 1.0, hn);
         if (useExcess) {
@@ -176,8 +191,14 @@ void LepticSolver::solve(bool homogeneous, LepticStats& S)
         launch_lep_vsolve(st_, ct, nct, tj, V.dev, F.dev, vertPhi, rhsP, f_gam, h_bcLo, h_bcHi, dz);
 
         if (useHorizPhi) {
-            V.exchange(vertPhi, st_);
-            launch_lep_hgrad(st_, ct, nct, tj, V.dev, F.dev, vertPhi, h_gx, h_gy);
+            if (full_) {
+                Vs.run_aux_program(0, vertPhi);   // extrapAllGhosts(phi, 2): every ghost of every box, then the exchanges
+                V.exchange(vertPhi, st_);
+                launch_lep_hgrad_full(st_, ct, nct, tj, V.dev, F.dev, vertPhi, h_gx, h_gy);
+            } else {
+                V.exchange(vertPhi, st_);
+                launch_lep_hgrad(st_, ct, nct, tj, V.dev, F.dev, vertPhi, h_gx, h_gy);
+            }
             launch_lep_hrhs(st_, ct, nct, tj, V.dev, F.dev, h_gx, h_gy, h_excess, Hs.rhs(), -1.0 / dx_[0],
                             -1.0 / dx_[1], -1.0 / H_, useExcess);
             const double horizRhsNorm = Hs.norm(0, Hs.rhs(), prm.normType);
@@ -218,7 +239,7 @@ void LepticSolver::solve(bool homogeneous, LepticStats& S)
             exitStatus = (order == 0) ? 4 : 2;
             break;
         }
-        useHorizPhi = false;  // LevelGeometry::isDiagonal()
+        if (!full_) useHorizPhi = false;  // LevelGeometry::isDiagonal()
     }
 
     if (exitStatus != 4) launch_lep_axpy(st_, ct, nct, tj, V.dev, Os.phi(), f_total, 1.0);

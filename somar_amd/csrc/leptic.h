@@ -10,7 +10,7 @@
 // as fallback, and the flat 2-D multigrid on the vertically averaged metric.  Everything in between is column
 // kernels (leptic_kernels.hip); the host sequences launches and reads back one norm per order.
 //
-// Scope: diagonal metric, one AMR level (no coarse-fine boundary), homogeneous-Neumann physical boundaries,
+// Scope: diagonal or non-diagonal metric, one AMR level (no coarse-fine boundary), homogeneous-Neumann physical boundaries,
 // non-periodic directions (the reference leaves the averaged gradient on a periodic horizontal boundary face
 // unset, LevelLepticSolver.cpp:997-1001, and refuses a periodic vertical, :1315).
 #pragma once
@@ -68,6 +68,7 @@ private:
     bool horizRemoveAvg_ = false;
     long long horizCells_ = 0;
     bool finalized_ = false;
+    bool full_ = false;   // non-diagonal metric (decided when orig()'s metric has been set)
     // 3-D work fields (vertical layout) and flat ones (horizontal layout)
     double *f_total = nullptr, *f_rhsA = nullptr, *f_rhsB = nullptr, *f_gam = nullptr;
     double *h_excess = nullptr, *h_bcLo = nullptr, *h_bcHi = nullptr, *h_gx = nullptr, *h_gy = nullptr;
@@ -75,6 +76,12 @@ private:
 };
 
 void launch_lep_avg_metric(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H);
+// non-diagonal metric: the horizontal block averaged, MAPPEDMACGRAD with cross terms, LEPTICVERTHORIZGRAD
+void launch_lep_avg_metric_full(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H);
+void launch_lep_hgrad_full(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
+                           const double* phi, double* gx, double* gy);
+void launch_lep_vhgrad(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
+                       const double* phi, double* bcLo, double* bcHi, double scale);
 void launch_lep_excess(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
                        const double* rhs, const double* bcLo, const double* bcHi, double* excess, double dzScale);
 void launch_lep_vsolve(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,

@@ -194,6 +194,110 @@ __global__ __launch_bounds__(512) void k_lep_hgrad(const Tile* __restrict__ tile
     }
 }
 
+// ---- non-diagonal metric ----------------------------------------------------------------------------------------
+struct LJ { const double* c[3][3]; };   // J g^{ab} on a-faces, c[faceDir][component]
+struct HJ { double* c[2][2]; };         // the flat problem's J g^{ab}, a, b < 2
+
+// vertical average of the horizontal block J g^{ab}, a, b < 2 (createVertAvgFCJgupPtr, LevelGeometryBasics.cpp:500-569)
+__global__ __launch_bounds__(512) void k_lep_avg_metric_full(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ vp,
+                                                             const PatchDesc* __restrict__ hpp, LJ J, HJ H)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = vp[t.patch], hp = hpp[t.patch];
+    const double scale = 1.0 / (double)p.n[2];
+    for (int q = 0; q < 2; ++q) {
+        const Col o = column(t, p, hp, q);
+        if (!o.ok) continue;
+        const bool xh = o.li == p.n[0] - 1, yh = o.lj == p.n[1] - 1;
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+                const double* src = J.c[a][b];
+                const long long hs = a == 0 ? 1 : (long long)p.pj;
+                const bool hi = a == 0 ? xh : yh;
+                double lo = 0.0, up = 0.0;
+                long long c = o.c;
+                for (int k = 0; k < p.n[2]; ++k, c += p.pk) {
+                    lo = lo + src[c] * scale;
+                    if (hi) up = up + src[c + hs] * scale;
+                }
+                H.c[a][b][o.h] = lo;
+                if (hi) H.c[a][b][o.h + (a == 0 ? 1 : (long long)hp.pj)] = up;
+            }
+    }
+}
+
+// MAPPEDMACGRAD, normal branch (DivCurlGradF.ChF:87-155), at the face that is the LOW face of cell c in direction a, phi
+// serving as its own extrap (LevelLepticSolver.cpp:1040-1049): the expression of flux19 (full19.hip) term for term
+__device__ __forceinline__ double lep_macgrad(const double* __restrict__ phi, const LJ& J, long long c, int a,
+                                              const long long st[3], const double dxi[3])
+{
+    const int b = (a + 1) % 3, cc = (a + 2) % 3;
+    const long long sa = st[a], sb = st[b], sc = st[cc];
+    const double aScale = 1.0 * dxi[a], bScale = 0.25 * 1.0 * dxi[b], cScale = 0.25 * 1.0 * dxi[cc];
+    return aScale * J.c[a][a][c] * (phi[c] - phi[c - sa]) +
+           bScale * J.c[a][b][c] * (phi[c + sb] - phi[c - sb] + phi[c + sb - sa] - phi[c - sb - sa]) +
+           cScale * J.c[a][cc][c] * (phi[c + sc] - phi[c - sc] + phi[c + sc - sa] - phi[c - sc - sa]);
+}
+
+// the same vertical averages as k_lep_hgrad with the full gradient; phi carries every ghost (extrapAllGhosts + exchange)
+__global__ __launch_bounds__(512) void k_lep_hgrad_full(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ vp,
+                                                        const PatchDesc* __restrict__ hpp, const double* __restrict__ phi,
+                                                        LJ J, double* __restrict__ gx, double* __restrict__ gy,
+                                                        StencilParams P)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = vp[t.patch], hp = hpp[t.patch];
+    const double dzScale = 1.0 / (double)p.n[2];
+    const double dxi[3] = {1.0 / P.dx[0], 1.0 / P.dx[1], 1.0 / P.dx[2]};
+    const long long st[3] = {1, (long long)p.pj, p.pk};
+    for (int q = 0; q < 2; ++q) {
+        const Col o = column(t, p, hp, q);
+        if (!o.ok) continue;
+        const int gi = p.lo[0] + o.li, gj = p.lo[1] + o.lj;
+        const bool xh = o.li == p.n[0] - 1, yh = o.lj == p.n[1] - 1;
+        const bool bxl = gi == P.dom_lo[0], bxh = gi == P.dom_hi[0];
+        const bool byl = gj == P.dom_lo[1], byh = gj == P.dom_hi[1];
+        double ax = 0.0, ay = 0.0, axh = 0.0, ayh = 0.0;
+        long long c = o.c;
+        for (int k = 0; k < p.n[2]; ++k, c += p.pk) {
+            if (!bxl) ax = ax + lep_macgrad(phi, J, c, 0, st, dxi) * dzScale;
+            if (!byl) ay = ay + lep_macgrad(phi, J, c, 1, st, dxi) * dzScale;
+            if (xh && !bxh) axh = axh + lep_macgrad(phi, J, c + 1, 0, st, dxi) * dzScale;
+            if (yh && !byh) ayh = ayh + lep_macgrad(phi, J, c + st[1], 1, st, dxi) * dzScale;
+        }
+        gx[o.h] = ax;
+        gy[o.h] = ay;
+        if (xh) gx[o.h + 1] = axh;
+        if (yh) gy[o.h + hp.pj] = ayh;
+    }
+}
+
+// LEPTICVERTHORIZGRAD (LevelLepticSolverF.ChF:59-99) on the bottom (side 0) and top (side 1) faces of every column:
+// scale * J g^{z m} d(phi)/dx^m, m = x, y, over the ghost and the first valid layer (phi's vertical ghosts, and the x / y
+// ghosts of those two layers, extrapolated by run_aux_program(1))
+__global__ __launch_bounds__(512) void k_lep_vhgrad(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ vp,
+                                                    const PatchDesc* __restrict__ hpp, const double* __restrict__ phi,
+                                                    const double* __restrict__ jgzx, const double* __restrict__ jgzy,
+                                                    double* __restrict__ bcLo, double* __restrict__ bcHi, StencilParams P,
+                                                    double scale)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = vp[t.patch], hp = hpp[t.patch];
+    const double dxinv0 = scale * 0.25 / P.dx[0], dxinv1 = scale * 0.25 / P.dx[1];
+    const long long sj = p.pj, sk = p.pk;
+    for (int q = 0; q < 2; ++q) {
+        const Col o = column(t, p, hp, q);
+        if (!o.ok) continue;
+        for (int side = 0; side < 2; ++side) {
+            const long long f = o.c + (side ? (long long)p.n[2] * sk : 0);   // the cell whose LOW face the boundary face is
+            const long long g = side ? f : f - sk, v = side ? f - sk : f;     // ghost / first valid cell
+            const double val = jgzx[f] * dxinv0 * (phi[g + 1] - phi[g - 1] + phi[v + 1] - phi[v - 1]) +
+                               jgzy[f] * dxinv1 * (phi[g + sj] - phi[g - sj] + phi[v + sj] - phi[v - sj]);
+            (side ? bcHi : bcLo)[o.h] = val;
+        }
+    }
+}
+
 // LEPTICACCUMDIV over both horizontal directions, minus excess / H, then the addTo into the zeroed horizontal rhs
 __global__ __launch_bounds__(512) void k_lep_hrhs(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ vp,
                                                   const PatchDesc* __restrict__ hpp, const double* __restrict__ gx,
@@ -272,6 +376,32 @@ void launch_lep_hgrad(hipStream_t st, const Tile* ct, int nct, int tj, const Lev
                       const double* phi, double* gx, double* gy)
 {
     if (nct) hipLaunchKernelGGL(k_lep_hgrad, LEP_GRID(nct, tj), ct, V.patches, H.patches, phi, V.jg[0], V.jg[1], gx, gy, V.P);
+}
+static LJ lj_of(const LevelDev& V)
+{
+    LJ J;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) J.c[a][b] = V.jgf[a][b];
+    return J;
+}
+void launch_lep_avg_metric_full(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H)
+{
+    if (!nct) return;
+    HJ h;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) h.c[a][b] = H.jgf[a][b];
+    hipLaunchKernelGGL(k_lep_avg_metric_full, LEP_GRID(nct, tj), ct, V.patches, H.patches, lj_of(V), h);
+}
+void launch_lep_hgrad_full(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
+                           const double* phi, double* gx, double* gy)
+{
+    if (nct) hipLaunchKernelGGL(k_lep_hgrad_full, LEP_GRID(nct, tj), ct, V.patches, H.patches, phi, lj_of(V), gx, gy, V.P);
+}
+void launch_lep_vhgrad(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
+                       const double* phi, double* bcLo, double* bcHi, double scale)
+{
+    if (nct) hipLaunchKernelGGL(k_lep_vhgrad, LEP_GRID(nct, tj), ct, V.patches, H.patches, phi, V.jgf[2][0], V.jgf[2][1], bcLo,
+                                bcHi, V.P, scale);
 }
 void launch_lep_hrhs(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
                      const double* gx, const double* gy, const double* excess, double* hrhs, double sx, double sy,

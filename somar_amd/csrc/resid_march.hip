@@ -25,7 +25,14 @@ __device__ __forceinline__ double2 rm_ld2(const double* __restrict__ a, long lon
     // branch-free: always one aligned 16-byte load (from `safe`, any valid aligned element of the patch, when
     // neither element may be touched), then selects.  Straight-line loads let the compiler count outstanding
     // loads exactly (s_waitcnt vmcnt(N)) instead of draining everything at every predicated branch.
+#ifdef SOMAR_NT_LOADS
+    // streamed once per launch: keep the coefficient / right-hand-side lines out of the way of the phi halo reuse in L2
+    typedef double v2d_ __attribute__((ext_vector_type(2)));
+    const v2d_ w = __builtin_nontemporal_load(reinterpret_cast<const v2d_*>(a + ((ok0 || ok1) ? idx : safe)));
+    const double2 v = make_double2(w.x, w.y);
+#else
     const double2 v = *reinterpret_cast<const double2*>(a + ((ok0 || ok1) ? idx : safe));
+#endif
     return make_double2(ok0 ? v.x : 0.0, ok1 ? v.y : 0.0);
 }
 

@@ -51,6 +51,7 @@ PressureSolver::~PressureSolver()
     for (double* f : f_psi) hipFree(f);
     for (double* f : f_W) hipFree(f);
     hipFree(d_fold);
+    for (FullProgram& q : aux_prog_) hipFree(q.d_ops);
     for (auto& pr : full_prog_)
         for (auto& q : pr) hipFree(q.d_ops);
     for (auto& L : lev)

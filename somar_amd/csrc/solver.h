@@ -57,6 +57,13 @@ public:
     // (LevelGeometry::getFCJgup's FluxBox layout).  Switches the solver to the 19-point kernels (full19.hip).
     void set_metric_full(int patch, const double* jg0, const double* jg1, const double* jg2, const double* jinv);
     bool is_full() const { return full_; }
+    // before finalize: switch this solver to the non-diagonal path with every cross plane allocated (zero) -- for callers that
+    // fill the metric planes of level(0).dev.jgf on the device themselves (the leptic solver's J-scaled and flat operators)
+    void make_full();
+    // ghost-op lists built with the reference's helpers for other callers (leptic): which 0 = extrapAllGhosts(phi, order 2)
+    // (ExtrapolationUtils.cpp:388-420), 1 = ExtrapolateFaceAndCopy(phi, phi, FAB & domain, vertical dir, lo then hi, order 2)
+    // (levelVertHorizGradient, LevelLepticSolver.cpp:1107-1176); run on depth 0, in place on phi
+    void run_aux_program(int which, double* phi);
     void set_amr_member() { amr_member_ = true; }  // a level of an AMRSolver hierarchy (whose reflux tables carry beta)
     void finalize();  // builds the semicoarsened hierarchy, coarse metrics, lapDiag, null-space probes
 
@@ -246,6 +253,8 @@ private:
     bool full_ = false;
     std::vector<double*> f_psi;                            // per depth: the extrapolated copy of phi
     // per depth: [0] operator, [1] smoother, [2] fillExtrap alone (getFlux of the flux register), [3] ExtrapolateCFEV
+    FullProgram aux_prog_[2];
+    bool aux_built_[2] = {false, false};
     std::vector<std::array<FullProgram, 6>> full_prog_;   // + [4] / [5]: [0] / [1] writing psi in the boxes' frames only (marching kernels)
     double* f_flux[3] = {nullptr, nullptr, nullptr};  // face fluxes of depth 0 (refluxing with a non-diagonal metric)
     void alloc_full_metric(Level& L);

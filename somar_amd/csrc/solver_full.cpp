@@ -343,6 +343,59 @@ void PressureSolver::copy_frames(int d, const double* src, double* dst)
     launch_ghost_ops(st_, L.dev, P.d_ops + P.first[0], P.count[0], const_cast<double*>(src), dst, true, false);
 }
 
+void PressureSolver::make_full()
+{
+    SOMAR_CHECK(!lev.empty() && !finalized, "make_full before define / after finalize");
+    full_ = true;
+    alloc_full_metric(*lev[0]);
+}
+
+void PressureSolver::run_aux_program(int which, double* phi)
+{
+    SOMAR_CHECK(finalized && (which == 0 || which == 1), "run_aux_program: bad argument");
+    Level& L = *lev[0];
+    FullProgram& P = aux_prog_[which];
+    if (!aux_built_[which]) {
+        std::vector<std::vector<GhostOp>> perPatch(L.npatches());
+        int g1[3];
+        for (int d = 0; d < 3; ++d) g1[d] = L.active[d] ? 1 : 0;
+        for (int pi = 0; pi < L.npatches(); ++pi) {
+            const IBox valid = L.boxes[L.local[pi]];
+            Builder B{valid, valid.grow(g1), pi, perPatch[pi]};
+            if (which == 0) {
+                IBox v = valid;
+                for (int d = 0; d < 3; ++d) {
+                    if (!L.active[d]) continue;
+                    B.face_no_ev(0, 0, v, d, 0, 2);
+                    B.face_no_ev(0, 0, v, d, 1, 2);
+                    v = grow_dir(v, d, 1);
+                }
+            } else {
+                const IBox domValid = B.fab & L.domain;
+                int vd = 2;
+                while (vd > 0 && !L.active[vd]) --vd;
+                B.face_and_copy(0, 0, domValid, vd, 0, 2, L.active);
+                B.face_and_copy(0, 0, domValid, vd, 1, 2, L.active);
+            }
+        }
+        const auto stages = schedule_stages(perPatch);
+        std::vector<GhostOp> flat;
+        for (const auto& sgs : stages) {
+            P.first.push_back((int)flat.size());
+            P.count.push_back((int)sgs.size());
+            flat.insert(flat.end(), sgs.begin(), sgs.end());
+        }
+        if (!flat.empty()) {
+            SOMAR_HIP(hipMalloc(&P.d_ops, flat.size() * sizeof(GhostOp)));
+            SOMAR_HIP(hipMemcpy(P.d_ops, flat.data(), flat.size() * sizeof(GhostOp), hipMemcpyHostToDevice));
+            SOMAR_HIP(hipDeviceSynchronize());
+        }
+        aux_built_[which] = true;
+    }
+    // these ops only use phi (dst = src = field 0); the metric planes are not read (no NEUM op)
+    for (size_t q = 0; q < P.first.size(); ++q) launch_ghost_ops(st_, L.dev, P.d_ops + P.first[q], P.count[q], phi, phi);
+}
+
 void PressureSolver::cf_ev(int d, double* phi)
 {
     if (!full_ || !hasCF_) return;

@@ -1,5 +1,5 @@
 """F-cycle multigrid (numMG < 0, MappedMultiGrid.H:577-619): a recursive F-cycle, pre-smoothing, |numMG| V-cycles with the
-"m_cycle = 1" hack, post-smoothing -- one cycle bit for bit against the oracle, and a whole solve's history."""
+"m_cycle = 1" hack, post-smoothing -- one cycle against the oracle (to round-off: 1e-12), and a whole solve's history."""
 import numpy as np
 import pytest
 
@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("numMG", [-1, -2])
-def test_fcycle_bit_exact_and_solve_history(oracle, numMG):
+def test_fcycle_matches_and_solve_history(oracle, numMG):
     from somar_amd import AMRPressureSolver
     from somar_amd import api as F
     so = oracle
@@ -36,8 +36,10 @@ def test_fcycle_bit_exact_and_solve_history(oracle, numMG):
         upload(s, F.F_RES, res)
         s.setVal(F.F_CORR, 0.0)
         s.vcycle(F.F_CORR, F.F_RES)
+        # (the depth-0 level has 16384 cells: its zero-average mean is a tree sum on the GPU, hence round-off, not bits)
+        scale = max(float(np.abs(b).max()) for b in valid_of(corr))
         for a, b in zip(download_valid(s, F.F_CORR, grids), valid_of(corr)):
-            np.testing.assert_array_equal(a, b)
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-12 * scale)
         x = so.LevelData(grids, 1, (1, 1, 1))
         amr.set_solver_parameters(2, 2, 2, numMG, 20, 1e-6, 1e-15, 1e-30)
         amr.solve(x, res)

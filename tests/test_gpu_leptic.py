@@ -87,6 +87,64 @@ def test_leptic_solve_matches_oracle(n, box, H, variant, maxOrder):
             np.testing.assert_allclose(g_, w_, rtol=0, atol=1e-12 * scale)
 
 
+def _gpu_leptic_full(dom, grids, dx, Jgup, Jinv, maxOrder, H):
+    from somar_amd import LevelLepticSolver
+    s = LevelLepticSolver()
+    s.params.max_order = maxOrder
+    s.params.domain_height = H
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids])
+    lv = s.level
+    for p_ in range(lv.num_local_patches):
+        _, _, gi = lv.patch_box(p_)
+        lv.setMetricFull(p_, *[np.asfortranarray(Jgup[gi][d].a) for d in range(3)], np.asfortranarray(Jinv[gi].a[..., 0]))
+    s.finalize()
+    return s
+
+
+FULL_CASES = [
+    # n, box, L, metric, maxOrder
+    ((32, 32, 8), (16, 16, 8), (64.0, 64.0, 1.0), "terrain", 4),
+    ((32, 32, 8), (32, 32, 8), (64.0, 64.0, 1.0), "terrain", 2),     # one box
+    ((32, 16, 12), (8, 16, 12), (64.0, 32.0, 1.0), "sheared", 3),    # every J g^{ab} non-zero
+]
+
+
+@pytest.mark.parametrize("n,box,L,metric,maxOrder", FULL_CASES)
+def test_leptic_nondiagonal_matches_oracle(n, box, L, metric, maxOrder):
+    """Non-diagonal metric: vertical boundary data from LEPTICVERTHORIZGRAD, MAPPEDMACGRAD with cross terms in the
+    horizontal right-hand side, a horizontal solve at every order (oracle: somar_leptic.py, isDiagonal False)."""
+    from somar_amd.api import F_PHI, F_RHS
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, box)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    if metric == "terrain":
+        Jgup, Jinv = so.make_terrain_metric(grids, dx, L, dom)
+    else:
+        Jgup, Jinv = so.make_full_metric(grids, dx, L, dom, amp=(0.05, 0.04, 0.03))
+    rhs = so.random_field(grids, 3, domainBox=dom.box)
+    so.remove_weighted_mean(rhs, Jinv)
+    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv, isDiagonal=False)
+    lep = sl.LevelLepticSolver(amr.op, maxOrder=maxOrder, domainHeight=L[2])
+    phi = so.random_field(grids, 11, ghost=(1, 1, 1), domainBox=dom.box)
+    for f in phi.fabs:
+        f.a[...] *= 1e-3
+    gpu = _gpu_leptic_full(dom, grids, dx, Jgup, Jinv, maxOrder, L[2])
+    upload(gpu.level, F_PHI, phi)
+    upload(gpu.level, F_RHS, rhs)
+    status = lep.solve(phi, rhs)
+    st = gpu.solve()
+    assert not lep.usedFullSolver and not st["usedFullSolver"]
+    assert st["exitStatus"] == status
+    assert st["horizSolves"] == lep.horizSolves and lep.horizSolves == maxOrder + 1
+    assert st["resNorms"] == lep.resNorms
+    for g_, w_ in zip(download_valid(gpu.level, F_PHI, grids), valid_of(phi)):
+        np.testing.assert_array_equal(g_, w_)
+    for name, view, fld in (("vertPhi", gpu.vert, F_PHI), ("horizPhi", gpu.horiz, F_PHI), ("horizRhs", gpu.horiz, F_RHS)):
+        ld = lep.last[name]
+        for g_, w_ in zip(download_valid(view, fld, ld.grids), valid_of(ld)):
+            np.testing.assert_array_equal(g_, w_, err_msg=name)
+
+
 def test_leptic_full_multigrid_fallback_matches_oracle():
     """maxOrder 0: the O(1) residual exceeds the initial one by construction, the full 3-D multigrid (LINE_GSRB
     4/4/4, DiagLineRelax) takes over; both sides must take the same branch and agree."""

@@ -103,3 +103,61 @@ def test_leptic_agrees_with_multigrid_solution():
     # point-GSRB multigrid stalls near 1e-4 on this thin domain (exit status 4) -- the reason the leptic solver
     # exists -- so the comparison can only be as good as the multigrid answer
     assert np.max(np.abs(a - b)) < 1e-3 * np.max(np.abs(b))
+
+
+def _terrain_problem(n=(32, 32, 8), box=(16, 16, 8), L=(64.0, 64.0, 1.0), seed=3, metric="terrain"):
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, box)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    if metric == "terrain":
+        Jgup, Jinv = so.make_terrain_metric(grids, dx, L, dom)
+    else:
+        Jgup, Jinv = so.make_full_metric(grids, dx, L, dom, amp=(0.05, 0.04, 0.03))
+    rhs = so.random_field(grids, seed, domainBox=dom.box)
+    so.remove_weighted_mean(rhs, Jinv)
+    return dom, grids, dx, Jgup, Jinv, rhs
+
+
+def test_leptic_nondiagonal_metric_converges_with_the_cross_terms():
+    """Terrain-following map (J g^{xz}, J g^{yz} != 0): every order runs a horizontal solve
+    (LevelLepticSolver.cpp:820-826 keeps m_doHorizSolve for a non-diagonal metric), the vertical boundary data of
+    order k is -J g^{z m} d_m phi_{k-1} (levelVertHorizGradient, :1107-1176), and the orders converge on the FULL
+    19-point operator: the reported J-scaled residual is the one of the level's own operator."""
+    dom, grids, dx, Jgup, Jinv, rhs = _terrain_problem()
+    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv, isDiagonal=False)
+    assert not amr.op.isDiagonal
+    lep = sl.LevelLepticSolver(amr.op, maxOrder=4, domainHeight=1.0)
+    phi = so.LevelData(grids, 1, (1, 1, 1))
+    status = lep.solve(phi, rhs)
+    h = lep.resNorms
+    assert status in (sl.EXIT_ITER, sl.EXIT_CONVERGE) and not lep.usedFullSolver
+    assert lep.horizSolves >= 4
+    assert h[-1] < 1e-4 * h[0]   # eps = H / dx = 0.5: about eps^2 ... eps^3 per order
+    assert all(h[k + 1] < 0.2 * h[k] for k in range(2, len(h) - 1))
+    res = so.LevelData(grids, 1, (0, 0, 0))
+    amr.op.residual(res, phi, rhs, False)
+    jres = max(float(np.max(np.abs(res[i].view(g) / Jinv[i].view(g)))) for i, g in enumerate(grids))
+    assert abs(jres - h[-1]) <= 1e-9 * h[0]
+
+
+def test_leptic_nondiagonal_reduces_to_diagonal_when_cross_terms_vanish():
+    """The non-diagonal code path fed a diagonal metric stored in full form must give the diagonal path's
+    vertical solves: bcLo / bcHi from levelVertHorizGradient are exactly zero, so order-k vertical problems agree;
+    only the extra horizontal solves (useHorizPhi stays on) differ, and they act on a right-hand side that is
+    zero up to round-off after order 0."""
+    L = (1.0, 1.0, 0.005)
+    dom, grids, dx, Jgup, Jinv, rhs = _thin_problem(L=L)
+    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv)
+    lepD = sl.LevelLepticSolver(amr.op, maxOrder=3, domainHeight=L[2])
+    phiD = so.LevelData(grids, 1, (1, 1, 1))
+    lepD.solve(phiD, rhs)
+    amrF = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv, isDiagonal=False)
+    lepF = sl.LevelLepticSolver(amrF.op, maxOrder=3, domainHeight=L[2])
+    phiF = so.LevelData(grids, 1, (1, 1, 1))
+    lepF.solve(phiF, rhs)
+    assert lepF.horizSolves > lepD.horizSolves
+    # order 0 is the same computation (zero vertical boundary data, one horizontal solve); later orders differ by the
+    # extra horizontal solves, which only help on a stretched metric (the average does not commute with the operator)
+    np.testing.assert_allclose(lepF.resNorms[:2], lepD.resNorms[:2], rtol=1e-12)
+    assert lepF.resNorms[3] < 0.1 * lepD.resNorms[3]
+    assert not lepF.usedFullSolver and lepF.resNorms[-1] < 1e-5 * lepF.resNorms[0]
