@@ -134,6 +134,10 @@ int somar_solver_finalize(somar_solver_t* s);
 int somar_solver_depth(somar_solver_t* s, int* depth);
 int somar_solver_mg_ref_ratio(somar_solver_t* s, int depth, int* r3); /* depth -> depth+1 */
 int somar_solver_zero_avg(somar_solver_t* s, int depth, int* flag);
+/* 1 when J g^{aa} and J^{-1} of this depth were found constant at finalize (a Cartesian map, CartesianMap.cpp:261-280):
+ * the sweep / residual kernels then take the four values from their parameter block instead of streaming four arrays;
+ * c4 (optional) = {J g^xx, J g^yy, J g^zz, J^{-1}}.  Environment SOMAR_NO_UNIFORM=1 turns the detection off. */
+int somar_solver_metric_uniform(somar_solver_t* s, int depth, int* flag, double* c4);
 int somar_solver_level_info(somar_solver_t* s, int depth, int* domain6, double* dx3, long long* cells,
                             long long* field_elems);
 

@@ -76,6 +76,7 @@ _SIGS = {
     "somar_solver_depth": [_H, _PI],
     "somar_solver_mg_ref_ratio": [_H, C.c_int, _PI],
     "somar_solver_zero_avg": [_H, C.c_int, _PI],
+    "somar_solver_metric_uniform": [_H, C.c_int, _PI, _PD],
     "somar_solver_level_info": [_H, C.c_int, _PI, _PD, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)],
     "somar_field_upload": [_H, C.c_int, C.c_int, _PD, _PI],
     "somar_field_download": [_H, C.c_int, C.c_int, _PD, _PI],
@@ -422,6 +423,12 @@ class AMRPressureSolver:
         d = C.c_int()
         _ck(lib().somar_solver_depth(self._h, C.byref(d)))
         return d.value
+
+    def metricUniform(self, depth=0):
+        """None, or (Jg^xx, Jg^yy, Jg^zz, Jinv) when this depth's metric was found constant at finalize"""
+        f, c = C.c_int(), (C.c_double * 4)()
+        _ck(lib().somar_solver_metric_uniform(self._h, depth, C.byref(f), c))
+        return tuple(c) if f.value else None
 
     def mgRefRatios(self):
         out = []

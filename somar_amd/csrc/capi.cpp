@@ -231,6 +231,17 @@ int somar_solver_mg_ref_ratio(somar_solver_t* s, int depth, int* r3)
     API_END
 }
 
+int somar_solver_metric_uniform(somar_solver_t* s, int depth, int* flag, double* c4)
+{
+    API_BEGIN
+    SOMAR_CHECK(depth >= 0 && depth < s->ps->depth(), "depth out of range");
+    const StencilParams& P = s->ps->level(depth).dev.P;
+    *flag = P.uniform;
+    if (c4)
+        for (int a = 0; a < 4; ++a) c4[a] = P.uniform ? P.uc[a] : 0.0;
+    API_END
+}
+
 int somar_solver_zero_avg(somar_solver_t* s, int depth, int* flag)
 {
     API_BEGIN

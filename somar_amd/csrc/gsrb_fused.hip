@@ -53,6 +53,9 @@ __device__ __forceinline__ double2 ld2(const double* __restrict__ a, long long i
     return make_double2(ok0 ? v.x : 0.0, ok1 ? v.y : 0.0);
 }
 
+// the "load" of a uniform coefficient: the same predicated pair ld2 would have returned
+__device__ __forceinline__ double2 uni2(double c, bool ok0, bool ok1) { return make_double2(ok0 ? c : 0.0, ok1 ? c : 0.0); }
+
 // One GSRB point update of cell (gi,gj,gk): interior form = GSRBITER3DORTHO, cells touching a domain
 // face = GSRBBOUNDARYITER3DORTHO (a Neumann face contributes neither flux nor diagonal; a Dirichlet face contributes
 // both, its ghost being -own).  own = the cell's value before this update.
@@ -116,7 +119,7 @@ __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS,
 //    post-smoothing sweep instead of a separate 16 B/cell pass.
 // 3: phi_in is read as value + crse(i / r): the prolongation (CONSTINTERPPS) folded into the first post-smoothing
 //    sweep -- ghosts included, which needs crse exchanged one cell deep.  4: as 3, minus sums[0]/sums[1].
-template <int FR_J, int INMODE, bool DIRI = false>
+template <int FR_J, int INMODE, bool DIRI = false, bool UNI = false>
 __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict__ tiles,
                                                      const PatchDesc* __restrict__ patches,
                                                      double* __restrict__ phi_out,
@@ -210,7 +213,8 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
     double2 Pm = ldphi(k - 1, f0 && fk, f1 && fk);
     fk = (k >= -FRAME) && (k < p.n[2] + FRAME);
     double2 Pc = ldphi(k, f0 && fk, f1 && fk);
-    double2 Gzc = ld2(jgz, base + sk * k, c0 && fk, c1 && fk, p.off);  // Jg^zz on the LOW face of plane k
+    // Jg^zz on the LOW face of plane k
+    double2 Gzc = UNI ? uni2(P.uc[2], c0 && fk, c1 && fk) : ld2(jgz, base + sk * k, c0 && fk, c1 && fk, p.off);
     // coefficients of the black cell of plane k-1 (column c), captured one step earlier
     double b_rhs = 0, b_ji = 1, b_gxl = 0, b_gxh = 0, b_gyl = 0, b_gyh = 0, b_gzl = 0;
     double redPrev1 = 0.0, redPrev2 = 0.0;
@@ -222,12 +226,13 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         const bool fkp = (k + 1 >= -FRAME) && (k + 1 < p.n[2] + FRAME);
         // ---- this step's loads: phi and Jg^zz of plane k+1, cell coefficients of plane k --------
         const double2 Pp = ldphi(k + 1, f0 && fkp, f1 && fkp);
-        const double2 Gzp = ld2(jgz, base + sk * (k + 1), c0 && fkp, c1 && fkp, p.off);
+        const double2 Gzp = UNI ? uni2(P.uc[2], c0 && fkp, c1 && fkp) : ld2(jgz, base + sk * (k + 1), c0 && fkp, c1 && fkp, p.off);
         const double2 Rh = ld2(rhs, base + sk * k, c0 && fk, c1 && fk, p.off);
-        const double2 Ji = ld2(jinv, base + sk * k, c0 && fk, c1 && fk, p.off);
-        const double2 Gx = ld2(jgx, base + sk * k, c0 && fk, c1 && fk, p.off);
-        const double2 Gy = ld2(jgy, base + sk * k, c0 && fk, c1 && fk, p.off);
-        const double2 Gyh = ld2(jgy, base + sk * k + sj, c0 && fk && fjh, c1 && fk && fjh, p.off);
+        const double2 Ji = UNI ? uni2(P.uc[3], c0 && fk, c1 && fk) : ld2(jinv, base + sk * k, c0 && fk, c1 && fk, p.off);
+        const double2 Gx = UNI ? uni2(P.uc[0], c0 && fk, c1 && fk) : ld2(jgx, base + sk * k, c0 && fk, c1 && fk, p.off);
+        const double2 Gy = UNI ? uni2(P.uc[1], c0 && fk, c1 && fk) : ld2(jgy, base + sk * k, c0 && fk, c1 && fk, p.off);
+        const double2 Gyh = UNI ? uni2(P.uc[1], c0 && fk && fjh, c1 && fk && fjh)
+                                : ld2(jgy, base + sk * k + sj, c0 && fk && fjh, c1 && fk && fjh, p.off);
         // Jg^xx on the face right of the pair = first component of the next lane's pair
         const double gx_next = __shfl_down(Gx.x, 1, 64);
 
@@ -347,6 +352,21 @@ void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const Leve
             if (in_mode == 1) SOMAR_LAUNCH_FUSED_D(16, 1); else if (in_mode == 3) SOMAR_LAUNCH_FUSED_D(16, 3); else SOMAR_LAUNCH_FUSED_D(16, 0);
         }
 #undef SOMAR_LAUNCH_FUSED_D
+        return;
+    }
+    if (L.P.uniform && fused_rows() == 16) {
+        // uniform metric: the four coefficient streams come from StencilParams
+#define SOMAR_LAUNCH_FUSED_U(M)                                                                                                 \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gsrb_fused<16, M, false, true>), dim3(ntiles), dim3(64, 16, 1), 0, st, tiles, L.patches, \
+                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2)
+        switch (in_mode) {
+            case 1: SOMAR_LAUNCH_FUSED_U(1); break;
+            case 2: SOMAR_LAUNCH_FUSED_U(2); break;
+            case 3: SOMAR_LAUNCH_FUSED_U(3); break;
+            case 4: SOMAR_LAUNCH_FUSED_U(4); break;
+            default: SOMAR_LAUNCH_FUSED_U(0);
+        }
+#undef SOMAR_LAUNCH_FUSED_U
         return;
     }
     if (fused_rows() == 8) { SOMAR_LAUNCH_FUSED_MODES(8) }

@@ -87,6 +87,9 @@ void launch_incr(hipStream_t st, double* y, const double* x, double a, long long
 void launch_scale(hipStream_t st, double* y, double a, long long n);
 void launch_mul(hipStream_t st, double* y, const double* x, long long n);   // y *= x elementwise
 void launch_axby(hipStream_t st, double* z, const double* x, const double* y, double a, double b, long long n);
+// (min, max) per (patch, k-chunk) of a over the valid cells (dir < 0) or valid dir-faces: out[2 * npatches * MM_CH] (device)
+constexpr int MM_CH = 64;
+void launch_minmax_valid(hipStream_t st, const LevelDev& L, const double* a, int dir, double* out);
 // mode 0: sum a*b, 1: max|a|, 2: sum|a|, 3: signed max a  -> out[0] (device)
 // ordered: reference-ordered serial sum (modes 0 and 2; meant for small levels, see k_reduce_ordered)
 void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const double* b, int mode, double* partials,

@@ -960,4 +960,47 @@ void launch_fill_hash(hipStream_t st, const LevelDev& L, double* f, unsigned lon
     hipLaunchKernelGGL(k_fill_hash, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, f, L.P, seed);
 }
 
+// min / max of one coefficient array over the valid cells (dir < 0) or the valid dir-faces of every patch, MM_CH chunks of
+// k-planes per patch: out[2 * (patch * MM_CH + chunk)] = min, [... + 1] = max (+-inf for an empty chunk).  Runs once per depth
+// at finalize (detect_uniform_metric).
+__global__ __launch_bounds__(256) void k_minmax_valid(const PatchDesc* __restrict__ patches, const double* __restrict__ a, int dir,
+                                                      double* __restrict__ out)
+{
+    const PatchDesc p = patches[blockIdx.x];
+    const int n0 = p.n[0] + (dir == 0), n1 = p.n[1] + (dir == 1), n2 = p.n[2] + (dir == 2);
+    const int per = (n2 + MM_CH - 1) / MM_CH;
+    const int k0 = per * blockIdx.y, k1 = k0 + per < n2 ? k0 + per : n2;
+    double lo = HUGE_VAL, hi = -HUGE_VAL;
+    for (int k = k0; k < k1; ++k)
+        for (int j = threadIdx.y; j < n1; j += 4) {
+            const double* row = a + p.off + (long long)p.pj * j + p.pk * k;
+            for (int i = threadIdx.x; i < n0; i += 64) {
+                const double v = row[i];
+                lo = v < lo ? v : lo;
+                hi = v > hi ? v : hi;
+            }
+        }
+    __shared__ double slo[256], shi[256];
+    const int t = threadIdx.x + 64 * threadIdx.y;
+    slo[t] = lo;
+    shi[t] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            slo[t] = slo[t + s] < slo[t] ? slo[t + s] : slo[t];
+            shi[t] = shi[t + s] > shi[t] ? shi[t + s] : shi[t];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const long long o = 2 * ((long long)blockIdx.x * MM_CH + blockIdx.y);
+        out[o] = slo[0];
+        out[o + 1] = shi[0];
+    }
+}
+void launch_minmax_valid(hipStream_t st, const LevelDev& L, const double* a, int dir, double* out)
+{
+    if (L.npatches) hipLaunchKernelGGL(k_minmax_valid, dim3(L.npatches, MM_CH), dim3(64, 4), 0, st, L.patches, a, dir, out);
+}
+
 }  // namespace somar

@@ -36,7 +36,10 @@ __device__ __forceinline__ double2 rm_ld2(const double* __restrict__ a, long lon
     return make_double2(ok0 ? v.x : 0.0, ok1 ? v.y : 0.0);
 }
 
-template <int MODE>
+__device__ __forceinline__ double2 rm_uni2(double c, bool ok0, bool ok1) { return make_double2(ok0 ? c : 0.0, ok1 ? c : 0.0); }
+
+// UNI: uniform metric, the four coefficient arrays are not read (StencilParams::uc)
+template <int MODE, bool UNI = false>
 __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restrict__ tiles,
                                                            const PatchDesc* __restrict__ patches,
                                                            double* __restrict__ out,
@@ -139,20 +142,20 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
     int k = t.k0;
     double2 Pm = rm_ld2(phi, base + sk * (k - 1), o[0], o[1], p.off);
     double2 Pc = rm_ld2(phi, base + sk * k, f0, f1, p.off);
-    double2 Gzc = rm_ld2(jgz, base + sk * k, o[0], o[1], p.off);
+    double2 Gzc = UNI ? rm_uni2(P.uc[2], o[0], o[1]) : rm_ld2(jgz, base + sk * k, o[0], o[1], p.off);
     const int kend = t.k0 + t.nk;
     for (; k < kend; ++k) {
         const int gk = p.lo[2] + k;
         const bool more = (k + 1 < kend);
         // ---- this step's loads ----
         const double2 Pp = rm_ld2(phi, base + sk * (k + 1), more ? f0 : o[0], more ? f1 : o[1], p.off);
-        const double2 Gzp = rm_ld2(jgz, base + sk * (k + 1), o[0], o[1], p.off);
+        const double2 Gzp = UNI ? rm_uni2(P.uc[2], o[0], o[1]) : rm_ld2(jgz, base + sk * (k + 1), o[0], o[1], p.off);
         double2 Rh = make_double2(0.0, 0.0);
         if (MODE != 1) Rh = rm_ld2(rhs, base + sk * k, o[0], o[1], p.off);
-        const double2 Ji = rm_ld2(jinv, base + sk * k, o[0], o[1], p.off);
-        const double2 Gx = rm_ld2(jgx, base + sk * k, gxo0, o[0] || o[1], p.off);
-        const double2 Gy = rm_ld2(jgy, base + sk * k, o[0], o[1], p.off);
-        const double2 Gyh = rm_ld2(jgy, base + sk * k + sj, o[0], o[1], p.off);
+        const double2 Ji = UNI ? rm_uni2(P.uc[3], o[0], o[1]) : rm_ld2(jinv, base + sk * k, o[0], o[1], p.off);
+        const double2 Gx = UNI ? rm_uni2(P.uc[0], gxo0, o[0] || o[1]) : rm_ld2(jgx, base + sk * k, gxo0, o[0] || o[1], p.off);
+        const double2 Gy = UNI ? rm_uni2(P.uc[1], o[0], o[1]) : rm_ld2(jgy, base + sk * k, o[0], o[1], p.off);
+        const double2 Gyh = UNI ? rm_uni2(P.uc[1], o[0], o[1]) : rm_ld2(jgy, base + sk * k + sj, o[0], o[1], p.off);
         const double gx_next = __shfl_down(Gx.x, 1, 64);
 
         // ---- stage plane k; slot k&1 was last read two steps ago, one barrier per plane suffices ----
@@ -238,6 +241,15 @@ void launch_resid_march(hipStream_t st, const Tile* tiles, int ntiles, const Lev
                         const double* phi, const double* rhs, int mode)
 {
     if (ntiles == 0) return;
+    if (L.P.uniform) {
+        if (mode == 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_resid_march<0, true>), dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, L.patches, out,
+                               phi, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, nullptr, 1, 1, 1, 0.0, nullptr);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_resid_march<1, true>), dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, L.patches, out,
+                               phi, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, nullptr, 1, 1, 1, 0.0, nullptr);
+        return;
+    }
     if (mode == 0)
         hipLaunchKernelGGL(k_resid_march<0>, dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, L.patches, out, phi, rhs,
                            L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, nullptr, 1, 1, 1, 0.0, nullptr);
@@ -254,6 +266,11 @@ void launch_resid_restrict(hipStream_t st, const Tile* tiles, int ntiles, const 
                            double* volsum)
 {
     if (ntiles == 0) return;
+    if (F.P.uniform) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_resid_march<2, true>), dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, F.patches, crse, phi,
+                           rhs, F.jg[0], F.jg[1], F.jg[2], F.jinv, F.P, C.patches, r[0], r[1], r[2], dxProduct, volsum);
+        return;
+    }
     hipLaunchKernelGGL(k_resid_march<2>, dim3(ntiles), dim3(64, RM_J, 1), 0, st, tiles, F.patches, crse, phi, rhs,
                        F.jg[0], F.jg[1], F.jg[2], F.jinv, F.P, C.patches, r[0], r[1], r[2], dxProduct, volsum);
 }

@@ -3,6 +3,7 @@
 
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace somar {
@@ -360,6 +361,53 @@ void PressureSolver::probe_null_space(int d)
     Level::free_field(res);
 }
 
+// A Cartesian map hands over constant arrays (CartesianMap.cpp:261-280): J g^{aa} and J^{-1} are then the same number on
+// every face / in every cell of a depth -- and of every coarser depth, whose averages of equal numbers are exact.  The
+// k-marching kernels take such coefficients from StencilParams instead of streaming them (same arithmetic, same bits).
+// SOMAR_NO_UNIFORM=1 disables the detection (A/B measurements, parity tests of the streaming path on Cartesian inputs).
+void PressureSolver::detect_uniform_metric()
+{
+    const char* e = getenv("SOMAR_NO_UNIFORM");
+    const bool off = e && atoi(e) != 0;
+    for (auto& Lp : lev) Lp->dev.P.uniform = 0;
+    if (off || full_ || prm.spaceDim != 3) return;
+    for (auto& Lp : lev) {
+        Level& L = *Lp;
+        if (!(L.active[0] && L.active[1] && L.active[2])) continue;
+        const int np = L.npatches();
+        // (max, -min) of the four arrays; a rank without boxes on this depth contributes -inf
+        double h[8];
+        for (double& v : h) v = -HUGE_VAL;
+        double* d_mm = nullptr;
+        const size_t nmm = 2 * (size_t)std::max(np, 1) * MM_CH;
+        SOMAR_HIP(hipMalloc(&d_mm, sizeof(double) * (nmm + 8)));
+        std::vector<double> mm(nmm);
+        for (int a = 0; a < 4; ++a) {
+            if (!np) break;
+            launch_minmax_valid(st_, L.dev, a < 3 ? L.dev.jg[a] : L.dev.jinv, a < 3 ? a : -1, d_mm);
+            SOMAR_HIP(hipMemcpyAsync(mm.data(), d_mm, sizeof(double) * nmm, hipMemcpyDeviceToHost, st_));
+            SOMAR_HIP(hipStreamSynchronize(st_));
+            for (size_t q = 0; q < (size_t)np * MM_CH; ++q) {
+                h[2 * a] = std::max(h[2 * a], mm[2 * q + 1]);
+                h[2 * a + 1] = std::max(h[2 * a + 1], -mm[2 * q]);
+            }
+        }
+        if (comm_->size > 1) {
+            double* d8 = d_mm + nmm;
+            SOMAR_HIP(hipMemcpyAsync(d8, h, sizeof(h), hipMemcpyHostToDevice, st_));
+            comm_->allreduce(d8, 8, 1, st_);
+            SOMAR_HIP(hipMemcpyAsync(h, d8, sizeof(h), hipMemcpyDeviceToHost, st_));
+            SOMAR_HIP(hipStreamSynchronize(st_));
+        }
+        hipFree(d_mm);
+        bool uni = true;
+        for (int a = 0; a < 4; ++a) uni = uni && std::isfinite(h[2 * a]) && h[2 * a] == -h[2 * a + 1];
+        if (!uni) continue;
+        L.dev.P.uniform = 1;
+        for (int a = 0; a < 4; ++a) L.dev.P.uc[a] = h[2 * a];
+    }
+}
+
 void PressureSolver::finalize()
 {
     SOMAR_CHECK(!lev.empty() && !finalized, "finalize before define / twice");
@@ -373,6 +421,7 @@ void PressureSolver::finalize()
         }
         ++depth;
     }
+    detect_uniform_metric();
     int maxTiles = 1;
     for (auto& L : lev) maxTiles = std::max(std::max(maxTiles, L->dev.ntiles), std::max(L->nrtiles, L->nftiles));
     SOMAR_HIP(hipMalloc(&d_partials, (size_t)maxTiles * 2 * sizeof(double)));

@@ -203,6 +203,7 @@ private:
     bool build_coarser(int depth);
     void probe_null_space(int d);
     void fill_metric_ghosts(Level& L);
+    void detect_uniform_metric();  // sets StencilParams::uniform / uc per depth (diagonal metric, 3-D)
     void line_relax(int d, double* e, const double* res);
     double* f_vel[3] = {nullptr, nullptr, nullptr};
     double* f_ccvel[3] = {nullptr, nullptr, nullptr};

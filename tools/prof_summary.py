@@ -46,6 +46,23 @@ def stats(d, out):
             v = big[g]
             lines.append("%s, largest grid (%d threads = depth 0): %d launches, avg %.1f us, min %.1f, max %.1f"
                          % (key, g, len(v), sum(v) / len(v), min(v), max(v)))
+    # by (kernel, grid): one row per multigrid depth, and how much of the wall span the GPU sat idle between kernels
+    by = {}
+    for r in tr:
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("somar::", "")
+        key = (name, int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1))
+        by.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    lines += ["", "| kernel | grid threads | calls | total ms | avg us |", "|---|---|---|---|---|"]
+    for (name, g), v in sorted(by.items(), key=lambda kv: -sum(kv[1]))[:28]:
+        lines.append("| %s | %d | %d | %.2f | %.1f |" % (name, g, len(v), sum(v) / 1e3, sum(v) / len(v)))
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in tr)
+    # the steady-state tail: the last half of the dispatches (the timed loop), gaps under 1 ms only (host pauses excluded)
+    tail = ev[len(ev) // 2:]
+    busy = sum(e - s_ for s_, e in tail)
+    gaps = [tail[i + 1][0] - max(x[1] for x in tail[max(0, i - 3):i + 1]) for i in range(len(tail) - 1)]
+    small = [g for g in gaps if 0 < g < 1e6]
+    lines += ["", "last half of the dispatches: busy %.2f ms, idle between kernels %.2f ms in %d gaps (median %.1f us)"
+              % (busy / 1e6, sum(small) / 1e6, len(small), (sorted(small)[len(small) // 2] / 1e3) if small else 0.0)]
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
