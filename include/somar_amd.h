@@ -444,6 +444,19 @@ int somar_leptic_finalize(somar_leptic_t* h);
 /* phi += leptic correction for L[phi] = rhs on the level's resident phi / rhs */
 int somar_leptic_solve(somar_leptic_t* h, int homogeneous, somar_leptic_stats_t* stats);
 
+/* AMRLepticSolver (calculus/LepticSolver/AMRLepticSolver.cpp:68-672; AMRPressureSolver.cpp:383-403, 542-550 when
+ * s_useAMRLepticSolver is set): the composite iteration of somar_amr_solve with LevelLepticSolver::solve in place of
+ * relax and of the base level's multigrid cycle.  somar_amr_enable_leptic (after somar_amr_finalize) defines one leptic level
+ * solver per level on the level's own operator, homogeneous, no coarse phi (init, :185-195); levels must consist of
+ * vertically complete columns (refinement ratios (r, r, 1)).  base_from_restricted = 0 is the reference as written: the
+ * base level solves a_uberCorrection from a_uberResidual and contributes nothing to the finer levels (:444-449), so a
+ * multi-level solve drifts after its first cycles; 1 (NOT the reference) feeds the base level the restricted residual, as
+ * MappedAMRMultiGrid::AMRVCycle does.  Stats: exit_status bitfield and history as somar_amr_solve; status 2 ("blew up") is
+ * never raised, the reference only prints there (:384-388). */
+int somar_amr_enable_leptic(somar_amr_t* a, const somar_leptic_params_t* lp, int base_from_restricted);
+int somar_amr_solve_leptic(somar_amr_t* a, int l_max, int l_base, int zero_phi, int force_homogeneous, somar_stats_t* stats);
+int somar_amr_leptic_stats(somar_amr_t* a, int level, somar_leptic_stats_t* stats); /* of the level's LAST leptic solve */
+
 /* one-process-per-GPU transport (RCCL over xGMI).  The unique id is created on rank 0 and
  * distributed by the launcher (torch.distributed store / MPI / file). */
 #define SOMAR_COMM_ID_BYTES 128

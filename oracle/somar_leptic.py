@@ -20,7 +20,15 @@ flat <-> horizontal re-layouts are identities; diagonal OR non-diagonal metric (
 terms in computeHorizRHS after extrapAllGhosts + exchanges, the vertical boundary data of levelVertHorizGradient, the
 vertically averaged horizontal block J g^{ab}, a, b < 2, as a 9-point flat problem solved at EVERY order); Neumann (or any non-periodic) physical
 boundaries in the vertical and non-periodic horizontal directions (the reference never fills the face gradient on
-a periodic horizontal boundary, LevelLepticSolver.cpp:997-1001 + :1056-1061); no coarse-fine boundary.
+a periodic horizontal boundary, LevelLepticSolver.cpp:997-1001 + :1056-1061); coarse-fine boundaries on the LATERAL sides
+of the columns only (homogeneousCFInterp / ExtrapolateCFEV in computeHorizRHS, :1003-1012; the J-scaled operator, the full
+multigrid and the flat problem carry the level's CFRegion and dxCrse, :216-266, :381) -- with the reference's (2,2,1)
+refinements a fine level's columns always span the domain, so the CF vertical ends of LepticLapackVerticalSolver never occur.
+
+  AMRLepticSolver (AMRLepticSolver.cpp:68-196 define/init, :200-424 solve*, :430-529 AMRVCycle, :535-672 residuals):
+  the composite V-cycle of MappedAMRMultiGrid with LevelLepticSolver::solve in place of relax, restated as written --
+  including that the base level solves for a_uberCorrection from a_uberResidual (not from the restricted m_residual) and
+  that m_correction[l_base] stays zero, so nothing is prolonged from the base level (:444-449, :486-487).
 Parity unpinned w.r.t. reference tests: the reference ships none; pinned by the
 analytic known answers in tests/test_oracle_leptic.py.
 """
@@ -29,6 +37,7 @@ import ctypes as C
 import numpy as np
 
 from . import somar_oracle as so
+from . import somar_amr as sa
 
 EXIT_NONE, EXIT_CONVERGE, EXIT_ITER, EXIT_HANG, EXIT_DIVERGE, EXIT_KABOOM = -1, 0, 1, 2, 3, 4
 
@@ -74,8 +83,13 @@ class LevelLepticSolver:
         assert normType == 0, "only the max norm (the reference's default) is restated"
         self.maxOrder, self.hang, self.normType, self.horizRhsTol = maxOrder, hang, normType, horizRhsTol
         op = self.origOp = origOp
-        assert op.cf is None and op.ndim == 3
+        assert op.ndim == 3
         self.isDiagonal = op.isDiagonal
+        # m_CFRegion.define(m_grids, m_domain), m_dxCrse = lepticOpPtr->getDxCrse()                 :164, :216-217
+        self.cf, self.dxCrse = op.cf, op.dxCrse
+        if self.cf is not None:
+            for (i, d, s_), (gb, m) in self.cf.ivs.items():
+                assert d != 2 or m is None, "coarse-fine vertical ends (LepticLapackVerticalSolver) are not restated"
         dom, grids, dx = op.domain, op.grids, op.dx
         self.domain, self.grids, self.dx = dom, grids, dx
         domBox = dom.box
@@ -88,7 +102,8 @@ class LevelLepticSolver:
         self.Jinv1 = so.LevelData(grids, 1, (0, 0, 0), fill=1.0)
         # full 3-D MG solver (also supplies m_opPtr: alpha 0, beta 1)            :254-300
         fac = so.Factory(dom, grids, dx, op.bc, self.Jgup, self.Jinv1, alpha=0.0, beta=1.0, isDiagonal=op.isDiagonal, ndim=3,
-                         maxDepth=fl["maxDepth"], precondIters=fl["precond"], relaxMode=fl["relaxMode"])
+                         maxDepth=fl["maxDepth"], precondIters=fl["precond"], relaxMode=fl["relaxMode"],
+                         dxCrse=self.dxCrse, cf=self.cf)
         bot = so.BiCGStab(imax=flb["imax"], numRestarts=flb["numRestarts"], normType=normType, hang=1e-8)
         self.mgSolver = so.AMRMultiGrid(fac, bot, fl["maxDepth"])
         self.mgSolver.imin = fl["imin"]
@@ -100,9 +115,10 @@ class LevelLepticSolver:
         # horizontal structures                                                   :304-432
         self.flatGrids, hJg, hJinv = vert_avg_metric(grids, self.Jgup, domBox, op.isDiagonal)
         self.horizDomain = so.Domain(flatten_box(domBox, domBox.lo[2]), dom.periodic)
+        hcf = sa.CFRegion(self.flatGrids, self.horizDomain) if self.cf is not None else None
         hfac = so.Factory(self.horizDomain, self.flatGrids, dx, so.BCHolder(), hJg, hJinv, alpha=0.0, beta=1.0,
                           isDiagonal=op.isDiagonal, ndim=2, maxDepth=hz["maxDepth"], precondIters=hz["precond"],
-                          relaxMode=hz["relaxMode"])
+                          relaxMode=hz["relaxMode"], dxCrse=self.dxCrse, cf=hcf)   # forceDxCrse(m_dxCrse), :381
         hbot = so.BiCGStab(imax=hzb["imax"], eps=hzb["eps"], numRestarts=hzb["numRestarts"], hang=hzb["hang"],
                            normType=normType)
         self.horizSolver = so.AMRMultiGrid(hfac, hbot, hz["maxDepth"])
@@ -157,6 +173,8 @@ class LevelLepticSolver:
             return
         # extrapAllGhosts(phi, 2) only matters on faces whose gradient is then overwritten by boundary data or
         # which the exchange refills; the exchange supplies the neighbour values
+        if self.cf is not None:
+            self.cf.homogeneous_cf_interp(phi, self.dx, self.dxCrse, (1, 1, 1))   # :1005
         so.exchange(phi, dom, phi.ghost)
         for i, g in enumerate(self.grids):
             Nz = g.size()[2]
@@ -202,7 +220,12 @@ class LevelLepticSolver:
                 for side in (0, 1):
                     so.extrapolate_face_no_ev(phi[i], phi[i], valid, d, side, 2)
                 valid = valid.growDir(d, 1)
+        if self.cf is not None:
+            self.cf.homogeneous_cf_interp(phi, self.dx, self.dxCrse, (1, 1, 1))   # :1005
         so.exchange(phi, dom, phi.ghost)
+        if self.cf is not None:
+            self.cf.extrapolate_cf_ev(phi, 2, (1, 1, 1))                          # :1008-1013
+            so.exchange(phi, dom, phi.ghost)
         for i, g in enumerate(self.grids):
             Nz = g.size()[2]
             dzScale = 1.0 / float(Nz)
@@ -363,3 +386,126 @@ class LevelLepticSolver:
             for i, g in enumerate(grids):
                 a_phi[i].view(g)[...] += phiTotal[i].view(g) * 1.0
         return self.exitStatus
+
+
+
+class AMRLepticSolver(sa.AMRComposite):
+    """AMRLepticSolver (calculus/LepticSolver/AMRLepticSolver.cpp): the level operators, CF interpolators and flux
+    registers are MappedAMRMultiGrid's (AMRnewOp per level, :68-110); every level owns a LevelLepticSolver defined
+    homogeneous with no coarse phi (:185-195)."""
+
+    def __init__(self, levels, refRatios, bc, leptic=None, baseFromRestricted=False, **kw):
+        """baseFromRestricted=True is NOT the reference: the base level then solves m_correction from m_residual, as
+        MappedAMRMultiGrid's V-cycle does (MappedAMRMultiGrid.H:1517-1521); it exists to show that the divergence of the
+        reference's multi-level leptic V-cycle comes from that one branch and not from the restated pieces."""
+        super().__init__(levels, refRatios, bc, sa.NoOpSolver(), **kw)
+        self.baseFromRestricted = baseFromRestricted
+        self.lepticParams = dict(leptic or {})
+        self.eps, self.hang, self.normThresh, self.imin, self.iterMax, self.numMG = 1e-6, 1e-15, 1e-30, 5, 20, 1   # :30-42
+        self.leptic = [None] * len(levels)
+
+    def set_solver_parameters(self, numMG, iterMax, eps, hang, normThresh):   # :55-66
+        self.numMG, self.iterMax, self.eps, self.hang, self.normThresh = numMG, iterMax, eps, hang, normThresh
+
+    def init(self, phi, rhs, l_max, l_base):
+        """init, :163-196"""
+        n = len(self.levels)
+        self.m_correction, self.m_residual, self.m_resC = [None] * n, [None] * n, [None] * n
+        for i in range(l_base, l_max + 1):
+            self.m_correction[i] = so.ld_create(phi[i])
+            self.m_residual[i] = so.ld_create(rhs[i])
+            if i != l_base:
+                r = self.ops[i].refToCoarser
+                self.m_resC[i] = so.LevelData([g.coarsen(r) for g in self.ops[i].grids], rhs[i].ncomp, rhs[i].ghost)
+        self.leptic = [None] * n
+        for l in range(l_base, l_max + 1):
+            self.leptic[l] = LevelLepticSolver(self.ops[l], **self.lepticParams)
+
+    def amr_vcycle(self, uberCorrection, uberResidual, ilev, l_max, l_base):
+        """AMRVCycle, :430-529"""
+        if ilev == l_max:
+            for l in range(l_base, l_max + 1):
+                so.ld_assign(self.m_residual[l], uberResidual[l])
+                so.ld_set(self.m_correction[l], 0.0)
+        if l_max == l_base:
+            self.leptic[l_base].solve(uberCorrection[ilev], uberResidual[ilev], True)
+        elif ilev == l_base:
+            if self.baseFromRestricted:
+                self.leptic[l_base].solve(self.m_correction[ilev], self.m_residual[ilev], True)
+            else:
+                self.leptic[l_base].solve(uberCorrection[ilev], uberResidual[ilev], True)   # as written, :444-449
+            so.ld_incr(uberCorrection[ilev], self.m_correction[ilev], 1.0)
+        else:
+            self.leptic[ilev].solve(self.m_correction[ilev], self.m_residual[ilev], True)
+            so.ld_incr(uberCorrection[ilev], self.m_correction[ilev], 1.0)
+            so.ld_set(self.m_correction[ilev - 1], 0.0)
+            self.compute_amr_residual_level(self.m_residual, uberCorrection, uberResidual, l_max, l_base, ilev - 1, True)
+            self.amr_restrict_s(ilev, self.m_resC[ilev], self.m_residual[ilev], self.m_correction[ilev],
+                                self.m_correction[ilev - 1], uberCorrection[ilev])
+            sa.copy_valid(self.m_residual[ilev - 1], self.m_resC[ilev])
+            for _ in range(self.numMG):
+                self.amr_vcycle(uberCorrection, uberResidual, ilev - 1, l_max, l_base)
+            self.amr_prolong_s(ilev, self.m_correction[ilev], self.m_correction[ilev - 1])
+            self.amr_update_residual(ilev, self.m_residual[ilev], self.m_correction[ilev], self.m_correction[ilev - 1])
+            dCorr = uberCorrection[ilev]
+            so.ld_set(dCorr, 0.0)
+            self.leptic[ilev].solve(dCorr, self.m_residual[ilev], True)
+            so.ld_incr(self.m_correction[ilev], dCorr, 1.0)
+            so.ld_assign(uberCorrection[ilev], self.m_correction[ilev])
+
+    def solve(self, phi, rhs, l_max, l_base, zeroPhi=True, forceHomogeneous=False):
+        """solve -> init + solveNoInit + solveNoInitResid, :200-424"""
+        self.init(phi, rhs, l_max, l_base)
+        lowlim = l_base - 1 if l_base > 0 else l_base
+        nl = len(self.levels)
+        uberCorrection, uberResidual, bestPhi = [None] * nl, [None] * nl, [None] * nl
+        for l in range(lowlim, l_max + 1):
+            uberCorrection[l] = so.ld_create(phi[l])
+            if l >= l_base:
+                uberResidual[l] = so.ld_create(rhs[l])
+            bestPhi[l] = so.ld_create(phi[l])
+        if zeroPhi:
+            for l in range(l_base, l_max + 1):
+                so.ld_set(phi[l], 0.0)
+        for l in range(lowlim, l_max + 1):
+            so.ld_assign(bestPhi[l], phi[l])
+        initial_rnorm = self.compute_amr_residual(uberResidual, phi, rhs, l_max, l_base, forceHomogeneous)
+        if self.convergenceMetric != 0.0:
+            initial_rnorm = self.convergenceMetric
+        rnorm, norm_last, best_rnorm = initial_rnorm, 2 * initial_rnorm, initial_rnorm
+        useBestPhi = False
+        it = 0
+        self.history = [rnorm]
+        goNorm = rnorm > self.normThresh
+        goRedu = rnorm > self.eps * initial_rnorm
+        goIter = it < self.iterMax
+        goHang = it < self.imin or rnorm < (1 - self.hang) * norm_last
+        while goIter and goRedu and goHang and goNorm:
+            norm_last = rnorm
+            self.amr_vcycle(uberCorrection, uberResidual, l_max, l_max, l_base)
+            for l in range(l_base, l_max + 1):   # postVCycleOps, :535-563
+                so.ld_incr(phi[l], uberCorrection[l], 1.0)
+                so.ld_set(uberCorrection[l], 0.0)
+            rnorm = self.compute_amr_residual(uberResidual, phi, rhs, l_max, l_base, forceHomogeneous)
+            it += 1
+            self.history.append(rnorm)
+            if rnorm <= best_rnorm:
+                best_rnorm = rnorm
+                for l in range(l_base, l_max + 1):
+                    so.ld_assign(bestPhi[l], phi[l])
+                useBestPhi = False
+            else:
+                useBestPhi = True
+            goNorm = rnorm > self.normThresh
+            goRedu = rnorm > self.eps * initial_rnorm
+            goIter = it < self.iterMax
+            goHang = it < self.imin or rnorm < (1 - self.hang) * norm_last
+        if useBestPhi:
+            rnorm = best_rnorm
+            for l in range(l_base, l_max + 1):
+                so.ld_assign(phi[l], bestPhi[l])
+        if rnorm > 10.0 * initial_rnorm and rnorm > 10.0 * self.eps:
+            raise RuntimeError("kaboom")   # :377-382; the "blew up" case below it only prints (:384-388)
+        self.exitStatus = int(not goRedu) + int(not goIter) * 2 + int(not goHang) * 4 + int(not goNorm) * 8
+        self.iters, self.final_rnorm, self.initial_rnorm = it, rnorm, initial_rnorm
+        return rnorm

@@ -156,6 +156,9 @@ _SIGS = {
     "somar_leptic_part": [_H, C.c_int, C.POINTER(_H)],
     "somar_leptic_finalize": [_H],
     "somar_leptic_solve": [_H, C.c_int, C.POINTER(LepticStats)],
+    "somar_amr_enable_leptic": [_H, C.POINTER(LepticParams), C.c_int],
+    "somar_amr_solve_leptic": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
+    "somar_amr_leptic_stats": [_H, C.c_int, C.POINTER(LepticStats)],
     "somar_comm_unique_id": [C.POINTER(C.c_ubyte)],
     "somar_comm_create": [C.POINTER(_H), C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int],
     "somar_comm_create_shm": [C.POINTER(_H), C.c_char_p, C.c_int, C.c_int, C.c_longlong],
@@ -300,6 +303,26 @@ class AMRPressureSolver:
         st = Stats()
         _ck(lib().somar_amr_solve(self._amr, lmax, lbase, int(zeroPhi), int(forceHomogeneous), C.byref(st)))
         return self._stats(st)
+
+    # -- AMRLepticSolver (AMRPressureSolver::s_useAMRLepticSolver) ------------------------------------------------
+    def enableLeptic(self, params=None, baseFromRestricted=False):
+        """One leptic level solver per level (AMRLepticSolver::init); params: LepticParams or None for the defaults.
+        baseFromRestricted=True is NOT the reference (see include/somar_amd.h)."""
+        if params is None:
+            params = LepticParams()
+            _ck(lib().somar_leptic_params_default(C.byref(params)))
+        _ck(lib().somar_amr_enable_leptic(self._amr, C.byref(params), int(baseFromRestricted)))
+
+    def solveAMRLeptic(self, lmax, lbase, zeroPhi=True, forceHomogeneous=False):
+        st = Stats()
+        _ck(lib().somar_amr_solve_leptic(self._amr, lmax, lbase, int(zeroPhi), int(forceHomogeneous), C.byref(st)))
+        return self._stats(st)
+
+    def lepticStats(self, level):
+        st = LepticStats()
+        _ck(lib().somar_amr_leptic_stats(self._amr, level, C.byref(st)))
+        return {"exitStatus": st.exit_status, "orders": st.orders, "horizSolves": st.horiz_solves,
+                "usedFullSolver": bool(st.used_full_solver), "resNorms": [st.res_norms[i] for i in range(st.nres)]}
 
     def solveAMRHost(self, phi, rhs, lmin, lmax, zeroPhi=True, forceHomogeneous=False, phi_ghost=(1, 1, 1),
                      rhs_ghost=(0, 0, 0)):

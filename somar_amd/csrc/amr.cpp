@@ -940,6 +940,33 @@ void AMRSolver::vcycle(double* const* uberCorr, double* const* uberRes, int ilev
             launch_set(st_, corr_[l], n, 0.0);
         }
     const long long n = S[ilev]->level(0).field_elems;
+    if (lepticCycle_) {
+        // AMRLepticSolver::AMRVCycle, AMRLepticSolver.cpp:430-529
+        auto lsolve = [&](int l, double* phi, const double* rhs) { leptic_[l]->solve_fields(phi, rhs, lepStats_[l]); };
+        if (l_max == l_base) {
+            lsolve(l_base, uberCorr[ilev], uberRes[ilev]);
+        } else if (ilev == l_base) {
+            if (lepticBaseFromRestricted_) lsolve(l_base, corr_[ilev], res_[ilev]);
+            else lsolve(l_base, uberCorr[ilev], uberRes[ilev]);   // as written, :444-449
+            launch_incr(st_, uberCorr[ilev], corr_[ilev], 1.0, n);
+        } else {
+            lsolve(ilev, corr_[ilev], res_[ilev]);
+            launch_incr(st_, uberCorr[ilev], corr_[ilev], 1.0, n);
+            launch_set(st_, corr_[ilev - 1], S[ilev - 1]->level(0).field_elems, 0.0);
+            compute_residual_level(res_.data(), uberCorr, uberRes, l_max, l_base, ilev - 1, true);
+            amr_restrict(ilev, res_[ilev], corr_[ilev], corr_[ilev - 1], uberCorr[ilev]);
+            assign_coarse_residual(ilev, res_[ilev - 1]);
+            for (int img = 0; img < prm.numMG; ++img) vcycle(uberCorr, uberRes, ilev - 1, l_max, l_base);
+            amr_prolong(ilev, corr_[ilev], corr_[ilev - 1]);
+            amr_update_residual(ilev, res_[ilev], corr_[ilev], corr_[ilev - 1]);
+            double* dCorr = uberCorr[ilev];
+            launch_set(st_, dCorr, n, 0.0);
+            lsolve(ilev, dCorr, res_[ilev]);
+            launch_incr(st_, corr_[ilev], dCorr, 1.0, n);
+            launch_copy(st_, uberCorr[ilev], corr_[ilev], n);
+        }
+        return;
+    }
     if (l_max == l_base) {
         S[l_base]->vcycle(uberCorr[ilev], uberRes[ilev]);
     } else if (ilev == l_base) {
@@ -964,7 +991,38 @@ void AMRSolver::vcycle(double* const* uberCorr, double* const* uberRes, int ilev
     }
 }
 
+void AMRSolver::enable_leptic(const LepticParams& lp, bool baseFromRestricted)
+{
+    SOMAR_CHECK(finalized_, "enable_leptic before finalize");
+    lepticBaseFromRestricted_ = baseFromRestricted;
+    leptic_.clear();
+    lepStats_.assign(nlevels(), LepticStats());
+    for (int l = 0; l < nlevels(); ++l) {
+        leptic_.emplace_back(new LepticSolver(comm_, st_));
+        leptic_.back()->attach(S[l].get(), lp);
+    }
+}
+
 void AMRSolver::solve(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous, SolveStats& s)
+{
+    lepticCycle_ = false;
+    solve_impl(l_max, l_base, zeroPhi, forceHomogeneous, s);
+}
+
+void AMRSolver::solve_leptic(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous, SolveStats& s)
+{
+    SOMAR_CHECK((int)leptic_.size() == nlevels(), "solve_leptic before enable_leptic");
+    lepticCycle_ = true;
+    try {
+        solve_impl(l_max, l_base, zeroPhi, forceHomogeneous, s);
+    } catch (...) {
+        lepticCycle_ = false;
+        throw;
+    }
+    lepticCycle_ = false;
+}
+
+void AMRSolver::solve_impl(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous, SolveStats& s)
 {
     SOMAR_CHECK(finalized_, "solve before finalize");
     SOMAR_CHECK(0 <= l_base && l_base <= l_max && l_max < nlevels(), "bad level range");
@@ -1036,7 +1094,8 @@ void AMRSolver::solve(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous
     }
     s.status = 0;
     if (rnorm > 10. * initial_rnorm && rnorm > 10. * prm.eps) s.status = 1;
-    else if (!somethingConverged && rnorm >= initial_rnorm && rnorm >= prm.eps) s.status = 2;
+    else if (!lepticCycle_ && !somethingConverged && rnorm >= initial_rnorm && rnorm >= prm.eps)
+        s.status = 2;   // AMRLepticSolver only prints here (AMRLepticSolver.cpp:384-388)
     s.exitStatus = int(!goRedu) + int(!goIter) * 2 + int(!goHang) * 4 + int(!goNorm) * 8;
     s.iters = iter;
     s.initial_rnorm = initial_rnorm;

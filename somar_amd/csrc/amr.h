@@ -17,6 +17,7 @@
 #include <memory>
 #include <vector>
 
+#include "leptic.h"
 #include "solver.h"
 
 namespace somar {
@@ -148,6 +149,14 @@ public:
     // MappedAMRMultiGrid::solve on the resident phi/rhs of levels l_base..l_max (phi of l_base-1 supplies the
     // CF values when l_base > 0)
     void solve(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous, SolveStats& st);
+    // AMRLepticSolver (calculus/LepticSolver/AMRLepticSolver.cpp): the same composite iteration with LevelLepticSolver::solve
+    // in place of relax / the base level's multigrid cycle.  enable_leptic (after finalize) builds one leptic level solver per
+    // level on the level's own operator (init, :185-195).  baseFromRestricted = false is the reference: the base level solves
+    // a_uberCorrection from a_uberResidual and its m_correction stays zero (:444-449); true (NOT the reference) feeds it the
+    // restricted residual as MappedAMRMultiGrid's V-cycle does.
+    void enable_leptic(const LepticParams& lp, bool baseFromRestricted);
+    void solve_leptic(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous, SolveStats& st);
+    const LepticStats& leptic_stats(int l) const { return lepStats_.at(l); }
 
     // BaseProjector<T>::levelProject -> project(lmin = lmax = l) (projection/BaseProjectorI.H:176-366) on the resident
     // velocity of level l: centring 0 = LevelMACProjector (vel()), 1 = LevelCCProjector (cc_vel(), level l-1's supplies the
@@ -202,6 +211,10 @@ public:
     void set_inspector(Inspector f, void* user) { inspector_ = f; inspector_user_ = user; }
 
 private:
+    std::vector<std::unique_ptr<LepticSolver>> leptic_;
+    std::vector<LepticStats> lepStats_;   // of each level's last leptic solve
+    bool lepticCycle_ = false, lepticBaseFromRestricted_ = false;
+    void solve_impl(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous, SolveStats& st);
     Inspector inspector_ = nullptr;
     void* inspector_user_ = nullptr;
     void build_link(int l);

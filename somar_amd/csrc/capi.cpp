@@ -1167,6 +1167,57 @@ int somar_leptic_params_default(somar_leptic_params_t* p)
     API_END
 }
 
+static LepticParams to_leptic_params(const somar_leptic_params_t* lp)
+{
+    LepticParams P;
+    if (lp) {
+        P.maxOrder = lp->max_order; P.normType = lp->norm_type;
+        P.hang = lp->hang; P.horizRhsTol = lp->horiz_rhs_tol; P.domainHeight = lp->domain_height;
+        P.horiz = to_params(&lp->horiz);
+        P.full = to_params(&lp->full);
+    }
+    return P;
+}
+
+static void fill_leptic_stats(const LepticStats& S, somar_leptic_stats_t* stats)
+{
+    std::memset(stats, 0, sizeof(*stats));
+    stats->exit_status = S.exitStatus;
+    stats->orders = S.orders;
+    stats->horiz_solves = S.horizSolves;
+    stats->used_full_solver = S.usedFullSolver;
+    stats->nres = (int)std::min<size_t>(S.resNorms.size(), SOMAR_MAX_HISTORY);
+    for (int i = 0; i < stats->nres; ++i) stats->res_norms[i] = S.resNorms[i];
+    fill_stats(S.horizStats, &stats->horiz);
+    fill_stats(S.fullStats, &stats->full);
+}
+
+// ---- AMRLepticSolver on an AMR hierarchy (AMRLepticSolver.cpp) -------------------------------------------------------------
+int somar_amr_enable_leptic(somar_amr_t* a, const somar_leptic_params_t* lp, int base_from_restricted)
+{
+    API_BEGIN
+    SOMAR_CHECK(a, "null argument");
+    a->amr->enable_leptic(to_leptic_params(lp), base_from_restricted != 0);
+    API_END
+}
+
+int somar_amr_solve_leptic(somar_amr_t* a, int l_max, int l_base, int zero_phi, int force_homogeneous, somar_stats_t* stats)
+{
+    API_BEGIN
+    SolveStats st;
+    a->amr->solve_leptic(l_max, l_base, zero_phi != 0, force_homogeneous != 0, st);
+    fill_stats(st, stats);
+    API_END
+}
+
+int somar_amr_leptic_stats(somar_amr_t* a, int level, somar_leptic_stats_t* stats)
+{
+    API_BEGIN
+    SOMAR_CHECK(a && stats && level >= 0 && level < a->amr->nlevels(), "bad argument");
+    fill_leptic_stats(a->amr->leptic_stats(level), stats);
+    API_END
+}
+
 int somar_leptic_create(somar_leptic_t** out, const int* domain_lo, const int* domain_hi, const int* periodic,
                         const double* dx, const int* bc_type, int nboxes, const int* boxes, const int* owner,
                         double alpha, double beta, const somar_params_t* level_prm, const somar_leptic_params_t* lp,
@@ -1190,13 +1241,7 @@ int somar_leptic_create(somar_leptic_t** out, const int* domain_lo, const int* d
             SOMAR_CHECK(bx[a].lo[d] >= dom.lo[d] && bx[a].hi[d] <= dom.hi[d], "box outside the domain");
         for (size_t b = a + 1; b < bx.size(); ++b) SOMAR_CHECK((bx[a] & bx[b]).empty(), "boxes overlap");
     }
-    LepticParams P;
-    if (lp) {
-        P.maxOrder = lp->max_order; P.normType = lp->norm_type;
-        P.hang = lp->hang; P.horizRhsTol = lp->horiz_rhs_tol; P.domainHeight = lp->domain_height;
-        P.horiz = to_params(&lp->horiz);
-        P.full = to_params(&lp->full);
-    }
+    const LepticParams P = to_leptic_params(lp);
     somar_leptic* h = new somar_leptic;
     try {
         h->lep = new LepticSolver(static_cast<Comm*>(comm));
@@ -1271,17 +1316,7 @@ int somar_leptic_solve(somar_leptic_t* h, int homogeneous, somar_leptic_stats_t*
     SOMAR_CHECK(h, "null argument");
     LepticStats S;
     h->lep->solve(homogeneous != 0, S);
-    if (stats) {
-        std::memset(stats, 0, sizeof(*stats));
-        stats->exit_status = S.exitStatus;
-        stats->orders = S.orders;
-        stats->horiz_solves = S.horizSolves;
-        stats->used_full_solver = S.usedFullSolver;
-        stats->nres = (int)std::min<size_t>(S.resNorms.size(), SOMAR_MAX_HISTORY);
-        for (int i = 0; i < stats->nres; ++i) stats->res_norms[i] = S.resNorms[i];
-        fill_stats(S.horizStats, &stats->horiz);
-        fill_stats(S.fullStats, &stats->full);
-    }
+    if (stats) fill_leptic_stats(S, stats);
     API_END
 }
 

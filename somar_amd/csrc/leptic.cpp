@@ -30,9 +30,10 @@ LepticParams::LepticParams()
     full.spaceDim = 3;
 }
 
-LepticSolver::LepticSolver(Comm* comm) : comm_(comm)
+LepticSolver::LepticSolver(Comm* comm, hipStream_t shared) : comm_(comm)
 {
-    SOMAR_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    if (shared) { st_ = shared; own_stream_ = false; }
+    else SOMAR_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
 }
 
 LepticSolver::~LepticSolver()
@@ -41,36 +42,59 @@ LepticSolver::~LepticSolver()
     hipFree(d_avg);
     horiz_.reset();
     vert_.reset();
-    orig_.reset();
-    if (st_) hipStreamDestroy(st_);
+    own_orig_.reset();
+    if (st_ && own_stream_) hipStreamDestroy(st_);
 }
 
 void LepticSolver::define(const IBox& domain, const bool periodic[3], const double dx[3], const int bc_type[3][2],
                           const std::vector<IBox>& boxes, const std::vector<int>& owner, double alpha, double beta,
-                          const SolverParams& prmOrig, const LepticParams& lp)
+                          const SolverParams& prmOrig, const LepticParams& lp, const double* dxCrse)
 {
     SOMAR_CHECK(!orig_, "leptic solver already defined");
     prm = lp;
     SOMAR_CHECK(prmOrig.spaceDim == 3, "the leptic solver is implemented for space_dim 3");
+    own_orig_.reset(new PressureSolver(comm_, st_));
+    orig_ = own_orig_.get();
+    orig_->define(domain, periodic, dx, bc_type, boxes, owner, alpha, beta, prmOrig, dxCrse);
+    define_inner(domain, periodic, dx, bc_type, boxes, owner, dxCrse, prmOrig.eps);
+}
+
+void LepticSolver::attach(PressureSolver* orig, const LepticParams& lp)
+{
+    SOMAR_CHECK(!orig_, "leptic solver already defined");
+    SOMAR_CHECK(orig && orig->prm.spaceDim == 3, "the leptic solver is implemented for space_dim 3");
+    prm = lp;
+    orig_ = orig;
+    const Level& L = orig->level(0);
+    define_inner(L.domain, L.periodic, L.dx, L.bc_type, L.boxes, L.owner, orig->dx_crse(), orig->prm.eps);
+    finalize();
+}
+
+void LepticSolver::define_inner(const IBox& domain, const bool periodic[3], const double dx[3], const int bc_type[3][2],
+                                const std::vector<IBox>& boxes, const std::vector<int>& owner, const double* dxCrse,
+                                double probeEps)
+{
     SOMAR_CHECK(prm.normType == 0, "the leptic solver offers the max norm (norm_type 0, the reference's default)");
     SOMAR_CHECK(prm.maxOrder >= 0, "max_order must be >= 0");
     SOMAR_CHECK(domain.size(2) >= 2, "the vertical line solver wants at least two cells per column");
     for (int d = 0; d < 3; ++d)
         SOMAR_CHECK(!periodic[d], "the leptic solver does not support periodic directions (neither does the reference: "
                                   "LevelLepticSolver.cpp:997-1001, 1315)");
+    // columns that span the domain: every coarse-fine boundary is then a lateral one (the CF vertical ends of
+    // LepticLapackVerticalSolver, LevelLepticSolverF.ChF:161-283, cannot occur)
     for (const IBox& b : boxes)
         SOMAR_CHECK(b.lo[2] == domain.lo[2] && b.hi[2] == domain.hi[2],
                     "the leptic solver wants vertically complete boxes (LepticBoxUtils::createVerticalSolverGrids layout)");
+    hasCF_ = dxCrse != nullptr;
     for (int d = 0; d < 3; ++d) dx_[d] = dx[d];
     H_ = prm.domainHeight > 0.0 ? prm.domainHeight : dx[2] * domain.size(2);
-    orig_.reset(new PressureSolver(comm_, st_));
-    orig_->define(domain, periodic, dx, bc_type, boxes, owner, alpha, beta, prmOrig);
-    // the J-scaled operator and the full multigrid on it (alpha 0, beta 1)            LevelLepticSolver.cpp:214-300
+    // the J-scaled operator and the full multigrid on it (alpha 0, beta 1), with the level's CFRegion and dxCrse
+    //                                                                                   LevelLepticSolver.cpp:214-300
     SolverParams pf = prm.full;
     pf.spaceDim = 3;
     vert_.reset(new PressureSolver(comm_, st_));
-    vert_->define(domain, periodic, dx, bc_type, boxes, owner, 0.0, 1.0, pf);
-    vert_->probe_eps = prmOrig.eps;
+    vert_->define(domain, periodic, dx, bc_type, boxes, owner, 0.0, 1.0, pf, dxCrse);
+    vert_->probe_eps = probeEps;
     // flat grids: the same boxes, one cell thick at the domain's lowest vertical index           :304-432
     IBox flatDom = domain;
     flatDom.hi[2] = flatDom.lo[2];
@@ -84,8 +108,8 @@ void LepticSolver::define(const IBox& domain, const bool periodic[3], const doub
     SolverParams ph = prm.horiz;
     ph.spaceDim = 2;
     horiz_.reset(new PressureSolver(comm_, st_));
-    horiz_->define(flatDom, periodic, dx, bc_type, flat, owner, 0.0, 1.0, ph);
-    horiz_->probe_eps = prmOrig.eps;
+    horiz_->define(flatDom, periodic, dx, bc_type, flat, owner, 0.0, 1.0, ph, dxCrse);   // forceDxCrse(m_dxCrse), :381
+    horiz_->probe_eps = probeEps;
 }
 
 void LepticSolver::finalize()
@@ -97,7 +121,7 @@ void LepticSolver::finalize()
         vert_->make_full();
         horiz_->make_full();
     }
-    orig_->finalize();
+    if (own_orig_) orig_->finalize();
     Level& O = orig_->level(0);
     Level& V = vert_->level(0);
     Level& F = horiz_->level(0);
@@ -145,8 +169,13 @@ void LepticSolver::set_zero_avg(double* hphi)
 
 void LepticSolver::solve(bool homogeneous, LepticStats& S)
 {
+    (void)homogeneous;  // physical BCs are homogeneous Neumann, CF values homogeneous (m_crsePhiPtr == NULL): nothing differs
+    solve_fields(orig_->phi(), orig_->rhs(), S);
+}
+
+void LepticSolver::solve_fields(double* a_phi, const double* a_rhs, LepticStats& S)
+{
     SOMAR_CHECK(finalized_, "solve before finalize");
-    (void)homogeneous;  // physical BCs are homogeneous Neumann and there is no coarse-fine boundary: nothing differs
     PressureSolver &Os = *orig_, &Vs = *vert_, &Hs = *horiz_;
     Level& V = Vs.level(0);
     Level& F = Hs.level(0);
@@ -162,7 +191,7 @@ void LepticSolver::solve(bool homogeneous, LepticStats& S)
     S = LepticStats();
 
     // J * residual of the level's own operator                                                   :697-715
-    Os.residual(0, rhsP, Os.phi(), Os.rhs());
+    Os.residual(0, rhsP, a_phi, a_rhs);
     launch_lep_divide(st_, ct, nct, tj, V.dev, rhsP, rhsP, Os.level(0).dev.jinv);
     double resNorm = Vs.norm(0, rhsP, prm.normType);
     S.resNorms.push_back(resNorm);
@@ -193,9 +222,15 @@ void LepticSolver::solve(bool homogeneous, LepticStats& S)
         if (useHorizPhi) {
             if (full_) {
                 Vs.run_aux_program(0, vertPhi);   // extrapAllGhosts(phi, 2): every ghost of every box, then the exchanges
+                if (hasCF_) V.cf_homog(vertPhi, st_);   // homogeneousCFInterp                                     :1005
                 V.exchange(vertPhi, st_);
+                if (hasCF_) {                           // ExtrapolateCFEV + the corner exchange                  :1008-1013
+                    Vs.cf_ev(0, vertPhi);
+                    V.exchange(vertPhi, st_);
+                }
                 launch_lep_hgrad_full(st_, ct, nct, tj, V.dev, F.dev, vertPhi, h_gx, h_gy);
             } else {
+                if (hasCF_) V.cf_homog(vertPhi, st_);
                 V.exchange(vertPhi, st_);
                 launch_lep_hgrad(st_, ct, nct, tj, V.dev, F.dev, vertPhi, h_gx, h_gy);
             }
@@ -242,7 +277,7 @@ void LepticSolver::solve(bool homogeneous, LepticStats& S)
         if (!full_) useHorizPhi = false;  // LevelGeometry::isDiagonal()
     }
 
-    if (exitStatus != 4) launch_lep_axpy(st_, ct, nct, tj, V.dev, Os.phi(), f_total, 1.0);
+    if (exitStatus != 4) launch_lep_axpy(st_, ct, nct, tj, V.dev, a_phi, f_total, 1.0);
     S.exitStatus = exitStatus;
     sync();
 }

@@ -10,7 +10,8 @@
 // as fallback, and the flat 2-D multigrid on the vertically averaged metric.  Everything in between is column
 // kernels (leptic_kernels.hip); the host sequences launches and reads back one norm per order.
 //
-// Scope: diagonal or non-diagonal metric, one AMR level (no coarse-fine boundary), homogeneous-Neumann physical boundaries,
+// Scope: diagonal or non-diagonal metric; coarse-fine boundaries on the lateral sides of the columns (the level of an AMR
+// hierarchy refined by (r, r, 1): attach()); homogeneous-Neumann physical boundaries,
 // non-periodic directions (the reference leaves the averaged gradient on a periodic horizontal boundary face
 // unset, LevelLepticSolver.cpp:997-1001, and refuses a periodic vertical, :1315).
 #pragma once
@@ -43,11 +44,15 @@ struct LepticStats {
 
 class LepticSolver {
 public:
-    explicit LepticSolver(Comm* comm = nullptr);
+    // shared: run on the caller's stream (an AMR hierarchy's) instead of an own one
+    explicit LepticSolver(Comm* comm = nullptr, hipStream_t shared = nullptr);
     ~LepticSolver();
     void define(const IBox& domain, const bool periodic[3], const double dx[3], const int bc_type[3][2],
                 const std::vector<IBox>& boxes, const std::vector<int>& owner, double alpha, double beta,
-                const SolverParams& prmOrig, const LepticParams& lp);
+                const SolverParams& prmOrig, const LepticParams& lp, const double* dxCrse = nullptr);
+    // LevelLepticSolver::define(opPtr, homogeneous) on the FINALIZED operator of an AMR level (AMRLepticSolver::init,
+    // AMRLepticSolver.cpp:185-195): layout, spacing, boundary types and dxCrse are the operator's; not owned
+    void attach(PressureSolver* orig, const LepticParams& lp);
     // the level's own operator: metric, phi and rhs go through it (somar_solver_* entry points)
     PressureSolver& orig() { return *orig_; }
     PressureSolver& vert() { return *vert_; }
@@ -55,6 +60,8 @@ public:
     void finalize();  // after the metric of orig() is set: finalizes all three solvers
     // LevelLepticSolver::solve(phi, rhs) on orig()'s resident phi / rhs: phi += leptic correction
     void solve(bool homogeneous, LepticStats& S);
+    // the same on any two fields of the level's layout: phi += leptic correction for rhs - L[phi] (homogeneous CF / BC values)
+    void solve_fields(double* phi, const double* rhs, LepticStats& S);
     void sync() { SOMAR_HIP(hipStreamSynchronize(st_)); }
     LepticParams prm;
 
@@ -62,7 +69,11 @@ private:
     void set_zero_avg(double* hphi);
     Comm* comm_;
     hipStream_t st_ = nullptr;
-    std::unique_ptr<PressureSolver> orig_, vert_, horiz_;
+    void define_inner(const IBox& domain, const bool periodic[3], const double dx[3], const int bc_type[3][2],
+                      const std::vector<IBox>& boxes, const std::vector<int>& owner, const double* dxCrse, double probeEps);
+    PressureSolver* orig_ = nullptr;
+    std::unique_ptr<PressureSolver> own_orig_, vert_, horiz_;
+    bool own_stream_ = true, hasCF_ = false;
     double dx_[3] = {1, 1, 1};
     double H_ = 1.0;
     bool horizRemoveAvg_ = false;

@@ -51,6 +51,7 @@ public:
                 const std::vector<IBox>& boxes, const std::vector<int>& owner, double alpha, double beta,
                 const SolverParams& prm, const double* dxCrse = nullptr);
     bool has_cf() const { return hasCF_; }
+    const double* dx_crse() const { return hasCF_ ? dxCrse_ : nullptr; }
     // Diagonal metric of one LOCAL patch in Chombo FRA layout: Jg_aa on faces(valid,a), Jinv on valid.
     void set_metric_ortho(int patch, const double* jg0, const double* jg1, const double* jg2, const double* jinv);
     // Non-diagonal metric of one LOCAL patch: jgD = J g^{Db} on faces(valid, D), 3 components, component slowest

@@ -103,14 +103,14 @@ def make_full_amr_levels(so, am, n, L, periodic, ratios, fine_boxes, cbox=8, ndi
 
 
 def make_gpu_amr(levels, ratios, alpha=0.0, beta=1.0, pre=2, post=2, bottom=2, maxDepth=-1, relaxMode=1, ndim=3,
-                 full=False):
+                 full=False, imin=None, imax=None):
     """The same hierarchy (oracle AMRLevel list) on the GPU through the C ABI."""
     from somar_amd import AMRPressureSolver
     s = AMRPressureSolver()
     s.setSpaceDim(ndim)
     p = s._p
-    s.setAMRMGParameters(p.imin, p.imax, p.eps, maxDepth, p.num_smooth_precond, pre, post, bottom, p.precond_mode,
-                         relaxMode, p.num_mg, p.hang, p.norm_thresh, 0)
+    s.setAMRMGParameters(p.imin if imin is None else imin, p.imax if imax is None else imax, p.eps, maxDepth,
+                         p.num_smooth_precond, pre, post, bottom, p.precond_mode, relaxMode, p.num_mg, p.hang, p.norm_thresh, 0)
     L0 = levels[0]
     s.defineAMR(L0.domain.box.lo, L0.domain.box.hi, L0.domain.periodic, L0.dx, ratios,
                 [[(g.lo, g.hi) for g in L.grids] for L in levels], alpha=alpha, beta=beta)

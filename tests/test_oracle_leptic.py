@@ -161,3 +161,67 @@ def test_leptic_nondiagonal_reduces_to_diagonal_when_cross_terms_vanish():
     np.testing.assert_allclose(lepF.resNorms[:2], lepD.resNorms[:2], rtol=1e-12)
     assert lepF.resNorms[3] < 0.1 * lepD.resNorms[3]
     assert not lepF.usedFullSolver and lepF.resNorms[-1] < 1e-5 * lepF.resNorms[0]
+
+
+# ---- lateral coarse-fine boundaries and the composite leptic solver ------------------------------------------------
+def _two_level(variant="cartesian", L=(1.0, 1.0, 0.005)):
+    from oracle import somar_amr as sa
+    from tests.helpers import make_amr_levels
+    n, ratios = (32, 32, 8), [(2, 2, 1)]
+    fine = [[so.Box((16, 16, 0), (31, 47, 7)), so.Box((32, 16, 0), (47, 47, 7))]]   # two column boxes, CF on all lateral sides
+    levels = make_amr_levels(so, sa, n, L, (False, False, False), ratios, fine, variant=variant, cbox=(16, 16, 8))
+    return levels, ratios
+
+
+def _compatible_rhs(amr, levels, lmax):
+    phi = [so.random_field(Lv.grids, 5 + l, (1, 1, 1), Lv.domain.box) for l, Lv in enumerate(levels)]
+    zero = [so.LevelData(Lv.grids, 1) for Lv in levels]
+    rhs = [so.LevelData(Lv.grids, 1) for Lv in levels]
+    amr.init(phi, zero, lmax, 0)
+    amr.compute_amr_residual(rhs, phi, zero, lmax, 0, True)
+    for r in rhs:
+        so.ld_scale(r, -1.0)
+    return rhs
+
+
+def test_level_leptic_with_lateral_cf_converges_on_the_fine_level():
+    """A refined level alone (l_base = l_max = 1, homogeneous CF values): columns span the domain, the flat problem is a
+    Dirichlet-like one (no mean removal), every order gains about eps^2."""
+    from oracle import somar_amr as sa
+    levels, ratios = _two_level()
+    comp = sa.AMRComposite(levels, ratios, so.BCHolder(), so.BiCGStab())
+    op = comp.ops[1]
+    assert op.cf is not None and op.cf.has_cf()
+    lep = sl.LevelLepticSolver(op, maxOrder=4, domainHeight=0.005)
+    assert not lep.horizRemoveAvg
+    rhs = so.random_field(levels[1].grids, 9, domainBox=levels[1].domain.box)
+    phi = so.LevelData(levels[1].grids, 1, (1, 1, 1))
+    status = lep.solve(phi, rhs, True)
+    h = lep.resNorms
+    assert status == sl.EXIT_ITER and not lep.usedFullSolver
+    assert h[-1] < 1e-4 * h[0] and all(b < 0.5 * a for a, b in zip(h[1:], h[2:]))
+    res = so.LevelData(levels[1].grids, 1, (0, 0, 0))
+    op.residual(res, phi, rhs, True)
+    jres = max(float(np.max(np.abs(res[i].view(g) / op.Jinv[i].view(g)))) for i, g in enumerate(levels[1].grids))
+    assert abs(jres - h[-1]) <= 1e-9 * h[0]
+
+
+def test_amr_leptic_vcycle_as_written_and_with_the_base_level_fed_the_restricted_residual():
+    """AMRLepticSolver::AMRVCycle as written solves the base level from a_uberResidual and never prolongs its correction
+    (AMRLepticSolver.cpp:444-449): the first cycle still removes the bulk of the residual, later ones drift.  Fed the
+    restricted residual (not the reference) the same pieces converge by five orders per cycle."""
+    levels, ratios = _two_level()
+    amr = sl.AMRLepticSolver(levels, ratios, so.BCHolder(), leptic=dict(maxOrder=3, domainHeight=0.005))
+    rhs = _compatible_rhs(amr, levels, 1)
+    sol = [so.LevelData(Lv.grids, 1, (1, 1, 1)) for Lv in levels]
+    amr.iterMax = 3
+    amr.solve(sol, rhs, 1, 0)
+    h = amr.history
+    assert amr.iters == 3 and h[1] < 1e-3 * h[0] and h[3] > h[2]
+    fixed = sl.AMRLepticSolver(levels, ratios, so.BCHolder(), leptic=dict(maxOrder=3, domainHeight=0.005),
+                               baseFromRestricted=True)
+    sol2 = [so.LevelData(Lv.grids, 1, (1, 1, 1)) for Lv in levels]
+    fixed.iterMax = 3
+    fixed.solve(sol2, rhs, 1, 0)
+    g = fixed.history
+    assert g[1] < 1e-4 * g[0] and g[2] < 1e-2 * g[1]
