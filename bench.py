@@ -17,7 +17,9 @@ profiled pass of the same V-cycle.
 One JSON line on rank 0.  Besides the contract keys it carries
   roofline      dominant kernel (k_gsrb_fused, depth 0): algorithmic bytes (64 B/cell per red+black sweep)
                 / HIP-event launch duration on the solver's stream, against the 8 TB/s HBM3E peak; `measured_copy_GBs`
-                = device-to-device copy bandwidth measured in this run (read + written bytes / time)
+                = device-to-device copy bandwidth measured in this run (read + written bytes / time);
+                `measured_stream_mix_GBs` = a bare kernel with the sweep's own stream mix (6 read streams + 1 write
+                stream of 512^3 doubles, no stencil, no halo; somar_diag_stream_probe) measured in this run
   cpu_baseline  the reference's V-cycle call sequence orchestrated in C over the restated Fortran kernels
                 (oracle/cpu_vcycle.c; the reference itself cannot be built here), OpenMP over k-slabs, timed on the
                 REAL 512^3 problem on all host cores given to this process and on 1 core, with the measured STREAM triad
@@ -320,6 +322,9 @@ def main():
     n = args.n
     failures = []
     copy_gbs = measured_copy_gbs(torch) if rank == 0 else None
+    # what this device streams for the fused sweep's own mix of streams (6 reads + 1 write, no stencil): the practical ceiling
+    mix_gbs = api.stream_probe(2, 512 ** 3, 10) if rank == 0 else None
+    read_gbs = api.stream_probe(1, 512 ** 3, 10) if rank == 0 else None
 
     # ---------------- headline: C2, stretched diagonal metric ----------------
     gpu, boxes, t_def = build_c2(api, synthetic, n, world, rank, comm, "stretched")
@@ -384,6 +389,8 @@ def main():
                      "algorithmic_bytes_per_launch": b_launch * cells_local, "launches": n_gsrb,
                      "avg_launch_ms": t_gsrb * 1e3, "measured_copy_GBs": copy_gbs,
                      "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
+                     "measured_stream_mix_GBs": mix_gbs, "measured_read_GBs": read_gbs,
+                     "frac_of_stream_mix": (achieved / mix_gbs) if mix_gbs else None,
                      "note": "per-launch HIP events from a separate profiled pass of the same V-cycle (5 cycles); the timed "
                              "loop runs without events"},
         "gsrb_cell_updates_per_s": cells_local / t_sweep * world,

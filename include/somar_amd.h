@@ -457,6 +457,11 @@ int somar_amr_enable_leptic(somar_amr_t* a, const somar_leptic_params_t* lp, int
 int somar_amr_solve_leptic(somar_amr_t* a, int l_max, int l_base, int zero_phi, int force_homogeneous, somar_stats_t* stats);
 int somar_amr_leptic_stats(somar_amr_t* a, int level, somar_leptic_stats_t* stats); /* of the level's LAST leptic solve */
 
+/* Diagnostics, no reference counterpart: what this device streams for a given mix of streams, in GB/s of algorithmic bytes
+ * -- kind 0 copy (16 B/cell), 1 read (8 B/cell), 2 six reads + one write (56 B/cell: the fused GSRB sweep's mix without
+ * stencil or halo).  bench.py reports kind 2 as the ceiling its roofline fraction is to be read against. */
+int somar_diag_stream_probe(int kind, long long cells, int reps, double* gbs);
+
 /* one-process-per-GPU transport (RCCL over xGMI).  The unique id is created on rank 0 and
  * distributed by the launcher (torch.distributed store / MPI / file). */
 #define SOMAR_COMM_ID_BYTES 128

@@ -159,6 +159,7 @@ _SIGS = {
     "somar_amr_enable_leptic": [_H, C.POINTER(LepticParams), C.c_int],
     "somar_amr_solve_leptic": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
     "somar_amr_leptic_stats": [_H, C.c_int, C.POINTER(LepticStats)],
+    "somar_diag_stream_probe": [C.c_int, C.c_longlong, C.c_int, _PD],
     "somar_comm_unique_id": [C.POINTER(C.c_ubyte)],
     "somar_comm_create": [C.POINTER(_H), C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int],
     "somar_comm_create_shm": [C.POINTER(_H), C.c_char_p, C.c_int, C.c_int, C.c_longlong],
@@ -833,6 +834,13 @@ def comm_create_shm(name, rank, nranks, outbox_bytes=64 << 20):
     h = _H()
     _ck(lib().somar_comm_create_shm(C.byref(h), name.encode(), rank, nranks, outbox_bytes))
     return h
+
+
+def stream_probe(kind, cells=512 ** 3, reps=10):
+    """GB/s this device streams for a stream mix (0 copy, 1 read, 2 six reads + one write); diagnostics"""
+    g = C.c_double()
+    _ck(lib().somar_diag_stream_probe(kind, cells, reps, C.byref(g)))
+    return g.value
 
 
 def comm_selftest(h):

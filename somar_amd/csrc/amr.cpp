@@ -51,7 +51,9 @@ AMRSolver::AMRSolver(Comm* comm) : comm_(comm ? comm : &self_)
 AMRSolver::~AMRSolver()
 {
     if (st_) hipStreamSynchronize(st_);
+    for (double* f : spare_) Level::free_field(f);
     links_.clear();
+    leptic_.clear();
     S.clear();
     if (st_) hipStreamDestroy(st_);
 }
@@ -115,6 +117,17 @@ void AMRSolver::finalize()
         corr_[l] = S[l]->amr_field(0);
         res_[l] = S[l]->amr_field(1);
     }
+    {
+        const char* e = getenv("SOMAR_AMR_PLAIN");
+        lean_ = !(e && atoi(e) != 0);
+    }
+    spare_.assign(n, nullptr);
+    rcur_ = res_;
+    visits_.assign(n, 0);
+    // the residual of an intermediate level ping-pongs between res_ and spare_ in AMRUpdateResidual (the finest level's
+    // between the caller's uberResidual and res_; the base level's is never updated)
+    if (lean_)
+        for (int l = 1; l + 1 < n; ++l) spare_[l] = S[l]->level(0).alloc_field();
     links_.resize(n);
     for (int l = 1; l < n; ++l) build_link(l);
     SOMAR_HIP(hipDeviceSynchronize());  // tables were uploaded with plain hipMemcpy (null stream)
@@ -858,6 +871,15 @@ void AMRSolver::amr_restrict(int l, double* residual, double* correction, const 
                              double* scratch)
 {
     AMRLink& K = *links_[l];
+    if (lean_ && !lepticCycle_) {
+        // residual and average in one pass where the marching kernel applies; the scratch (the caller's uberCorrection, rebuilt
+        // at the end of the level's branch and not read before) then stays untouched
+        if (coarseCorrection) interp_cf(l, correction, coarseCorrection);
+        if (S[l]->residual_restrict_i(K.cfl->dev, K.resC, correction, residual, K.r)) return;
+        S[l]->residual_i(0, scratch, correction, residual, true);
+        launch_restrict(st_, K.cfl->dev, S[l]->level(0).dev, K.resC, scratch, K.r);
+        return;
+    }
     amr_residual_nf(l, scratch, correction, coarseCorrection, residual);
     launch_restrict(st_, K.cfl->dev, S[l]->level(0).dev, K.resC, scratch, K.r);
 }
@@ -918,27 +940,39 @@ double AMRSolver::compute_residual(double* const* resid, double* const* phi, dou
 }
 
 // MappedAMRMultiGrid::relax, MappedAMRMultiGrid.H:736-766
-void AMRSolver::level_relax(int l, double* corr, const double* res, int iters)
+// corr_zero: corr is to be taken as all zeros whatever it holds (the fused sweep then neither reads nor needs it zeroed)
+void AMRSolver::level_relax(int l, double* corr, const double* res, int iters, bool corr_zero)
 {
     if (!S[l]->forcedRatios.empty()) {
+        if (corr_zero) launch_set(st_, corr, S[l]->level(0).field_elems, 0.0);
         S[l]->prm.num_smooth_down = prm.num_smooth_down;
         S[l]->prm.num_smooth_up = prm.num_smooth_up;
         S[l]->prm.num_smooth_bottom = prm.num_smooth_bottom;
         S[l]->prm.numMG = prm.numMG;
         S[l]->mini_vcycle(corr, res);
     } else {
-        S[l]->relax(0, corr, res, iters);
+        S[l]->relax(0, corr, res, iters, corr_zero);
     }
 }
 
 void AMRSolver::vcycle(double* const* uberCorr, double* const* uberRes, int ilev, int l_max, int l_base)
 {
-    if (ilev == l_max)
+    const bool lean = lean_ && !lepticCycle_ && l_max != l_base;
+    if (ilev == l_max) {
+        // m_residual := uberResidual, m_correction := 0 on every level (MappedAMRMultiGrid.H:1504-1510).  Lean: the copies of
+        // the levels below the finest are dead stores (computeAMRResidualLevel + assignCopier rewrite m_residual before it
+        // is read, the coarser m_correction is zeroed again before its level is entered); the finest level reads the
+        // caller's uberResidual in place and starts its first sweep from an implicit zero.
         for (int l = l_base; l <= l_max; ++l) {
+            rcur_[l] = res_[l];
+            visits_[l] = 0;
+            if (lean) continue;
             const long long n = S[l]->level(0).field_elems;
             launch_copy(st_, res_[l], uberRes[l], n);
             launch_set(st_, corr_[l], n, 0.0);
         }
+        if (lean) rcur_[l_max] = uberRes[l_max];
+    }
     const long long n = S[ilev]->level(0).field_elems;
     if (lepticCycle_) {
         // AMRLepticSolver::AMRVCycle, AMRLepticSolver.cpp:430-529
@@ -973,6 +1007,34 @@ void AMRSolver::vcycle(double* const* uberCorr, double* const* uberRes, int ilev
         S[l_base]->vcycle(corr_[ilev], res_[ilev], true);  // m_correction was set to zero above
         launch_incr(st_, uberCorr[ilev], corr_[ilev], 1.0, n);
     } else {
+        if (lean) {
+            // the same operations on the same values, minus the whole-field passes that only move or clear data:
+            //  - m_correction[ilev] is all zeros on the level's first visit in this cycle: the first sweep starts from an
+            //    implicit zero (no memset, no read);
+            //  - restriction: residual + average in one marching pass (amr_restrict);
+            //  - AMRUpdateResidual writes the new residual into the level's other buffer instead of copying the old one;
+            //  - dCorr (= uberCorrection[ilev]) likewise starts as an implicit zero;
+            //  - m_correction += dCorr and uberCorrection := m_correction in one pass.
+            double* R = rcur_[ilev];
+            level_relax(ilev, corr_[ilev], R, prm.num_smooth_down, visits_[ilev] == 0);
+            ++visits_[ilev];
+            launch_incr(st_, uberCorr[ilev], corr_[ilev], 1.0, n);
+            launch_set(st_, corr_[ilev - 1], S[ilev - 1]->level(0).field_elems, 0.0);
+            rcur_[ilev - 1] = res_[ilev - 1];
+            compute_residual_level(res_.data(), uberCorr, uberRes, l_max, l_base, ilev - 1, true);
+            amr_restrict(ilev, R, corr_[ilev], corr_[ilev - 1], uberCorr[ilev]);
+            assign_coarse_residual(ilev, res_[ilev - 1]);
+            for (int img = 0; img < prm.numMG; ++img) vcycle(uberCorr, uberRes, ilev - 1, l_max, l_base);
+            amr_prolong(ilev, corr_[ilev], corr_[ilev - 1]);
+            double* Rn = (R == res_[ilev]) ? spare_[ilev] : res_[ilev];
+            SOMAR_CHECK(Rn, "internal: no spare residual buffer on this level");
+            amr_residual_nf(ilev, Rn, corr_[ilev], corr_[ilev - 1], R);   // AMRUpdateResidual
+            rcur_[ilev] = Rn;
+            double* dCorr = uberCorr[ilev];
+            level_relax(ilev, dCorr, Rn, prm.num_smooth_up, true);
+            launch_incr_copy(st_, corr_[ilev], dCorr, 1.0, n);
+            return;
+        }
         level_relax(ilev, corr_[ilev], res_[ilev], prm.num_smooth_down);
         launch_incr(st_, uberCorr[ilev], corr_[ilev], 1.0, n);
         launch_set(st_, corr_[ilev - 1], S[ilev - 1]->level(0).field_elems, 0.0);

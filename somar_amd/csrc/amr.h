@@ -197,7 +197,7 @@ public:
     double compute_residual(double* const* resid, double* const* phi, double* const* rhs, int l_max, int l_base,
                             bool homogeneous);
     void vcycle(double* const* uberCorr, double* const* uberRes, int ilev, int l_max, int l_base);
-    void level_relax(int l, double* corr, const double* res, int iters);
+    void level_relax(int l, double* corr, const double* res, int iters, bool corr_zero = false);
     double* corr(int l) { return corr_[l]; }
     double* res(int l) { return res_[l]; }
     AMRLink& link(int l) { return *links_[l]; }
@@ -228,6 +228,11 @@ private:
     std::vector<std::unique_ptr<AMRLink>> links_;  // links_[l] ties l to l-1 (links_[0] unused)
     std::vector<std::array<int, 3>> ratios_;
     std::vector<double*> corr_, res_;
+    // lean V-cycle (default; SOMAR_AMR_PLAIN=1 restores the reference's pass-by-pass structure): where level l's residual
+    // currently lives (res_[l], spare_[l], or -- finest level -- the caller's uberResidual, which is then never written)
+    std::vector<double*> spare_, rcur_;
+    std::vector<int> visits_;
+    bool lean_ = true;
     bool finalized_ = false;
 };
 

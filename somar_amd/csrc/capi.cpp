@@ -1154,6 +1154,53 @@ int somar_altered_jgup(long long n, double* dest, const double* nsq_fc, const do
     API_END
 }
 
+// Diagnostics: the streaming rate of this device for a given stream mix, GB/s of algorithmic bytes (kind 0: 16 B/cell,
+// 1: 8 B/cell, 2: 56 B/cell), best of the workgroup counts tried.  bench.py reports kind 2 next to the fused sweep's rate.
+int somar_diag_stream_probe(int kind, long long cells, int reps, double* gbs)
+{
+    API_BEGIN
+    SOMAR_CHECK(gbs && kind >= 0 && kind <= 2 && cells >= 1024 && cells % 2 == 0 && reps >= 1, "bad argument");
+    double* buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int nin = kind == 2 ? 6 : 1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    try {
+        for (int q = 0; q < nin; ++q) {
+            SOMAR_HIP(hipMalloc(&buf[q], cells * sizeof(double)));
+            SOMAR_HIP(hipMemset(buf[q], 0, cells * sizeof(double)));
+        }
+        for (int q = nin; q < 6; ++q) buf[q] = buf[0];
+        SOMAR_HIP(hipMalloc(&buf[6], cells * sizeof(double)));
+        SOMAR_HIP(hipMemset(buf[6], 0, cells * sizeof(double)));
+        SOMAR_HIP(hipEventCreate(&e0));
+        SOMAR_HIP(hipEventCreate(&e1));
+        const double bytes = (kind == 0 ? 16.0 : kind == 1 ? 8.0 : 56.0) * (double)cells;
+        double best = 0.0;
+        for (int wgs : {1024, 2048, 8192, 32768}) {
+            for (int w = 0; w < 2; ++w) launch_stream_probe(nullptr, kind, wgs, buf, buf[6], cells);
+            SOMAR_HIP(hipDeviceSynchronize());
+            SOMAR_HIP(hipEventRecord(e0, nullptr));
+            for (int r = 0; r < reps; ++r) launch_stream_probe(nullptr, kind, wgs, buf, buf[6], cells);
+            SOMAR_HIP(hipEventRecord(e1, nullptr));
+            SOMAR_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            SOMAR_HIP(hipEventElapsedTime(&ms, e0, e1));
+            best = std::max(best, bytes * reps / (ms * 1e-3) * 1e-9);
+        }
+        *gbs = best;
+    } catch (...) {
+        for (int q = 0; q < nin; ++q) hipFree(buf[q]);
+        hipFree(buf[6]);
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+        throw;
+    }
+    for (int q = 0; q < nin; ++q) hipFree(buf[q]);
+    hipFree(buf[6]);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    API_END
+}
+
 // ---- leptic level solver -----------------------------------------------------------------------------------
 int somar_leptic_params_default(somar_leptic_params_t* p)
 {

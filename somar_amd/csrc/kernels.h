@@ -84,9 +84,12 @@ void launch_publish(hipStream_t st, const double* src, int n, double* host_dst, 
                     unsigned long long seq);
 void launch_copy(hipStream_t st, double* d, const double* s, long long n);
 void launch_incr(hipStream_t st, double* y, const double* x, double a, long long n);
+void launch_incr_copy(hipStream_t st, double* y, double* x, double a, long long n);  // y += a*x; x = y
 void launch_scale(hipStream_t st, double* y, double a, long long n);
 void launch_mul(hipStream_t st, double* y, const double* x, long long n);   // y *= x elementwise
 void launch_axby(hipStream_t st, double* z, const double* x, const double* y, double a, double b, long long n);
+// streaming probe (diagnostics): kind 0 copy, 1 read, 2 six reads + one write; in6: six arrays of `cells` doubles
+void launch_stream_probe(hipStream_t st, int kind, int workgroups, double* const* in6, double* out, long long cells);
 // (min, max) per (patch, k-chunk) of a over the valid cells (dir < 0) or valid dir-faces: out[2 * npatches * MM_CH] (device)
 constexpr int MM_CH = 64;
 void launch_minmax_valid(hipStream_t st, const LevelDev& L, const double* a, int dir, double* out);

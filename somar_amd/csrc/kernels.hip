@@ -551,6 +551,15 @@ __global__ void k_incr(double* __restrict__ y, const double* __restrict__ x, dou
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         y[i] = y[i] + a * x[i];
 }
+// y += a*x; x = y   (AMRVCycle's "m_correction += dCorr; uberCorrection = m_correction" in one pass)
+__global__ void k_incr_copy(double* __restrict__ y, double* __restrict__ x, double a, long long n)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double t = y[i] + a * x[i];
+        y[i] = t;
+        x[i] = t;
+    }
+}
 __global__ void k_scale(double* __restrict__ y, double a, long long n)
 {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -898,6 +907,10 @@ void launch_incr(hipStream_t st, double* y, const double* x, double a, long long
 {
     hipLaunchKernelGGL(k_incr, dim3(flat_grid(n)), dim3(256), 0, st, y, x, a, n);
 }
+void launch_incr_copy(hipStream_t st, double* y, double* x, double a, long long n)
+{
+    hipLaunchKernelGGL(k_incr_copy, dim3(flat_grid(n)), dim3(256), 0, st, y, x, a, n);
+}
 void launch_scale(hipStream_t st, double* y, double a, long long n)
 {
     hipLaunchKernelGGL(k_scale, dim3(flat_grid(n)), dim3(256), 0, st, y, a, n);
@@ -1001,6 +1014,35 @@ __global__ __launch_bounds__(256) void k_minmax_valid(const PatchDesc* __restric
 void launch_minmax_valid(hipStream_t st, const LevelDev& L, const double* a, int dir, double* out)
 {
     if (L.npatches) hipLaunchKernelGGL(k_minmax_valid, dim3(L.npatches, MM_CH), dim3(64, 4), 0, st, L.patches, a, dir, out);
+}
+
+// ---- what this device streams (somar_diag_stream_probe) -----------------------------------------------------------------------
+// kind 0: copy (1 read + 1 write stream); 1: read only; 2: the fused sweep's mix, 6 read streams + 1 write stream, no stencil,
+// no halo -- the ceiling the sweep's achieved bandwidth is to be read against (tools/bw_probe.hip measures more variants)
+typedef double v2d_probe __attribute__((ext_vector_type(2)));
+template <int KIND>
+__global__ __launch_bounds__(256) void k_stream_probe(const v2d_probe* __restrict__ a, const v2d_probe* __restrict__ b,
+                                                      const v2d_probe* __restrict__ c, const v2d_probe* __restrict__ d,
+                                                      const v2d_probe* __restrict__ e, const v2d_probe* __restrict__ f,
+                                                      v2d_probe* __restrict__ o, long long n)
+{
+    v2d_probe acc = {0.0, 0.0};
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
+        if (KIND == 0) o[i] = a[i];
+        else if (KIND == 1) acc += a[i];
+        else o[i] = a[i] + b[i] + c[i] + d[i] + e[i] + f[i];
+    }
+    if (KIND == 1 && acc.x + acc.y == 1.2345e300) o[0] = acc;
+}
+void launch_stream_probe(hipStream_t st, int kind, int workgroups, double* const* in6, double* out, long long cells)
+{
+    const v2d_probe* p[6];
+    for (int q = 0; q < 6; ++q) p[q] = reinterpret_cast<const v2d_probe*>(in6[q]);
+    v2d_probe* o = reinterpret_cast<v2d_probe*>(out);
+    const long long n = cells / 2;
+    if (kind == 0) hipLaunchKernelGGL(k_stream_probe<0>, dim3(workgroups), dim3(256), 0, st, p[0], p[1], p[2], p[3], p[4], p[5], o, n);
+    else if (kind == 1) hipLaunchKernelGGL(k_stream_probe<1>, dim3(workgroups), dim3(256), 0, st, p[0], p[1], p[2], p[3], p[4], p[5], o, n);
+    else hipLaunchKernelGGL(k_stream_probe<2>, dim3(workgroups), dim3(256), 0, st, p[0], p[1], p[2], p[3], p[4], p[5], o, n);
 }
 
 }  // namespace somar

@@ -766,6 +766,18 @@ double* PressureSolver::amr_field(int which)
     return f_amr[which];
 }
 
+bool PressureSolver::residual_restrict_i(const LevelDev& C, double* crse, double* phi, const double* rhs, const int r[3])
+{
+    Level& F = *lev[0];
+    for (int d = 0; d < 3; ++d)
+        if (r[d] != 1 && r[d] != 2) return false;
+    if (!(F.valid_cells_global >= march_min_cells_ && F.active[2] && !full_)) return false;
+    F.exchange(phi, st_);  // exchangeComplete, as residual_i
+    if (diri_) apply_diri(0, phi, true);
+    launch_resid_restrict(st_, F.d_rtiles, F.nrtiles, F.dev, C, crse, phi, rhs, r, F.dxProduct, nullptr);
+    return true;
+}
+
 void PressureSolver::restrict_residual(int d, double* resCoarse, double* phiFine, const double* rhsFine)
 {
     // restrictResidual, MappedAMRPoissonOp.cpp:1281-1304

@@ -115,6 +115,10 @@ public:
     void residual(int d, double* out, double* phi, const double* rhs, bool homogeneous = true);   // homogeneous CF ghosts, then residual_i
     void apply_op(int d, double* out, double* phi, bool homogeneous = true);
     void residual_i(int d, double* out, double* phi, const double* rhs, bool homogeneous = true); // residualI: CF ghosts as they are
+    // residualI of depth 0 and its J-weighted average (MAPPEDAVERAGE2) onto the layout C coarsened by r, in ONE marching pass
+    // (the fine residual is never stored); CF ghosts of phi as they are.  false: not available here (non-diagonal metric, small
+    // level, a ratio entry other than 1 or 2) -- the caller then runs residual_i + launch_restrict
+    bool residual_restrict_i(const LevelDev& C, double* crse, double* phi, const double* rhs, const int r[3]);
     void apply_op_i(int d, double* out, double* phi, bool homogeneous = true);
     // Dirichlet sides (EllipticConstDiriBCGhostClass, BCInterface/EllipticBCUtils.cpp:382-424): values per
     // {loX,hiX,loY,hiY,loZ,hiZ}, before finalize.  Such a solver runs the two-pass / direct-load kernels.

@@ -40,8 +40,10 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
     gpu.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, pre, post, bottom, p.precond_mode, 1, p.num_mg,
                            p.hang, p.norm_thresh, 0)
     t0 = time.perf_counter()
+    tm = {"host_metric_arrays": 0.0, "metric_upload": 0.0}
     gpu.defineAMR((0, 0, 0), tuple(a - 1 for a in n0), H["periodic"], dx0, ratios, levels,
                   owners_per_level=H["owners"], comm=comm)
+    tm["define_tables"] = time.perf_counter() - t0
     cells = []
     dxl = list(dx0)
     for l, v in enumerate(gpu.levels):
@@ -53,13 +55,26 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
             shp = [h - a + 1 for a, h in zip(lo, hi)]
             tot += shp[0] * shp[1] * shp[2]
             if H.get("metric") == "terrain":
+                ta = time.perf_counter()
                 jg, jinv = synthetic.terrain_metric(lo, hi, dxl, H["L"])   # non-diagonal: the 19-point kernels
+                tb = time.perf_counter()
                 v.setMetricFull(q, jg[0], jg[1], jg[2], jinv)
+                tm["host_metric_arrays"] += tb - ta
+                tm["metric_upload"] += time.perf_counter() - tb
                 continue
+            ta = time.perf_counter()
             ones = [np.ones((shp[0] + (d == 0), shp[1] + (d == 1), shp[2] + (d == 2)), order="F") for d in range(3)]
-            v.setMetricOrtho(q, ones[0], ones[1], None if flat else ones[2], np.ones(shp, order="F"))   # Cartesian: J = 1, Jg^aa = 1
+            one_c = np.ones(shp, order="F")
+            tb = time.perf_counter()
+            v.setMetricOrtho(q, ones[0], ones[1], None if flat else ones[2], one_c)   # Cartesian: J = 1, Jg^aa = 1
+            tm["host_metric_arrays"] += tb - ta
+            tm["metric_upload"] += time.perf_counter() - tb
         cells.append(tot)
+    ta = time.perf_counter()
     gpu.finalize()
+    gpu.levels[0].sync()
+    tm["finalize"] = time.perf_counter() - ta
+    build_hierarchy.last_breakdown = {k: round(v, 4) for k, v in tm.items()}
     return gpu, levels, cells, time.perf_counter() - t0, dx0, ratios
 
 
@@ -105,7 +120,7 @@ def main():
         gpu.zeroCovered(l, F.F_SCRATCH)
     r1 = max(v.norm(F.F_SCRATCH, 0) for v in gpu.levels)
     print(json.dumps({"config": args.config, "amr_vcycle_contraction": r1 / r0, "scale": s, "levels": nlev, "cells_per_level": cells,
-                      "boxes_per_level": [len(b) for b in levels], "define_seconds": t_def, "ms_per_amr_vcycle": dt * 1e3,
+                      "boxes_per_level": [len(b) for b in levels], "define_seconds": t_def, "define_breakdown_s": getattr(build_hierarchy, "last_breakdown", None), "ms_per_amr_vcycle": dt * 1e3,
                       "amr_vcycles_per_s": 1.0 / dt, "mg_depth_per_level": [v.depth() for v in gpu.levels],
                       "cell_updates_per_s": sum(cells) * 8 / dt}))
     gpu.undefine()
