@@ -444,6 +444,26 @@ int somar_leptic_finalize(somar_leptic_t* h);
 /* phi += leptic correction for L[phi] = rhs on the level's resident phi / rhs */
 int somar_leptic_solve(somar_leptic_t* h, int homogeneous, somar_leptic_stats_t* stats);
 
+/* The level heat integrators on level `level` of a hierarchy (multi-level part):
+ * MappedLevelBackwardEuler / MappedLevelCrankNicolson::updateSoln, MappedLevelTGA::updateSolnWithTimeIndependentOp
+ * (AMRParabolic/MappedLevelBackwardEuler.cpp:52-158, MappedLevelCrankNicolson.cpp:52-152, MappedLevelTGA.cpp:231-387) with
+ * applyHelm -> AMROperatorNF, solveHelm -> m_solver->solve(phi, rhs, level, level), timeInterp
+ * (MappedBaseLevelHeatSolver.cpp:154-300).  Level handles (somar_amr_level): phiNew = SOMAR_F_PHI (the guess unless
+ * zero_phi), phiOld = SOMAR_F_HEAT_OLD, src = SOMAR_F_HEAT_SRC of `level`; for level > 0 the coarse-fine values are the
+ * linear interpolation in time of level-1's SOMAR_F_HEAT_OLD (a_crsePhiOldPtr, at crse_old_time) and SOMAR_F_PHI
+ * (a_crsePhiNewPtr, at crse_new_time) -- i.e. step level-1 first, then `level`, as the subcycled advance does.  scheme 0 / 1 /
+ * 2 as somar_heat_step; stats = the LAST solve's.  a_flux (incrementFlux: J Grad(phi) of every stage, without beta,
+ * MappedAMRPoissonOp.cpp:2129-2151) accumulates on the level and is read with somar_heat_flux_download, so the adapter can
+ * run MappedLevelFluxRegister::incrementCoarse / incrementFine on its own registers as before; faces on the domain boundary
+ * are not meaningful (no register reads them).
+ * somar_amr_set_alpha_beta = resetSolverAlphaAndBeta on every op of every level.  The hierarchy's own flux-register scales
+ * keep the beta of somar_amr_create: composite operations (somar_amr_solve with l_base < l_max) fail loudly until the
+ * coefficients are back; level solves and somar_amr_heat_step never reflux. */
+int somar_amr_set_alpha_beta(somar_amr_t* a, double alpha, double beta);
+int somar_amr_heat_step(somar_amr_t* a, int level, int scheme, double dt, int zero_phi, double old_time, double crse_old_time,
+                        double crse_new_time, somar_stats_t* stats);
+int somar_heat_flux_download(somar_solver_t* s, int dir, int patch, double* host); /* faces(valid, dir), Fortran order */
+
 /* AMRLepticSolver (calculus/LepticSolver/AMRLepticSolver.cpp:68-672; AMRPressureSolver.cpp:383-403, 542-550 when
  * s_useAMRLepticSolver is set): the composite iteration of somar_amr_solve with LevelLepticSolver::solve in place of
  * relax and of the base level's multigrid cycle.  somar_amr_enable_leptic (after somar_amr_finalize) defines one leptic level

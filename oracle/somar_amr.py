@@ -995,3 +995,141 @@ def level_project(comp, l, vel, phi, dt, centring="mac", velCoarse=None, zeroPhi
             for d in range(nd):
                 vel[i][d].a += dtScale * corr[i][d].a
     return rhs[l]
+
+
+# ----------------------------------------------------------------------------
+# Viscous / diffusive Helmholtz steps on a level of a hierarchy (the multi-level part):
+#   MappedLevelBackwardEuler::updateSoln                    AMRParabolic/MappedLevelBackwardEuler.cpp:52-158
+#   MappedLevelCrankNicolson::updateSoln                    AMRParabolic/MappedLevelCrankNicolson.cpp:52-152
+#   MappedLevelTGA::updateSolnWithTimeIndependentOp         AMRParabolic/MappedLevelTGA.cpp:231-387
+#   applyHelm (AMROperatorNF with the time-interpolated coarse data), solveHelm (m_solver->solve(phi, rhs, l, l)),
+#   incrementFlux, timeInterp, resetSolverAlphaAndBeta      AMRParabolic/MappedBaseLevelHeatSolver.cpp:154-300
+# The flux-register increments after the solve use the caller's registers (AMRNavierStokes owns them) and a_flux, which
+# incrementFlux fills with J Grad(phi) -- getFlux(FluxBox&, ...) applies NO beta, MappedAMRPoissonOp.cpp:2129-2151 -- of
+# every stage: returned here face by face so an adapter can run incrementCoarse / incrementFine as before.
+# ----------------------------------------------------------------------------
+def amr_reset_alpha_beta(comp, a, b):
+    """resetSolverAlphaAndBeta: every op of the solver (all levels, all depths)."""
+    for mg in comp.mg:
+        for op in mg.ops:
+            if not hasattr(op, "aCoef"):
+                op.aCoef, op.bCoef = op.alpha, op.beta
+            op.alpha = a * op.aCoef
+            op.beta = b * op.bCoef
+
+
+def time_interp(oldData, newData, time, oldTime, newTime):
+    """timeInterp, MappedBaseLevelHeatSolver.cpp:273-300"""
+    out = so.ld_create(oldData)
+    so.ld_set(out, 0.0)
+    diff = newTime - oldTime
+    if diff < 1.0e-10:
+        so.ld_incr(out, oldData, 1.0)
+    else:
+        factor = (time - oldTime) / (newTime - oldTime)
+        so.ld_incr(out, oldData, 1.0 - factor)
+        so.ld_incr(out, newData, factor)
+    return out
+
+
+def increment_flux(comp, l, flux, phi, setToZero):
+    """incrementFlux: thisFlux (+)= getFlux(phi) = J Grad(phi) on every face of every box (ghosts of phi as they are)."""
+    op = comp.ops[l]
+    for i, valid in enumerate(op.grids):
+        phiF = phi[i]
+        extrap = so.Fab(phiF.box, phi.ncomp, np.nan)
+        op.fill_extrap(extrap, phiF, 2)
+        for d in range(op.ndim):
+            tmp = so.Fab(valid.faces(d), phi.ncomp, 0.0)
+            op.get_flux_complete(tmp, phiF, extrap, valid.faces(d), i, d)
+            if setToZero:
+                flux[i][d].a[...] = 0.0
+            flux[i][d].a[..., 0] += tmp.a[..., 0]
+
+
+def amr_level_heat(comp, l, scheme, phiNew, phiOld, src, crseOld=None, crseNew=None, oldTime=0.0, crseOldTime=0.0,
+                   crseNewTime=0.0, dt=0.0, zeroPhi=True, flux=None):
+    """One level step on level l of the hierarchy; phi of level l-1 for the coarse-fine values is the time interpolation of
+    (crseOld, crseNew).  scheme 0 backward Euler, 1 Crank-Nicolson, 2 TGA.  flux: optional so.FluxData of level l that
+    receives a_flux.  Returns nothing; comp.history / iters / exitStatus are the LAST solve's."""
+    op = comp.ops[l]
+    nl = len(comp.levels)
+    grids = comp.levels[l].grids
+
+    def coarse_at(t):
+        return time_interp(crseOld, crseNew, t, crseOldTime, crseNewTime) if l > 0 else None
+
+    def apply_helm(ans, phi, phiC, mu, homogeneous):
+        amr_reset_alpha_beta(comp, 1.0, mu * dt)          # m_ops[l]->setAlphaAndBeta(1, mu dt)
+        if phiC is None or l == 0:
+            op.apply_op(ans, phi, homogeneous)
+        else:
+            comp.amr_operator(l, ans, None, phi, phiC, homogeneous)
+
+    def solve_helm(phi, phiC, rhs, mu):
+        if zeroPhi:
+            so.ld_set(phi, 0.0)
+        P, R = [None] * nl, [None] * nl
+        P[l], R[l] = phi, rhs
+        if l > 0:
+            P[l - 1] = phiC
+        amr_reset_alpha_beta(comp, 1.0, -dt * mu)
+        comp.solve(P, R, l, l, zeroPhi=zeroPhi)
+
+    def incr_flux(phi, setToZero):
+        if flux is not None:
+            increment_flux(comp, l, flux, phi, setToZero)
+
+    rhst = so.ld_create(src)
+    so.ld_set(rhst, 0.0)
+    if scheme == 0:
+        phit = so.ld_create(phiNew)
+        so.ld_set(phit, 0.0)
+        if zeroPhi:
+            so.ld_set(phiNew, 0.0)
+        so.ld_incr(phit, phiOld, 1.0)
+        so.ld_incr(rhst, phit, 1.0)
+        coarse = coarse_at(oldTime)                       # as written: a_oldTime, not the new time (:112-113)
+        solve_helm(phiNew, coarse, rhst, 1.0)
+        incr_flux(phiNew, True)
+    elif scheme == 1:
+        phit = so.ld_create(phiNew)
+        so.ld_set(phit, 0.0)
+        if zeroPhi:
+            so.ld_set(phiNew, 0.0)
+        coarse = coarse_at(oldTime)
+        apply_helm(phit, phiOld, coarse, 0.5, False)
+        so.ld_incr(rhst, src, dt)
+        so.ld_incr(rhst, phit, 1.0)
+        solve_helm(phiNew, coarse, rhst, 0.5)
+        incr_flux(phiNew, True)
+    else:
+        mu1, mu2, mu3, mu4, r1 = so.tga_coefficients()
+        srct = so.ld_create(phiNew)
+        phis = so.ld_create(phiNew)
+        so.ld_set(srct, 0.0)
+        so.ld_incr(srct, src, dt)
+        if not zeroPhi:
+            so.ld_set(phis, 0.0)
+            so.ld_incr(phis, phiNew, 1.0)
+        # setSourceGhostCells(srct): only ghosts, all of which applyOp refills (exchange, homogeneous CF / BC values)
+        apply_helm(rhst, srct, None, mu4, True)
+        incr_flux(srct, True)
+        coarse = coarse_at(oldTime)
+        apply_helm(phiNew, phiOld, coarse, mu3, False)
+        incr_flux(phiOld, False)
+        so.ld_incr(rhst, phiNew, 1.0)
+        coarse = coarse_at(oldTime + (1.0 - r1) * dt)
+        if not zeroPhi:
+            so.ld_set(phiNew, 0.0)
+            so.ld_incr(phiNew, phis, 1.0)
+        solve_helm(phiNew, coarse, rhst, mu2)
+        incr_flux(phiNew, False)
+        for dF, f in zip(rhst.fabs, phiNew.fabs):
+            dF.copy_from(f)
+        coarse = coarse_at(oldTime + dt)
+        if not zeroPhi:
+            so.ld_set(phiNew, 0.0)
+            so.ld_incr(phiNew, phis, 1.0)
+        solve_helm(phiNew, coarse, rhst, mu1)
+        incr_flux(phiNew, False)

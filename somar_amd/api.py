@@ -156,6 +156,9 @@ _SIGS = {
     "somar_leptic_part": [_H, C.c_int, C.POINTER(_H)],
     "somar_leptic_finalize": [_H],
     "somar_leptic_solve": [_H, C.c_int, C.POINTER(LepticStats)],
+    "somar_amr_set_alpha_beta": [_H, C.c_double, C.c_double],
+    "somar_amr_heat_step": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(Stats)],
+    "somar_heat_flux_download": [_H, C.c_int, C.c_int, _PD],
     "somar_amr_enable_leptic": [_H, C.POINTER(LepticParams), C.c_int],
     "somar_amr_solve_leptic": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
     "somar_amr_leptic_stats": [_H, C.c_int, C.POINTER(LepticStats)],
@@ -305,6 +308,16 @@ class AMRPressureSolver:
         _ck(lib().somar_amr_solve(self._amr, lmax, lbase, int(zeroPhi), int(forceHomogeneous), C.byref(st)))
         return self._stats(st)
 
+    # -- level heat integrators on a level of the hierarchy (AMRParabolic) -------------------------------------------
+    def setAlphaAndBetaAMR(self, a, b):
+        _ck(lib().somar_amr_set_alpha_beta(self._amr, a, b))
+
+    def heatStepAMR(self, level, scheme, dt, zeroPhi=True, oldTime=0.0, crseOldTime=0.0, crseNewTime=0.0):
+        st = Stats()
+        _ck(lib().somar_amr_heat_step(self._amr, level, scheme, dt, int(zeroPhi), oldTime, crseOldTime, crseNewTime,
+                                      C.byref(st)))
+        return self._stats(st)
+
     # -- AMRLepticSolver (AMRPressureSolver::s_useAMRLepticSolver) ------------------------------------------------
     def enableLeptic(self, params=None, baseFromRestricted=False):
         """One leptic level solver per level (AMRLepticSolver::init); params: LepticParams or None for the defaults.
@@ -410,6 +423,14 @@ class AMRPressureSolver:
     def setBCValues(self, values6):
         """values of the Dirichlet sides {loX,hiX,loY,hiY,loZ,hiZ} (before finalize)"""
         _ck(lib().somar_solver_set_bc_values(self._h, _da(values6)))
+
+    def heatFlux(self, dir, patch):
+        """a_flux of the last heat step(s) on faces(valid, dir) of one local patch"""
+        lo, hi, _ = self.patch_box(patch)
+        shp = [h - l + 1 + (1 if d == dir else 0) for d, (l, h) in enumerate(zip(lo, hi))]
+        out = np.zeros(shp, order="F")
+        _ck(lib().somar_heat_flux_download(self._h, dir, patch, _dp(out)))
+        return out
 
     def setMetricFull(self, patch, jg0, jg1, jg2, jinv):
         """jgD: array (faces(valid, D) shape + (SpaceDim,)), Fortran order = component slowest; jg2 = None in 2-D"""

@@ -2,7 +2,9 @@
 #include "amr.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 
@@ -136,6 +138,7 @@ void AMRSolver::finalize()
 
 void AMRSolver::build_link(int l)
 {
+    const auto tl0 = std::chrono::steady_clock::now();
     std::unique_ptr<AMRLink> K(new AMRLink);
     Level& F = S[l]->level(0);
     Level& C = S[l - 1]->level(0);
@@ -166,9 +169,19 @@ void AMRSolver::build_link(int l)
     }
     K->ncover = (int)cover.size();
     K->d_cover = to_device(cover);
+    if (getenv("SOMAR_TIMING") && atoi(getenv("SOMAR_TIMING")) != 0)
+        fprintf(stderr, "[somar timing] link %d: coarsened-fine layout + copiers %.3f s\n", l,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count());
     links_[l] = std::move(K);
+    static const bool timing = getenv("SOMAR_TIMING") && atoi(getenv("SOMAR_TIMING")) != 0;
+    const auto t0 = std::chrono::steady_clock::now();
     build_quad_tables(l);
+    const auto t1 = std::chrono::steady_clock::now();
     build_reflux_tables(l);
+    const auto t2 = std::chrono::steady_clock::now();
+    if (timing)
+        fprintf(stderr, "[somar timing] link %d: quad CF tables %.3f s, reflux tables %.3f s\n", l,
+                std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
 }
 
 // ------------------------------------------------------------------------------------
@@ -197,6 +210,58 @@ struct Mask {
             for (iv[1] = r.lo[1]; iv[1] <= r.hi[1]; ++iv[1])
                 for (iv[0] = r.lo[0]; iv[0] <= r.hi[0]; ++iv[0]) m[idx(iv)] = v;
     }
+};
+}  // namespace
+
+namespace {
+// "is this cell inside one of these boxes" in O(1): the boxes binned into a uniform grid of buckets over their bounding box
+// (table builders asked that once per surface cell with a loop over the whole layout: 1.7 s of C4's 2 s re-definition)
+class BoxIndex {
+public:
+    explicit BoxIndex(const std::vector<IBox>& boxes) : boxes_(boxes)
+    {
+        if (boxes.empty()) return;
+        bb_ = boxes[0];
+        long long ext[3] = {0, 0, 0};
+        for (const IBox& b : boxes) {
+            for (int d = 0; d < 3; ++d) {
+                bb_.lo[d] = std::min(bb_.lo[d], b.lo[d]);
+                bb_.hi[d] = std::max(bb_.hi[d], b.hi[d]);
+                ext[d] += b.size(d);
+            }
+        }
+        for (int d = 0; d < 3; ++d) {
+            w_[d] = (int)std::max<long long>(1, ext[d] / (long long)boxes.size());   // the mean box extent
+            nb_[d] = (bb_.size(d) + w_[d] - 1) / w_[d];
+        }
+        bins_.resize((size_t)nb_[0] * nb_[1] * nb_[2]);
+        for (int i = 0; i < (int)boxes.size(); ++i) {
+            int lo[3], hi[3];
+            for (int d = 0; d < 3; ++d) {
+                lo[d] = (boxes[i].lo[d] - bb_.lo[d]) / w_[d];
+                hi[d] = (boxes[i].hi[d] - bb_.lo[d]) / w_[d];
+            }
+            for (int c = lo[2]; c <= hi[2]; ++c)
+                for (int b = lo[1]; b <= hi[1]; ++b)
+                    for (int a = lo[0]; a <= hi[0]; ++a) bins_[a + (size_t)nb_[0] * (b + (size_t)nb_[1] * c)].push_back(i);
+        }
+    }
+    int find(const int iv[3]) const
+    {
+        if (boxes_.empty() || !contains(bb_, iv)) return -1;
+        const size_t q = (size_t)((iv[0] - bb_.lo[0]) / w_[0]) +
+                         (size_t)nb_[0] * ((size_t)((iv[1] - bb_.lo[1]) / w_[1]) + (size_t)nb_[1] * (size_t)((iv[2] - bb_.lo[2]) / w_[2]));
+        for (int i : bins_[q])
+            if (contains(boxes_[i], iv)) return i;
+        return -1;
+    }
+    bool has(const int iv[3]) const { return find(iv) >= 0; }
+
+private:
+    const std::vector<IBox>& boxes_;
+    IBox bb_;
+    int w_[3] = {1, 1, 1}, nb_[3] = {0, 0, 0};
+    std::vector<std::vector<int>> bins_;
 };
 }  // namespace
 
@@ -424,6 +489,7 @@ void AMRSolver::build_reflux_tables(int l)
     const std::vector<IBox>& cf = K.cfl->boxes;
     const auto shifts = periodic_shifts(C.domain, C.periodic);
     const double beta = C.beta;
+    K.beta_built = beta;
     for (int d = 0; d < 3; ++d) {
         const double scale = beta / C.dx[d];
         const double denom = (double)(r[0] * r[1] * r[2] / r[d]);
@@ -467,11 +533,8 @@ void AMRSolver::build_reflux_tables(int l)
         const IBox slab = adj_cell(cf[fi], d, s);
         return regbase[pi][d][s] + (c[0] - slab.lo[0]) + slab.size(0) * ((c[1] - slab.lo[1]) + slab.size(1) * (c[2] - slab.lo[2]));
     };
-    auto covered = [&](const int c[3]) {
-        for (const IBox& b : cf)
-            if (contains(b, c)) return true;
-        return false;
-    };
+    const BoxIndex cfIndex(cf);
+    auto covered = [&](const int c[3]) { return cfIndex.has(c); };
     // ---- per coarse cell records ----
     struct Tmp { int patch; long long coff; std::vector<RefluxA> A; std::vector<std::pair<int, int>> B; };  // B: (peer or -1, index)
     std::vector<Tmp> tmp;
@@ -667,15 +730,8 @@ void AMRSolver::build_one_sided_tables(int l)
     Level& F = S[l]->level(0);
     std::vector<IBox> cfb;
     for (const IBox& b : F.boxes) cfb.push_back(b.coarsen(K.r));
-    auto is_copy = [&](const int iv[3]) {
-        bool in = false;
-        for (const IBox& b : C.boxes)
-            if (contains(b, iv)) { in = true; break; }
-        if (!in) return false;
-        for (const IBox& b : cfb)
-            if (contains(b, iv)) return false;
-        return true;
-    };
+    const BoxIndex crseIndex(C.boxes), cfbIndex(cfb);
+    auto is_copy = [&](const int iv[3]) { return crseIndex.has(iv) && !cfbIndex.has(iv); };
     struct E { OneSided o; int stage; };
     std::vector<E> ents;
     std::map<std::pair<int, long long>, int> wrote;   // (dir, face) -> stage of its last writer
@@ -848,6 +904,9 @@ void AMRSolver::amr_residual_nf(int l, double* res, double* phi, const double* p
 
 void AMRSolver::reflux(int l, double* phiFine, double* phi, double* LofPhi)
 {
+    SOMAR_CHECK(!links_[l + 1]->fluxDefined || S[l]->level(0).beta == links_[l + 1]->beta_built,
+                "refluxing with operator coefficients other than the hierarchy was built with is not implemented: level solves "
+                "only after somar_amr_set_alpha_beta (restore alpha, beta for composite operations)");
     SOMAR_CHECK(l >= 0 && l + 1 < nlevels(), "reflux: level has no finer level");
     AMRLink& K = *links_[l + 1];
     interp_cf(l + 1, phiFine, phi);
@@ -1053,6 +1112,109 @@ void AMRSolver::vcycle(double* const* uberCorr, double* const* uberRes, int ilev
     }
 }
 
+void AMRSolver::set_alpha_beta(double a, double b)
+{
+    SOMAR_CHECK(finalized_, "set_alpha_beta before finalize");
+    for (auto& s : S) s->set_alpha_beta(a, b, true);
+}
+
+void AMRSolver::heat_step(int l, int scheme, double dt, bool zeroPhi, double oldTime, double crseOldTime, double crseNewTime,
+                          SolveStats& st)
+{
+    SOMAR_CHECK(finalized_ && l >= 0 && l < nlevels(), "bad level / hierarchy not finalized");
+    SOMAR_CHECK(scheme >= 0 && scheme <= 2, "heat scheme: 0 backward Euler, 1 Crank-Nicolson, 2 TGA");
+    SOMAR_CHECK(dt >= 0.0 && crseNewTime >= crseOldTime, "negative time step");
+    PressureSolver& P = *S[l];
+    const long long n = P.level(0).field_elems;
+    double* phiNew = P.phi();
+    double* rhst = P.rhs();
+    double* phiOld = P.heat_field(0);
+    double* src = P.heat_field(1);
+    double* tmp = P.heat_field(2);
+    double* scratch = P.field(0, 5);
+    double* coarse = l > 0 ? S[l - 1]->heat_field(2) : nullptr;
+    // timeInterp, MappedBaseLevelHeatSolver.cpp:273-300
+    auto coarse_at = [&](double t) {
+        if (l == 0) return;
+        const long long nc = S[l - 1]->level(0).field_elems;
+        const double* cOld = S[l - 1]->heat_field(0);
+        const double* cNew = S[l - 1]->phi();
+        launch_set(st_, coarse, nc, 0.0);
+        const double diff = crseNewTime - crseOldTime;
+        if (diff < 1.0e-10) {
+            launch_incr(st_, coarse, cOld, 1.0, nc);
+        } else {
+            const double factor = (t - crseOldTime) / (crseNewTime - crseOldTime);
+            launch_incr(st_, coarse, cOld, 1.0 - factor, nc);
+            launch_incr(st_, coarse, cNew, factor, nc);
+        }
+    };
+    // applyHelm: (I + mu dt L) phi, through AMROperatorNF when there is coarse data (:154-180)
+    auto apply_helm = [&](double* ans, double* phi, bool withCoarse, double mu, bool homogeneous) {
+        set_alpha_beta(1.0, mu * dt);
+        if (!withCoarse || l == 0) P.apply_op(0, ans, phi, homogeneous);
+        else amr_operator(l, ans, nullptr, phi, coarse, homogeneous);
+    };
+    // solveHelm: m_solver->solve(phi, rhs, l, l, zeroPhi) with alpha 1, beta -dt mu (:217-251)
+    auto solve_helm = [&](double mu) {
+        set_alpha_beta(1.0, -dt * mu);
+        crse_override_ = coarse;
+        try {
+            solve(l, l, zeroPhi, false, st);
+        } catch (...) {
+            crse_override_ = nullptr;
+            throw;
+        }
+        crse_override_ = nullptr;
+    };
+    if (scheme == 0) {
+        launch_copy(st_, rhst, phiOld, n);
+        coarse_at(oldTime);   // as written: a_oldTime (MappedLevelBackwardEuler.cpp:112-113)
+        solve_helm(1.0);
+        P.increment_heat_flux(phiNew, true);
+    } else if (scheme == 1) {
+        coarse_at(oldTime);
+        apply_helm(scratch, phiOld, true, 0.5, false);
+        launch_copy(st_, rhst, src, n);
+        launch_scale(st_, rhst, dt, n);
+        launch_incr(st_, rhst, scratch, 1.0, n);
+        solve_helm(0.5);
+        P.increment_heat_flux(phiNew, true);
+    } else {
+        const double tgaEpsilon = 1.e-12;
+        const double a = 2.0 - std::sqrt(2.0) - tgaEpsilon;
+        const double discr = std::sqrt(a * a - 4.0 * a + 2.0);
+        const double mu1 = (a - discr) / 2.0, mu2 = (a + discr) / 2.0, mu3 = 1.0 - a, mu4 = 0.5 - a;
+        const double r1 = (2.0 * a - 1.0) / (a + discr);
+        double* phis = S[l]->field(0, 4);        // bestPhi's array: free between solves (each solve rewrites it first)
+        launch_copy(st_, tmp, src, n);           // srct = dt * src
+        launch_scale(st_, tmp, dt, n);
+        if (!zeroPhi) launch_copy(st_, phis, phiNew, n);
+        apply_helm(rhst, tmp, false, mu4, true);
+        P.increment_heat_flux(tmp, true);
+        coarse_at(oldTime);
+        apply_helm(scratch, phiOld, true, mu3, false);
+        P.increment_heat_flux(phiOld, false);
+        launch_incr(st_, rhst, scratch, 1.0, n);
+        coarse_at(oldTime + (1.0 - r1) * dt);
+        double* keep = nullptr;
+        if (!zeroPhi) {
+            // the guess has to survive the first solve, whose bestPhi bookkeeping overwrites `phis`: park it in srct's array
+            keep = tmp;
+            launch_copy(st_, keep, phis, n);
+            launch_copy(st_, phiNew, keep, n);
+        }
+        solve_helm(mu2);
+        P.increment_heat_flux(phiNew, false);
+        launch_copy(st_, rhst, phiNew, n);       // assign(rhst, phiNew)
+        coarse_at(oldTime + dt);
+        if (!zeroPhi) launch_copy(st_, phiNew, keep, n);
+        solve_helm(mu1);
+        P.increment_heat_flux(phiNew, false);
+    }
+    sync();
+}
+
 void AMRSolver::enable_leptic(const LepticParams& lp, bool baseFromRestricted)
 {
     SOMAR_CHECK(finalized_, "enable_leptic before finalize");
@@ -1091,7 +1253,7 @@ void AMRSolver::solve_impl(int l_max, int l_base, bool zeroPhi, bool forceHomoge
     const int n = nlevels();
     std::vector<double*> phi(n), rhs(n), uRes(n), uCorr(n), best(n);
     for (int l = 0; l < n; ++l) {
-        phi[l] = S[l]->phi();
+        phi[l] = (crse_override_ && l == l_base - 1) ? crse_override_ : S[l]->phi();
         rhs[l] = S[l]->rhs();
         uRes[l] = S[l]->work(0);
         uCorr[l] = S[l]->work(1);

@@ -125,6 +125,7 @@ struct AMRLink {
     long long nsend = 0;
     double* d_sendbuf = nullptr;
     double sc_fine[3][2];
+    double beta_built = 0.0;   // the coarse operator's beta the register scales were built with
     // compGradientCC's one-sided faces on the COARSE level next to this (fine) level, in stages (entries of one stage are
     // independent; normally there is one stage)
     bool osg_built = false;
@@ -154,6 +155,15 @@ public:
     // level on the level's own operator (init, :185-195).  baseFromRestricted = false is the reference: the base level solves
     // a_uberCorrection from a_uberResidual and its m_correction stays zero (:444-449); true (NOT the reference) feeds it the
     // restricted residual as MappedAMRMultiGrid's V-cycle does.
+    // MappedBaseLevelHeatSolver::resetSolverAlphaAndBeta on every op of every level (MappedBaseLevelHeatSolver.cpp:257-270).
+    // The flux-register scales keep the beta they were built with: composite (multi-level) operators then raise until the
+    // coefficients are back; level solves (l_base == l_max), which is what the level heat integrators run, never reflux.
+    void set_alpha_beta(double a, double b);
+    // MappedLevelBackwardEuler / MappedLevelCrankNicolson / MappedLevelTGA::updateSoln on level l of the hierarchy
+    // (AMRParabolic/*.cpp): phiNew = level l's PHI, phiOld / src = its HEAT_OLD / HEAT_SRC; for l > 0 the coarse-fine values
+    // are timeInterp(level l-1's HEAT_OLD at crseOldTime, level l-1's PHI at crseNewTime); a_flux accumulates in heat_flux(d)
+    void heat_step(int l, int scheme, double dt, bool zeroPhi, double oldTime, double crseOldTime, double crseNewTime,
+                   SolveStats& st);
     void enable_leptic(const LepticParams& lp, bool baseFromRestricted);
     void solve_leptic(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous, SolveStats& st);
     const LepticStats& leptic_stats(int l) const { return lepStats_.at(l); }
@@ -214,6 +224,7 @@ private:
     std::vector<std::unique_ptr<LepticSolver>> leptic_;
     std::vector<LepticStats> lepStats_;   // of each level's last leptic solve
     bool lepticCycle_ = false, lepticBaseFromRestricted_ = false;
+    double* crse_override_ = nullptr;   // solve_impl: stands in for phi of level l_base - 1 (the heat integrators' coarseData)
     void solve_impl(int l_max, int l_base, bool zeroPhi, bool forceHomogeneous, SolveStats& st);
     Inspector inspector_ = nullptr;
     void* inspector_user_ = nullptr;

@@ -1239,6 +1239,34 @@ static void fill_leptic_stats(const LepticStats& S, somar_leptic_stats_t* stats)
     fill_stats(S.fullStats, &stats->full);
 }
 
+// ---- level heat integrators on a level of a hierarchy (AMRParabolic/*.cpp) -------------------------------------------------
+int somar_amr_set_alpha_beta(somar_amr_t* a, double alpha, double beta)
+{
+    API_BEGIN
+    SOMAR_CHECK(a, "null argument");
+    a->amr->set_alpha_beta(alpha, beta);
+    API_END
+}
+
+int somar_amr_heat_step(somar_amr_t* a, int level, int scheme, double dt, int zero_phi, double old_time, double crse_old_time,
+                        double crse_new_time, somar_stats_t* stats)
+{
+    API_BEGIN
+    SOMAR_CHECK(a, "null argument");
+    SolveStats st;
+    a->amr->heat_step(level, scheme, dt, zero_phi != 0, old_time, crse_old_time, crse_new_time, st);
+    fill_stats(st, stats);
+    API_END
+}
+
+int somar_heat_flux_download(somar_solver_t* s, int dir, int patch, double* host)
+{
+    API_BEGIN
+    SOMAR_CHECK(s && host, "null pointer");
+    s->ps->download_heat_flux(dir, patch, host);
+    API_END
+}
+
 // ---- AMRLepticSolver on an AMR hierarchy (AMRLepticSolver.cpp) -------------------------------------------------------------
 int somar_amr_enable_leptic(somar_amr_t* a, const somar_leptic_params_t* lp, int base_from_restricted)
 {

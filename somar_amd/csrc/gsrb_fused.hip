@@ -26,6 +26,8 @@
 //
 // Arithmetic: identical operation order to GSRBITER3DORTHO / GSRBBOUNDARYITER3DORTHO
 // (GSRBF.ChF:545-701, 1362-1505) => bit-identical to the two-pass kernel and to the CPU oracle.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -53,8 +55,11 @@ __device__ __forceinline__ double2 ld2(const double* __restrict__ a, long long i
     return make_double2(ok0 ? v.x : 0.0, ok1 ? v.y : 0.0);
 }
 
-// the "load" of a uniform coefficient: the same predicated pair ld2 would have returned
-__device__ __forceinline__ double2 uni2(double c, bool ok0, bool ok1) { return make_double2(ok0 ? c : 0.0, ok1 ? c : 0.0); }
+// the "load" of a uniform coefficient.  ld2 returns zeros where its predicate is off; those values only ever reach cells that
+// are not computed (a computed cell's coefficients lie inside the frame by construction), so the constant may stand in
+// unconditionally -- which makes every coefficient a wave-uniform loop invariant: the diagonal and the selects between the
+// pair's two members fold away.
+__device__ __forceinline__ double2 uni2(double c, bool, bool) { return make_double2(c, c); }
 
 // One GSRB point update of cell (gi,gj,gk): interior form = GSRBITER3DORTHO, cells touching a domain
 // face = GSRBBOUNDARYITER3DORTHO (a Neumann face contributes neither flux nor diagonal; a Dirichlet face contributes
@@ -218,16 +223,39 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
     // coefficients of the black cell of plane k-1 (column c), captured one step earlier
     double b_rhs = 0, b_ji = 1, b_gxl = 0, b_gxh = 0, b_gyl = 0, b_gyh = 0, b_gzl = 0;
     double redPrev1 = 0.0, redPrev2 = 0.0;
+    // UNI: with the coefficient streams gone a plane's loads are 2 x 16 bytes per lane, too little in flight to cover the memory
+    // latency a lock-stepped (one barrier per plane) workgroup exposes: phi and rhs are fetched ONE PLANE FURTHER AHEAD
+    // (phi of plane k+2 and rhs of plane k+1 are issued in step k and consumed in step k+1)
+    double2 Pn = make_double2(0.0, 0.0), Rn = make_double2(0.0, 0.0);
+    if (UNI) {
+        const bool fkp0 = (k + 1 >= -FRAME) && (k + 1 < p.n[2] + FRAME);
+        Pn = ldphi(k + 1, f0 && fkp0, f1 && fkp0);
+        Rn = ld2(rhs, base + sk * k, c0 && fk, c1 && fk, p.off);
+    }
 
     const int kend = t.k0 + t.nk;  // last red plane (the ring above the tile)
-    for (; k <= kend; ++k) {
+    // One plane of the march.  The colour column c = (i + j + k) & 1 of the pair is the same for every lane of a wavefront
+    // (li is even, gj and gk are wave-uniform) and alternates from plane to plane: the body is instantiated for c = 0 and
+    // c = 1 and the loop below calls them in turn, so every select between the pair's two members is resolved at compile
+    // time (a quarter of the loop's vector instructions were v_cndmask on a lane-varying-looking c).
+    auto step = [&](auto CC) {
+        constexpr int c = decltype(CC)::value;
         const int gk = p.lo[2] + k;
         fk = (k >= -FRAME) && (k < p.n[2] + FRAME);
         const bool fkp = (k + 1 >= -FRAME) && (k + 1 < p.n[2] + FRAME);
         // ---- this step's loads: phi and Jg^zz of plane k+1, cell coefficients of plane k --------
-        const double2 Pp = ldphi(k + 1, f0 && fkp, f1 && fkp);
+        double2 Pp, Rh;
+        if (UNI) {
+            Pp = Pn;
+            Rh = Rn;
+            const bool fkpp = (k + 2 >= -FRAME) && (k + 2 < p.n[2] + FRAME);
+            Pn = ldphi(k + 2, f0 && fkpp, f1 && fkpp);
+            Rn = ld2(rhs, base + sk * (k + 1), c0 && fkp, c1 && fkp, p.off);
+        } else {
+            Pp = ldphi(k + 1, f0 && fkp, f1 && fkp);
+            Rh = ld2(rhs, base + sk * k, c0 && fk, c1 && fk, p.off);
+        }
         const double2 Gzp = UNI ? uni2(P.uc[2], c0 && fkp, c1 && fkp) : ld2(jgz, base + sk * (k + 1), c0 && fkp, c1 && fkp, p.off);
-        const double2 Rh = ld2(rhs, base + sk * k, c0 && fk, c1 && fk, p.off);
         const double2 Ji = UNI ? uni2(P.uc[3], c0 && fk, c1 && fk) : ld2(jinv, base + sk * k, c0 && fk, c1 && fk, p.off);
         const double2 Gx = UNI ? uni2(P.uc[0], c0 && fk, c1 && fk) : ld2(jgx, base + sk * k, c0 && fk, c1 && fk, p.off);
         const double2 Gy = UNI ? uni2(P.uc[1], c0 && fk, c1 && fk) : ld2(jgy, base + sk * k, c0 && fk, c1 && fk, p.off);
@@ -244,7 +272,7 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         __syncthreads();
 
         // ---- red(k) at column c: reads only black cells of the plane, writes only red ones ---------
-        const int c = (p.lo[0] + li + gj + gk) & 1;  // red = pass 0 = even i+j+k (GSRBF.ChF:381-387)
+        // red = pass 0 = even i+j+k (GSRBF.ChF:381-387): c is this plane's red column of the pair
         const int rc = ri + c;
         double red = pick(Pc, c);  // cells not computed here keep their old value
         {
@@ -317,6 +345,26 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         Pm = Pc;
         Pc = Pp;
         Gzc = Gzp;
+    };
+    const int cfirst = __builtin_amdgcn_readfirstlane((p.lo[0] + li + gj + p.lo[2] + k) & 1);
+    if (cfirst) {
+        for (;;) {
+            if (k > kend) break;
+            step(std::integral_constant<int, 1>{});
+            ++k;
+            if (k > kend) break;
+            step(std::integral_constant<int, 0>{});
+            ++k;
+        }
+    } else {
+        for (;;) {
+            if (k > kend) break;
+            step(std::integral_constant<int, 0>{});
+            ++k;
+            if (k > kend) break;
+            step(std::integral_constant<int, 1>{});
+            ++k;
+        }
     }
 }
 

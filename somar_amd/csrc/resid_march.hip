@@ -36,7 +36,8 @@ __device__ __forceinline__ double2 rm_ld2(const double* __restrict__ a, long lon
     return make_double2(ok0 ? v.x : 0.0, ok1 ? v.y : 0.0);
 }
 
-__device__ __forceinline__ double2 rm_uni2(double c, bool ok0, bool ok1) { return make_double2(ok0 ? c : 0.0, ok1 ? c : 0.0); }
+// unconditional: the zeros rm_ld2 returns under a false predicate only reach cells that are not written (see gsrb_fused.hip)
+__device__ __forceinline__ double2 rm_uni2(double c, bool, bool) { return make_double2(c, c); }
 
 // UNI: uniform metric, the four coefficient arrays are not read (StencilParams::uc)
 template <int MODE, bool UNI = false>

@@ -2,7 +2,9 @@
 #include "solver.h"
 
 #include <array>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -53,6 +55,7 @@ PressureSolver::~PressureSolver()
     for (double* f : f_W) hipFree(f);
     hipFree(d_fold);
     for (FullProgram& q : aux_prog_) hipFree(q.d_ops);
+    for (double* f : f_heatflux) Level::free_field(f);
     for (auto& pr : full_prog_)
         for (auto& q : pr) hipFree(q.d_ops);
     for (auto& L : lev)
@@ -170,6 +173,7 @@ double* PressureSolver::field(int depth, int which)
         case 7: return depth == 0 ? amr_field(1) : nullptr;
         case 8: return depth == 0 ? heat_field(0) : nullptr;
         case 9: return depth == 0 ? heat_field(1) : nullptr;
+        case 10: case 11: case 12: return (depth == 0 && which - 10 < prm.spaceDim) ? heat_flux(which - 10) : nullptr;
         default: return nullptr;
     }
 }
@@ -411,6 +415,13 @@ void PressureSolver::detect_uniform_metric()
 void PressureSolver::finalize()
 {
     SOMAR_CHECK(!lev.empty() && !finalized, "finalize before define / twice");
+    // SOMAR_TIMING=1: wall time of the stages below on stderr (what a re-definition of the hierarchy costs)
+    static const bool timing = getenv("SOMAR_TIMING") && atoi(getenv("SOMAR_TIMING")) != 0;
+    auto now = [&]() { if (timing) hipDeviceSynchronize(); return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double>(b - a).count();
+    };
+    const auto t0 = now();
     launch_lapdiag(st_, lev[0]->dev);
     fill_metric_ghosts(*lev[0]);
     int depth = 1;
@@ -421,7 +432,21 @@ void PressureSolver::finalize()
         }
         ++depth;
     }
+    const auto t1 = now();
     detect_uniform_metric();
+    const auto t2 = now();
+    struct Report {
+        bool on; std::chrono::steady_clock::time_point t0, t1, t2; long long cells;
+        ~Report() {
+            if (!on) return;
+            hipDeviceSynchronize();
+            const auto t3 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[somar timing] finalize %lld cells: coarse hierarchy %.3f s, uniform detection %.3f s, fields + probes %.3f s\n",
+                    cells, std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(),
+                    std::chrono::duration<double>(t3 - t2).count());
+        }
+    } report{timing, t0, t1, t2, lev[0]->valid_cells_global};
+    (void)secs;
     int maxTiles = 1;
     for (auto& L : lev) maxTiles = std::max(std::max(maxTiles, L->dev.ntiles), std::max(L->nrtiles, L->nftiles));
     SOMAR_HIP(hipMalloc(&d_partials, (size_t)maxTiles * 2 * sizeof(double)));
@@ -1035,10 +1060,11 @@ void PressureSolver::mac_project(double dt, bool zeroPressure, bool forceHomogen
 //   the same values (it depends on neither coefficient) and keeps the prolongation strategy the factory's null-space
 //   probe chose at construction; so does this.
 // ------------------------------------------------------------------------------------
-void PressureSolver::set_alpha_beta(double a, double b)
+void PressureSolver::set_alpha_beta(double a, double b, bool amr_member_ok)
 {
     SOMAR_CHECK(finalized, "set_alpha_beta before finalize");
-    SOMAR_CHECK(!amr_member_, "set_alpha_beta on a level of an AMR hierarchy is not implemented (its flux-register scales carry beta)");
+    SOMAR_CHECK(!amr_member_ || amr_member_ok,
+                "set_alpha_beta on a level of an AMR hierarchy goes through the hierarchy (somar_amr_set_alpha_beta)");
     if (!coefs_saved_) {
         aCoef_ = lev[0]->alpha;
         bCoef_ = lev[0]->beta;
@@ -1051,6 +1077,34 @@ void PressureSolver::set_alpha_beta(double a, double b)
     }
     drop_graphs();  // captured launches carry the old coefficients in their kernel arguments
     if (coarse_) coarse_->set_alpha_beta(a, b);
+}
+
+double* PressureSolver::heat_flux(int dir)
+{
+    SOMAR_CHECK(dir >= 0 && dir < prm.spaceDim && finalized, "bad direction / solver not finalized");
+    if (!f_heatflux[dir]) f_heatflux[dir] = lev[0]->alloc_field();
+    return f_heatflux[dir];
+}
+
+void PressureSolver::download_heat_flux(int dir, int patch, double* host)
+{
+    Level& L = *lev[0];
+    SOMAR_CHECK(patch >= 0 && patch < L.npatches(), "bad patch index");
+    IBox fb = L.boxes[L.local[patch]];
+    fb.hi[dir] += 1;
+    L.download(heat_flux(dir), patch, host, fb, fb, st_);
+    sync();
+}
+
+void PressureSolver::increment_heat_flux(double* phi, bool setToZero)
+{
+    Level& L = *lev[0];
+    double* const* G = full_ ? flux_fields(phi) : mac_grad(phi);
+    for (int d = 0; d < prm.spaceDim; ++d) {
+        double* acc = heat_flux(d);
+        if (setToZero) launch_set(st_, acc, L.field_elems, 0.0);
+        launch_incr(st_, acc, G[d], 1.0, L.field_elems);   // thisFlux += tempFlux
+    }
 }
 
 double* PressureSolver::heat_field(int which)

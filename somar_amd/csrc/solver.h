@@ -167,7 +167,14 @@ public:
     void mac_project(double dt, bool zeroPressure, bool forceHomogeneous, SolveStats& st);
     void vel_wall_bc();   // the velocity BC levelDivergenceMAC applies through a_fluxBC, solid walls: zero wall-normal faces of vel()
     // viscous / diffusive Helmholtz solves through the same operator
-    void set_alpha_beta(double a, double b);   // MappedAMRPoissonOp::setAlphaAndBeta on every depth: alpha = a*aCoef, beta = b*bCoef
+    // amr_member_ok: the caller (AMRSolver::set_alpha_beta) looks after the flux-register scales, which carry beta
+    void set_alpha_beta(double a, double b, bool amr_member_ok = false);
+    // a_flux of the level heat integrators: thisFlux (+)= getFlux(phi) = J Grad(phi), NO beta (MappedBaseLevelHeatSolver::
+    // incrementFlux, MappedBaseLevelHeatSolver.cpp:183-209; MappedAMRPoissonOp::getFlux(FluxBox&,...), :2129-2151); phi's ghosts
+    // as the last operation left them
+    void increment_heat_flux(double* phi, bool setToZero);
+    double* heat_flux(int dir);
+    void download_heat_flux(int dir, int patch, double* host);   // host: faces(valid, dir), Fortran order   // MappedAMRPoissonOp::setAlphaAndBeta on every depth: alpha = a*aCoef, beta = b*bCoef
     double* heat_field(int which);             // 0: phiOld, 1: src (depth 0, allocated on first use)
     void heat_step(int scheme, double dt, bool zeroPhi, SolveStats& st);   // 0 backward Euler, 1 Crank-Nicolson, 2 TGA
     // cell-centred level projection (LevelCCProjector): velocity J*u, SpaceDim comps, resident with one ghost layer
@@ -220,6 +227,7 @@ private:
     bool amr_member_ = false;
     double* f_amr[2] = {nullptr, nullptr};
     bool hasCF_ = false;
+    double* f_heatflux[3] = {nullptr, nullptr, nullptr};
     bool own_stream_ = true;
     double dxCrse_[3] = {0, 0, 0};
     std::vector<double*> f_pp;  // per-depth ping-pong buffer of the fused sweep
