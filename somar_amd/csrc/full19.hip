@@ -40,14 +40,13 @@ __global__ void k_ghost_ops(const GhostOp* __restrict__ ops, const PatchDesc* __
     const GhostOp op = ops[blockIdx.x];
     const PatchDesc p = patches[op.patch];
     const int n0 = op.n[0], n01 = op.n[0] * op.n[1];
-    const long long cells = (long long)n01 * op.n[2];
+    const int cells = n01 * op.n[2];   // a ghost region of one box: far below 2^31 (32-bit index arithmetic: no 64-bit divisions)
     double* dst = op.dstf ? psi : phi;
     const double* src = op.srcf ? psi : phi;
     const long long st[3] = {1, (long long)p.pj, p.pk};
-    for (long long idx = (long long)blockIdx.y * blockDim.x + threadIdx.x; idx < cells;
-         idx += (long long)gridDim.y * blockDim.x) {
-        const int k = (int)(idx / n01);
-        const int r = (int)(idx - (long long)k * n01);
+    for (int idx = (int)(blockIdx.y * blockDim.x + threadIdx.x); idx < cells; idx += (int)(gridDim.y * blockDim.x)) {
+        const int k = idx / n01;
+        const int r = idx - k * n01;
         const int j = r / n0, i = r - j * n0;
         const int l0 = op.lo[0] + i, l1 = op.lo[1] + j, l2 = op.lo[2] + k;
         const long long c = fidx(p, l0, l1, l2);
@@ -317,8 +316,8 @@ void launch_ghost_ops(hipStream_t st, const LevelDev& L, const GhostOp* ops, int
     if (nops == 0) return;
     StencilParams P = L.P;
     P.bc_homog = bc_homog ? 1 : 0;
-    if (redirect) hipLaunchKernelGGL(k_ghost_ops<true>, dim3(nops, 16), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
-    else hipLaunchKernelGGL(k_ghost_ops<false>, dim3(nops, 16), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
+    if (redirect) hipLaunchKernelGGL(k_ghost_ops<true>, dim3(nops, L.ghost_gy), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
+    else hipLaunchKernelGGL(k_ghost_ops<false>, dim3(nops, L.ghost_gy), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
 }
 
 void launch_flux_full(hipStream_t st, const LevelDev& L, double* const out[3], const double* phi, const double* psi)

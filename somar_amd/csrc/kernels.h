@@ -9,6 +9,7 @@ struct LevelDev {
     const Tile* tiles = nullptr;        // XCD-contiguous order
     int ntiles = 0;
     int tile_j = 4;                     // blockDim.y of every tile kernel on this level
+    int ghost_gy = 16;                  // workgroups per ghost op (k_ghost_ops): the largest box face / 1024, within [16, 256]
     const PatchDesc* patches = nullptr;
     int npatches = 0;
     double* jg[3] = {nullptr, nullptr, nullptr};  // J g^{aa} on a-faces

@@ -688,6 +688,14 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     dev.ntiles = N;
     dev.patches = d_patches;
     dev.npatches = (int)hpatches.size();
+    {
+        long long face = 0;
+        for (const PatchDesc& q : hpatches) {
+            const long long a = (long long)(q.n[0] + 2 * FRAME), b = (long long)(q.n[1] + 2 * FRAME), c = (long long)(q.n[2] + 2 * FRAME);
+            face = std::max(face, std::max(a * b, std::max(a * c, b * c)));
+        }
+        dev.ghost_gy = (int)std::min<long long>(256, std::max<long long>(16, (face + 1023) / 1024));
+    }
     // A Dirichlet wall on the HIGH side of direction d: the fused sweep's recomputed red ring needs, in a neighbouring
     // box's frame, the coefficient of that box's top face -- a face no box owns as a low face, so the cell-shaped
     // exchange never carries it (with a Neumann wall the face's flux is dropped and the value is never read).
