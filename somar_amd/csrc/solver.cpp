@@ -28,6 +28,7 @@ PressureSolver::PressureSolver(Comm* comm, hipStream_t shared) : comm_(comm ? co
     if (const char* e = getenv("SOMAR_FUSED_MIN_CELLS")) fused_min_cells_ = atoll(e);
     march_min_cells_ = fused_min_cells_;
     if (const char* e = getenv("SOMAR_MARCH_MIN_CELLS")) march_min_cells_ = atoll(e);
+    if (const char* e = getenv("SOMAR_TINY_MAX_CELLS")) tiny_max_cells_ = atoll(e);
     // levels up to this many cells sum in the reference's serial order (k_reduce_ordered); tests raise it to
     // make whole solves reproduce the oracle's histories to the last bits
     if (const char* e = getenv("SOMAR_ORDERED_REDUCE_MAX")) ordered_max_cells_ = atoll(e);
@@ -608,6 +609,39 @@ void PressureSolver::download_field(const double* field, int depth, int patch, d
 // ------------------------------------------------------------------------------------
 // level operator
 // ------------------------------------------------------------------------------------
+// A level small enough for the single-workgroup program kernel: everything on this rank (no remote halo), the 7-point
+// operator without Dirichlet ghosts or coarse-fine faces, point GSRB
+bool PressureSolver::tiny(int d) const
+{
+    const Level& L = *lev[d];
+    return tiny_max_cells_ > 0 && !full_ && !diri_ && L.ncf == 0 && L.plan.peers.empty() && !profiling_ &&
+           L.valid_cells_global <= tiny_max_cells_ && L.dev.ntiles > 0 && L.dev.tile_j >= 1 && L.dev.tile_j <= 16 &&
+           (1024 % (64 * L.dev.tile_j)) == 0;
+}
+
+void PressureSolver::tiny_run(int d, double* const* fields, int nfields, const std::vector<TinyOp>& ops)
+{
+    Level& L = *lev[d];
+    launch_tiny_program(st_, L.dev, L.d_local_items, (int)L.plan.local.size(), L.field_elems, fields, nfields, ops.data(),
+                        (int)ops.size());
+}
+
+static TinyOp tiny_op(int type, int f0, int f1 = 0, int f2 = 0, int arg = 0, double a = 0.0)
+{
+    TinyOp o;
+    o.type = type; o.f0 = f0; o.f1 = f1; o.f2 = f2; o.arg = arg; o.pad_ = 0; o.a = a;
+    return o;
+}
+// LevelGSRB::relax on a tiny level as program steps: fields[0] = e, fields[1] = res
+static void tiny_push_sweeps(std::vector<TinyOp>& ops, int iters)
+{
+    for (int it = 0; it < iters; ++it)
+        for (int pass = 0; pass < 2; ++pass) {
+            ops.push_back(tiny_op(TINY_EXCHANGE, 0));
+            ops.push_back(tiny_op(TINY_GSRB, 0, 1, 0, pass));
+        }
+}
+
 bool PressureSolver::fused_relax(int d, int iters) const
 {
     const Level& L = *lev[d];
@@ -626,6 +660,14 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
     if (e_zero && (!fused_path || no_zero_start)) {
         launch_set(st_, e, L.field_elems, 0.0);
         e_zero = false;
+    }
+    if (!fused_path && prm.relaxMode == RELAX_LEVEL_GSRB && tiny(d)) {
+        // the same exchanges and colour passes, one launch (cf_homog: no coarse-fine faces on a tiny() level)
+        std::vector<TinyOp> ops;
+        tiny_push_sweeps(ops, iters);
+        double* fld[2] = {e, const_cast<double*>(res)};
+        tiny_run(d, fld, 2, ops);
+        return;
     }
     if (fused_path) {
         // LevelGSRB::relax (GSRB.cpp:58-98) as ONE fused red+black launch per sweep (gsrb_fused.hip):
@@ -741,6 +783,12 @@ void PressureSolver::apply_op(int d, double* out, double* phi, bool homogeneous)
 void PressureSolver::residual_i(int d, double* out, double* phi, const double* rhs, bool homogeneous)
 {
     Level& L = *lev[d];
+    if (tiny(d)) {
+        std::vector<TinyOp> ops{tiny_op(TINY_EXCHANGE, 1), tiny_op(TINY_OP, 0, 1, 2, 0)};
+        double* fld[3] = {out, phi, const_cast<double*>(rhs)};
+        tiny_run(d, fld, 3, ops);
+        return;
+    }
     L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
     if (diri_ && !full_) apply_diri(d, phi, homogeneous);  // m_bc.setGhosts, :822 (non-diagonal: inside the program)
     if (profiling_ && d == 0) prof_begin(1);
@@ -759,6 +807,12 @@ void PressureSolver::residual_i(int d, double* out, double* phi, const double* r
 void PressureSolver::apply_op_i(int d, double* out, double* phi, bool homogeneous)
 {
     Level& L = *lev[d];
+    if (tiny(d)) {
+        std::vector<TinyOp> ops{tiny_op(TINY_EXCHANGE, 1), tiny_op(TINY_OP, 0, 1, 1, 1)};
+        double* fld[2] = {out, phi};
+        tiny_run(d, fld, 2, ops);
+        return;
+    }
     L.exchange(phi, st_);
     if (diri_ && !full_) apply_diri(d, phi, homogeneous);
     if (full_march(d)) {
@@ -848,6 +902,16 @@ void PressureSolver::pre_cond(int d, double* phi, const double* rhs)
     Level& L = *lev[d];
     if (prm.num_smooth_precond == 0 || prm.precondMode == PRECOND_NONE) {
         launch_copy(st_, phi, rhs, L.field_elems);
+        return;
+    }
+    if (prm.precondMode != PRECOND_DIAG_LINE_RELAX && prm.relaxMode == RELAX_LEVEL_GSRB && tiny(d) &&
+        !fused_relax(d, prm.num_smooth_precond)) {
+        // DIAGPRECOND + the sweeps in one launch
+        std::vector<TinyOp> ops;
+        ops.push_back(tiny_op(TINY_DIAG, 0, 1));
+        tiny_push_sweeps(ops, prm.num_smooth_precond);
+        double* fld[2] = {phi, const_cast<double*>(rhs)};
+        tiny_run(d, fld, 2, ops);
         return;
     }
     launch_diag(st_, L.dev, phi, rhs, 0);

@@ -231,6 +231,14 @@ private:
     bool own_stream_ = true;
     double dxCrse_[3] = {0, 0, 0};
     std::vector<double*> f_pp;  // per-depth ping-pong buffer of the fused sweep
+    // EXPERIMENT, off by default (SOMAR_TINY_MAX_CELLS=8192 switches it on): levels of at most this many cells run their
+    // sweeps / preconditioner / operator as one single-workgroup program launch (k_tiny_program).  Bit-identical, but measured
+    // SLOWER than the launch-per-operation path it was meant to replace (C3: 91 vs 21 ms per AMR V-cycle): the bodies keep the
+    // tile shape (64 lanes x i-pairs), of which a 4-cell-wide bottom box fills 2 lanes, and one CU runs the 64 boxes in 16
+    // rounds that 64 CUs run at once.  The launch-bound tail needs flat per-cell work lists, not fewer launches of this shape.
+    long long tiny_max_cells_ = 0;
+    bool tiny(int d) const;
+    void tiny_run(int d, double* const* fields, int nfields, const std::vector<TinyOp>& ops);
     long long fused_min_cells_ = 262144;
     long long march_min_cells_ = 262144;  // levels at least this big use the k-marching operator/residual
     long long ordered_max_cells_ = 4096;
