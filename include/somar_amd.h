@@ -477,6 +477,16 @@ int somar_amr_enable_leptic(somar_amr_t* a, const somar_leptic_params_t* lp, int
 int somar_amr_solve_leptic(somar_amr_t* a, int l_max, int l_base, int zero_phi, int force_homogeneous, somar_stats_t* stats);
 int somar_amr_leptic_stats(somar_amr_t* a, int level, somar_leptic_stats_t* stats); /* of the level's LAST leptic solve */
 
+/* Metric producers.  The coordinate maps themselves stay with the caller (LevelGeometry /
+ * GeoSourceInterface subclasses evaluate dx/dXi); what the device takes over is
+ *  - GeoSourceInterface::fill_Jgup's generic algebra (geometry/GeoSourceInterface.cpp:200-450: fill_dXidx by cofactors,
+ *    fill_gup, times det J, times scale) in 3-D: dxdxi9 = dx^rho/dXi^sigma at [(3 rho + sigma) n + i], detJ, out
+ *    jgup3[nu n + i] = scale J g^{mu nu} -- the layout somar_solver_set_metric_full takes for face direction mu;
+ *  - a Cartesian map (CartesianMap::fill_Jgup / fill_Jinv, geometry/maps/CartesianMap.cpp:230-280): c4 = {J g^xx, J g^yy,
+ *    J g^zz, J^{-1}} written into every local patch on the device, nothing crosses PCIe (before somar_solver_finalize). */
+int somar_metric_jgup_from_dxdxi(long long n, int mu, const double* dxdxi9, const double* detJ, double scale, double* jgup3);
+int somar_solver_set_metric_uniform(somar_solver_t* s, const double* c4);
+
 /* Diagnostics, no reference counterpart: what this device streams for a given mix of streams, in GB/s of algorithmic bytes
  * -- kind 0 copy (16 B/cell), 1 read (8 B/cell), 2 six reads + one write (56 B/cell: the fused GSRB sweep's mix without
  * stencil or halo).  bench.py reports kind 2 as the ceiling its roofline fraction is to be read against. */

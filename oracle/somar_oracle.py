@@ -1768,3 +1768,32 @@ def altered_jgup(nsq_fc, dximu_dz, dxinu_dz, gup, J, dt_theta, coriolis_f, hjac=
         d = d + ftilde * invfCoeff * (ix * jy - iy * jx)
     d = d + np.asarray(gup) * invfCoeff
     return d * np.asarray(J)
+
+
+# ----------------------------------------------------------------------------
+# GeoSourceInterface's generic metric algebra: geometry/GeoSourceInterface.cpp
+#   fill_dXidx (3-D, cofactors / det J) :200-291, fill_gup :373-415, fill_Jgup :417-450; ADDPROD2 / SUBPROD2
+#   geometry/GeoSourceInterfaceF.ChF:251-300.  One numpy statement per whole-FAB statement of the reference.
+# ----------------------------------------------------------------------------
+def geo_fill_dXidx(dxdxi, detJ, mu, nu):
+    """dxdxi[:, rho, sigma] = dx^rho / dXi^sigma"""
+    mu1, mu2 = (nu + 1) % 3, (nu + 2) % 3
+    nu1, nu2 = (mu + 1) % 3, (mu + 2) % 3
+    d = np.zeros_like(detJ)
+    d = d + dxdxi[:, mu1, nu1] * dxdxi[:, mu2, nu2]
+    d = d - dxdxi[:, mu1, nu2] * dxdxi[:, mu2, nu1]
+    return d / detJ
+
+
+def geo_fill_jgup(dxdxi, detJ, mu, scale=1.0):
+    """-> (n, 3): scale * J g^{mu nu}, nu = 0..2"""
+    out = np.zeros((detJ.size, 3))
+    for nu in range(3):
+        g = np.zeros_like(detJ)
+        for rho in range(3):
+            g = g + geo_fill_dXidx(dxdxi, detJ, mu, rho) * geo_fill_dXidx(dxdxi, detJ, nu, rho)
+        g = g * detJ
+        if scale != 1.0:
+            g = g * scale
+        out[:, nu] = g
+    return out

@@ -163,6 +163,8 @@ _SIGS = {
     "somar_amr_solve_leptic": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
     "somar_amr_leptic_stats": [_H, C.c_int, C.POINTER(LepticStats)],
     "somar_diag_stream_probe": [C.c_int, C.c_longlong, C.c_int, _PD],
+    "somar_metric_jgup_from_dxdxi": [C.c_longlong, C.c_int, _PD, _PD, C.c_double, _PD],
+    "somar_solver_set_metric_uniform": [_H, _PD],
     "somar_comm_unique_id": [C.POINTER(C.c_ubyte)],
     "somar_comm_create": [C.POINTER(_H), C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int],
     "somar_comm_create_shm": [C.POINTER(_H), C.c_char_p, C.c_int, C.c_int, C.c_longlong],
@@ -431,6 +433,10 @@ class AMRPressureSolver:
         out = np.zeros(shp, order="F")
         _ck(lib().somar_heat_flux_download(self._h, dir, patch, _dp(out)))
         return out
+
+    def setMetricUniform(self, jgxx, jgyy, jgzz, jinv):
+        """CartesianMap's constants into every local patch, on the device (no host arrays)"""
+        _ck(lib().somar_solver_set_metric_uniform(self._h, _da([jgxx, jgyy, jgzz, jinv])))
 
     def setMetricFull(self, patch, jg0, jg1, jg2, jinv):
         """jgD: array (faces(valid, D) shape + (SpaceDim,)), Fortran order = component slowest; jg2 = None in 2-D"""
@@ -855,6 +861,18 @@ def comm_create_shm(name, rank, nranks, outbox_bytes=64 << 20):
     h = _H()
     _ck(lib().somar_comm_create_shm(C.byref(h), name.encode(), rank, nranks, outbox_bytes))
     return h
+
+
+def jgup_from_dxdxi(dxdxi, detJ, mu, scale=1.0):
+    """GeoSourceInterface::fill_Jgup's generic algebra on the device.  dxdxi: array (n, 3, 3) with [i, rho, sigma] =
+    dx^rho/dXi^sigma; detJ: (n,).  Returns (n, 3): scale * J g^{mu nu}, nu = 0..2."""
+    d = np.ascontiguousarray(np.asarray(dxdxi, dtype=np.float64).reshape(-1, 9).T)   # component slowest
+    J = np.ascontiguousarray(np.asarray(detJ, dtype=np.float64).ravel())
+    n = J.size
+    out = np.zeros((3, n))
+    _ck(lib().somar_metric_jgup_from_dxdxi(n, mu, d.ctypes.data_as(_PD), J.ctypes.data_as(_PD), float(scale),
+                                           out.ctypes.data_as(_PD)))
+    return out.T.copy()
 
 
 def stream_probe(kind, cells=512 ** 3, reps=10):

@@ -45,6 +45,32 @@ AMRLink::~AMRLink()
 // ------------------------------------------------------------------------------------
 // AMRSolver
 // ------------------------------------------------------------------------------------
+// (lives here for FillItem / launch_fill_items, which the AMR tables introduced)
+// CartesianMap::fill_Jgup / fill_Jinv: the same regions set_metric_ortho uploads (valid faces / cells of every local patch),
+// written by a fill kernel
+void PressureSolver::set_metric_uniform(const double c4[4])
+{
+    SOMAR_CHECK(!lev.empty() && !finalized, "set_metric before define / after finalize");
+    SOMAR_CHECK(!full_, "set_metric_uniform is the diagonal-metric (Cartesian) producer");
+    Level& L = *lev[0];
+    for (int a = 0; a < 4; ++a) {
+        if (a < 3 && a >= prm.spaceDim) continue;
+        std::vector<FillItem> items;
+        for (int pi = 0; pi < L.npatches(); ++pi) {
+            const IBox valid = L.boxes[L.local[pi]];
+            FillItem it;
+            std::memset(&it, 0, sizeof(it));
+            it.patch = pi;
+            for (int d = 0; d < 3; ++d) { it.lo[d] = 0; it.n[d] = valid.size(d) + ((a < 3 && d == a) ? 1 : 0); }
+            items.push_back(it);
+        }
+        FillItem* d_items = to_device(items);
+        launch_fill_items(st_, L.dev.patches, d_items, (int)items.size(), a < 3 ? L.dev.jg[a] : L.dev.jinv, c4[a]);
+        sync();
+        hipFree(d_items);
+    }
+}
+
 AMRSolver::AMRSolver(Comm* comm) : comm_(comm ? comm : &self_)
 {
     SOMAR_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));

@@ -1154,6 +1154,38 @@ int somar_altered_jgup(long long n, double* dest, const double* nsq_fc, const do
     API_END
 }
 
+// GeoSourceInterface::fill_Jgup's generic algebra on the device: host arrays in, host array out
+int somar_metric_jgup_from_dxdxi(long long n, int mu, const double* dxdxi9, const double* detJ, double scale, double* jgup3)
+{
+    API_BEGIN
+    SOMAR_CHECK(n > 0 && mu >= 0 && mu < 3 && dxdxi9 && detJ && jgup3, "null/empty argument");
+    double* dev = nullptr;
+    SOMAR_HIP(hipMalloc(&dev, (size_t)13 * n * sizeof(double)));
+    try {
+        SOMAR_HIP(hipMemcpy(dev, dxdxi9, (size_t)9 * n * sizeof(double), hipMemcpyHostToDevice));
+        SOMAR_HIP(hipMemcpy(dev + (size_t)9 * n, detJ, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        const double* x9[9];
+        for (int q = 0; q < 9; ++q) x9[q] = dev + (size_t)q * n;
+        launch_jgup_from_dxdxi(nullptr, n, mu, x9, dev + (size_t)9 * n, scale, dev + (size_t)10 * n);
+        SOMAR_HIP(hipDeviceSynchronize());
+        SOMAR_HIP(hipMemcpy(jgup3, dev + (size_t)10 * n, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    } catch (...) {
+        hipFree(dev);
+        throw;
+    }
+    hipFree(dev);
+    API_END
+}
+
+// CartesianMap::fill_Jgup / fill_Jinv (geometry/maps/CartesianMap.cpp:230-280): constants, written on the device
+int somar_solver_set_metric_uniform(somar_solver_t* s, const double* c4)
+{
+    API_BEGIN
+    SOMAR_CHECK(s && c4, "null argument");
+    s->ps->set_metric_uniform(c4);
+    API_END
+}
+
 // Diagnostics: the streaming rate of this device for a given stream mix, GB/s of algorithmic bytes (kind 0: 16 B/cell,
 // 1: 8 B/cell, 2: 56 B/cell), best of the workgroup counts tried.  bench.py reports kind 2 next to the fused sweep's rate.
 int somar_diag_stream_probe(int kind, long long cells, int reps, double* gbs)

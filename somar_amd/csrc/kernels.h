@@ -130,6 +130,8 @@ void launch_reduce_ordered_flat(hipStream_t st, int nboxes, const long long* box
                                 int mode, double* out);
 void launch_div_mac(hipStream_t st, const LevelDev& L, double* out, const double* u0, const double* u1,
                     const double* u2, double dt);
+void launch_jgup_from_dxdxi(hipStream_t st, long long n, int mu, const double* const x9[9], const double* J, double scale,
+                            double* out);
 void launch_altered_jgup(hipStream_t st, long long n, double* dest, const double* nsq, const double* dmu,
                          const double* dnu, const double* ix, const double* jy, const double* iy, const double* jx,
                          const double* gup, const double* J, double theta, double coriolisF, bool offdiag);

@@ -127,6 +127,46 @@ void launch_altered_jgup(hipStream_t st, long long n, double* dest, const double
                        coriolisF, offdiag ? 1 : 0);
 }
 
+// GeoSourceInterface's generic metric algebra, 3-D (geometry/GeoSourceInterface.cpp:200-450), after the map has handed over
+// its Jacobian matrix dx^rho/dXi^sigma (x[3 * rho + sigma], each n values at the destination's centring) and det J:
+//   fill_dXidx(mu, nu) = ((0 + A B) - C D) / J,  A = dx^{mu1}/dXi^{nu1}, B = dx^{mu2}/dXi^{nu2}, C = dx^{mu1}/dXi^{nu2},
+//                        D = dx^{mu2}/dXi^{nu1}, mu1 = (nu+1)%3, mu2 = (nu+2)%3, nu1 = (mu+1)%3, nu2 = (mu+2)%3   (:236-291)
+//   fill_gup(mu, nu)   = ((0 + dXidx(mu,0) dXidx(nu,0)) + dXidx(mu,1) dXidx(nu,1)) + dXidx(mu,2) dXidx(nu,2)        (:373-415)
+//   fill_Jgup(mu, nu)  = gup * J [* scale when scale != 1]                                                         (:417-450)
+// one whole-FAB statement of the reference per line, so the roundings are the same.  out: J g^{mu nu}, nu = 0..2 (3 n values)
+struct DX9 { const double* x[9]; };
+__global__ void k_jgup_from_dxdxi(long long n, int mu, DX9 X, const double* __restrict__ J, double scale, double* __restrict__ out)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double detJ = J[i];
+        auto dXidx = [&](int a, int b) {
+            const int mu1 = (b + 1) % 3, mu2 = (b + 2) % 3, nu1 = (a + 1) % 3, nu2 = (a + 2) % 3;
+            double d = 0.0;
+            d = d + X.x[3 * mu1 + nu1][i] * X.x[3 * mu2 + nu2][i];   // ADDPROD2
+            d = d - X.x[3 * mu1 + nu2][i] * X.x[3 * mu2 + nu1][i];   // SUBPROD2
+            return d / detJ;
+        };
+        double m[3];
+        for (int rho = 0; rho < 3; ++rho) m[rho] = dXidx(mu, rho);
+        for (int nu = 0; nu < 3; ++nu) {
+            double g = 0.0;
+            for (int rho = 0; rho < 3; ++rho) g = g + m[rho] * (nu == mu ? m[rho] : dXidx(nu, rho));
+            g = g * detJ;
+            if (scale != 1.0) g = g * scale;
+            out[(long long)nu * n + i] = g;
+        }
+    }
+}
+void launch_jgup_from_dxdxi(hipStream_t st, long long n, int mu, const double* const x9[9], const double* J, double scale,
+                            double* out)
+{
+    if (n <= 0) return;
+    DX9 X;
+    for (int q = 0; q < 9; ++q) X.x[q] = x9[q];
+    const int blocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    hipLaunchKernelGGL(k_jgup_from_dxdxi, dim3(blocks), dim3(256), 0, st, n, mu, X, J, scale, out);
+}
+
 // vel^a += s * g^a on every a-face of every box (low face at the cell, the last cell of a row also its high face)
 struct FA3 { double* v[3]; const double* g[3]; };
 __global__ __launch_bounds__(512) void k_face_axpy(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ patches,

@@ -57,6 +57,8 @@ public:
     // Non-diagonal metric of one LOCAL patch: jgD = J g^{Db} on faces(valid, D), 3 components, component slowest
     // (LevelGeometry::getFCJgup's FluxBox layout).  Switches the solver to the 19-point kernels (full19.hip).
     void set_metric_full(int patch, const double* jg0, const double* jg1, const double* jg2, const double* jinv);
+    // a Cartesian map's constants (CartesianMap::fill_Jgup / fill_Jinv) into every local patch, on the device
+    void set_metric_uniform(const double c4[4]);
     bool is_full() const { return full_; }
     // before finalize: switch this solver to the non-diagonal path with every cross plane allocated (zero) -- for callers that
     // fill the metric planes of level(0).dev.jgf on the device themselves (the leptic solver's J-scaled and flat operators)

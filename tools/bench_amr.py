@@ -62,6 +62,8 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
                 tm["host_metric_arrays"] += tb - ta
                 tm["metric_upload"] += time.perf_counter() - tb
                 continue
+            if not os.environ.get("SOMAR_BENCH_HOST_METRIC"):
+                continue   # Cartesian: J = 1, Jg^aa = 1 -- written on the device below (setMetricUniform), no host arrays
             ta = time.perf_counter()
             ones = [np.ones((shp[0] + (d == 0), shp[1] + (d == 1), shp[2] + (d == 2)), order="F") for d in range(3)]
             one_c = np.ones(shp, order="F")
@@ -70,6 +72,10 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
             tm["host_metric_arrays"] += tb - ta
             tm["metric_upload"] += time.perf_counter() - tb
         cells.append(tot)
+        if H.get("metric") != "terrain" and not os.environ.get("SOMAR_BENCH_HOST_METRIC"):
+            ta = time.perf_counter()
+            v.setMetricUniform(1.0, 1.0, 1.0, 1.0)   # CartesianMap::fill_Jgup / fill_Jinv on the device
+            tm["metric_upload"] += time.perf_counter() - ta
     ta = time.perf_counter()
     gpu.finalize()
     gpu.levels[0].sync()

@@ -88,14 +88,28 @@ def pmc(fd, wd, out, cells):
         v = [r[2] for r in sel if r[1] == g]
         return sum(v) / len(v) * 1024.0, len(v)
 
-    res = {"cells": cells, "note": "bytes per launch at depth 0; fetch calibrate on k_sub_mean (reads 8 B and writes 8 B per element of the whole depth-0 allocation)"}
+    res = {"cells": cells, "note": "bytes per launch at depth 0 (largest grid of each kernel); the gfx950 FETCH_SIZE correction is "
+                                   "calibrated in the same run on kernels of exactly known traffic: k_sub_mean (8 B read + 8 B written "
+                                   "per element) when present, and bench.py's k_stream_probe<1> (reads 8 B per cell of a 512^3 array, "
+                                   "writes nothing) / k_stream_probe<2> (48 B read + 8 B written per cell)"}
     inc_f, inc_w = biggest(fetch, "k_sub_mean"), biggest(write, "k_sub_mean")
     res["k_sub_mean_raw_fetch"], res["k_sub_mean_raw_write"] = inc_f, inc_w
+    p1, p2f, p2w = biggest(fetch, "k_stream_probe<1>"), biggest(fetch, "k_stream_probe<2>"), biggest(write, "k_stream_probe<2>")
+    if p1:
+        res["k_stream_probe_read_raw_fetch"] = p1[0]
+        res["fetch_correction_from_read_probe"] = 8.0 * 512 ** 3 / p1[0]
+    if p2f and p2w:
+        res["k_stream_probe_mix_raw_fetch"], res["k_stream_probe_mix_write"] = p2f[0], p2w[0]
+        res["fetch_correction_from_mix_probe"] = 48.0 * 512 ** 3 / p2f[0]
+        res["write_check_from_mix_probe"] = p2w[0] / (8.0 * 512 ** 3)
     res["raw"] = {}
-    for key in ("k_gsrb_ortho", "k_gsrb_fused", "k_op_ortho<0>", "k_resid_march<0>", "k_restrict", "k_prolong"):
+    for key in ("k_gsrb_ortho", "k_gsrb_fused", "k_op_ortho<0>", "k_resid_march<0", "k_resid_march<2", "k_restrict", "k_prolong"):
         f, w = biggest(fetch, key), biggest(write, key)
         if f and w:
             res["raw"][key] = {"fetch_bytes_raw": f[0], "write_bytes": w[0], "launches": f[1]}
+    corr = res.get("fetch_correction_from_read_probe") or 2.0
+    res["corrected"] = {k: {"bytes_per_launch": v["fetch_bytes_raw"] * corr + v["write_bytes"], "per_cell": (v["fetch_bytes_raw"] * corr + v["write_bytes"]) / cells,
+                            "fetch_correction_used": corr} for k, v in res["raw"].items()}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
