@@ -11,9 +11,20 @@ _LIBS = {}
 _PD = C.POINTER(C.c_double)
 
 
+def _host_tag():
+    """identifies the CPU the -march=native build is for (model name + ISA flags)"""
+    import hashlib
+    try:
+        txt = open("/proc/cpuinfo").read()
+        keep = [ln for ln in txt.splitlines() if ln.startswith(("model name", "flags"))][:2]
+    except OSError:
+        keep = ["unknown"]
+    return hashlib.sha1("\n".join(keep).encode()).hexdigest()[:10]
+
+
 def lib(fast=True):
-    """fast: -O3 -march=native (timing build); otherwise -O2 -ffp-contract=off (parity build, as liboracle.so)"""
-    name = "liboracle_cpu.so" if fast else "liboracle_cpu_exact.so"
+    """fast: -O3 -march=native (timing build, one per host CPU); otherwise -O2 -ffp-contract=off (parity build, as liboracle.so)"""
+    name = ("liboracle_cpu_%s.so" % _host_tag()) if fast else "liboracle_cpu_exact.so"
     if name not in _LIBS:
         subprocess.check_call(["make", "-s", "-C", _HERE, name])
         L = C.CDLL(os.path.join(_HERE, name))
