@@ -1013,6 +1013,78 @@ int orc_linegsrbiter3d(double *phi_, const int *plo, const int *phi_hi,
 }
 
 /* ------------------------------------------------------------------------
+ * K5  LineGSRBIter2D   RelaxationMethods/GSRBF.ChF:1529-1724  (CH_SPACEDIM = 2: the vertical is direction 1)
+ * One colour (columns i with i + redBlack even): per column assemble B = -lphi + rhs/Jinv, D = alpha/Jinv + lapDiag,
+ * DL_j = DU_j = Jg1^{11}_{j+1} yyScale with the x and cross terms lagged, dgtsv, overwrite the column.  The x neighbour of
+ * a column on the REGION bound is dropped iff that side's BC code is Neumann (region bounds, as written, :1607-1611).
+ * The region must start at the vertical index 0 (:1561-1565).  bc = {loX, hiX, loY, hiY}; Jg0 / Jg1 carry 2 comps.
+ * Arrays are the 3-D FRAs of this oracle with one cell in the third direction (index k0).
+ * ---------------------------------------------------------------------- */
+int orc_linegsrbiter2d(double *phi_, const int *plo, const int *phi_hi,
+                       const double *ext_, const int *elo, const int *ehi,
+                       const double *rhs_, const int *rlo, const int *rhi,
+                       const double *jg0_, const int *xlo, const int *xhi,
+                       const double *jg1_, const int *ylo, const int *yhi,
+                       const double *jinv_, const int *jlo, const int *jhi,
+                       const int *reglo, const int *reghi, const double *dx, double dzCrse,
+                       double alpha, double beta, int redBlack, const int *bc)
+{
+    fra_t phi = mk(phi_, plo, phi_hi), extrap = mk((double *)ext_, elo, ehi);
+    fra_t rhs = mk((double *)rhs_, rlo, rhi);
+    fra_t Jg0 = mk((double *)jg0_, xlo, xhi), Jg1 = mk((double *)jg1_, ylo, yhi), Jinv = mk((double *)jinv_, jlo, jhi);
+    const int loX = bc[0], hiX = bc[1], loY = bc[2], hiY = bc[3];
+    const int k = reglo[2];
+    if (reglo[1] != 0) return -2;   /* 'LineGSRBIter2D: region must have a vertical lower bound of zero' */
+    const int jmax = reghi[1], N = jmax + 1;
+    const double xxScale = beta * 1.0 / (dx[0] * dx[0]);
+    const double yyScale = beta * 1.0 / (dx[1] * dx[1]);
+    const double xyScale = beta * 0.25 / (dx[0] * dx[1]);
+    double *D = (double *)malloc(sizeof(double) * (size_t)N), *B = (double *)malloc(sizeof(double) * (size_t)N);
+    double *DL = (double *)malloc(sizeof(double) * (size_t)N), *DU = (double *)malloc(sizeof(double) * (size_t)N);
+    int worst = 0;
+#define E(a, b) AT(extrap, a, b, k, 0)
+    int imin = reglo[0] + abs((reglo[0] + redBlack) % 2);
+    for (int i = imin; i <= reghi[0]; i += 2) {
+        for (int j = 0; j <= jmax; ++j) {
+            double coeff1, lapDiag;
+            if (j == 0) {
+                coeff1 = (loY == BC_NEUM) ? 0.0 : (loY == 1 /*Diri*/ ? 2.0 : (loY == 3 /*CF*/ ? 2.0 * dx[1] / (dzCrse + dx[1]) : 0.0));
+                lapDiag = -yyScale * (AT(Jg1, i, j + 1, k, 1) + coeff1 * AT(Jg1, i, j, k, 1));
+            } else if (j == jmax) {
+                coeff1 = (hiY == BC_NEUM) ? 0.0 : (hiY == 1 ? 2.0 : (hiY == 3 ? 2.0 * dx[1] / (dzCrse + dx[1]) : 0.0));
+                lapDiag = -yyScale * (coeff1 * AT(Jg1, i, j + 1, k, 1) + AT(Jg1, i, j, k, 1));
+            } else {
+                lapDiag = -yyScale * (AT(Jg1, i, j, k, 1) + AT(Jg1, i, j + 1, k, 1));
+            }
+            double JDxx = 0.0;
+            if ((loX != BC_NEUM) || (i != reglo[0])) {
+                JDxx = JDxx + AT(Jg0, i, j, k, 0) * AT(phi, i - 1, j, k, 0);
+                lapDiag = lapDiag - xxScale * AT(Jg0, i, j, k, 0);
+            }
+            if ((hiX != BC_NEUM) || (i != reghi[0])) {
+                JDxx = JDxx + AT(Jg0, i + 1, j, k, 0) * AT(phi, i + 1, j, k, 0);
+                lapDiag = lapDiag - xxScale * AT(Jg0, i + 1, j, k, 0);
+            }
+            double JDxy = AT(Jg0, i + 1, j, k, 1) * (E(i + 1, j + 1) - E(i + 1, j - 1) + E(i, j + 1) - E(i, j - 1)) -
+                          AT(Jg0, i, j, k, 1) * (E(i, j + 1) - E(i, j - 1) + E(i - 1, j + 1) - E(i - 1, j - 1));
+            double JDyx = AT(Jg1, i, j + 1, k, 0) * (E(i + 1, j + 1) - E(i - 1, j + 1) + E(i + 1, j) - E(i - 1, j)) -
+                          AT(Jg1, i, j, k, 0) * (E(i + 1, j) - E(i - 1, j) + E(i + 1, j - 1) - E(i - 1, j - 1));
+            double lphi = JDxx * xxScale + (JDxy + JDyx) * xyScale;
+            B[j] = -lphi + AT(rhs, i, j, k, 0) / AT(Jinv, i, j, k, 0);
+            D[j] = alpha / AT(Jinv, i, j, k, 0) + lapDiag;
+            if (j < jmax) DL[j] = AT(Jg1, i, j + 1, k, 1) * yyScale;
+        }
+        for (int q = 0; q < N - 1; ++q) DU[q] = DL[q];
+        int info = orc_dgtsv_nopivot(N, DL, D, DU, B);
+        if (info != 0 && info != N) { if (worst == 0) worst = info; }
+        for (int j = 0; j <= jmax; ++j) AT(phi, i, j, k, 0) = B[j];
+    }
+#undef E
+    free(D); free(B); free(DL); free(DU);
+    return worst;
+}
+
+/* ------------------------------------------------------------------------
  * K18 TriDiagPoissonNN1DFAB   utils/TridiagUtilsF.ChF:85-166
  * Along every line that starts in bottomBox and runs Nx cells in direction dir: solves the homogeneous
  * Neumann-Neumann 1-D Poisson problem  D(sigma D phi) = rhs  (sigma face-centred in dir) with the

@@ -634,8 +634,24 @@ class LineGSRB(Relaxer):
 
     def relax(self, phi, rhs):
         op = self.op
-        assert op.ndim == 3 and op.activeDirs == (1, 1, 1)
         L = lib()
+        if op.ndim == 2:
+            # CH_SPACEDIM = 2 build: LineGSRBIter2D, the vertical is direction 1 (GSRB.cpp:262-289, GSRBF.ChF:1529-1724)
+            for whichPass in (0, 1):
+                exchange(phi, op.domain, op.activeDirs)
+                self.fill_ghosts_and_extrapolate(phi)
+                for i, valid in enumerate(op.grids):
+                    st = [op.bc.stencil(valid, op.domain, d, s) for d in range(2) for s in (0, 1)]
+                    ex = self.extrap[i] if not op.isDiagonal else phi[i]
+                    lo, hi = _b(valid)
+                    Jg = op.Jgup[i]
+                    dzCrse = op.dxCrse[1] if op.dxCrse is not None else float("nan")
+                    info = L.orc_linegsrbiter2d(*phi[i].fra1(0), *ex.fra1(0), *rhs[i].fra1(0), *Jg[0].fran(), *Jg[1].fran(),
+                                                *op.Jinv[i].fra1(0), lo, hi, _rv(op.dx), C.c_double(dzCrse),
+                                                C.c_double(op.alpha), C.c_double(op.beta), whichPass, (C.c_int * 4)(*st))
+                    assert info == 0, "LineGSRBIter2D: INFO = %d" % info
+            return
+        assert op.ndim == 3 and op.activeDirs == (1, 1, 1)
         for whichPass in (0, 1):
             exchange(phi, op.domain, op.activeDirs)
             self.fill_ghosts_and_extrapolate(phi)
