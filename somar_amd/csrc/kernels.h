@@ -61,6 +61,9 @@ void launch_sum_partials(hipStream_t st, const double* partials, int n, double* 
 // out[0] = a[0] + b[0]; out[1] = c[0]
 void launch_combine_sums(hipStream_t st, double* out, const double* a, const double* b, const double* c);
 // one colour of vertical-line GSRB (line_gsrb.hip); ctiles = whole-column tiles (k0 = 0, nk = n2)
+// LineGSRBIter2D (space_dim 2: lines along y); maxN0: the widest local box in x
+void launch_line_gsrb_2d(hipStream_t st, const LevelDev& L, int maxN0, double* phi, const double* rhs, double* dmod, int color,
+                         const double* psi);
 void launch_line_gsrb_ortho(hipStream_t st, const Tile* ctiles, int nctiles, int tile_j, const LevelDev& L,
                             double* phi, const double* rhs, double* dmod, int color, const double* psi = nullptr);
 void launch_op_ortho(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* rhs, int mode);

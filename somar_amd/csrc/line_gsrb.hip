@@ -141,4 +141,96 @@ void launch_line_gsrb_ortho(hipStream_t st, const Tile* ctiles, int nctiles, int
                            L.jg[0], L.jg[1], L.jg[2], L.jinv, dmod, L.P, color, J, psi);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// CH_SPACEDIM = 2: LineGSRBIter2D (GSRBF.ChF:1529-1724).  The vertical is direction 1; one colour = the columns i with
+// i + colour even (the 2-D routine colours by i alone); a lane owns one column, 64 adjacent columns per wavefront (half of
+// them of the colour), and marches in j with the same in-register dgtsv elimination as the 3-D kernel.  The x neighbour of a
+// column on the box bound is dropped iff that side is a Neumann domain face (the routine tests the REGION bound, :1607-1611).
+// FULL: the cross terms J g^{01}, J g^{10} from the extrapolated copy E, explicit, as written.
+// grid (chunks of 64 columns, patches), 64 threads.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <bool FULL>
+__global__ __launch_bounds__(64) void k_line_gsrb_2d(const PatchDesc* __restrict__ patches, double* __restrict__ phi,
+                                                     const double* __restrict__ rhs, const double* __restrict__ jgx,
+                                                     const double* __restrict__ jgy, const double* __restrict__ jinv,
+                                                     double* __restrict__ dmod, StencilParams P, int color,
+                                                     const double* __restrict__ jg01, const double* __restrict__ jg10,
+                                                     const double* __restrict__ E)
+{
+    const PatchDesc p = patches[blockIdx.y];
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= p.n[0]) return;
+    const int gi = p.lo[0] + li;
+    if ((gi + color) & 1) return;   // imin = lbound + |mod(lbound + redBlack, 2)|, step 2: columns with i + redBlack even
+    const int N = p.n[1];
+    const long long sj = p.pj;
+    const double xxScale = P.beta * 1.0 / (P.dx[0] * P.dx[0]);
+    const double yyScale = P.beta * 1.0 / (P.dx[1] * P.dx[1]);
+    const double xyScale = P.beta * 0.25 / (P.dx[0] * P.dx[1]);
+    const bool nxl = (gi == P.dom_lo[0]) && P.neum[0][0];
+    const bool nxh = (gi == P.dom_hi[0]) && P.neum[0][1];
+    // vertical ends: Neumann and "None" 0, Dirichlet 2 (CF ends are refused at define)
+    const double c1lo = (p.lo[1] == P.dom_lo[1] && P.diri[1][0]) ? 2.0 : 0.0;
+    const double c1hi = (p.lo[1] + N - 1 == P.dom_hi[1] && P.diri[1][1]) ? 2.0 : 0.0;
+    long long c = p.off + li;   // j = 0 (k = 0: the one plane of a 2-D level)
+    double d_prev = 0.0, b_prev = 0.0, dl_prev = 0.0;
+    for (int j = 0; j < N; ++j, c += sj) {
+        const double gyl = jgy[c], gyh = jgy[c + sj];
+        double lapDiag;
+        if (j == 0) lapDiag = -yyScale * (gyh + c1lo * gyl);
+        else if (j == N - 1) lapDiag = -yyScale * (c1hi * gyh + gyl);
+        else lapDiag = -yyScale * (gyl + gyh);
+        double JDxx = 0.0;
+        if (!nxl) { JDxx = JDxx + jgx[c] * phi[c - 1];      lapDiag = lapDiag - xxScale * jgx[c]; }
+        if (!nxh) { JDxx = JDxx + jgx[c + 1] * phi[c + 1];  lapDiag = lapDiag - xxScale * jgx[c + 1]; }
+        double lphi;
+        if (FULL) {
+#define EE(di, dj) E[c + (di) + sj * (dj)]
+            const double JDxy = jg01[c + 1] * (EE(1, 1) - EE(1, -1) + EE(0, 1) - EE(0, -1)) -
+                                jg01[c] * (EE(0, 1) - EE(0, -1) + EE(-1, 1) - EE(-1, -1));
+            const double JDyx = jg10[c + sj] * (EE(1, 1) - EE(-1, 1) + EE(1, 0) - EE(-1, 0)) -
+                                jg10[c] * (EE(1, 0) - EE(-1, 0) + EE(1, -1) - EE(-1, -1));
+#undef EE
+            lphi = JDxx * xxScale + (JDxy + JDyx) * xyScale;
+        } else {
+            lphi = JDxx * xxScale;   // J g^{01} = J g^{10} = 0: (0 + 0) * xyScale adds nothing
+        }
+        const double Ji = jinv[c];
+        double B = -lphi + rhs[c] / Ji;
+        double D = P.alpha / Ji + lapDiag;
+        if (j > 0) {   // dgtsv elimination step i = j-1 (no interchange), du(i) == dl(i)
+            const double fact = dl_prev / d_prev;
+            D = D - fact * dl_prev;
+            B = B - fact * b_prev;
+        }
+        dmod[c] = D;
+        phi[c] = B;
+        d_prev = D;
+        b_prev = B;
+        dl_prev = gyh * yyScale;   // DL(j) = DU(j) = Jg1(j+1) * yyScale
+    }
+    c -= sj;
+    double x = b_prev / d_prev;
+    phi[c] = x;
+    for (int j = N - 2; j >= 0; --j) {
+        c -= sj;
+        const double du = jgy[c + sj] * yyScale;
+        x = (phi[c] - du * x) / dmod[c];
+        phi[c] = x;
+    }
+}
+
+void launch_line_gsrb_2d(hipStream_t st, const LevelDev& L, int maxN0, double* phi, const double* rhs, double* dmod, int color,
+                         const double* psi)
+{
+    if (L.npatches == 0) return;
+    const dim3 grid((maxN0 + 63) / 64, L.npatches);
+    if (psi)
+        hipLaunchKernelGGL(k_line_gsrb_2d<true>, grid, dim3(64), 0, st, L.patches, phi, rhs, L.jg[0], L.jg[1], L.jinv, dmod, L.P,
+                           color, L.jgf[0][1], L.jgf[1][0], psi);
+    else
+        hipLaunchKernelGGL(k_line_gsrb_2d<false>, grid, dim3(64), 0, st, L.patches, phi, rhs, L.jg[0], L.jg[1], L.jinv, dmod, L.P,
+                           color, nullptr, nullptr, psi);
+}
+
 }  // namespace somar

@@ -210,8 +210,10 @@ void PressureSolver::define(const IBox& domain, const bool periodic[3], const do
     std::unique_ptr<Level> L(new Level);
     if (prm.spaceDim == 2) {
         SOMAR_CHECK(domain.size(2) == 1, "space_dim 2 wants a domain (and boxes) one cell thick in z");
-        SOMAR_CHECK(prm.relaxMode != RELAX_LINE_GSRB && prm.precondMode != PRECOND_DIAG_LINE_RELAX,
-                    "line relaxation is implemented for space_dim 3 only");
+        if (prm.relaxMode == RELAX_LINE_GSRB || prm.precondMode == PRECOND_DIAG_LINE_RELAX)
+            for (const IBox& b : boxes)   // 'LineGSRBIter2D: region must have a vertical lower bound of zero' (GSRBF.ChF:1561-1565)
+                SOMAR_CHECK(b.lo[1] == domain.lo[1] && b.hi[1] == domain.hi[1],
+                            "2-D line relaxation wants boxes that span the vertical (direction 1)");
         L->active[2] = 0;
     }
     L->alpha = alpha;
@@ -222,8 +224,9 @@ void PressureSolver::define(const IBox& domain, const bool periodic[3], const do
         L->define_cf(dxCrse_);
         if (prm.relaxMode == RELAX_LINE_GSRB || prm.precondMode == PRECOND_DIAG_LINE_RELAX)
             for (const CFCell& c : L->hcf)
-                SOMAR_CHECK((c.dir & 3) != 2, "line relaxation: coarse-fine boundaries at the vertical ends of a column "
-                                              "(the CF row of LineGSRBIter3D, GSRBF.ChF:1804-1817) are not implemented");
+                SOMAR_CHECK((c.dir & 3) != (prm.spaceDim == 3 ? 2 : 1),
+                            "line relaxation: coarse-fine boundaries at the vertical ends of a column (the CF row of "
+                            "LineGSRBIter3D / 2D, GSRBF.ChF:1804-1817, 1588-1590) are not implemented");
     }
     lev.push_back(std::move(L));
 }
@@ -459,8 +462,7 @@ void PressureSolver::finalize()
     if (full_) {
         SOMAR_CHECK(prm.relaxMode == RELAX_LEVEL_GSRB || prm.relaxMode == RELAX_JACOBI || prm.relaxMode == RELAX_LINE_GSRB,
                     "the non-diagonal metric path offers LevelGSRB, LineGSRB and Jacobi");
-        SOMAR_CHECK(prm.spaceDim == 3 || (prm.relaxMode != RELAX_LINE_GSRB && prm.precondMode != PRECOND_DIAG_LINE_RELAX),
-                    "line relaxation is implemented for space_dim 3 only");
+        // (space_dim 2: LineGSRBIter2D with its two cross terms, line_gsrb.hip)
         f_psi.assign(D, nullptr);
         full_prog_.resize(D);
         for (int d = 0; d < D; ++d) {
@@ -762,6 +764,12 @@ void PressureSolver::line_relax(int d, double* e, const double* res)
         L.cf_homog(e, st_);  // fillGhostsAndExtrapolate: homogeneous CF values in the lateral ghost cells
         if (diri_ && !full_) apply_diri(d, e, true);  // ... and the ghosts of lateral Dirichlet sides (the vertical ends are folded in)
         if (full_) run_full_program(d, 1, e);  // extrap copy (order 1) + physical ghosts: the cross terms are explicit
+        if (prm.spaceDim == 2) {
+            int maxN0 = 1;
+            for (const PatchDesc& q : L.hpatches) maxN0 = std::max(maxN0, q.n[0]);
+            launch_line_gsrb_2d(st_, L.dev, maxN0, e, res, f_pp[d], pass, full_ ? f_psi[d] : nullptr);
+            continue;
+        }
         launch_line_gsrb_ortho(st_, L.d_ctiles, L.nctiles, L.ctile_j, L.dev, e, res, f_pp[d], pass, full_ ? f_psi[d] : nullptr);
     }
 }
