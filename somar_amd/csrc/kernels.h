@@ -9,6 +9,10 @@ struct LevelDev {
     const Tile* tiles = nullptr;        // XCD-contiguous order
     int ntiles = 0;
     int tile_j = 4;                     // blockDim.y of every tile kernel on this level
+    // pull exchange (small single-rank levels): per tile, the local ghost copies that land in the tile's one-cell halo; a
+    // stencil kernel refreshes exactly the ghosts it is about to read, so the separate copy launch disappears (null: not built)
+    const CopyItem* tile_items = nullptr;
+    const int* tile_item_start = nullptr;
     int ghost_gy = 16;                  // workgroups per ghost op (k_ghost_ops): the largest box face / 1024, within [16, 256]
     const PatchDesc* patches = nullptr;
     int npatches = 0;
@@ -38,7 +42,9 @@ void launch_op_full(hipStream_t st, const LevelDev& L, double* out, const double
 void launch_gsrb_full(hipStream_t st, const LevelDev& L, double* phi, const double* psi, const double* rhs, int color);
 
 // loose: 0 LevelGSRB pass; 1 / 2: interior / box-shell phase of LooseGSRB (see k_gsrb_ortho)
-void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color, int loose = 0);
+// pull: refresh the ghosts the pass reads inside the kernel (LevelDev::tile_items; LevelGSRB passes only)
+void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color, int loose = 0,
+                       bool pull = false);
 // one full red+black sweep, phi_in -> phi_out (gsrb_fused.hip); needs phi_in ghosts 2 deep and
 // rhs / Jg / Jinv ghosts 1 deep wherever a neighbouring box or periodic image exists
 // in_mode 0: plain; 1: phi_in is taken to be all zeros and is not read; 2: phi_in is read as
@@ -66,7 +72,8 @@ void launch_line_gsrb_2d(hipStream_t st, const LevelDev& L, int maxN0, double* p
                          const double* psi);
 void launch_line_gsrb_ortho(hipStream_t st, const Tile* ctiles, int nctiles, int tile_j, const LevelDev& L,
                             double* phi, const double* rhs, double* dmod, int color, const double* psi = nullptr);
-void launch_op_ortho(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* rhs, int mode);
+void launch_op_ortho(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* rhs, int mode,
+                     bool pull = false);
 void launch_lapdiag(hipStream_t st, const LevelDev& L);
 void launch_diag(hipStream_t st, const LevelDev& L, double* phi, const double* r, int mode);
 void launch_restrict(hipStream_t st, const LevelDev& C, const LevelDev& F, double* crse, const double* fine,
@@ -88,6 +95,8 @@ void launch_publish(hipStream_t st, const double* src, int n, double* host_dst, 
                     unsigned long long seq);
 void launch_copy(hipStream_t st, double* d, const double* s, long long n);
 void launch_incr(hipStream_t st, double* y, const double* x, double a, long long n);
+void launch_incr2(hipStream_t st, double* y1, const double* x1, double a1, double* y2, const double* x2, double a2, long long n);
+void launch_bicg_p(hipStream_t st, double* p, const double* v, const double* r, double beta, double bw, long long n);  // p = (p*beta + bw*v) + r
 void launch_incr_copy(hipStream_t st, double* y, double* x, double a, long long n);  // y += a*x; x = y
 void launch_scale(hipStream_t st, double* y, double a, long long n);
 void launch_mul(hipStream_t st, double* y, const double* x, long long n);   // y *= x elementwise
@@ -121,10 +130,13 @@ void launch_stream_probe(hipStream_t st, int kind, int workgroups, double* const
 // (min, max) per (patch, k-chunk) of a over the valid cells (dir < 0) or valid dir-faces: out[2 * npatches * MM_CH] (device)
 constexpr int MM_CH = 64;
 void launch_minmax_valid(hipStream_t st, const LevelDev& L, const double* a, int dir, double* out);
+// where a reduction's result is also stored for the host: coherent host memory + a sequence number the host spins on
+// (PressureSolver::fetch_scalars); fused into the reduction's last kernel it saves the separate one-thread publish launch
+struct ScalarPublish { double* host_dst; unsigned long long* host_seq; unsigned long long seq; };
 // mode 0: sum a*b, 1: max|a|, 2: sum|a|, 3: signed max a  -> out[0] (device)
 // ordered: reference-ordered serial sum (modes 0 and 2; meant for small levels, see k_reduce_ordered)
 void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const double* b, int mode, double* partials,
-                   double* out, bool ordered = false);
+                   double* out, bool ordered = false, const ScalarPublish* pub = nullptr);
 // sharded small level: the rank's per-cell terms into their slot of the serial sequence (mode 0: a*b, 2: |a|, 6: X = dxProduct/b*a,
 // Y = dxProduct/b), then -- after a sum-allreduce of X (and Y) -- the walk in the reference's order (k_reduce_ordered_flat)
 void launch_ord_fill(hipStream_t st, const LevelDev& L, const long long* start, const double* a, const double* b,

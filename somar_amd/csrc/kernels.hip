@@ -170,6 +170,33 @@ __device__ __forceinline__ void gsrb_ortho_body(const Tile* __restrict__ tiles, 
     }
 }
 
+// Pull exchange: before a stencil kernel's workgroup computes, it refreshes the ghost cells in the one-cell halo of ITS tile from
+// their source cells (the clipped local copy items of Level::define) -- the values a preceding k_copy_items launch would have
+// put there.  Workgroups refresh shared ghost cells redundantly with the same value.  Race-free for a colour pass: a cell of
+// the pass's colour reads only neighbours of the other colour, which no workgroup updates in this launch; ghosts of the
+// pass's own colour may catch an old or a new value, are not read here, and are pulled again before the next pass reads them.
+__device__ __forceinline__ void pull_tile_ghosts(const CopyItem* __restrict__ items, const int* __restrict__ start,
+                                                 const PatchDesc* __restrict__ patches, double* __restrict__ f)
+{
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
+    for (int q = start[blockIdx.x]; q < start[blockIdx.x + 1]; ++q) {
+        const CopyItem it = items[q];
+        const PatchDesc sp = patches[it.src_patch];
+        const PatchDesc dp = patches[it.dst_patch];
+        const int n0 = it.n[0], n01 = it.n[0] * it.n[1];
+        const int cells = n01 * it.n[2];
+        for (int idx = tid; idx < cells; idx += nt) {
+            const int k = idx / n01;
+            const int r = idx - k * n01;
+            const int j = r / n0, i = r - j * n0;
+            f[cidx(dp, it.dst_lo[0] + i, it.dst_lo[1] + j, it.dst_lo[2] + k)] =
+                f[cidx(sp, it.src_lo[0] + i, it.src_lo[1] + j, it.src_lo[2] + k)];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(512) void k_gsrb_ortho(const Tile* __restrict__ tiles,
                                                     const PatchDesc* __restrict__ patches,
                                                     double* __restrict__ phi,
@@ -179,8 +206,10 @@ __global__ __launch_bounds__(512) void k_gsrb_ortho(const Tile* __restrict__ til
                                                     const double* __restrict__ jgz,
                                                     const double* __restrict__ jinv,
                                                     const double* __restrict__ lapd,
-                                                    StencilParams P, int color, int loose)
+                                                    StencilParams P, int color, int loose,
+                                                    const CopyItem* __restrict__ titems, const int* __restrict__ tstart)
 {
+    if (tstart) pull_tile_ghosts(titems, tstart, patches, phi);
     gsrb_ortho_body(tiles, patches, phi, rhs, jgx, jgy, jgz, jinv, lapd, P, color, loose, blockIdx.x, threadIdx.x, threadIdx.y);
 }
 
@@ -252,8 +281,11 @@ __global__ __launch_bounds__(512) void k_op_ortho(const Tile* __restrict__ tiles
                                                   const double* __restrict__ jgx,
                                                   const double* __restrict__ jgy,
                                                   const double* __restrict__ jgz,
-                                                  const double* __restrict__ jinv, StencilParams P)
+                                                  const double* __restrict__ jinv, StencilParams P,
+                                                  const CopyItem* __restrict__ titems, const int* __restrict__ tstart)
 {
+    // (the exchange writes phi's ghost cells, as Level::exchange does on the same pointer)
+    if (tstart) pull_tile_ghosts(titems, tstart, patches, const_cast<double*>(phi));
     op_ortho_body<MODE>(tiles, patches, out, phi, rhs, jgx, jgy, jgz, jinv, P, blockIdx.x, threadIdx.x, threadIdx.y);
 }
 
@@ -440,9 +472,16 @@ __global__ __launch_bounds__(512) void k_prolong(const Tile* __restrict__ ftiles
 
 // final stage of every reduction: ONE block, fixed order => deterministic.
 // nvals interleaved values per partial; op 0 = sum, 1 = max (of non-negatives), 2 = signed max.
-__global__ __launch_bounds__(512) void k_reduce_final(const double* __restrict__ partials, int nparts,
-                                                      int nvals, int op, double* __restrict__ out)
+__device__ __forceinline__ void publish_scalars(const double* vals, int n, ScalarPublish pub)
 {
+    for (int i = 0; i < n; ++i) __hip_atomic_store(pub.host_dst + i, vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(pub.host_seq, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(512) void k_reduce_final(const double* __restrict__ partials, int nparts,
+                                                      int nvals, int op, double* __restrict__ out, ScalarPublish pub)
+{
+    double first = 0.0;
     for (int v = 0; v < nvals; ++v) {
         double acc = (op == 2) ? -1.7976931348623157e308 : 0.0;
         for (int i = threadIdx.x; i < nparts; i += 256) {
@@ -451,7 +490,9 @@ __global__ __launch_bounds__(512) void k_reduce_final(const double* __restrict__
         }
         acc = op ? block_reduce<true>(acc) : block_reduce<false>(acc);
         if (threadIdx.x == 0) out[v] = acc;
+        if (v == 0) first = acc;
     }
+    if (threadIdx.x == 0 && pub.host_seq && nvals == 1) publish_scalars(&first, 1, pub);
 }
 
 // field[all] -= sums[0]/sums[1]  (whole allocation incl. ghosts: a_phiThisLevel[dit] -= avgPhi,
@@ -592,6 +633,27 @@ __global__ void k_incr_copy(double* __restrict__ y, double* __restrict__ x, doub
         x[i] = t;
     }
 }
+// two independent updates in one pass: y1 += a1*x1; y2 += a2*x2   (BiCGStab's "r -= alpha v; e += alpha p~" and its omega twin)
+__global__ void k_incr2(double* __restrict__ y1, const double* __restrict__ x1, double a1, double* __restrict__ y2,
+                        const double* __restrict__ x2, double a2, long long n)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        y1[i] = y1[i] + a1 * x1[i];
+        y2[i] = y2[i] + a2 * x2[i];
+    }
+}
+// BiCGStab's direction update, the three LevelDataOps calls of Chombo's solver as one pass with the same roundings:
+// p *= beta; p += bw * v; p += 1.0 * r
+__global__ void k_bicg_p(double* __restrict__ p, const double* __restrict__ v, const double* __restrict__ r, double beta,
+                         double bw, long long n)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        double t = p[i] * beta;
+        t = t + bw * v[i];
+        t = t + 1.0 * r[i];
+        p[i] = t;
+    }
+}
 __global__ void k_scale(double* __restrict__ y, double a, long long n)
 {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -652,7 +714,7 @@ __global__ __launch_bounds__(512) void k_reduce_valid(const Tile* __restrict__ t
 template <int MODE>
 __global__ __launch_bounds__(64) void k_reduce_ordered(const PatchDesc* __restrict__ patches, int npatches,
                                                        const double* __restrict__ a, const double* __restrict__ b,
-                                                       double dxProduct, double* __restrict__ out)
+                                                       double dxProduct, double* __restrict__ out, ScalarPublish pub)
 {
     // one wavefront: 512 cells are fetched coalesced (8 per lane) into LDS, then every lane walks them in order
     // (uniform LDS reads are broadcasts), so the dependent chain is 512 adds per chunk, not 512 cross-lane hops
@@ -708,6 +770,7 @@ __global__ __launch_bounds__(64) void k_reduce_ordered(const PatchDesc* __restri
     if (lane == 0) {
         if (MODE == 6) { out[0] = run_s; out[1] = run_v; }
         else out[0] = tot;
+        if (pub.host_seq && MODE != 6) publish_scalars(&tot, 1, pub);
     }
 }
 
@@ -806,21 +869,26 @@ static inline int flat_grid(long long n)
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
-void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color, int loose)
+void launch_gsrb_ortho(hipStream_t st, const LevelDev& L, double* phi, const double* rhs, int color, int loose, bool pull)
 {
     if (L.ntiles == 0) return;
+    const bool pl = pull && L.tile_item_start && loose == 0;
     hipLaunchKernelGGL(k_gsrb_ortho, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, phi, rhs,
-                       L.jg[0], L.jg[1], L.jg[2], L.jinv, L.lapdiag, L.P, color, loose);
+                       L.jg[0], L.jg[1], L.jg[2], L.jinv, L.lapdiag, L.P, color, loose, pl ? L.tile_items : nullptr,
+                       pl ? L.tile_item_start : nullptr);
 }
-void launch_op_ortho(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* rhs, int mode)
+void launch_op_ortho(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* rhs, int mode, bool pull)
 {
     if (L.ntiles == 0) return;
+    const bool pl = pull && L.tile_item_start;
+    const CopyItem* ti = pl ? L.tile_items : nullptr;
+    const int* ts = pl ? L.tile_item_start : nullptr;
     if (mode == 0)
         hipLaunchKernelGGL(k_op_ortho<0>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, out, phi,
-                           rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+                           rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, ti, ts);
     else
         hipLaunchKernelGGL(k_op_ortho<1>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, out, phi,
-                           rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P);
+                           rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, ti, ts);
 }
 void launch_lapdiag(hipStream_t st, const LevelDev& L)
 {
@@ -854,7 +922,7 @@ void launch_prolong(hipStream_t st, const LevelDev& F, const LevelDev& C, double
         hipLaunchKernelGGL(k_prolong<false>, dim3(F.ntiles), tile_block(F), 0, st, F.tiles, F.patches, C.patches,
                            fine, crse, F.jinv, r[0], r[1], r[2], dxProduct, partials);
         hipLaunchKernelGGL(k_reduce_ordered<6>, dim3(1), dim3(64), 0, st, F.patches, F.npatches, fine, F.jinv, dxProduct,
-                           sums);
+                           sums, ScalarPublish{nullptr, nullptr, 0ull});
         return;
     }
     if (!zeroAvg) {
@@ -863,7 +931,7 @@ void launch_prolong(hipStream_t st, const LevelDev& F, const LevelDev& C, double
     } else {
         hipLaunchKernelGGL(k_prolong<true>, dim3(F.ntiles), tile_block(F), 0, st, F.tiles, F.patches, C.patches,
                            fine, crse, F.jinv, r[0], r[1], r[2], dxProduct, partials);
-        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, F.ntiles, 2, 0, sums);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, F.ntiles, 2, 0, sums, ScalarPublish{nullptr, nullptr, 0ull});
     }
     (void)fieldElems;
 }
@@ -876,7 +944,7 @@ void launch_child_volume(hipStream_t st, const LevelDev& C, const LevelDev& F, d
 }
 void launch_sum_partials(hipStream_t st, const double* partials, int n, double* out)
 {
-    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, n, 1, 0, out);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, n, 1, 0, out, ScalarPublish{nullptr, nullptr, 0ull});
 }
 void launch_combine_sums(hipStream_t st, double* out, const double* a, const double* b, const double* c)
 {
@@ -943,6 +1011,14 @@ void launch_incr_copy(hipStream_t st, double* y, double* x, double a, long long 
 {
     hipLaunchKernelGGL(k_incr_copy, dim3(flat_grid(n)), dim3(256), 0, st, y, x, a, n);
 }
+void launch_incr2(hipStream_t st, double* y1, const double* x1, double a1, double* y2, const double* x2, double a2, long long n)
+{
+    hipLaunchKernelGGL(k_incr2, dim3(flat_grid(n)), dim3(256), 0, st, y1, x1, a1, y2, x2, a2, n);
+}
+void launch_bicg_p(hipStream_t st, double* p, const double* v, const double* r, double beta, double bw, long long n)
+{
+    hipLaunchKernelGGL(k_bicg_p, dim3(flat_grid(n)), dim3(256), 0, st, p, v, r, beta, bw, n);
+}
 void launch_scale(hipStream_t st, double* y, double a, long long n)
 {
     hipLaunchKernelGGL(k_scale, dim3(flat_grid(n)), dim3(256), 0, st, y, a, n);
@@ -956,17 +1032,19 @@ void launch_axby(hipStream_t st, double* z, const double* x, const double* y, do
     hipLaunchKernelGGL(k_axby, dim3(flat_grid(n)), dim3(256), 0, st, z, x, y, a, b, n);
 }
 void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const double* b, int mode, double* partials,
-                   double* out, bool ordered)
+                   double* out, bool ordered, const ScalarPublish* pub)
 {
+    const ScalarPublish P = pub ? *pub : ScalarPublish{nullptr, nullptr, 0ull};
     if (ordered && (mode == 0 || mode == 2) && L.ntiles > 0) {
         if (mode == 0)
-            hipLaunchKernelGGL(k_reduce_ordered<0>, dim3(1), dim3(64), 0, st, L.patches, L.npatches, a, b, 0.0, out);
+            hipLaunchKernelGGL(k_reduce_ordered<0>, dim3(1), dim3(64), 0, st, L.patches, L.npatches, a, b, 0.0, out, P);
         else
-            hipLaunchKernelGGL(k_reduce_ordered<2>, dim3(1), dim3(64), 0, st, L.patches, L.npatches, a, b, 0.0, out);
+            hipLaunchKernelGGL(k_reduce_ordered<2>, dim3(1), dim3(64), 0, st, L.patches, L.npatches, a, b, 0.0, out, P);
         return;
     }
     if (L.ntiles == 0) {
         hipLaunchKernelGGL(k_set, dim3(1), dim3(64), 0, st, out, 1, 0.0);
+        if (pub) launch_publish(st, out, 1, pub->host_dst, pub->host_seq, pub->seq);
         return;
     }
     if (mode == 0)
@@ -982,7 +1060,7 @@ void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const dou
     else
         hipLaunchKernelGGL(k_reduce_valid<5>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, L.ntiles, 1,
-                       mode == 1 ? 1 : (mode == 3 ? 2 : 0), out);
+                       mode == 1 ? 1 : (mode == 3 ? 2 : 0), out, P);
 }
 void launch_ord_fill(hipStream_t st, const LevelDev& L, const long long* start, const double* a, const double* b,
                      int mode, double dxProduct, double* X, double* Y)

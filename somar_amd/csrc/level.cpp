@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cstdlib>
 #include <cstring>
 
 namespace somar {
@@ -490,6 +491,8 @@ Level::~Level()
     hipFree(d_qtiles);
     hipFree(d_ctiles);
     hipFree(d_local_items);
+    hipFree(d_tile_items);
+    hipFree(d_tile_item_start);
     hipFree(d_send_items);
     hipFree(d_recv_items);
     hipFree(d_send_off);
@@ -688,6 +691,46 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     dev.ntiles = N;
     dev.patches = d_patches;
     dev.npatches = (int)hpatches.size();
+    // ---- pull exchange: per tile, the local copy items clipped to the tile's one-cell halo (k_gsrb_ortho / k_op_ortho) ----
+    {
+        static const long long pullMax = getenv("SOMAR_PULL_MAX_CELLS") ? atoll(getenv("SOMAR_PULL_MAX_CELLS")) : 262144;
+        long long cells = 0;
+        for (const IBox& b : boxes) cells += b.numPts();
+        if (plan.peers.empty() && cells <= pullMax && N > 0) {
+            std::vector<std::vector<int>> byDst(hpatches.size());
+            for (int q = 0; q < (int)plan.local.size(); ++q) byDst[plan.local[q].dst_patch].push_back(q);
+            std::vector<CopyItem> titems;
+            std::vector<int> tstart(N + 1, 0);
+            for (int b = 0; b < N; ++b) {
+                const Tile& t = htiles[b];
+                const PatchDesc& p = hpatches[t.patch];
+                int lo[3] = {t.i0, t.j0, t.k0};
+                int hi[3] = {std::min(t.i0 + TILE_I, p.n[0]) - 1, std::min(t.j0 + dev.tile_j, p.n[1]) - 1, t.k0 + t.nk - 1};
+                for (int d = 0; d < 3; ++d)
+                    if (active[d]) { lo[d] -= 1; hi[d] += 1; }
+                tstart[b] = (int)titems.size();
+                for (int q : byDst[t.patch]) {
+                    const CopyItem& it = plan.local[q];
+                    CopyItem c = it;
+                    bool empty = false;
+                    for (int d = 0; d < 3; ++d) {
+                        const int a = std::max(lo[d], it.dst_lo[d]), e = std::min(hi[d], it.dst_lo[d] + it.n[d] - 1);
+                        if (e < a) { empty = true; break; }
+                        c.dst_lo[d] = a;
+                        c.src_lo[d] = it.src_lo[d] + (a - it.dst_lo[d]);
+                        c.n[d] = e - a + 1;
+                    }
+                    if (!empty) titems.push_back(c);
+                }
+            }
+            tstart[N] = (int)titems.size();
+            if (titems.empty()) titems.push_back(CopyItem());   // keep the table pointer non-null (one box, no ghosts to move)
+            d_tile_items = to_device(titems);
+            d_tile_item_start = to_device(tstart);
+            dev.tile_items = d_tile_items;
+            dev.tile_item_start = d_tile_item_start;
+        }
+    }
     {
         long long face = 0;
         for (const PatchDesc& q : hpatches) {

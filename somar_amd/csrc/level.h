@@ -115,6 +115,10 @@ public:
     PatchDesc* d_patches = nullptr;
     Tile* d_tiles = nullptr;
     CopyItem* d_local_items = nullptr;
+    // pull exchange tables (LevelDev::tile_items): built for single-rank levels of at most PULL_MAX_CELLS cells
+    CopyItem* d_tile_items = nullptr;
+    int* d_tile_item_start = nullptr;
+    bool pull_ready() const { return d_tile_item_start != nullptr; }
     CopyItem* d_send_items = nullptr;
     CopyItem* d_recv_items = nullptr;
     long long* d_send_off = nullptr;

@@ -142,6 +142,12 @@ void PressureSolver::fetch_scalars(int slot, int n)
     }
     const unsigned long long want = ++fetch_seq_;
     launch_publish(st_, d_scalars + slot, n, h_scalars + slot, h_seq_, want);
+    wait_published(want);
+}
+
+// the host side of a published scalar: spin on the sequence number the device stores last
+void PressureSolver::wait_published(unsigned long long want)
+{
     unsigned long long spins = 0;
     while (__atomic_load_n(h_seq_, __ATOMIC_ACQUIRE) != want) {
         if ((++spins & 0xfffff) == 0) {  // every ~1M spins: has the stream died or drained without publishing?
@@ -724,13 +730,16 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
             // fillGhostsAndExtrapolate is dead code for a diagonal metric (the boundary
             // stencil never reads a Neumann ghost), so only the exchange remains.
             for (int pass = 0; pass < 2; ++pass) {
+                // pull exchange: the colour pass refreshes the ghosts it reads itself (coarse-fine and Dirichlet ghosts are
+                // other cells, computed from valid cells only: their order against the exchange does not matter)
+                const bool pull = !full_ && L.pull_ready();
                 L.cf_homog(e, st_);  // homogeneousCFInterp (Relaxer::fillGhostsAndExtrapolate)
-                L.exchange(e, st_);
+                if (!pull) L.exchange(e, st_);
                 if (diri_ && !full_) apply_diri(d, e, true);  // ... and its physical ghosts (doBCs); non-diagonal: in the program
                 if (full_) run_full_program(d, 1, e);  // psi snapshot + extrapolation (order 1) + Neumann ghosts
                 if (profiling_ && d == 0) prof_begin(0);
                 if (full_) launch_gsrb_full(st_, L.dev, e, f_psi[d], res, pass);
-                else launch_gsrb_ortho(st_, L.dev, e, res, pass);
+                else launch_gsrb_ortho(st_, L.dev, e, res, pass, 0, pull);
                 if (profiling_ && d == 0) prof_end(0);
             }
         } else if (prm.relaxMode == RELAX_LOOSE_GSRB) {
@@ -797,7 +806,9 @@ void PressureSolver::residual_i(int d, double* out, double* phi, const double* r
         tiny_run(d, fld, 3, ops);
         return;
     }
-    L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
+    // small levels (direct-load operator): the kernel pulls the ghosts it reads, no copy launch
+    const bool pull = !full_ && L.pull_ready() && !(L.valid_cells_global >= march_min_cells_ && L.active[2]);
+    if (!pull) L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
     if (diri_ && !full_) apply_diri(d, phi, homogeneous);  // m_bc.setGhosts, :822 (non-diagonal: inside the program)
     if (profiling_ && d == 0) prof_begin(1);
     if (full_march(d)) {
@@ -808,7 +819,7 @@ void PressureSolver::residual_i(int d, double* out, double* phi, const double* r
         run_full_program(d, 0, phi, homogeneous);
         launch_op_full(st_, L.dev, out, phi, f_psi[d], rhs, 0);
     } else if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, rhs, 0);  // Dirichlet sides: their ghosts were just written, the kernel only zeroes NEUMANN fluxes
-    else launch_op_ortho(st_, L.dev, out, phi, rhs, 0);
+    else launch_op_ortho(st_, L.dev, out, phi, rhs, 0, pull);
     if (profiling_ && d == 0) prof_end(1);
 }
 
@@ -821,7 +832,8 @@ void PressureSolver::apply_op_i(int d, double* out, double* phi, bool homogeneou
         tiny_run(d, fld, 2, ops);
         return;
     }
-    L.exchange(phi, st_);
+    const bool pull = !full_ && L.pull_ready() && !(L.valid_cells_global >= march_min_cells_ && L.active[2]);
+    if (!pull) L.exchange(phi, st_);
     if (diri_ && !full_) apply_diri(d, phi, homogeneous);
     if (full_march(d)) {
         run_full_program_frames(d, 0, phi, homogeneous);
@@ -830,7 +842,7 @@ void PressureSolver::apply_op_i(int d, double* out, double* phi, bool homogeneou
         run_full_program(d, 0, phi, homogeneous);
         launch_op_full(st_, L.dev, out, phi, f_psi[d], nullptr, 1);
     } else if (L.valid_cells_global >= march_min_cells_ && L.active[2]) launch_resid_march(st_, L.d_rtiles, L.nrtiles, L.dev, out, phi, nullptr, 1);
-    else launch_op_ortho(st_, L.dev, out, phi, nullptr, 1);
+    else launch_op_ortho(st_, L.dev, out, phi, nullptr, 1, pull);
 }
 
 void PressureSolver::prolong_from(const LevelDev& C, const double* crse, const int r[3], double* fine)
@@ -934,21 +946,46 @@ double PressureSolver::norm(int d, const double* a, int ord)
 {
     Level& L = *lev[d];
     if (ord == 0) {
+        if (fused_publish(d)) {
+            const ScalarPublish P{h_scalars + SLOT_TMP, h_seq_, ++fetch_seq_};
+            launch_reduce(st_, L.dev, a, nullptr, 1, d_partials, d_scalars + SLOT_TMP, false, &P);
+            wait_published(P.seq);
+            return h_scalars[SLOT_TMP];
+        }
         launch_reduce(st_, L.dev, a, nullptr, 1, d_partials, d_scalars + SLOT_TMP);
         comm_->allreduce(d_scalars + SLOT_TMP, 1, 1, st_);
         return fetch_scalar(SLOT_TMP);
     }
     if (ord == 1) {
+        if (fused_publish(d)) return reduce_fetch(d, a, nullptr, 2);
         reduce_sum(d, a, nullptr, 2, d_scalars + SLOT_TMP);
         return fetch_scalar(SLOT_TMP);
     }
     SOMAR_CHECK(ord == 2, "norm order must be 0, 1 or 2");
+    if (fused_publish(d)) return std::sqrt(reduce_fetch(d, a, a, 0));
     reduce_sum(d, a, a, 0, d_scalars + SLOT_TMP);
     return std::sqrt(fetch_scalar(SLOT_TMP));
 }
 
+// single-rank, polling fetch: the reduction's last kernel publishes its result itself (one launch less per scalar)
+bool PressureSolver::fused_publish(int d) const
+{
+    static const bool poll = !(getenv("SOMAR_POLL_FETCH") && atoi(getenv("SOMAR_POLL_FETCH")) == 0);
+    static const bool off = getenv("SOMAR_NO_FUSED_PUBLISH") != nullptr;
+    return poll && !off && !capturing_ && comm_->size == 1 && !ord_sharded(d);
+}
+
+double PressureSolver::reduce_fetch(int d, const double* a, const double* b, int mode)
+{
+    const ScalarPublish P{h_scalars + SLOT_TMP, h_seq_, ++fetch_seq_};
+    launch_reduce(st_, lev[d]->dev, a, b, mode, d_partials, d_scalars + SLOT_TMP, ordered(d), &P);
+    wait_published(P.seq);
+    return h_scalars[SLOT_TMP];
+}
+
 double PressureSolver::dot(int d, const double* a, const double* b)
 {
+    if (fused_publish(d)) return reduce_fetch(d, a, b, 0);
     reduce_sum(d, a, b, 0, d_scalars + SLOT_TMP);
     return fetch_scalar(SLOT_TMP);
 }
@@ -1589,18 +1626,15 @@ void PressureSolver::bottom_solve(double* phi, const double* rhs)
             init = false;
         } else {
             beta[1] = (rho[1] / rho[2]) * (alpha[1] / omega[1]);
-            launch_scale(st_, p, beta[1], n);
-            launch_incr(st_, p, v, -beta[1] * omega[1], n);
-            launch_incr(st_, p, r, 1.0, n);
+            launch_bicg_p(st_, p, v, r, beta[1], -beta[1] * omega[1], n);   // scale, incr, incr in one pass (same roundings)
         }
         pre_cond(d, p_tilde, p);
         apply_op(d, v, p_tilde);
         const double m = dot(d, r_tilde, v);
         alpha[0] = rho[1] / m;
         if (std::fabs(m) > prm.bottom_small * std::fabs(rho[1])) {
-            launch_incr(st_, r, v, -alpha[0], n);
+            launch_incr2(st_, r, v, -alpha[0], e, p_tilde, alpha[0], n);   // r -= alpha v; e += alpha p~ (independent)
             nrm[0] = norm(d, r, nt);
-            launch_incr(st_, e, p_tilde, alpha[0], n);
         } else {
             launch_set(st_, r, n, 0.0);
             nrm[0] = 0.0;
@@ -1620,8 +1654,7 @@ void PressureSolver::bottom_solve(double* phi, const double* rhs)
             fetch_scalars(SLOT_TMP, 2);
             const double tr = h_scalars[SLOT_TMP], tt = h_scalars[SLOT_TMP + 1];
             omega[0] = tr / tt;
-            launch_incr(st_, e, s_tilde, omega[0], n);
-            launch_incr(st_, r, t, -omega[0], n);
+            launch_incr2(st_, e, s_tilde, omega[0], r, t, -omega[0], n);
             nrm[0] = norm(d, r, nt);
         }
         if (nrm[0] <= eps * initial_norm || nrm[0] <= prm.bottom_reps * initial_rnorm) {

@@ -253,6 +253,9 @@ private:
     std::vector<long long*> d_ord_start_, d_box_start_;  // per depth: serial start of each LOCAL patch / of every box (+ end)
     void ordered_sums(int d, const double* a, const double* b, int mode, double dxProduct, double* out);
     // out[0] = sum over the level (mode 0: a*b, 2: |a|), every rank: serial order on small levels, tree order on large ones
+    bool fused_publish(int d) const;
+    double reduce_fetch(int d, const double* a, const double* b, int mode);   // reduction + host fetch, published by the reduction
+    void wait_published(unsigned long long want);
     void reduce_sum(int d, const double* a, const double* b, int mode, double* out);
 
     Comm* comm_;
