@@ -164,7 +164,8 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         if (INMODE == 1) return make_double2(0.0, 0.0);
         double2 v = ld2(phi_in, p.off + li + (long long)p.pj * lj + p.pk * kp, ok0, ok1, p.off);
         if (INMODE >= 3) {
-            const int ck = kp >= 0 ? kp / r2 : -((-kp + r2 - 1) / r2);
+            // floor(kp / r2); multigrid ratios are 1 or 2 per direction: a shift instead of an integer division per plane
+            const int ck = (r2 == 2) ? (kp >> 1) : (r2 == 1 ? kp : (kp >= 0 ? kp / r2 : -((-kp + r2 - 1) / r2)));
             const long long c = (ok0 || ok1) ? cbase + cpk * ck : cbase - (cbase - cpatches[t.patch].off);
             const double c0 = crse[c], c1 = crse[c + ((ok0 || ok1) ? cstep : 0)];
             v.x = ok0 ? v.x + c0 : 0.0;

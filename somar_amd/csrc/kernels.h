@@ -13,6 +13,7 @@ struct LevelDev {
     // stencil kernel refreshes exactly the ghosts it is about to read, so the separate copy launch disappears (null: not built)
     const CopyItem* tile_items = nullptr;
     const int* tile_item_start = nullptr;
+    unsigned int* red_counter = nullptr;   // arrival counter of the single-launch tree reduction (k_reduce_valid's last workgroup)
     int ghost_gy = 16;                  // workgroups per ghost op (k_ghost_ops): the largest box face / 1024, within [16, 256]
     const PatchDesc* patches = nullptr;
     int npatches = 0;

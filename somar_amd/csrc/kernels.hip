@@ -69,6 +69,12 @@ __device__ __forceinline__ double block_reduce(double v)
     return v;
 }
 
+__device__ __forceinline__ void publish_scalars(const double* vals, int n, ScalarPublish pub)
+{
+    for (int i = 0; i < n; ++i) __hip_atomic_store(pub.host_dst + i, vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(pub.host_seq, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------------------------------
 // GSRB, diagonal metric, one colour.  Interior cells follow GSRBITER3DORTHO, cells that
 // touch a DOMAIN face (periodic ones included: GSRB.cpp:76,87-92) follow
@@ -472,12 +478,6 @@ __global__ __launch_bounds__(512) void k_prolong(const Tile* __restrict__ ftiles
 
 // final stage of every reduction: ONE block, fixed order => deterministic.
 // nvals interleaved values per partial; op 0 = sum, 1 = max (of non-negatives), 2 = signed max.
-__device__ __forceinline__ void publish_scalars(const double* vals, int n, ScalarPublish pub)
-{
-    for (int i = 0; i < n; ++i) __hip_atomic_store(pub.host_dst + i, vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(pub.host_seq, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 __global__ __launch_bounds__(512) void k_reduce_final(const double* __restrict__ partials, int nparts,
                                                       int nvals, int op, double* __restrict__ out, ScalarPublish pub)
 {
@@ -679,7 +679,8 @@ __global__ __launch_bounds__(512) void k_reduce_valid(const Tile* __restrict__ t
                                                       const PatchDesc* __restrict__ patches,
                                                       const double* __restrict__ a,
                                                       const double* __restrict__ b,
-                                                      double* __restrict__ partials)
+                                                      double* __restrict__ partials, unsigned int* __restrict__ counter,
+                                                      double* __restrict__ out, ScalarPublish pub)
 {
     const Tile t = tiles[blockIdx.x];
     const PatchDesc p = patches[t.patch];
@@ -702,6 +703,38 @@ __global__ __launch_bounds__(512) void k_reduce_valid(const Tile* __restrict__ t
     }
     acc = (MODE == 1 || MODE == 3) ? block_reduce<true>(acc) : block_reduce<false>(acc);
     if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x] = acc;
+    if (!counter) return;   // two-launch form: k_reduce_final follows
+    // Single-launch form: the LAST workgroup to arrive adds the partials up, with k_reduce_final's own arithmetic -- 256
+    // (virtual) threads striding the partials, a shuffle tree per (virtual) wavefront, the four wavefront sums added in order
+    // -- so the result has the same bits as the two-launch form; it then clears the counter and publishes the scalar.
+    constexpr int OP = (MODE == 1) ? 1 : (MODE == 3 ? 2 : 0);
+    __shared__ int isLast;
+    __shared__ double sv[4];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    __threadfence();
+    if (tid == 0) isLast = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!isLast) return;
+    __threadfence();
+    const int lane = tid & 63, w = tid >> 6, nw = (blockDim.x * blockDim.y) >> 6;
+    const int nparts = (int)gridDim.x;
+    for (int q = w; q < 4; q += nw) {
+        double r = (OP == 2) ? -1.7976931348623157e308 : 0.0;
+        for (int i = 64 * q + lane; i < nparts; i += 256) {
+            const double x = __hip_atomic_load(partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r = OP ? fmax(r, x) : r + x;
+        }
+        r = OP ? wave_max(r) : wave_sum(r);
+        if (lane == 0) sv[q] = r;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double r = sv[0];
+        for (int q = 1; q < 4; ++q) r = OP ? fmax(r, sv[q]) : r + sv[q];
+        out[0] = r;
+        *counter = 0u;
+        if (pub.host_seq) publish_scalars(&r, 1, pub);
+    }
 }
 
 // Reference-ordered sums for SMALL levels (one wavefront): box after box, cells in Fortran order, one running
@@ -1047,18 +1080,20 @@ void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const dou
         if (pub) launch_publish(st, out, 1, pub->host_dst, pub->host_seq, pub->seq);
         return;
     }
-    if (mode == 0)
-        hipLaunchKernelGGL(k_reduce_valid<0>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
-    else if (mode == 1)
-        hipLaunchKernelGGL(k_reduce_valid<1>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
-    else if (mode == 2)
-        hipLaunchKernelGGL(k_reduce_valid<2>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
-    else if (mode == 3)
-        hipLaunchKernelGGL(k_reduce_valid<3>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
-    else if (mode == 4)
-        hipLaunchKernelGGL(k_reduce_valid<4>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
-    else
-        hipLaunchKernelGGL(k_reduce_valid<5>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials);
+    // single launch when the level has an arrival counter (SOMAR_TWO_LAUNCH_REDUCE=1 keeps k_reduce_final behind it)
+    static const bool two = getenv("SOMAR_TWO_LAUNCH_REDUCE") != nullptr;
+    unsigned int* cnt = two ? nullptr : L.red_counter;
+#define SOMAR_RV(M)                                                                                                           \
+    hipLaunchKernelGGL(k_reduce_valid<M>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials, cnt, out, \
+                       cnt ? P : ScalarPublish{nullptr, nullptr, 0ull})
+    if (mode == 0) SOMAR_RV(0);
+    else if (mode == 1) SOMAR_RV(1);
+    else if (mode == 2) SOMAR_RV(2);
+    else if (mode == 3) SOMAR_RV(3);
+    else if (mode == 4) SOMAR_RV(4);
+    else SOMAR_RV(5);
+#undef SOMAR_RV
+    if (cnt) return;
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, L.ntiles, 1,
                        mode == 1 ? 1 : (mode == 3 ? 2 : 0), out, P);
 }

@@ -491,6 +491,7 @@ Level::~Level()
     hipFree(d_qtiles);
     hipFree(d_ctiles);
     hipFree(d_local_items);
+    hipFree(d_red_counter);
     hipFree(d_tile_items);
     hipFree(d_tile_item_start);
     hipFree(d_send_items);
@@ -691,6 +692,9 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     dev.ntiles = N;
     dev.patches = d_patches;
     dev.npatches = (int)hpatches.size();
+    SOMAR_HIP(hipMalloc(&d_red_counter, sizeof(unsigned int)));
+    SOMAR_HIP(hipMemset(d_red_counter, 0, sizeof(unsigned int)));
+    dev.red_counter = d_red_counter;
     // ---- pull exchange: per tile, the local copy items clipped to the tile's one-cell halo (k_gsrb_ortho / k_op_ortho) ----
     {
         static const long long pullMax = getenv("SOMAR_PULL_MAX_CELLS") ? atoll(getenv("SOMAR_PULL_MAX_CELLS")) : 262144;

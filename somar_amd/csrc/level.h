@@ -116,6 +116,7 @@ public:
     Tile* d_tiles = nullptr;
     CopyItem* d_local_items = nullptr;
     // pull exchange tables (LevelDev::tile_items): built for single-rank levels of at most PULL_MAX_CELLS cells
+    unsigned int* d_red_counter = nullptr;
     CopyItem* d_tile_items = nullptr;
     int* d_tile_item_start = nullptr;
     bool pull_ready() const { return d_tile_item_start != nullptr; }
