@@ -1080,9 +1080,12 @@ void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const dou
         if (pub) launch_publish(st, out, 1, pub->host_dst, pub->host_seq, pub->seq);
         return;
     }
-    // single launch when the level has an arrival counter (SOMAR_TWO_LAUNCH_REDUCE=1 keeps k_reduce_final behind it)
-    static const bool two = getenv("SOMAR_TWO_LAUNCH_REDUCE") != nullptr;
-    unsigned int* cnt = two ? nullptr : L.red_counter;
+    // EXPERIMENT, off by default (SOMAR_ONE_LAUNCH_REDUCE=1): the last workgroup to arrive finishes the reduction, one launch
+    // instead of two.  Bit-identical, but measured slower on every workload -- each workgroup pays a device-scope fence and an
+    // atomic on one counter, and the finishing workgroup's serial tail is longer than a launch: C3 19.4 -> 23.8 ms, C2 95.1 ->
+    // 92.3 V-cycles/s on grids <= 512 tiles; on million-tile levels far worse (C4 147 -> 201 ms).
+    static const bool one = getenv("SOMAR_ONE_LAUNCH_REDUCE") != nullptr;
+    unsigned int* cnt = (!one || L.ntiles > 512) ? nullptr : L.red_counter;
 #define SOMAR_RV(M)                                                                                                           \
     hipLaunchKernelGGL(k_reduce_valid<M>, dim3(L.ntiles), tile_block(L), 0, st, L.tiles, L.patches, a, b, partials, cnt, out, \
                        cnt ? P : ScalarPublish{nullptr, nullptr, 0ull})

@@ -145,3 +145,57 @@ def test_leptic_cycle_needs_enable_and_column_boxes():
             gpu.enableLeptic()
     finally:
         gpu.undefine()
+
+
+def _terrain_three_levels():
+    """C5's shape in small: terrain-following NON-diagonal metric, three levels nested by (2,2,1) around the bump, every level
+    made of whole columns; leptic aspect ratio (lepticity dx/H = 2 on the base level)"""
+    n, L = (16, 16, 8), (32.0, 32.0, 1.0)
+    ratios = [(2, 2, 1), (2, 2, 1)]
+    fine = [[so.Box((8, 8, 0), (23, 23, 7))], [so.Box((24, 24, 0), (39, 39, 7))]]
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    dx = tuple(L[d] / n[d] for d in range(3))
+    grids = [so.split_domain(dom.box, (8, 8, 8))] + [list(b) for b in fine]
+    levels = []
+    for l, g in enumerate(grids):
+        if l > 0:
+            dom = dom.refine(ratios[l - 1])
+            dx = tuple(a / b for a, b in zip(dx, ratios[l - 1]))
+        Jgup, Jinv = so.make_terrain_metric(g, dx, L, dom)
+        levels.append(sa.AMRLevel(dom, g, dx, Jgup, Jinv))
+    return levels, ratios
+
+
+def test_c5_shaped_three_level_leptic_solve_matches_oracle():
+    from somar_amd import api as F
+    levels, ratios = _terrain_three_levels()
+    iters, maxOrder = 2, 3
+    amr = sl.AMRLepticSolver(levels, ratios, so.BCHolder(), leptic=dict(maxOrder=maxOrder, domainHeight=1.0),
+                             baseFromRestricted=True, isDiagonal=False)
+    amr.iterMax = iters
+    rhs = _compatible_rhs(amr, levels, 2)
+    sol = [so.LevelData(Lv.grids, 1, (1, 1, 1)) for Lv in levels]
+    amr.solve(sol, rhs, 2, 0)
+    gpu = make_gpu_amr(levels, ratios, full=True, imax=iters)
+    lp = F.LepticParams()
+    F._ck(F.lib().somar_leptic_params_default(lp))
+    lp.max_order, lp.domain_height = maxOrder, 1.0
+    gpu.enableLeptic(lp, baseFromRestricted=True)
+    try:
+        for l, v in enumerate(gpu.levels):
+            upload(v, F.F_RHS, rhs[l])
+        st = gpu.solveAMRLeptic(2, 0)
+        h = np.array(amr.history)
+        assert st["iters"] == amr.iters and st["exitStatus"] == amr.exitStatus
+        np.testing.assert_allclose(st["history"], h, rtol=0, atol=1e-9 * h[0])
+        assert h[1] < 0.2 * h[0] and h[2] < h[1]
+        for l in range(3):
+            ls, lep = gpu.lepticStats(l), amr.leptic[l]
+            assert ls["exitStatus"] == lep.exitStatus and ls["horizSolves"] == lep.horizSolves
+            assert ls["usedFullSolver"] == lep.usedFullSolver
+            want = valid_of(sol[l])
+            scale = max(float(np.max(np.abs(w))) for w in want)
+            for g_, w_ in zip(download_valid(gpu.levels[l], F.F_PHI, levels[l].grids), want):
+                np.testing.assert_allclose(g_, w_, rtol=0, atol=1e-7 * scale)
+    finally:
+        gpu.undefine()
