@@ -218,8 +218,8 @@ void PressureSolver::define(const IBox& domain, const bool periodic[3], const do
         SOMAR_CHECK(domain.size(2) == 1, "space_dim 2 wants a domain (and boxes) one cell thick in z");
         if (prm.relaxMode == RELAX_LINE_GSRB || prm.precondMode == PRECOND_DIAG_LINE_RELAX)
             for (const IBox& b : boxes)   // 'LineGSRBIter2D: region must have a vertical lower bound of zero' (GSRBF.ChF:1561-1565)
-                SOMAR_CHECK(b.lo[1] == domain.lo[1] && b.hi[1] == domain.hi[1],
-                            "2-D line relaxation wants boxes that span the vertical (direction 1)");
+                SOMAR_CHECK(b.lo[1] == domain.lo[1],
+                            "2-D line relaxation wants boxes that start at the bottom of the vertical (direction 1)");
         L->active[2] = 0;
     }
     L->alpha = alpha;
@@ -228,11 +228,10 @@ void PressureSolver::define(const IBox& domain, const bool periodic[3], const do
     L->alloc_metric();
     if (hasCF_) {
         L->define_cf(dxCrse_);
-        if (prm.relaxMode == RELAX_LINE_GSRB || prm.precondMode == PRECOND_DIAG_LINE_RELAX)
-            for (const CFCell& c : L->hcf)
-                SOMAR_CHECK((c.dir & 3) != (prm.spaceDim == 3 ? 2 : 1),
-                            "line relaxation: coarse-fine boundaries at the vertical ends of a column (the CF row of "
-                            "LineGSRBIter3D / 2D, GSRBF.ChF:1804-1817, 1588-1590) are not implemented");
+        // Line relaxation with coarse-fine boundaries at the ENDS of a column: LineGSRB::relax hands the Fortran the codes of
+        // BCDescriptor::stencil (BCInterface/BCDescriptor.H:218-229), which is BCType::None for every box end inside the domain --
+        // the BCType_CF row of LineGSRBIter3D / 2D (GSRBF.ChF:1804-1817, 1588-1590) is never reached from there -- so such an end
+        // gets coeff1 = 0 ("low-order extrapolation") and the coarse-fine ghost is not read.  The kernels do exactly that.
     }
     lev.push_back(std::move(L));
 }

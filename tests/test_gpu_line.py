@@ -200,3 +200,45 @@ def test_line_gsrb_with_a_nondiagonal_metric_bit_exact_and_solve(oracle, per):
         np.testing.assert_allclose(st["history"], amr.history, rtol=1e-9, atol=1e-12 * amr.history[0])
     finally:
         s.undefine()
+
+
+def test_line_relaxation_on_a_fine_level_whose_columns_end_at_coarse_fine_faces(oracle):
+    """(2,2,2) refinement, fine box strictly inside the domain: the columns of the fine level end at coarse-fine faces.
+    LineGSRB::relax passes BCDescriptor::stencil's codes, None for such ends (BCDescriptor.H:218-229), so the Fortran's CF row
+    is never reached: coeff1 = 0, the CF ghost is not read.  Level relaxation and a whole AMR V-cycle, bit for bit."""
+    from oracle import somar_amr as am
+    from somar_amd import api as F
+    from helpers import make_amr_levels, make_gpu_amr
+    so = oracle
+    ratios = [(2, 2, 2)]
+    fb = [[so.Box((8, 8, 4), (23, 23, 11))]]
+    levels = make_amr_levels(so, am, (16, 16, 8), (2.0, 1.0, 0.25), (False, False, False), ratios, fb)
+    comp = am.AMRComposite(levels, ratios, so.BCHolder(), so.BiCGStab(), relaxMode=so.RELAX_LINE_GSRB)
+    gpu = make_gpu_amr(levels, ratios, relaxMode=3)
+    try:
+        L, v = levels[1], gpu.levels[1]
+        res = so.random_field(L.grids, 70, (0, 0, 0), L.domain.box)
+        corr = so.random_field(L.grids, 71, (1, 1, 1), L.domain.box)
+        upload(v, F.F_RES, res)
+        upload(v, F.F_CORR, corr)
+        comp.ops[1].relax(corr, res, 2)
+        v.relax(0, F.F_CORR, F.F_RES, 2)
+        for g, w in zip(download_valid(v, F.F_CORR, L.grids), valid_of(corr)):
+            np.testing.assert_array_equal(g, w)
+        # one AMR V-cycle on a compatible composite residual
+        phi = [so.random_field(X.grids, 5 + l, (1, 1, 1), X.domain.box) for l, X in enumerate(levels)]
+        zero = [so.LevelData(X.grids, 1) for X in levels]
+        rhs = [so.LevelData(X.grids, 1) for X in levels]
+        comp.init(phi, zero, 1, 0)
+        comp.compute_amr_residual(rhs, phi, zero, 1, 0, True)
+        for r in rhs:
+            so.ld_scale(r, -1.0)
+        sol = [so.LevelData(X.grids, 1, (1, 1, 1)) for X in levels]
+        comp.solve(sol, rhs, 1, 0)
+        for l, vv in enumerate(gpu.levels):
+            upload(vv, F.F_RHS, rhs[l])
+        st = gpu.solveAMR(1, 0)
+        assert st["iters"] == comp.iters and st["exitStatus"] == comp.exitStatus
+        np.testing.assert_allclose(st["history"], comp.history, rtol=0, atol=1e-10 * comp.history[0])
+    finally:
+        gpu.undefine()

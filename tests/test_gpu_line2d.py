@@ -100,6 +100,6 @@ def test_line2d_refuses_columns_split_in_the_vertical():
     p = s._p
     s.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 3, p.num_mg, p.hang,
                          p.norm_thresh, 0)
-    with pytest.raises(SomarError, match="span the vertical"):
+    with pytest.raises(SomarError, match="start at the bottom"):
         s.define((0, 0, 0), (15, 15, 0), (False, False, False), (0.1, 0.1, 1.0),
                  [((0, 0, 0), (15, 7, 0)), ((0, 8, 0), (15, 15, 0))])
