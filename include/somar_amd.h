@@ -45,8 +45,11 @@ extern "C" {
 
 /* 4: + cell-centred level projection, level projections on hierarchy levels, Helmholtz coefficients and heat
  *    integrators, operator / residual with the BC flag, MAC wall BC (additions only: version-3 callers are unaffected)
- * 5: + somar_amr_solve_host (multi-level host boundary), somar_k_gsrbiter3dortho (box-by-box kernel hook); additions only */
-#define SOMAR_AMD_ABI_VERSION 5
+ * 5: + somar_amr_solve_host (multi-level host boundary), somar_k_gsrbiter3dortho (box-by-box kernel hook); additions only
+ * 6: + somar_amr_tga_step (composite MappedAMRTGA::oneStep); composite operations with heat coefficients installed no
+ *    longer fail (the flux-register scales follow beta); somar_solver_set_vel_bc (inflow / outflow sides); somar_solver_set_metric_map (cylindrical and bathymetric
+ *    metric producers on the device); additions only */
+#define SOMAR_AMD_ABI_VERSION 6
 
 /* BCType codes, calculus/BCInterface/BCDescriptor.H:34-39 */
 #define SOMAR_BC_NONE (-1)
@@ -195,6 +198,15 @@ int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* ite
  * BasicVelocityBCGhostClass -> setSideDiriBC(0) on the wall-normal faces of the resident velocity, in place as in the
  * reference (Divergence.cpp:73-100, EllipticBCUtils.cpp:1284-1327, 96-100).  Call it between upload and projection. */
 int somar_vel_wall_bc(somar_solver_t* s);
+/* Inflow / outflow sides of BasicVelocityBCGhostClass (calculus/BCInterface/EllipticBCUtils.cpp:1244-1327; chosen by
+ * PhysBCUtil::basicVelFuncBC, BCutil/PhysBCUtil.cpp:1261-1276) for the face-centred velocity: kind[2*dir + side] = 0 solid
+ * wall (setSideDiriBC(0), the default), 1 prescribed normal velocity value[2*dir + side] (setSideDiriBC(inflowVel), an
+ * inflow side, or the class's viscous walls of the inflow component), 2 outflow (setSideExtrapBC order 0: the boundary face
+ * takes the next face inside, EllipticBCUtilsF.ChF:148-154).  From then on somar_vel_wall_bc and the face BC inside the
+ * cell-centred divergence (somar_level_divergence_cc / somar_cc_project / the AMR projections with wall_bc = 1) apply these
+ * instead of solid walls on every side.  Periodic directions are never touched.  Values are in the velocity's own form
+ * (flux form J u^a when the projector runs with velIsFlux = true), exactly as the reference writes inflowVel into it. */
+int somar_solver_set_vel_bc(somar_solver_t* s, const int* kind, const double* value);
 int somar_vel_upload(somar_solver_t* s, int dir, int patch, const double* host);
 int somar_vel_download(somar_solver_t* s, int dir, int patch, double* host);
 int somar_level_divergence_mac(somar_solver_t* s, int out_field, double dt);
@@ -457,9 +469,17 @@ int somar_leptic_solve(somar_leptic_t* h, int homogeneous, somar_leptic_stats_t*
  * run MappedLevelFluxRegister::incrementCoarse / incrementFine on its own registers as before; faces on the domain boundary
  * are not meaningful (no register reads them).
  * somar_amr_set_alpha_beta = resetSolverAlphaAndBeta on every op of every level.  The hierarchy's own flux-register scales
- * keep the beta of somar_amr_create: composite operations (somar_amr_solve with l_base < l_max) fail loudly until the
- * coefficients are back; level solves and somar_amr_heat_step never reflux. */
+ * follow the coarse operator's beta the next time a composite operation refluxes (MappedAMRPoissonOp::reflux takes
+ * m_beta / m_dx when it runs, MappedAMRPoissonOp.cpp:1661, 1693), so composite solves work with any coefficients installed.
+ * somar_amr_tga_step = MappedAMRTGA<T>::oneStep (AMRElliptic/MappedAMRTGA.H:417-497), the COMPOSITE TGA step over levels
+ * l_base..l_max in one call: applyHelm = computeAMROperator with (1, mu dt) (MappedAMRMultiGrid.H:862-878), solveHelm =
+ * solveNoInit(..., zeroPhi = false) with (1, -mu dt), the guess of both solves is phiOld (:473-476, 493-496).  phiNew =
+ * SOMAR_F_PHI, phiOld = SOMAR_F_HEAT_OLD, source = SOMAR_F_HEAT_SRC of every level in the range; for l_base > 0 level
+ * l_base-1's SOMAR_F_HEAT_OLD / SOMAR_F_PHI supply the coarse-fine values of phiOld / phiNew.  stats = the LAST solve's.
+ * (No driver of the reference calls MappedAMRTGA -- AMRNavierStokes steps level by level with the integrators above -- it
+ * is provided because the class ships with the operator.) */
 int somar_amr_set_alpha_beta(somar_amr_t* a, double alpha, double beta);
+int somar_amr_tga_step(somar_amr_t* a, int l_max, int l_base, double dt, somar_stats_t* stats);
 int somar_amr_heat_step(somar_amr_t* a, int level, int scheme, double dt, int zero_phi, double old_time, double crse_old_time,
                         double crse_new_time, somar_stats_t* stats);
 int somar_heat_flux_download(somar_solver_t* s, int dir, int patch, double* host); /* faces(valid, dir), Fortran order */
@@ -486,6 +506,23 @@ int somar_amr_leptic_stats(somar_amr_t* a, int level, somar_leptic_stats_t* stat
  *    J g^zz, J^{-1}} written into every local patch on the device, nothing crosses PCIe (before somar_solver_finalize). */
 int somar_metric_jgup_from_dxdxi(long long n, int mu, const double* dxdxi9, const double* detJ, double scale, double* jgup3);
 int somar_solver_set_metric_uniform(somar_solver_t* s, const double* c4);
+/*  - the coordinate maps whose evaluation is closed-form or needs only a 2-D input, evaluated on the device into EVERY local
+ *    patch of the level (faces J g^{ab}, cells J^{-1}; before somar_solver_finalize; CH_SPACEDIM = 3):
+ *      SOMAR_MAP_CYLINDRICAL  CylindricalMap::fill_dxdXi / fill_J (geometry/maps/CylindricalMap.cpp:125-190,
+ *          CylindricalMapF.ChF), diagonal: x = xi cos(eta), y = xi sin(eta), z = zeta; L, depth unused;
+ *      SOMAR_MAP_BATHYMETRIC  BathymetricBaseMap::fill_dxdXi / fill_J (geometry/maps/BathymetricBaseMap.cpp:133-313,
+ *          BathymetricBaseMapF.ChF) with CONVERTFAB's centring averages (ConvertFABF.ChF:32-150), non-diagonal:
+ *          z = d + (1 - d / H) zeta; L = domain lengths (H = L[2]); depth = the NODAL depth d the subclass's
+ *          fill_bathymetry returns (DEMMap, LedgeMap, BeamGeneratorMap ...), host array over nodes
+ *          [depth_lo, depth_lo + depth_n) of this level's index space, i fastest, covering nodes lo-1 .. hi+2 of every
+ *          local box in both horizontal directions.  AVG3IX's misprinted eighth term (AddlFortranMacros.H:88) is reproduced.
+ *    Both run GeoSourceInterface::fill_Jgup / fill_Jinv's generic algebra per point at the point's own centring, as
+ *    LevelGeometry does.  Maps not listed (Twisted, NewBeamGenerator's spline, DEM interpolation itself) stay with the caller
+ *    through somar_solver_set_metric_full or somar_metric_jgup_from_dxdxi. */
+#define SOMAR_MAP_CYLINDRICAL 1
+#define SOMAR_MAP_BATHYMETRIC 2
+int somar_solver_set_metric_map(somar_solver_t* s, int kind, const double* L, const double* depth, const int* depth_lo,
+                                const int* depth_n);
 
 /* Diagnostics, no reference counterpart: what this device streams for a given mix of streams, in GB/s of algorithmic bytes
  * -- kind 0 copy (16 B/cell), 1 read (8 B/cell), 2 six reads + one write (56 B/cell: the fused GSRB sweep's mix without

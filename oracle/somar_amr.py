@@ -1133,3 +1133,64 @@ def amr_level_heat(comp, l, scheme, phiNew, phiOld, src, crseOld=None, crseNew=N
             so.ld_incr(phiNew, phis, 1.0)
         solve_helm(phiNew, coarse, rhst, mu1)
         incr_flux(phiNew, False)
+
+
+# ----------------------------------------------------------------------------
+# MappedAMRTGA<T>::oneStep -- the COMPOSITE TGA step over levels l_base..l_max (AMRElliptic/MappedAMRTGA.H:417-497).
+#   applyHelm  (:499-523): resetAlphaAndBeta(1, mu dt); m_solver->computeAMROperator(ans, phi, l_max, l_base, homogeneous)
+#   solveHelm  (:525-546): resetAlphaAndBeta(1, -mu dt); m_solver->solveNoInit(ans, rhs, l_max, l_base, zeroPhi = false)
+#   computeAMROperator (MappedAMRMultiGrid.H:862-878): computeAMRResidual against a zero m_residual with
+#   a_computeNorm = false (no zeroCovered), then scale(-1).
+#   divideByIdentityCoef / diagonalScale: no-ops of MappedAMRPoissonOp (MappedAMRPoissonOp.cpp:814-825).
+# The register scale of the refluxing inside is the coarse operator's CURRENT beta / dx (reflux(), above).
+# No driver of the reference calls this class (AMRNavierStokes advances level by level, amr_level_heat above).
+# ----------------------------------------------------------------------------
+def compute_amr_operator(comp, lph, phi, l_max, l_base, homogeneous):
+    nl = len(comp.levels)
+    zero = [None] * nl
+    for l in range(l_base, l_max + 1):
+        zero[l] = so.ld_create(lph[l])
+        so.ld_set(zero[l], 0.0)
+    comp.compute_amr_residual(lph, phi, zero, l_max, l_base, homogeneous, computeNorm=False)
+    for l in range(l_base, l_max + 1):
+        so.ld_scale(lph[l], -1.0)
+
+
+def amr_tga_one_step(comp, phiNew, phiOld, source, dt, l_base, l_max):
+    """phiNew / phiOld / source: per-level lists (entries below l_base: the coarser level's data for the CF values of
+    phiOld resp. phiNew, or None when l_base == 0).  comp.history / iters / exitStatus are the LAST solve's."""
+    mu1, mu2, mu3, mu4, _ = so.tga_coefficients()
+    nl = len(comp.levels)
+    rng = range(l_base, l_max + 1)
+    rhst, srct = [None] * nl, [None] * nl
+    if l_base > 0:
+        rhst[l_base - 1] = None
+        srct[l_base - 1] = phiOld[l_base - 1]   # homogeneous CF values: the coarse data is not read
+    for l in rng:
+        rhst[l] = so.ld_create(source[l])
+        srct[l] = so.ld_create(phiNew[l])
+        so.ld_set(srct[l], 0.0)
+        so.ld_incr(srct[l], source[l], 1.0)
+
+    def apply_helm(ans, phi, mu, homogeneous):
+        amr_reset_alpha_beta(comp, 1.0, mu * dt)
+        compute_amr_operator(comp, ans, phi, l_max, l_base, homogeneous)
+
+    def solve_helm(ans, rhs, mu):
+        amr_reset_alpha_beta(comp, 1.0, -mu * dt)
+        comp.solve(ans, rhs, l_max, l_base, zeroPhi=False)
+
+    apply_helm(rhst, srct, mu4, True)
+    for l in rng:
+        so.ld_scale(rhst[l], dt)
+    apply_helm(phiNew, phiOld, mu3, False)
+    for l in rng:
+        so.ld_incr(rhst[l], phiNew[l], 1.0)
+    for l in rng:
+        so.ld_assign(phiNew[l], phiOld[l])
+    solve_helm(phiNew, rhst, mu2)
+    for l in rng:
+        so.ld_assign(rhst[l], phiNew[l])
+    for l in rng:
+        so.ld_assign(phiNew[l], phiOld[l])
+    solve_helm(phiNew, rhst, mu1)

@@ -1,0 +1,165 @@
+"""CPU restatement (TEST INFRASTRUCTURE, never imported by the product) of the coordinate maps' metric producers
+(SURVEY.md 8f rank 3), numpy over whole boxes, one statement per Fortran statement so the roundings are the reference's:
+
+  CylindricalMap::fill_dxdXi / fill_J           geometry/maps/CylindricalMap.cpp:125-190, CylindricalMapF.ChF
+                                                (CYLINDRICAL_FILL_DXDXI, CYLINDRICAL_FILL_J); isDiagonal() = true
+  BathymetricBaseMap::fill_dxdXi / fill_J       geometry/maps/BathymetricBaseMap.cpp:133-313 (the !isDiagonal() branches),
+                                                BathymetricBaseMapF.ChF (FILL_BATHYDXDXI, FILL_BATHYDZDXI, FILL_BATHYDZDZETA,
+                                                VERTPHI(f) = f, DVERTPHI(f) = one, HORIZPHI(f) = f)
+  CONVERTFAB                                    calculus/interpolation/ConvertFABF.ChF:32-150 with AVG1IX / AVG2IX / AVG3IX of
+                                                utils/AddlFortranMacros.H:74-88
+  GeoSourceInterface::fill_Jgup / fill_Jinv     geometry/GeoSourceInterface.cpp:296-311, 417-450 (somar_oracle.geo_fill_jgup)
+
+Parity unpinned w.r.t. reference tests (the reference ships none); tests/test_oracle_maps.py pins it by known answers.
+
+Reference quirk reproduced, not fixed: AVG3IX's eighth term reads f(i0+ii0+jj0+kk0, i1+ii1+kk1+kk1, i2+ii2+jj2+kk2) -- kk1
+twice where jj1 belongs (AddlFortranMacros.H:88) -- so an average over all three directions takes the corner (ii + kk) twice
+and never the corner (ii + jj + kk).  It is what BathymetricBaseMap's cell-centred J (hence J^{-1}) goes through.
+
+The nodal depth (BathymetricBaseMap::fill_bathymetry, a virtual of the DEM / Ledge / BeamGenerator maps) is an INPUT here:
+a 2-D array over nodes [dlo, dlo + shape) of the level's index space."""
+import numpy as np
+
+from . import somar_oracle as so
+
+CYLINDRICAL, BATHYMETRIC = 1, 2
+
+
+def _idx(lo, hi):
+    return np.meshgrid(*[np.arange(lo[d], hi[d] + 1) for d in range(3)], indexing="ij")
+
+
+def convert_fab(f, I, J, K, srcType, destType):
+    """dest(i) of CONVERTFAB for a pointwise-evaluable source f(i0, i1, i2)"""
+    ii = (srcType[0] - destType[0], 0, 0)
+    jj = (0, srcType[1] - destType[1], 0)
+    kk = (0, 0, srcType[2] - destType[2])
+    num = abs(ii[0]) + abs(jj[1]) + abs(kk[2])
+
+    def at(*offs):
+        o = [sum(x[d] for x in offs) for d in range(3)]
+        return f(I + o[0], J + o[1], K + o[2])
+
+    if num == 0:
+        return at()
+    if num == 1:
+        o = ii if ii[0] else (jj if jj[1] else kk)
+        return 0.5 * (at() + at(o))
+    if num == 2:
+        if ii[0] == 0:
+            a, b = jj, kk
+        elif jj[1] == 0:
+            a, b = kk, ii
+        else:
+            a, b = ii, jj
+        return 0.25 * (((at() + at(a)) + at(b)) + at(a, b))
+    # AVG3IX, eighth term as written: (i0+ii0, i1, i2+kk2)
+    s = at() + at(ii)
+    s = s + at(jj)
+    s = s + at(ii, jj)
+    s = s + at(kk)
+    s = s + at(ii, kk)
+    s = s + at(jj, kk)
+    s = s + at(ii, kk)
+    return 0.125 * s
+
+
+class CylindricalMap:
+    diagonal = True
+
+    def __init__(self, dXi):
+        self.dXi = tuple(float(x) for x in dXi)
+
+    def dxdXi(self, mu, nu, T, I, J, K, scale=1.0):
+        shape = np.broadcast(I, J, K).shape
+        if mu == 2 or nu == 2:
+            return np.full(shape, scale if mu == nu else 0.0)
+        off0 = (1.0 - T[0]) * 0.5
+        off1 = (1.0 - T[1]) * 0.5
+        Xi0 = self.dXi[0] * (I + off0)
+        Xi1 = self.dXi[1] * (J + off1)
+        if mu == 0:
+            v = scale * np.cos(Xi1) if nu == 0 else -scale * Xi0 * np.sin(Xi1)
+        else:
+            v = scale * np.sin(Xi1) if nu == 0 else scale * Xi0 * np.cos(Xi1)
+        return np.broadcast_to(v, shape).copy()
+
+    def J(self, T, I, J, K, scale=1.0):
+        off0 = (1.0 - T[0]) * 0.5
+        scaleDXi0 = scale * self.dXi[0]
+        return np.broadcast_to(scaleDXi0 * (I + off0), np.broadcast(I, J, K).shape).copy()
+
+
+class BathymetricMap:
+    diagonal = False
+
+    def __init__(self, dXi, L, depth, dlo):
+        self.dXi, self.L = tuple(float(x) for x in dXi), tuple(float(x) for x in L)
+        self.depth, self.dlo = np.asarray(depth, dtype=np.float64), tuple(dlo)
+
+    def _d(self, a, b):
+        return self.depth[a - self.dlo[0], b - self.dlo[1]]
+
+    def dxdXi(self, mu, nu, T, I, J, K, scale=1.0):
+        shape = np.broadcast(I, J, K).shape
+        if mu != 2:
+            if nu != 2 and mu == nu:
+                offsetF = 0.5 * (1.0 - float(T[nu])) + 0.5
+                offsetB = 0.5 * (1.0 - float(T[nu])) - 0.5
+                twoDXiOnL = 2.0 * self.dXi[nu] / self.L[nu]
+                invDXi = scale / twoDXiOnL
+                i = (I, J)[nu].astype(np.float64)
+                XiF = twoDXiOnL * (i + offsetF)
+                XiB = twoDXiOnL * (i + offsetB)
+                return np.broadcast_to((XiF - XiB) * invDXi, shape).copy()
+            return np.zeros(shape)
+        H, dZeta = self.L[2], self.dXi[2]
+        if nu != 2:
+            E = [1, 1, 1]
+            E[nu] = 0
+            invDXi = 1.0 / self.dXi[nu]
+            e = (1, 0) if nu == 0 else (0, 1)
+
+            def edge(a, b, c):
+                zetaFrac = c.astype(np.float64) * dZeta / H
+                DDepthDXi = (self._d(a + e[0], b + e[1]) - self._d(a, b)) * invDXi
+                return scale * (1.0 - zetaFrac) * DDepthDXi
+            return np.broadcast_to(convert_fab(edge, I, J, K, E, T), shape).copy()
+
+        def node(a, b, c):
+            depthFrac = self._d(a, b) / H
+            return np.broadcast_to(scale * (1.0 - depthFrac) * 1.0, np.broadcast(a, b, c).shape)
+        return np.broadcast_to(convert_fab(node, I, J, K, (1, 1, 1), T), shape).copy()
+
+    def J(self, T, I, J, K, scale=1.0):
+        d = self.dxdXi(2, 2, T, I, J, K, scale)
+        d = d * self.dxdXi(0, 0, T, I, J, K, 1.0)
+        d = d * self.dxdXi(1, 1, T, I, J, K, 1.0)
+        return d
+
+
+def fill_jgup(m, valid, mu):
+    """LevelGeometry's FC J g^{mu nu} on faces(valid, mu): -> array (faces..., 3) (for a diagonal map the nu != mu
+    components are zero, GeoSourceInterface.cpp:431-436)"""
+    fb = valid.faces(mu)
+    I, J, K = _idx(fb.lo, fb.hi)
+    T = [0, 0, 0]
+    T[mu] = 1
+    n = I.size
+    dx = np.empty((n, 3, 3))
+    for r in range(3):
+        for s in range(3):
+            dx[:, r, s] = m.dxdXi(r, s, T, I, J, K).reshape(-1)
+    detJ = m.J(T, I, J, K).reshape(-1)
+    g = so.geo_fill_jgup(dx, detJ, mu)
+    if m.diagonal:
+        for nu in range(3):
+            if nu != mu:
+                g[:, nu] = 0.0
+    return g.reshape(I.shape + (3,))
+
+
+def fill_jinv(m, valid):
+    """fill_Jinv = fill_J then FArrayBox::invert(1.0) on the cell-centred valid box"""
+    I, J, K = _idx(valid.lo, valid.hi)
+    return 1.0 / m.J((0, 0, 0), I, J, K)

@@ -1626,6 +1626,29 @@ def set_wall_normal_flux(edge, grids, domain, ndim=3):
                 edge[i][d].view(fb.edgeCells(d, 1))[...] = 0.0
 
 
+def set_normal_flux_bc(edge, grids, domain, kind, value, ndim=3):
+    """BasicVelocityBCGhostClass with inflow / outflow sides on the FC normal faces (EllipticBCUtils.cpp:1244-1327):
+    kind[2*d + side] = 0 solid wall -> setSideDiriBC(0); 1 -> setSideDiriBC(value[2*d + side]) (both set the boundary faces of
+    a face-centred FAB directly, :96-100); 2 outflow -> setSideExtrapBC order 0 = ELLIPTICEXTRAPBCGHOST on the boundary
+    faces: state(i) = state(i + ii), the next face inside (EllipticBCUtilsF.ChF:148-154)"""
+    for i, g in enumerate(grids):
+        for d in range(ndim):
+            if domain.periodic[d]:
+                continue
+            fb = g.faces(d)
+            for side in (0, 1):
+                if (g.lo[d] != domain.box.lo[d]) if side == 0 else (g.hi[d] != domain.box.hi[d]):
+                    continue
+                k, v = kind[2 * d + side], value[2 * d + side]
+                dest = fb.edgeCells(d, side)
+                if k == 2:
+                    sh = [0, 0, 0]
+                    sh[d] = 1 if side == 0 else -1
+                    edge[i][d].view(dest)[...] = edge[i][d].view(dest.shift(sh))
+                else:
+                    edge[i][d].view(dest)[...] = v if k == 1 else 0.0
+
+
 def edge_to_cell(edge, cc, ndim=3):
     for i, g in enumerate(cc.grids):
         for d in range(ndim):
@@ -1634,10 +1657,12 @@ def edge_to_cell(edge, cc, ndim=3):
             cc[i].view(g, d)[...] = 0.5 * (edge[i][d].view(g, 0) + edge[i][d].view(g.shift(sh), 0))
 
 
-def level_divergence_cc(div, vel, Jinv, grids, domain, dx, ndim=3, wall=True):
+def level_divergence_cc(div, vel, Jinv, grids, domain, dx, ndim=3, wall=True, velbc=None):
     edge = FluxData(grids, 1, ndim)
     cell_to_edge(vel, edge, ndim)
-    if wall:
+    if wall and velbc is not None:
+        set_normal_flux_bc(edge, grids, domain, velbc[0], velbc[1], ndim)
+    elif wall:
         set_wall_normal_flux(edge, grids, domain, ndim)
     level_divergence_mac(div, edge, Jinv, grids, dx, ndim)
     return edge

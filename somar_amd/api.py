@@ -14,6 +14,7 @@ _LIB = None
 
 BC_NONE, BC_NEUM, BC_DIRI = -1, 0, 1
 F_PHI, F_RHS, F_RES, F_CORR, F_BEST, F_SCRATCH, F_AMR_CORR, F_AMR_RES, F_HEAT_OLD, F_HEAT_SRC = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+MAP_CYLINDRICAL, MAP_BATHYMETRIC = 1, 2   # SOMAR_MAP_* of include/somar_amd.h
 MAX_HISTORY = 64
 COMM_ID_BYTES = 128
 
@@ -158,6 +159,9 @@ _SIGS = {
     "somar_leptic_solve": [_H, C.c_int, C.POINTER(LepticStats)],
     "somar_amr_set_alpha_beta": [_H, C.c_double, C.c_double],
     "somar_amr_heat_step": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(Stats)],
+    "somar_solver_set_metric_map": [_H, C.c_int, _PD, _PD, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "somar_solver_set_vel_bc": [_H, C.POINTER(C.c_int), _PD],
+    "somar_amr_tga_step": [_H, C.c_int, C.c_int, C.c_double, C.POINTER(Stats)],
     "somar_heat_flux_download": [_H, C.c_int, C.c_int, _PD],
     "somar_amr_enable_leptic": [_H, C.POINTER(LepticParams), C.c_int],
     "somar_amr_solve_leptic": [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)],
@@ -320,6 +324,12 @@ class AMRPressureSolver:
                                       C.byref(st)))
         return self._stats(st)
 
+    def tgaStepAMR(self, lmax, lbase, dt):
+        """MappedAMRTGA::oneStep over levels lbase..lmax (PHI = phiNew, HEAT_OLD = phiOld, HEAT_SRC = source)"""
+        st = Stats()
+        _ck(lib().somar_amr_tga_step(self._amr, lmax, lbase, dt, C.byref(st)))
+        return self._stats(st)
+
     # -- AMRLepticSolver (AMRPressureSolver::s_useAMRLepticSolver) ------------------------------------------------
     def enableLeptic(self, params=None, baseFromRestricted=False):
         """One leptic level solver per level (AMRLepticSolver::init); params: LepticParams or None for the defaults.
@@ -437,6 +447,17 @@ class AMRPressureSolver:
     def setMetricUniform(self, jgxx, jgyy, jgzz, jinv):
         """CartesianMap's constants into every local patch, on the device (no host arrays)"""
         _ck(lib().somar_solver_set_metric_uniform(self._h, _da([jgxx, jgyy, jgzz, jinv])))
+
+    def setMetricMap(self, kind, L=(0.0, 0.0, 0.0), depth=None, depth_lo=(0, 0)):
+        """SOMAR_MAP_CYLINDRICAL (1) / SOMAR_MAP_BATHYMETRIC (2) evaluated on the device into every local patch; depth:
+        2-D array of NODAL depths, depth[i - depth_lo[0], j - depth_lo[1]]"""
+        if depth is None:
+            _ck(lib().somar_solver_set_metric_map(self._h, int(kind), _da(list(L)), None, None, None))
+            return
+        d = np.asfortranarray(depth, dtype=np.float64)
+        lo = (C.c_int * 2)(int(depth_lo[0]), int(depth_lo[1]))
+        n = (C.c_int * 2)(int(d.shape[0]), int(d.shape[1]))
+        _ck(lib().somar_solver_set_metric_map(self._h, int(kind), _da(list(L)), _dp(d), lo, n))
 
     def setMetricFull(self, patch, jg0, jg1, jg2, jinv):
         """jgD: array (faces(valid, D) shape + (SpaceDim,)), Fortran order = component slowest; jg2 = None in 2-D"""
@@ -616,8 +637,14 @@ class AMRPressureSolver:
         return out
 
     def velWallBC(self):
-        """zero wall-normal faces of the resident MAC velocity (uStarFuncBC, solid walls)"""
+        """zero wall-normal faces of the resident MAC velocity (uStarFuncBC, solid walls; or what setVelBC installed)"""
         _ck(lib().somar_vel_wall_bc(self._h))
+
+    def setVelBC(self, kind, value):
+        """BasicVelocityBCGhostClass's inflow / outflow sides: kind[2*dir+side] 0 wall, 1 prescribed value, 2 outflow"""
+        k = (C.c_int * 6)(*[int(x) for x in kind])
+        v = (C.c_double * 6)(*[float(x) for x in value])
+        _ck(lib().somar_solver_set_vel_bc(self._h, k, v))
 
     def divergenceMAC(self, out_field, dt):
         _ck(lib().somar_level_divergence_mac(self._h, out_field, float(dt)))

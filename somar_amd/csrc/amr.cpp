@@ -605,6 +605,7 @@ void AMRSolver::build_reflux_tables(int l)
                                     a.face = t.coff + (s == 0 ? st[d] : 0);
                                     a.sc = sc;
                                     a.dir = d;
+                                    a.sgn = s == 0 ? 1 : -1;
                                     t.A.push_back(a);
                                 }
                     }
@@ -687,6 +688,7 @@ void AMRSolver::build_reflux_tables(int l)
     K.d_reg = to_device(reg);
     K.d_reflux = to_device(cells);
     K.d_A = to_device(A);
+    K.nA = (long long)A.size();
     K.d_B = to_device(B);
     const size_t nvals = (size_t)std::max(1, K.nreg_local + K.nreg_recv);
     SOMAR_HIP(hipMalloc(&K.d_regvals, nvals * sizeof(double)));
@@ -846,6 +848,7 @@ void AMRSolver::comp_divergence_cc(int l, int l_max, double* out, bool wall)
     if (!K.fluxDefined) return;
     // the register's scales carry the operator's beta / dx_coarse; the divergence wants 1 / dx_coarse
     SOMAR_CHECK(L.beta == 1.0, "the composite projector needs the pressure operator's beta = 1 (AMRPressureSolver's)");
+    sync_reflux_scales(l + 1);
     double* fe[3] = {Q.vel(0), Q.vel(1), Q.vel(2)};
     double* fc[3] = {Q.cc_vel(0), Q.cc_vel(1), nd == 3 ? Q.cc_vel(2) : nullptr};
     launch_cell_to_edge(st_, F.dev, fe, fc, false);   // only the box-side faces are used: cells astride a CF face
@@ -928,12 +931,32 @@ void AMRSolver::amr_residual_nf(int l, double* res, double* phi, const double* p
     S[l]->residual_i(0, res, phi, rhs, homogeneous);
 }
 
+// MappedAMRPoissonOp::reflux takes its register scale m_beta / m_dx[idir] from the coarse operator when it runs
+// (MappedAMRPoissonOp.cpp:1661, 1693), so after setAlphaAndBeta (the heat integrators' resetAlphaAndBeta) the tables built
+// at define are rewritten with the same expressions: three numbers on the host, one pass over the coarse-side entries.
+void AMRSolver::sync_reflux_scales(int lf)
+{
+    AMRLink& K = *links_[lf];
+    if (!K.fluxDefined) return;
+    const Level& C = S[lf - 1]->level(0);
+    const double beta = C.beta;
+    if (beta == K.beta_built) return;
+    double sc[3];
+    for (int d = 0; d < 3; ++d) {
+        const double scale = beta / C.dx[d];
+        const double denom = (double)(K.r[0] * K.r[1] * K.r[2] / K.r[d]);
+        K.sc_fine[d][0] = -1.0 * scale / denom;
+        K.sc_fine[d][1] = 1.0 * scale / denom;
+        sc[d] = scale;
+    }
+    launch_reflux_rescale(st_, K.d_A, K.nA, sc);
+    K.beta_built = beta;
+}
+
 void AMRSolver::reflux(int l, double* phiFine, double* phi, double* LofPhi)
 {
-    SOMAR_CHECK(!links_[l + 1]->fluxDefined || S[l]->level(0).beta == links_[l + 1]->beta_built,
-                "refluxing with operator coefficients other than the hierarchy was built with is not implemented: level solves "
-                "only after somar_amr_set_alpha_beta (restore alpha, beta for composite operations)");
     SOMAR_CHECK(l >= 0 && l + 1 < nlevels(), "reflux: level has no finer level");
+    sync_reflux_scales(l + 1);
     AMRLink& K = *links_[l + 1];
     interp_cf(l + 1, phiFine, phi);
     if (!K.fluxDefined) return;
@@ -1010,6 +1033,13 @@ void AMRSolver::compute_residual_level(double* const* resid, double* const* phi,
         if (l_base == 0) S[0]->residual(0, resid[0], phi[0], rhs[0], homogeneous);
         else amr_residual_nf(l_max, resid[l_max], phi[l_max], phi[l_max - 1], rhs[l_max], homogeneous);
     }
+}
+
+// computeAMRResidual with a_computeNorm = false (MappedAMRMultiGrid.H:793-836): no zeroCovered, no norm
+void AMRSolver::compute_residual_levels_only(double* const* resid, double* const* phi, double* const* rhs, int l_max,
+                                             int l_base, bool homogeneous)
+{
+    for (int ilev = l_base; ilev <= l_max; ++ilev) compute_residual_level(resid, phi, rhs, l_max, l_base, ilev, homogeneous);
 }
 
 double AMRSolver::compute_residual(double* const* resid, double* const* phi, double* const* rhs, int l_max, int l_base,
@@ -1238,6 +1268,60 @@ void AMRSolver::heat_step(int l, int scheme, double dt, bool zeroPhi, double old
         solve_helm(mu1);
         P.increment_heat_flux(phiNew, false);
     }
+    sync();
+}
+
+// MappedAMRTGA<T>::oneStep (AMRElliptic/MappedAMRTGA.H:417-497): the COMPOSITE TGA step over levels l_base..l_max at once --
+// applyHelm = resetAlphaAndBeta(1, mu dt) + MappedAMRMultiGrid::computeAMROperator (:499-523; MappedAMRMultiGrid.H:862-878:
+// the composite residual of a zero right-hand side, negated; covered cells are NOT zeroed because a_computeNorm is false),
+// solveHelm = resetAlphaAndBeta(1, -mu dt) + solveNoInit(ans, rhs, l_max, l_base, zeroPhi = false) (:525-546).
+// divideByIdentityCoef and diagonalScale are no-ops of MappedAMRPoissonOp (MappedAMRPoissonOp.cpp:814-825).
+// Per level: phiNew = phi(), rhst = rhs(), phiOld = heat_field(0), source = heat_field(1), srct = heat_field(2).
+void AMRSolver::tga_step(int l_max, int l_base, double dt, SolveStats& st)
+{
+    SOMAR_CHECK(finalized_ && l_base >= 0 && l_base <= l_max && l_max < nlevels(), "tga_step: bad level range");
+    SOMAR_CHECK(dt >= 0.0, "negative time step");
+    const double tgaEpsilon = 1.e-12;
+    const double a = 2.0 - std::sqrt(2.0) - tgaEpsilon;
+    const double discr = std::sqrt(a * a - 4.0 * a + 2.0);
+    const double mu1 = (a - discr) / 2.0, mu2 = (a + discr) / 2.0, mu3 = 1.0 - a, mu4 = 0.5 - a;
+    const int nl = nlevels();
+    std::vector<double*> phiNew(nl), rhst(nl), phiOld(nl), src(nl), srct(nl), zero(nl);
+    std::vector<long long> n(nl);
+    for (int l = 0; l < nl; ++l) {
+        PressureSolver& P = *S[l];
+        n[l] = P.level(0).field_elems;
+        phiNew[l] = P.phi();
+        rhst[l] = P.rhs();
+        phiOld[l] = P.heat_field(0);
+        src[l] = P.heat_field(1);
+        srct[l] = P.heat_field(2);
+        zero[l] = P.field(0, 5);   // m_residual, set to zero: computeAMROperator's right-hand side
+    }
+    // a level below l_base supplies the coarse-fine values of BOTH a_phiOld and a_phiNew from its own arrays
+    auto apply_helm = [&](std::vector<double*>& ans, std::vector<double*>& phi, double mu, bool homogeneous) {
+        set_alpha_beta(1.0, mu * dt);
+        for (int l = l_base; l <= l_max; ++l) launch_set(st_, zero[l], n[l], 0.0);
+        compute_residual_levels_only(ans.data(), phi.data(), zero.data(), l_max, l_base, homogeneous);
+        for (int l = l_base; l <= l_max; ++l) launch_scale(st_, ans[l], -1.0, n[l]);
+    };
+    auto solve_helm = [&](double mu) {
+        set_alpha_beta(1.0, -mu * dt);
+        solve(l_max, l_base, false, false, st);
+    };
+    for (int l = l_base; l <= l_max; ++l) {
+        launch_set(st_, srct[l], n[l], 0.0);
+        launch_incr(st_, srct[l], src[l], 1.0, n[l]);
+    }
+    apply_helm(rhst, srct, mu4, true);
+    for (int l = l_base; l <= l_max; ++l) launch_scale(st_, rhst[l], dt, n[l]);
+    apply_helm(phiNew, phiOld, mu3, false);
+    for (int l = l_base; l <= l_max; ++l) launch_incr(st_, rhst[l], phiNew[l], 1.0, n[l]);
+    for (int l = l_base; l <= l_max; ++l) launch_copy(st_, phiNew[l], phiOld[l], n[l]);
+    solve_helm(mu2);
+    for (int l = l_base; l <= l_max; ++l) launch_copy(st_, rhst[l], phiNew[l], n[l]);
+    for (int l = l_base; l <= l_max; ++l) launch_copy(st_, phiNew[l], phiOld[l], n[l]);
+    solve_helm(mu1);
     sync();
 }
 

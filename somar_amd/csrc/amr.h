@@ -53,7 +53,7 @@ struct RefluxA {      // coarse-side contribution: coar += sc * F_c(face)
     long long face;   // offset (coarse field) of the cell whose LOW face it is
     double sc;
     int dir;
-    int pad_;
+    int sgn;          // sc = sgn * (beta / dx[dir]) of the coarse operator (MappedAMRPoissonOp::reflux, :1661)
 };
 struct RefluxCell {   // one coarse cell next to the fine level
     long long coff;
@@ -87,6 +87,7 @@ void launch_fine_register(hipStream_t st, const FRegCell* cells, int n, const Pa
                           double* const jg[3], const double dxf[3], const double sc[3][2], const int r[3], double* out,
                           double* const* fluxes = nullptr);
 void launch_gather(hipStream_t st, const int* idx, long long n, const double* src, double* dst);
+void launch_reflux_rescale(hipStream_t st, RefluxA* A, long long n, const double scale[3]);
 void launch_reflux(hipStream_t st, const RefluxCell* cells, int n, const RefluxA* A, const int* B,
                    const PatchDesc* cpatches, const double* phi, double* const jg[3], const double* jinv,
                    const double dxc[3], const double* freg, double* LofPhi, double* const* fluxes = nullptr);
@@ -117,6 +118,7 @@ struct AMRLink {
     double* d_regvals = nullptr;       // [local | received]
     RefluxCell* d_reflux = nullptr;
     RefluxA* d_A = nullptr;
+    long long nA = 0;
     int* d_B = nullptr;
     // register values that travel between ranks
     std::vector<int> peers;
@@ -156,9 +158,12 @@ public:
     // a_uberCorrection from a_uberResidual and its m_correction stays zero (:444-449); true (NOT the reference) feeds it the
     // restricted residual as MappedAMRMultiGrid's V-cycle does.
     // MappedBaseLevelHeatSolver::resetSolverAlphaAndBeta on every op of every level (MappedBaseLevelHeatSolver.cpp:257-270).
-    // The flux-register scales keep the beta they were built with: composite (multi-level) operators then raise until the
-    // coefficients are back; level solves (l_base == l_max), which is what the level heat integrators run, never reflux.
+    // The flux-register scales follow: reflux() rewrites them when the coarse operator's beta differs from the one they hold
+    // (sync_reflux_scales), as MappedAMRPoissonOp::reflux takes m_beta / m_dx when it runs.
     void set_alpha_beta(double a, double b);
+    // MappedAMRTGA<T>::oneStep (AMRElliptic/MappedAMRTGA.H:417-497): one composite TGA step over levels l_base..l_max;
+    // phiNew = PHI, phiOld = HEAT_OLD, source = HEAT_SRC of every level; st = the LAST solve's
+    void tga_step(int l_max, int l_base, double dt, SolveStats& st);
     // MappedLevelBackwardEuler / MappedLevelCrankNicolson / MappedLevelTGA::updateSoln on level l of the hierarchy
     // (AMRParabolic/*.cpp): phiNew = level l's PHI, phiOld / src = its HEAT_OLD / HEAT_SRC; for l > 0 the coarse-fine values
     // are timeInterp(level l-1's HEAT_OLD at crseOldTime, level l-1's PHI at crseNewTime); a_flux accumulates in heat_flux(d)
@@ -197,6 +202,9 @@ public:
     void amr_residual_nf(int l, double* res, double* phi, const double* phiCoarse, const double* rhs,
                          bool homogeneous = true);
     void reflux(int l, double* phiFine, double* phi, double* LofPhi);
+    void sync_reflux_scales(int lf);
+    void compute_residual_levels_only(double* const* resid, double* const* phi, double* const* rhs, int l_max, int l_base,
+                                      bool homogeneous);
     void amr_restrict(int l, double* residual, double* correction, const double* coarseCorrection, double* scratch);
     void assign_coarse_residual(int l, double* coarseResidual);  // assignCopier of link l's resC
     void amr_prolong(int l, double* correction, const double* coarseCorrection);

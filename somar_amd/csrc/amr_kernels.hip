@@ -332,6 +332,22 @@ void launch_gather(hipStream_t st, const int* idx, long long n, const double* sr
     if (n == 0) return;
     hipLaunchKernelGGL(k_gather, dim3(grid1(n)), dim3(256), 0, st, idx, n, src, dst);
 }
+// the register scale m_beta / m_dx[idir] is taken when reflux runs (MappedAMRPoissonOp.cpp:1661, 1693): after
+// setAlphaAndBeta the coarse-side table entries are rewritten with the same expression sgn * (beta / dx)
+__global__ void k_reflux_rescale(RefluxA* __restrict__ A, long long n, D3 scale)
+{
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RefluxA e = A[i];
+    A[i].sc = -(e.sgn > 0 ? -1.0 : 1.0) * scale.v[e.dir];
+}
+
+void launch_reflux_rescale(hipStream_t st, RefluxA* A, long long n, const double scale[3])
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_reflux_rescale, dim3(grid1(n)), dim3(256), 0, st, A, n, d3(scale));
+}
+
 void launch_reflux(hipStream_t st, const RefluxCell* cells, int n, const RefluxA* A, const int* B,
                    const PatchDesc* cpatches, const double* phi, double* const jg[3], const double* jinv,
                    const double dxc[3], const double* freg, double* LofPhi, double* const* fluxes)

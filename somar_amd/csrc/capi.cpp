@@ -535,6 +535,14 @@ int somar_vel_download(somar_solver_t* s, int dir, int patch, double* host)
     API_END
 }
 
+int somar_solver_set_vel_bc(somar_solver_t* s, const int* kind, const double* value)
+{
+    API_BEGIN
+    SOMAR_CHECK(s && kind && value, "null argument");
+    s->ps->set_vel_bc(kind, value);
+    API_END
+}
+
 int somar_vel_wall_bc(somar_solver_t* s)
 {
     API_BEGIN
@@ -1178,6 +1186,16 @@ int somar_metric_jgup_from_dxdxi(long long n, int mu, const double* dxdxi9, cons
 }
 
 // CartesianMap::fill_Jgup / fill_Jinv (geometry/maps/CartesianMap.cpp:230-280): constants, written on the device
+int somar_solver_set_metric_map(somar_solver_t* s, int kind, const double* L, const double* depth, const int* depth_lo,
+                                const int* depth_n)
+{
+    API_BEGIN
+    SOMAR_CHECK(s && L, "null argument");
+    const int z[2] = {0, 0};
+    s->ps->set_metric_map(kind, L, depth, depth_lo ? depth_lo : z, depth_n ? depth_n : z);
+    API_END
+}
+
 int somar_solver_set_metric_uniform(somar_solver_t* s, const double* c4)
 {
     API_BEGIN
@@ -1287,6 +1305,16 @@ int somar_amr_heat_step(somar_amr_t* a, int level, int scheme, double dt, int ze
     SOMAR_CHECK(a, "null argument");
     SolveStats st;
     a->amr->heat_step(level, scheme, dt, zero_phi != 0, old_time, crse_old_time, crse_new_time, st);
+    fill_stats(st, stats);
+    API_END
+}
+
+int somar_amr_tga_step(somar_amr_t* a, int l_max, int l_base, double dt, somar_stats_t* stats)
+{
+    API_BEGIN
+    SOMAR_CHECK(a, "null argument");
+    SolveStats st;
+    a->amr->tga_step(l_max, l_base, dt, st);
     fill_stats(st, stats);
     API_END
 }

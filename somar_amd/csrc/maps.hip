@@ -1,0 +1,187 @@
+// somar_amd/csrc/maps.hip -- coordinate maps' metric producers on the device: the level's
+// J g^{ab} on faces and J^{-1} at cell centres written straight into the level's resident metric arrays, nothing of
+// O(N^3) crosses PCIe.
+//
+//   CylindricalMap::fill_dxdXi / fill_J        geometry/maps/CylindricalMap.cpp:125-190, CylindricalMapF.ChF
+//                                              (CYLINDRICAL_FILL_DXDXI, CYLINDRICAL_FILL_J); isDiagonal() = true
+//   BathymetricBaseMap::fill_dxdXi / fill_J    geometry/maps/BathymetricBaseMap.cpp:133-313 (the !isDiagonal() branches),
+//                                              BathymetricBaseMapF.ChF: FILL_BATHYDXDXI, FILL_BATHYDZDXI, FILL_BATHYDZDZETA
+//                                              with VERTPHI(f) = f, DVERTPHI(f) = one, HORIZPHI(f) = f
+//   CONVERTFAB                                 calculus/interpolation/ConvertFABF.ChF:32-150, AVG1IX / AVG2IX / AVG3IX of
+//                                              utils/AddlFortranMacros.H:74-88
+//   GeoSourceInterface::fill_dXidx / fill_gup / fill_Jgup / fill_Jinv   geometry/GeoSourceInterface.cpp:200-450
+//
+// One thread per face / cell evaluates the nine dx^rho/dXi^sigma and det J at its own centring and runs the generic
+// cofactor algebra (the statement order of k_jgup_from_dxdxi, projection.hip).  The nodal depth of a bathymetric map
+// (BathymetricBaseMap::fill_bathymetry, a virtual of the DEM / Ledge / BeamGenerator maps) is the caller's: a 2-D array,
+// O(N^2).  Reference quirk reproduced, not fixed: AVG3IX's eighth term has kk1 where jj1 belongs
+// (AddlFortranMacros.H:88), so an average over all three directions takes the corner (ii + kk) twice and never
+// (ii + jj + kk) -- the cell-centred J (hence J^{-1}) of a bathymetric map goes through it.
+#include "common.h"
+#include "kernels.h"
+
+namespace somar {
+
+struct MapParams {
+    int kind;            // 1 cylindrical, 2 bathymetric
+    double dXi[3];
+    double L[3];
+    const double* depth; // nodes [dlo, dlo + dn), i fastest
+    int dlo[2], dn[2];
+};
+
+struct MapEval {
+    const MapParams& M;
+    __device__ double depth(int a, int b) const { return M.depth[(a - M.dlo[0]) + (long long)M.dn[0] * (b - M.dlo[1])]; }
+
+    // CONVERTFAB of a pointwise-evaluable source
+    template <class F>
+    __device__ double convert(F f, int i, int j, int k, const int* S, const int* T) const
+    {
+        const int ii = S[0] - T[0], jj = S[1] - T[1], kk = S[2] - T[2];
+        const int num = (ii != 0) + (jj != 0) + (kk != 0);
+        if (num == 0) return f(i, j, k);
+        if (num == 1) return 0.5 * (f(i, j, k) + f(i + ii, j + jj, k + kk));
+        if (num == 2) {
+            // AVG2IX(src, i, A, B): (jj, kk) when ii = 0, (kk, ii) when jj = 0, (ii, jj) otherwise
+            int a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+            if (ii == 0) { a[1] = jj; b[2] = kk; }
+            else if (jj == 0) { a[2] = kk; b[0] = ii; }
+            else { a[0] = ii; b[1] = jj; }
+            double s = f(i, j, k) + f(i + a[0], j + a[1], k + a[2]);
+            s = s + f(i + b[0], j + b[1], k + b[2]);
+            s = s + f(i + a[0] + b[0], j + a[1] + b[1], k + a[2] + b[2]);
+            return 0.25 * s;
+        }
+        double s = f(i, j, k) + f(i + ii, j, k);
+        s = s + f(i, j + jj, k);
+        s = s + f(i + ii, j + jj, k);
+        s = s + f(i, j, k + kk);
+        s = s + f(i + ii, j, k + kk);
+        s = s + f(i, j + jj, k + kk);
+        s = s + f(i + ii, j, k + kk);   // as written: (i0+ii0+jj0+kk0, i1+ii1+kk1+kk1, i2+ii2+jj2+kk2)
+        return 0.125 * s;
+    }
+
+    __device__ double dxdXi(int mu, int nu, const int* T, int i, int j, int k, double scale) const
+    {
+        if (M.kind == 1) {
+            if (mu == 2 || nu == 2) return mu == nu ? scale : 0.0;
+            const double off0 = (1.0 - T[0]) * 0.5, off1 = (1.0 - T[1]) * 0.5;
+            const double Xi0 = M.dXi[0] * (i + off0);
+            const double Xi1 = M.dXi[1] * (j + off1);
+            if (mu == 0) return nu == 0 ? scale * cos(Xi1) : -scale * Xi0 * sin(Xi1);
+            return nu == 0 ? scale * sin(Xi1) : scale * Xi0 * cos(Xi1);
+        }
+        if (mu != 2) {
+            if (nu == 2 || mu != nu) return 0.0;
+            const double offsetF = 0.5 * (1.0 - (double)T[nu]) + 0.5;
+            const double offsetB = 0.5 * (1.0 - (double)T[nu]) - 0.5;
+            const double twoDXiOnL = 2.0 * M.dXi[nu] / M.L[nu];
+            const double invDXi = scale / twoDXiOnL;
+            const double x = (double)(nu == 0 ? i : j);
+            const double XiF = twoDXiOnL * (x + offsetF);
+            const double XiB = twoDXiOnL * (x + offsetB);
+            return (XiF - XiB) * invDXi;
+        }
+        const double H = M.L[2], dZeta = M.dXi[2];
+        if (nu != 2) {
+            int E[3] = {1, 1, 1};
+            E[nu] = 0;
+            const double invDXi = 1.0 / M.dXi[nu];
+            const int e0 = nu == 0 ? 1 : 0, e1 = nu == 1 ? 1 : 0;
+            auto edge = [&](int a, int b, int c) {
+                const double zetaFrac = (double)c * dZeta / H;
+                const double DDepthDXi = (depth(a + e0, b + e1) - depth(a, b)) * invDXi;
+                return scale * (1.0 - zetaFrac) * DDepthDXi;
+            };
+            return convert(edge, i, j, k, E, T);
+        }
+        auto node = [&](int a, int b, int) {
+            const double depthFrac = depth(a, b) / H;
+            return scale * (1.0 - depthFrac) * 1.0;
+        };
+        const int Nd[3] = {1, 1, 1};
+        return convert(node, i, j, k, Nd, T);
+    }
+
+    __device__ double detJ(const int* T, int i, int j, int k) const
+    {
+        if (M.kind == 1) {
+            const double off0 = (1.0 - T[0]) * 0.5;
+            const double scaleDXi0 = 1.0 * M.dXi[0];
+            return scaleDXi0 * (i + off0);
+        }
+        double d = dxdXi(2, 2, T, i, j, k, 1.0);
+        d = d * dxdXi(0, 0, T, i, j, k, 1.0);
+        d = d * dxdXi(1, 1, T, i, j, k, 1.0);
+        return d;
+    }
+};
+
+struct MapOut { double* jg[3][3]; double* jinv; };
+
+// target 0..2: faces of that direction (J g^{target nu}); target 3: cell centres (J^{-1})
+__global__ void k_map_metric(const PatchDesc* __restrict__ patches, int npatches, MapParams M, MapOut O, int target,
+                             int diagonal)
+{
+    const PatchDesc p = patches[blockIdx.y];
+    int n[3] = {p.n[0], p.n[1], p.n[2]};
+    if (target < 3) n[target] += 1;
+    const long long tot = (long long)n[0] * n[1] * n[2];
+    const MapEval E{M};
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < tot; q += (long long)gridDim.x * blockDim.x) {
+        const int li = (int)(q % n[0]);
+        const int lj = (int)((q / n[0]) % n[1]);
+        const int lk = (int)(q / ((long long)n[0] * n[1]));
+        const int i = p.lo[0] + li, j = p.lo[1] + lj, k = p.lo[2] + lk;
+        const long long c = p.off + li + (long long)p.pj * lj + p.pk * lk;
+        int T[3] = {0, 0, 0};
+        if (target == 3) {
+            O.jinv[c] = 1.0 / E.detJ(T, i, j, k);   // fill_J, then FArrayBox::invert(a_scale = 1)
+            continue;
+        }
+        const int mu = target;
+        T[mu] = 1;
+        double X[9];
+        for (int r = 0; r < 3; ++r)
+            for (int s = 0; s < 3; ++s) X[3 * r + s] = E.dxdXi(r, s, T, i, j, k, 1.0);
+        const double J = E.detJ(T, i, j, k);
+        auto dXidx = [&](int a, int b) {
+            const int mu1 = (b + 1) % 3, mu2 = (b + 2) % 3, nu1 = (a + 1) % 3, nu2 = (a + 2) % 3;
+            double d = 0.0;
+            d = d + X[3 * mu1 + nu1] * X[3 * mu2 + nu2];   // ADDPROD2
+            d = d - X[3 * mu1 + nu2] * X[3 * mu2 + nu1];   // SUBPROD2
+            return d / J;
+        };
+        double m[3];
+        for (int rho = 0; rho < 3; ++rho) m[rho] = dXidx(mu, rho);
+        for (int nu = 0; nu < 3; ++nu) {
+            if (diagonal && nu != mu) continue;   // GeoSourceInterface::fill_Jgup: zero, and not stored on this path
+            double g = 0.0;
+            for (int rho = 0; rho < 3; ++rho) g = g + m[rho] * (nu == mu ? m[rho] : dXidx(nu, rho));
+            g = g * J;
+            O.jg[mu][nu][c] = g;
+        }
+    }
+}
+
+void launch_map_metric(hipStream_t st, const LevelDev& L, int kind, const double dXi[3], const double Lc[3],
+                       const double* d_depth, const int dlo[2], const int dn[2], bool diagonal)
+{
+    if (L.npatches == 0) return;
+    MapParams M;
+    M.kind = kind;
+    for (int d = 0; d < 3; ++d) { M.dXi[d] = dXi[d]; M.L[d] = Lc[d]; }
+    M.depth = d_depth;
+    for (int d = 0; d < 2; ++d) { M.dlo[d] = dlo[d]; M.dn[d] = dn[d]; }
+    MapOut O;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) O.jg[a][b] = diagonal ? (a == b ? L.jg[a] : nullptr) : L.jgf[a][b];
+    O.jinv = L.jinv;
+    for (int target = 0; target < 4; ++target)
+        hipLaunchKernelGGL(k_map_metric, dim3(64, L.npatches), dim3(256), 0, st, L.patches, L.npatches, M, O, target,
+                           diagonal ? 1 : 0);
+}
+
+}  // namespace somar

@@ -276,6 +276,46 @@ __global__ __launch_bounds__(512) void k_face_wall(const Tile* __restrict__ tile
         }
 }
 
+// BasicVelocityBCGhostClass with inflow / outflow sides (EllipticBCUtils.cpp:1244-1327) on face-centred data: per domain
+// side kind 0 = solid wall, setSideDiriBC(0); 1 = prescribed normal velocity, setSideDiriBC(value) (on a face-centred FAB
+// both set the boundary faces directly, :96-100); 2 = outflow, setSideExtrapBC(order 0) = ELLIPTICEXTRAPBCGHOST order 0
+// on the boundary faces: the value of the next face inside (EllipticBCUtilsF.ChF:148-154)
+struct FaceBC { int kind[6]; double value[6]; };
+template <int DIR>
+__global__ __launch_bounds__(512) void k_face_bc(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ patches,
+                                                 double* __restrict__ edge, StencilParams P, FaceBC B)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int lj = t.j0 + threadIdx.y;
+    const int li0 = t.i0 + 2 * threadIdx.x;
+    if (lj >= p.n[1] || P.periodic[DIR]) return;
+    const long long s = DIR == 0 ? 1 : (DIR == 1 ? (long long)p.pj : p.pk);
+    const int klo = B.kind[2 * DIR], khi = B.kind[2 * DIR + 1];
+    for (int kk = 0; kk < t.nk; ++kk)
+        for (int q = 0; q < 2; ++q) {
+            const int li = li0 + q;
+            if (li >= p.n[0]) continue;
+            const int lk = t.k0 + kk;
+            const int l = DIR == 0 ? li : (DIR == 1 ? lj : lk);
+            const int g = p.lo[DIR] + l;
+            const long long c = pidx(p, li, lj, lk);
+            if (g == P.dom_lo[DIR]) edge[c] = klo == 2 ? edge[c + s] : (klo == 1 ? B.value[2 * DIR] : 0.0);
+            if (g == P.dom_hi[DIR]) edge[c + s] = khi == 2 ? edge[c] : (khi == 1 ? B.value[2 * DIR + 1] : 0.0);
+        }
+}
+
+void launch_face_bc(hipStream_t st, const LevelDev& L, double* const edge[3], const int kind[6], const double value[6])
+{
+    if (L.ntiles == 0) return;
+    FaceBC B;
+    for (int i = 0; i < 6; ++i) { B.kind[i] = kind[i]; B.value[i] = value[i]; }
+    const dim3 g(L.ntiles), b(64, L.tile_j, 1);
+    if (edge[0]) hipLaunchKernelGGL(k_face_bc<0>, g, b, 0, st, L.tiles, L.patches, edge[0], L.P, B);
+    if (edge[1]) hipLaunchKernelGGL(k_face_bc<1>, g, b, 0, st, L.tiles, L.patches, edge[1], L.P, B);
+    if (edge[2]) hipLaunchKernelGGL(k_face_bc<2>, g, b, 0, st, L.tiles, L.patches, edge[2], L.P, B);
+}
+
 void launch_face_wall(hipStream_t st, const LevelDev& L, double* const edge[3])
 {
     if (L.ntiles == 0) return;

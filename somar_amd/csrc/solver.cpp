@@ -1149,7 +1149,21 @@ double* const* PressureSolver::mac_grad(double* phi)
 void PressureSolver::vel_wall_bc()
 {
     double* e[3] = {vel(0), vel(1), prm.spaceDim == 3 ? vel(2) : nullptr};
-    launch_face_wall(st_, lev[0]->dev, e);
+    if (velbc_default_) launch_face_wall(st_, lev[0]->dev, e);
+    else launch_face_bc(st_, lev[0]->dev, e, velbc_kind_, velbc_value_);
+}
+
+// BasicVelocityBCGhostClass's inflow / outflow sides (EllipticBCUtils.cpp:1244-1327): what vel_wall_bc and the
+// cell-centred divergence's face BC apply from now on
+void PressureSolver::set_vel_bc(const int kind[6], const double value[6])
+{
+    velbc_default_ = true;
+    for (int i = 0; i < 6; ++i) {
+        SOMAR_CHECK(kind[i] >= 0 && kind[i] <= 2, "velocity BC kind: 0 solid wall, 1 prescribed normal velocity, 2 outflow");
+        velbc_kind_[i] = kind[i];
+        velbc_value_[i] = kind[i] == 1 ? value[i] : 0.0;
+        if (kind[i] != 0) velbc_default_ = false;
+    }
 }
 
 void PressureSolver::mac_project(double dt, bool zeroPressure, bool forceHomogeneous, SolveStats& s)
@@ -1310,7 +1324,11 @@ void PressureSolver::divergence_cc(double* out, double dt, bool wall)
 {
     double* e[3] = {vel(0), vel(1), vel(2)};
     double* c[3] = {cc_vel(0), cc_vel(1), prm.spaceDim == 3 ? cc_vel(2) : nullptr};
-    launch_cell_to_edge(st_, lev[0]->dev, e, c, wall);  // Divergence::levelDivergenceCC, Divergence.cpp:361-396
+    launch_cell_to_edge(st_, lev[0]->dev, e, c, wall && velbc_default_);  // Divergence::levelDivergenceCC, Divergence.cpp:361-396
+    if (wall && !velbc_default_) {
+        double* eb[3] = {e[0], e[1], prm.spaceDim == 3 ? e[2] : nullptr};
+        launch_face_bc(st_, lev[0]->dev, eb, velbc_kind_, velbc_value_);
+    }
     divergence_mac(out, dt);
 }
 

@@ -167,6 +167,8 @@ public:
     void divergence_mac(double* out, double dt);                 // out = div(vel) [/ dt]
     void mac_correct(double* phi, double dt);                    // vel -= dt * G(phi)
     void mac_project(double dt, bool zeroPressure, bool forceHomogeneous, SolveStats& st);
+    void set_metric_map(int kind, const double Lc[3], const double* depth, const int dlo[2], const int dn[2]);
+    void set_vel_bc(const int kind[6], const double value[6]);   // inflow / outflow sides of BasicVelocityBCGhostClass
     void vel_wall_bc();   // the velocity BC levelDivergenceMAC applies through a_fluxBC, solid walls: zero wall-normal faces of vel()
     // viscous / diffusive Helmholtz solves through the same operator
     // amr_member_ok: the caller (AMRSolver::set_alpha_beta) looks after the flux-register scales, which carry beta
@@ -226,6 +228,9 @@ private:
     double* f_sc_face[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     double aCoef_ = 0.0, bCoef_ = 1.0;  // the factory's alpha / beta (MappedAMRPoissonOpFactory.cpp:585-586)
     bool coefs_saved_ = false;
+    bool velbc_default_ = true;                      // every non-periodic side a solid wall
+    int velbc_kind_[6] = {0, 0, 0, 0, 0, 0};
+    double velbc_value_[6] = {0, 0, 0, 0, 0, 0};
     bool amr_member_ = false;
     double* f_amr[2] = {nullptr, nullptr};
     bool hasCF_ = false;

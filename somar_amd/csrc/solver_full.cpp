@@ -489,6 +489,44 @@ void PressureSolver::set_metric_full(int patch, const double* jg0, const double*
     sync();
 }
 
+// LevelGeometry's FC J g^{ab} / CC J^{-1} of a coordinate map evaluated on the device into the level's resident arrays
+// (maps.hip): what set_metric_ortho / set_metric_full upload, for every local patch at once.  Only the nodal depth of a
+// bathymetric map (O(N^2)) crosses PCIe.
+void PressureSolver::set_metric_map(int kind, const double Lc[3], const double* depth, const int dlo[2], const int dn[2])
+{
+    SOMAR_CHECK(!lev.empty() && !finalized, "set_metric before define / after finalize");
+    SOMAR_CHECK(prm.spaceDim == 3, "the map producers restate the CH_SPACEDIM = 3 algebra (GeoSourceInterface.cpp:236-291)");
+    SOMAR_CHECK(kind == 1 || kind == 2, "map kind: 1 cylindrical, 2 bathymetric");
+    Level& L = *lev[0];
+    SOMAR_CHECK(L.npatches() < 65536, "too many local patches for one launch");
+    double* d_depth = nullptr;
+    int lo[2] = {0, 0}, n[2] = {0, 0};
+    if (kind == 2) {
+        SOMAR_CHECK(depth && dn[0] > 0 && dn[1] > 0, "the bathymetric map needs the nodal depth");
+        SOMAR_CHECK(Lc[0] > 0.0 && Lc[1] > 0.0 && Lc[2] > 0.0, "the bathymetric map needs the domain lengths");
+        // FILL_BATHYDZDXI after CONVERTFAB reaches nodes lo-1 .. hi+2 of a box (BathymetricBaseMap.cpp:190-196)
+        for (int pi = 0; pi < L.npatches(); ++pi) {
+            const IBox b = L.boxes[L.local[pi]];
+            for (int d = 0; d < 2; ++d)
+                SOMAR_CHECK(dlo[d] <= b.lo[d] - 1 && dlo[d] + dn[d] - 1 >= b.hi[d] + 2,
+                            "nodal depth must cover nodes lo-1 .. hi+2 of every local box in both horizontal directions");
+        }
+        const size_t bytes = (size_t)dn[0] * dn[1] * sizeof(double);
+        SOMAR_HIP(hipMalloc(&d_depth, bytes));
+        SOMAR_HIP(hipMemcpy(d_depth, depth, bytes, hipMemcpyHostToDevice));
+        for (int d = 0; d < 2; ++d) { lo[d] = dlo[d]; n[d] = dn[d]; }
+        full_ = true;
+        alloc_full_metric(L);
+    } else {
+        SOMAR_CHECK(!full_, "the cylindrical map is diagonal: the level already holds a non-diagonal metric");
+        // r = dXi0 (i + offset) > 0 on every face / cell the level owns
+        SOMAR_CHECK(L.domain.lo[0] >= 0, "the cylindrical map needs r >= 0: domain index 0 starts below zero");
+    }
+    launch_map_metric(st_, L.dev, kind, L.dx, Lc, d_depth, lo, n, kind == 1);
+    sync();
+    if (d_depth) hipFree(d_depth);
+}
+
 void PressureSolver::alloc_full_metric(Level& L)
 {
     for (int d = 0; d < 3; ++d)

@@ -78,3 +78,111 @@ def test_uniform_producer_equals_uploaded_constant_arrays():
     finally:
         s.undefine()
         up.undefine()
+
+
+# ---- coordinate maps evaluated on the device (somar_solver_set_metric_map) ------------------------------------------------
+def _twin(dom, grids, dx, install):
+    from somar_amd import AMRPressureSolver
+    s = AMRPressureSolver()
+    p = s._p
+    s.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg, p.hang,
+                         p.norm_thresh, 0)
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids])
+    install(s)
+    s.finalize()
+    return s
+
+
+def _compare_operators(a, b, grids, dom, exact):
+    from somar_amd import api as F
+    phi = so.random_field(grids, 7, (1, 1, 1), dom.box)
+    out = []
+    for s in (a, b):
+        upload(s, F.F_PHI, phi)
+        s.applyOp(0, F.F_RES, F.F_PHI)
+        out.append(download_valid(s, F.F_RES, grids))
+    for x, y in zip(*out):
+        if exact:
+            np.testing.assert_array_equal(x, y)
+        else:
+            np.testing.assert_allclose(x, y, rtol=0, atol=1e-12 * float(np.max(np.abs(y))))
+    assert a.depth() == b.depth()
+
+
+def test_bathymetric_map_on_the_device_equals_the_uploaded_oracle_metric():
+    """BathymetricBaseMap's dx/dXi from a NODAL depth (a bump plus a slope, every derivative non-zero), CONVERTFAB to the
+    face / cell centrings (AVG3IX's misprint included) and GeoSourceInterface's algebra: the device fills what the oracle's
+    restatement fills, bit for bit -- seen through the 19-point operator of two solvers, one fed each way -- and on every
+    multigrid depth (same coarsened metric)."""
+    from oracle import somar_maps as sm
+    from somar_amd import api as F
+    n, L, bs = (32, 16, 8), (4.0, 2.0, 1.0), (16, 8, 8)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, bs)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    dlo, dn = (-1, -1), (n[0] + 4, n[1] + 4)
+    x = (np.arange(dlo[0], dlo[0] + dn[0]) * dx[0])[:, None]
+    y = (np.arange(dlo[1], dlo[1] + dn[1]) * dx[1])[None, :]
+    depth = 0.15 + 0.02 * x - 0.03 * y + 0.25 * np.exp(-((x - 1.7) ** 2 + (y - 0.9) ** 2) / 0.5)
+    m = sm.BathymetricMap(dx, L, depth, dlo)
+
+    def upload_metric(s):
+        for q in range(s.num_local_patches):
+            _, _, gi = s.patch_box(q)
+            g = grids[gi]
+            jg = [np.asfortranarray(sm.fill_jgup(m, g, mu)) for mu in range(3)]
+            s.setMetricFull(q, jg[0], jg[1], jg[2], np.asfortranarray(sm.fill_jinv(m, g)))
+
+    a = _twin(dom, grids, dx, upload_metric)
+    b = _twin(dom, grids, dx, lambda s: s.setMetricMap(F.MAP_BATHYMETRIC, L, depth, dlo))
+    try:
+        _compare_operators(a, b, grids, dom, exact=True)
+        rhs = so.random_field(grids, 5, domainBox=dom.box)
+        hist = []
+        for s in (a, b):
+            upload(s, F.F_RHS, rhs)
+            hist.append(s.solveResident(True, False)["history"])
+        assert hist[0] == hist[1]
+    finally:
+        a.undefine()
+        b.undefine()
+
+
+def test_cylindrical_map_on_the_device_matches_the_oracle_metric():
+    """CylindricalMap (diagonal): J g^{rr} = r, J g^{theta theta} = 1/r, J g^{zz} = r, 1/J = 1/r through cos / sin of the
+    device's libm (a few ulp from numpy's), periodic in theta"""
+    from oracle import somar_maps as sm
+    from somar_amd import api as F
+    n, bs = (16, 32, 8), (8, 16, 8)
+    dom = so.Domain(so.Box((8, 0, 0), (8 + n[0] - 1, n[1] - 1, n[2] - 1)), (False, True, False))
+    grids = so.split_domain(dom.box, bs)
+    dx = (0.05, 2 * np.pi / n[1], 0.1)
+    m = sm.CylindricalMap(dx)
+
+    def upload_metric(s):
+        for q in range(s.num_local_patches):
+            _, _, gi = s.patch_box(q)
+            g = grids[gi]
+            jg = [np.asfortranarray(sm.fill_jgup(m, g, mu)[..., mu]) for mu in range(3)]
+            s.setMetricOrtho(q, jg[0], jg[1], jg[2], np.asfortranarray(sm.fill_jinv(m, g)))
+
+    a = _twin(dom, grids, dx, upload_metric)
+    b = _twin(dom, grids, dx, lambda s: s.setMetricMap(F.MAP_CYLINDRICAL))
+    try:
+        _compare_operators(a, b, grids, dom, exact=False)
+    finally:
+        a.undefine()
+        b.undefine()
+
+
+def test_map_producer_argument_checks():
+    from somar_amd import SomarError
+    from somar_amd import api as F
+    n = (16, 16, 8)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, 8)
+    dx = (0.1, 0.1, 0.1)
+    with pytest.raises(SomarError, match="nodal depth must cover"):
+        _twin(dom, grids, dx, lambda s: s.setMetricMap(F.MAP_BATHYMETRIC, (1.6, 1.6, 0.8), np.zeros((17, 17)), (0, 0)))
+    with pytest.raises(SomarError, match="map kind"):
+        _twin(dom, grids, dx, lambda s: s.setMetricMap(7))

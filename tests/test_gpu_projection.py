@@ -292,6 +292,57 @@ def test_mac_velocity_wall_bc_bit_exact(oracle, case):
         gpu.undefine()
 
 
+VELBC = ([1, 2, 0, 0, 2, 1], [0.7, 0.0, 0.0, 0.0, 0.0, -0.3])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_inflow_outflow_velocity_bc_bit_exact_on_both_centrings(oracle, case):
+    """somar_solver_set_vel_bc: BasicVelocityBCGhostClass's inflow (prescribed value) and outflow (order-0 extrapolation of
+    the next face inside) sides on the MAC velocity and on the faces the cell-centred divergence averages"""
+    from somar_amd import api as F
+    so = oracle
+    n, boxsz, variant, periodic, L = case
+    dom, grids, dx, Jgup, Jinv = make_problem(so, n, boxsz, variant, periodic, L)
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv)
+    try:
+        kind, value = VELBC
+        gpu.setVelBC(kind, value)
+        vel = so.FluxData(grids, 1, 3)
+        rng = np.random.default_rng(5)
+        for i in range(len(grids)):
+            for d in range(3):
+                vel[i][d].a[...] = rng.uniform(0.5, 1.5, vel[i][d].a.shape)
+        for p in range(gpu.num_local_patches):
+            gi = gpu.patch_box(p)[2]
+            for d in range(3):
+                gpu.uploadVel(d, p, np.asfortranarray(vel[gi][d].a[..., 0]))
+        so.set_normal_flux_bc(vel, grids, dom, kind, value)
+        gpu.velWallBC()
+        for p in range(gpu.num_local_patches):
+            gi = gpu.patch_box(p)[2]
+            for d in range(3):
+                np.testing.assert_array_equal(gpu.downloadVel(d, p), vel[gi][d].a[..., 0])
+        # cell-centred divergence with the same sides
+        ghost = (1, 1, 1)
+        cc = _cc_velocity(so, dom, grids, ghost)
+        for p in range(gpu.num_local_patches):
+            gpu.uploadCCVel(p, cc[gpu.patch_box(p)[2]].a, ghost)
+        div = so.LevelData(grids, 1)
+        so.level_divergence_cc(div, cc, Jinv, grids, dom, dx, wall=True, velbc=VELBC)
+        gpu.divergenceCC(F.F_RHS, 1.0, True)
+        for g, w in zip(download_valid(gpu, F.F_RHS, grids), valid_of(div)):
+            np.testing.assert_array_equal(g, w)
+        # back to solid walls
+        gpu.setVelBC([0] * 6, [0.0] * 6)
+        div = so.LevelData(grids, 1)
+        so.level_divergence_cc(div, cc, Jinv, grids, dom, dx, wall=True)
+        gpu.divergenceCC(F.F_RHS, 1.0, True)
+        for g, w in zip(download_valid(gpu, F.F_RHS, grids), valid_of(div)):
+            np.testing.assert_array_equal(g, w)
+    finally:
+        gpu.undefine()
+
+
 def test_mult_and_div_by_j_on_the_resident_velocities(oracle):
     """LevelGeometry::multByJ / divByJ (geometry/LevelGeometryUtil.cpp:287-339, 372-420, 456-...): data *= J, data *= Jinv on
     the device, for the cell-centred velocity (ghost layer included) and the MAC velocity -- the same products, bit for bit."""

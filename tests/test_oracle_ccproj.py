@@ -61,6 +61,47 @@ def test_wall_bc_zeroes_exactly_the_physical_boundary_faces(oracle, periodic):
             np.testing.assert_array_equal(e[i][d].a[..., 0], want)
 
 
+def test_inflow_outflow_sides_channel_flow_is_divergence_free_and_carries_the_inflow(oracle):
+    """BasicVelocityBCGhostClass with an inflow side (x lo, value U) and an outflow side (x hi, order-0 extrapolation):
+    a uniform x-velocity U then has zero divergence in EVERY cell (solid walls would leave a source / sink layer at both
+    ends), the inflow faces hold U, the outflow faces the value of the next face inside, the other walls stay solid"""
+    so = oracle
+    dom, grids, dx, Jgup, Jinv = make_problem(so, (16, 8, 8), (8, 4, 8), "cartesian", (False, False, False))
+    U = 0.75
+    u = so.LevelData(grids, 3, (1, 1, 1), 0.0)
+    for f in u.fabs:
+        f.a[..., 0] = U
+    kind, value = [1, 2, 0, 0, 0, 0], [U, 0.0, 0.0, 0.0, 0.0, 0.0]
+    div = so.LevelData(grids, 1, (0, 0, 0), np.nan)
+    edge = so.level_divergence_cc(div, u, Jinv, grids, dom, dx, velbc=(kind, value))
+    assert all(np.all(f.a == 0.0) for f in div.fabs)
+    for i, g in enumerate(grids):
+        assert np.all(edge[i][0].a == U)
+        assert np.all(edge[i][1].a == 0.0) and np.all(edge[i][2].a == 0.0)
+    so.level_divergence_cc(div, u, Jinv, grids, dom, dx)            # solid walls at both ends: a sink and a source layer
+    tot = sum(float(f.a.sum()) for f in div.fabs)
+    assert abs(tot) < 1e-12 and any(np.any(f.a != 0.0) for f in div.fabs)
+    # outflow copies the next face inside, not the cell average
+    e = so.FluxData(grids, 1, 3)
+    rng = np.random.default_rng(1)
+    for i in range(len(grids)):
+        for d in range(3):
+            e[i][d].a[...] = rng.uniform(1.0, 2.0, e[i][d].a.shape)
+    ref = [[e[i][d].a.copy() for d in range(3)] for i in range(len(grids))]
+    so.set_normal_flux_bc(e, grids, dom, kind, value)
+    for i, g in enumerate(grids):
+        a, r = e[i][0].a[..., 0], ref[i][0][..., 0]
+        if g.lo[0] == dom.box.lo[0]:
+            assert np.all(a[0] == U)
+        else:
+            np.testing.assert_array_equal(a[0], r[0])
+        if g.hi[0] == dom.box.hi[0]:
+            np.testing.assert_array_equal(a[-1], r[-2])
+        else:
+            np.testing.assert_array_equal(a[-1], r[-1])
+        np.testing.assert_array_equal(a[1:-1], r[1:-1])
+
+
 def test_constant_flux_is_divergence_free_except_next_to_walls(oracle):
     so = oracle
     dom, grids, dx, Jgup, Jinv = make_problem(so, (16, 8, 8), (8, 4, 8), "stretched", (True, False, True))

@@ -1,0 +1,114 @@
+"""Known answers for the coordinate maps' metric producers (oracle/somar_maps.py: CylindricalMap, BathymetricBaseMap,
+CONVERTFAB).  The reference ships no fixtures: parity unpinned w.r.t. reference tests; pinned here by the analytic metrics
+of the two maps and by the averaging identities CONVERTFAB has to satisfy -- including the one it does NOT satisfy because
+of AVG3IX's misprinted eighth term (utils/AddlFortranMacros.H:88), which the restatement reproduces."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def sm(oracle):
+    from oracle import somar_maps
+    return somar_maps
+
+
+def test_convert_fab_is_exact_on_linear_fields_in_one_and_two_directions(oracle, sm):
+    def f(i, j, k):
+        return 1.0 + 0.5 * i - 0.25 * j + 0.125 * k
+    I, J, K = np.meshgrid(np.arange(3, 7), np.arange(-2, 2), np.arange(0, 3), indexing="ij")
+    # node -> x-face (average over j, k forward), node -> xy-edge... every 1- and 2-direction combination
+    for S, T in [((1, 1, 1), (1, 0, 0)), ((1, 1, 1), (0, 1, 0)), ((1, 1, 1), (0, 0, 1)), ((0, 1, 1), (0, 0, 1)),
+                 ((0, 1, 1), (0, 1, 0)), ((1, 0, 1), (1, 0, 0)), ((0, 1, 1), (1, 1, 1)), ((0, 0, 0), (1, 0, 0))]:
+        got = sm.convert_fab(f, I, J, K, S, T)
+        off = [0.5 * (S[d] - T[d]) for d in range(3)]
+        want = f(I + off[0], J + off[1], K + off[2])
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-14)
+
+
+def test_convert_fab_in_three_directions_reproduces_the_avg3ix_misprint(oracle, sm):
+    I, J, K = np.meshgrid(np.arange(0, 2), np.arange(0, 2), np.arange(0, 2), indexing="ij")
+
+    def fx(i, j, k):
+        return 1.0 * i + 0.0 * j
+
+    def fy(i, j, k):
+        return 1.0 * j + 0.0 * i
+
+    def fz(i, j, k):
+        return 1.0 * k + 0.0 * i
+    S, T = (1, 1, 1), (0, 0, 0)
+    # linear in x or z: the doubled corner (ii + kk) and the missing corner (ii + jj + kk) weigh the same -> still exact
+    np.testing.assert_allclose(sm.convert_fab(fx, I, J, K, S, T), I + 0.5, atol=1e-15)
+    np.testing.assert_allclose(sm.convert_fab(fz, I, J, K, S, T), K + 0.5, atol=1e-15)
+    # linear in y: 3 of the 8 terms sit at j + 1 instead of 4 -> j + 3/8, not j + 1/2
+    np.testing.assert_allclose(sm.convert_fab(fy, I, J, K, S, T), J + 0.375, atol=1e-15)
+
+
+def test_cylindrical_metric_is_r_one_over_r_r(oracle, sm):
+    so = oracle
+    dXi = (0.05, 2 * np.pi / 32, 0.1)
+    m = sm.CylindricalMap(dXi)
+    valid = so.Box((4, 0, 0), (11, 7, 3))
+    for mu in range(3):
+        g = sm.fill_jgup(m, valid, mu)
+        fb = valid.faces(mu)
+        i = np.arange(fb.lo[0], fb.hi[0] + 1)
+        r = dXi[0] * (i + (0.0 if mu == 0 else 0.5))
+        want = {0: r, 1: 1.0 / r, 2: r}[mu]
+        np.testing.assert_allclose(g[..., mu], np.broadcast_to(want[:, None, None], g.shape[:3]), rtol=1e-13)
+        for nu in range(3):
+            if nu != mu:
+                assert np.all(g[..., nu] == 0.0)
+    i = np.arange(valid.lo[0], valid.hi[0] + 1)
+    r = dXi[0] * (i + 0.5)
+    np.testing.assert_allclose(sm.fill_jinv(m, valid), np.broadcast_to((1.0 / r)[:, None, None], valid.size()), rtol=1e-15)
+
+
+def _plane_depth(dXi, lo, n, a, bx, by):
+    i = np.arange(lo[0], lo[0] + n[0])[:, None] * dXi[0]
+    j = np.arange(lo[1], lo[1] + n[1])[None, :] * dXi[1]
+    return a + bx * i + by * j
+
+
+def test_bathymetric_metric_of_a_plane_bottom_is_the_terrain_following_metric(oracle, sm):
+    """z = d + (1 - d/H) zeta with d = a + bx x + by y: z_zeta = 1 - d/H, z_xi = (1 - zeta/H) bx, z_eta = (1 - zeta/H) by;
+    J g^{xi xi} = J g^{eta eta} = z_zeta, J g^{xi zeta} = -z_xi, J g^{eta zeta} = -z_eta, J g^{xi eta} = 0,
+    J g^{zeta zeta} = (1 + z_xi^2 + z_eta^2) / z_zeta.  Face centrings average a plane exactly."""
+    so = oracle
+    L, n = (4.0, 2.0, 1.0), (16, 8, 8)
+    dXi = tuple(L[d] / n[d] for d in range(3))
+    a, bx, by = 0.2, 0.05, -0.08
+    dlo, dn = (-1, -1), (n[0] + 4, n[1] + 4)
+    depth = _plane_depth(dXi, dlo, dn, a, bx, by)
+    m = sm.BathymetricMap(dXi, L, depth, dlo)
+    valid = so.Box((0, 0, 0), tuple(x - 1 for x in n))
+    H = L[2]
+    for mu in range(3):
+        fb = valid.faces(mu)
+        I, J, K = np.meshgrid(*[np.arange(fb.lo[d], fb.hi[d] + 1) for d in range(3)], indexing="ij")
+        off = [0.5] * 3
+        off[mu] = 0.0
+        x, y, zeta = (I + off[0]) * dXi[0], (J + off[1]) * dXi[1], (K + off[2]) * dXi[2]
+        d = a + bx * x + by * y
+        zz, zx, zy = 1.0 - d / H, (1.0 - zeta / H) * bx, (1.0 - zeta / H) * by
+        want = {0: [zz, 0 * zz, -zx], 1: [0 * zz, zz, -zy], 2: [-zx, -zy, (1.0 + zx * zx + zy * zy) / zz]}[mu]
+        g = sm.fill_jgup(m, valid, mu)
+        for nu in range(3):
+            np.testing.assert_allclose(g[..., nu], want[nu], rtol=1e-12, atol=1e-14)
+
+
+def test_bathymetric_cell_centred_j_carries_the_misprint(oracle, sm):
+    so = oracle
+    L, n = (4.0, 2.0, 1.0), (8, 8, 4)
+    dXi = tuple(L[d] / n[d] for d in range(3))
+    valid = so.Box((0, 0, 0), tuple(x - 1 for x in n))
+    dlo, dn = (-1, -1), (n[0] + 4, n[1] + 4)
+    I, J, K = np.meshgrid(*[np.arange(valid.lo[d], valid.hi[d] + 1) for d in range(3)], indexing="ij")
+    # depth varying in x only: exact cell-centre value
+    mx = sm.BathymetricMap(dXi, L, _plane_depth(dXi, dlo, dn, 0.2, 0.05, 0.0), dlo)
+    d = 0.2 + 0.05 * (I + 0.5) * dXi[0]
+    np.testing.assert_allclose(sm.fill_jinv(mx, valid), 1.0 / (1.0 - d / L[2]), rtol=1e-13)
+    # depth varying in y: the average sits at j + 3/8
+    my = sm.BathymetricMap(dXi, L, _plane_depth(dXi, dlo, dn, 0.2, 0.0, -0.08), dlo)
+    d = 0.2 - 0.08 * (J + 0.375) * dXi[1]
+    np.testing.assert_allclose(sm.fill_jinv(my, valid), 1.0 / (1.0 - d / L[2]), rtol=1e-13)
