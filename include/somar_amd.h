@@ -474,8 +474,9 @@ int somar_leptic_solve(somar_leptic_t* h, int homogeneous, somar_leptic_stats_t*
  * somar_amr_tga_step = MappedAMRTGA<T>::oneStep (AMRElliptic/MappedAMRTGA.H:417-497), the COMPOSITE TGA step over levels
  * l_base..l_max in one call: applyHelm = computeAMROperator with (1, mu dt) (MappedAMRMultiGrid.H:862-878), solveHelm =
  * solveNoInit(..., zeroPhi = false) with (1, -mu dt), the guess of both solves is phiOld (:473-476, 493-496).  phiNew =
- * SOMAR_F_PHI, phiOld = SOMAR_F_HEAT_OLD, source = SOMAR_F_HEAT_SRC of every level in the range; for l_base > 0 level
- * l_base-1's SOMAR_F_HEAT_OLD / SOMAR_F_PHI supply the coarse-fine values of phiOld / phiNew.  stats = the LAST solve's.
+ * SOMAR_F_PHI, phiOld = SOMAR_F_HEAT_OLD, source = SOMAR_F_HEAT_SRC of every level in the range.  l_base must be 0: for
+ * l_base > 0 the reference reads *m_srct[l_base - 1], which createData never allocates (:388-403) -- undefined there, refused
+ * here.  stats = the LAST solve's.
  * (No driver of the reference calls MappedAMRTGA -- AMRNavierStokes steps level by level with the integrators above -- it
  * is provided because the class ships with the operator.) */
 int somar_amr_set_alpha_beta(somar_amr_t* a, double alpha, double beta);

@@ -1157,15 +1157,14 @@ def compute_amr_operator(comp, lph, phi, l_max, l_base, homogeneous):
 
 
 def amr_tga_one_step(comp, phiNew, phiOld, source, dt, l_base, l_max):
-    """phiNew / phiOld / source: per-level lists (entries below l_base: the coarser level's data for the CF values of
-    phiOld resp. phiNew, or None when l_base == 0).  comp.history / iters / exitStatus are the LAST solve's."""
+    """phiNew / phiOld / source: per-level lists.  comp.history / iters / exitStatus are the LAST solve's.
+    l_base must be 0: createData allocates m_srct for l_base..l_max only (:388-403) and computeAMROperator on it reads
+    *m_srct[l_base - 1] for level l_base's coarse-fine values (MappedAMRMultiGrid.H:907-909) -- a null pointer."""
+    assert l_base == 0, "MappedAMRTGA::oneStep with l_base > 0 dereferences a null m_srct[l_base - 1]"
     mu1, mu2, mu3, mu4, _ = so.tga_coefficients()
     nl = len(comp.levels)
     rng = range(l_base, l_max + 1)
     rhst, srct = [None] * nl, [None] * nl
-    if l_base > 0:
-        rhst[l_base - 1] = None
-        srct[l_base - 1] = phiOld[l_base - 1]   # homogeneous CF values: the coarse data is not read
     for l in rng:
         rhst[l] = so.ld_create(source[l])
         srct[l] = so.ld_create(phiNew[l])

@@ -69,6 +69,28 @@ def vert_avg_metric(grids, Jgup, domBox, isDiagonal=True):
     return flat, hJg, hJinv
 
 
+VBC_NEUM, VBC_DIRI, VBC_CF = 0, 1, 2   # BCType::Neum / Diri / CF as verticalLineSolver sees them
+
+
+def dptsv(D, E, B):
+    """LAPACK dptsv (EXTERNAL, declared utils/lapack.H, called LevelLepticSolverF.ChF:262): dpttrf's L D L^T factorisation
+    (unrolled by four there, the same operations in the same order) followed by dptts2, for many systems at once
+    (last axis = the unknowns).  In place: D, E hold the factors, B the solution.  Raises if a pivot is not positive
+    (INFO != 0; the reference tolerates INFO == N only)."""
+    n = D.shape[-1]
+    for i in range(n - 1):
+        assert np.all(D[..., i] > 0.0), "dptsv: INFO = %d" % (i + 1)
+        ei = E[..., i].copy()
+        E[..., i] = ei / D[..., i]
+        D[..., i + 1] = D[..., i + 1] - E[..., i] * ei
+    assert np.all(D[..., n - 1] > 0.0), "dptsv: INFO = N"
+    for i in range(1, n):
+        B[..., i] = B[..., i] - B[..., i - 1] * E[..., i - 1]
+    B[..., n - 1] = B[..., n - 1] / D[..., n - 1]
+    for i in range(n - 2, -1, -1):
+        B[..., i] = B[..., i] / D[..., i] - B[..., i + 1] * E[..., i]
+
+
 class LevelLepticSolver:
     def __init__(self, origOp, maxOrder=4, hang=1e-15, normType=0, horizRhsTol=1e-14, domainHeight=None,
                  horiz=None, horizBottom=None, full=None, fullBottom=None):
@@ -87,15 +109,29 @@ class LevelLepticSolver:
         self.isDiagonal = op.isDiagonal
         # m_CFRegion.define(m_grids, m_domain), m_dxCrse = lepticOpPtr->getDxCrse()                 :164, :216-217
         self.cf, self.dxCrse = op.cf, op.dxCrse
-        if self.cf is not None:
-            for (i, d, s_), (gb, m) in self.cf.ivs.items():
-                assert d != 2 or m is None, "coarse-fine vertical ends (LepticLapackVerticalSolver) are not restated"
         dom, grids, dx = op.domain, op.grids, op.dx
         self.domain, self.grids, self.dx = dom, grids, dx
         domBox = dom.box
-        for g in grids:
-            assert g.lo[2] == domBox.lo[2] and g.hi[2] == domBox.hi[2], "boxes must be vertically complete columns"
         assert not any(dom.periodic), "periodic directions are not supported by the reference's leptic path"
+        # gatherVerticalBCTypes                                                                     :1523-1640
+        self.vertBCTypes = []
+        for i, g in enumerate(grids):
+            t = []
+            for side in (0, 1):
+                atDom = (g.lo[2] == domBox.lo[2]) if side == 0 else (g.hi[2] == domBox.hi[2])
+                if atDom:
+                    t.append(VBC_NEUM if op.bc.types[2][side] == so.BC_NEUM else VBC_DIRI)
+                else:
+                    gb, m = (self.cf.ivs[(i, 2, side)] if self.cf is not None else (None, None))
+                    assert m is not None and bool(m.all()), "Vertical grids are ill-formed"
+                    t.append(VBC_CF)
+            self.vertBCTypes.append(tuple(t))
+        self.doHorizSolve = any(t == (VBC_NEUM, VBC_NEUM) for t in self.vertBCTypes)
+        if self.doHorizSolve:
+            # m_flatDI / m_flatDIComplement (columns that do not span the domain next to columns that do, :318-333) are
+            # not restated: either every column is Neumann-Neumann or none is
+            assert all(t == (VBC_NEUM, VBC_NEUM) for t in self.vertBCTypes), \
+                "layouts mixing Neumann-Neumann columns with Dirichlet / coarse-fine ended ones are not restated"
         self.H = dx[2] * domBox.size()[2] if domainHeight is None else domainHeight
         # vertical grids == original grids; Jgup is shared, Jinv := 1 (the residual equation is scaled by J)
         self.Jgup = op.Jgup
@@ -110,8 +146,13 @@ class LevelLepticSolver:
         self.mgSolver.set_solver_parameters(fl["pre"], fl["post"], fl["bottom"], 1, fl["imax"], fl["eps"], fl["hang"],
                                             fl["normThresh"])
         self.op = self.mgSolver.op
-        # gatherVerticalBCTypes: physical Neumann at both ends => horizontal solves                 :1523-1640
-        self.doHorizSolve = True
+        self.exitStatus = EXIT_NONE
+        self.resNorms = []
+        self.usedFullSolver = False
+        self.horizSolves = 0
+        self.flatGrids = [flatten_box(g, g.lo[2]) for g in grids]
+        if not self.doHorizSolve:
+            return
         # horizontal structures                                                   :304-432
         self.flatGrids, hJg, hJinv = vert_avg_metric(grids, self.Jgup, domBox, op.isDiagonal)
         self.horizDomain = so.Domain(flatten_box(domBox, domBox.lo[2]), dom.periodic)
@@ -144,10 +185,53 @@ class LevelLepticSolver:
                 e = e + r[:, :, k] * dzScale
             excess[i][...] = e
 
+    def lapack_vertical_solver(self, i, vertPhi, vertRhs):
+        """LepticLapackVerticalSolver (LevelLepticSolverF.ChF:161-283) on box i: the symmetric tridiagonal system of a column
+        whose ends are Neumann / Dirichlet / coarse-fine (linear interpolation), solved by LAPACK dptsv (EXTERNAL; restated
+        from the published dpttrf + dptts2 loops, pinned against SciPy's dptsv in tests/test_oracle_leptic.py).  DU is
+        assembled by the reference but not handed to dptsv.  All columns of the box at once, k sequential."""
+        g = self.grids[i]
+        dz, dzCrse = self.dx[2], (self.dxCrse[2] if self.dxCrse is not None else 0.0)
+        lo, hi = self.vertBCTypes[i]
+        kmax = g.size()[2]
+        invdzsq = 1.0 / (dz * dz)
+        Jf = self.Jgup[i][2]
+        fb = g.faces(2)
+        Jgzz = Jf.view(fb)[..., 2]                       # Jgzz(IDX(k)), k = 0..kmax: face k is the low face of cell k
+        rhs = vertRhs[i].view(g)[..., 0]
+        D = np.empty(rhs.shape)
+        DL = np.empty(rhs.shape[:2] + (kmax - 1,))
+        B = -rhs
+        for k in range(1, kmax + 1):
+            D[:, :, k - 1] = (Jgzz[:, :, k - 1] + Jgzz[:, :, k]) * invdzsq
+            if k < kmax:
+                DL[:, :, k - 1] = -Jgzz[:, :, k] * invdzsq
+        alpha = 1.0 - 2.0 * dz / (dzCrse + dz)
+        if lo == VBC_NEUM:
+            D[:, :, 0] = Jgzz[:, :, 1] * invdzsq
+        elif lo == VBC_DIRI:
+            D[:, :, 0] = (2.0 * Jgzz[:, :, 0] + Jgzz[:, :, 1]) * invdzsq
+        else:
+            D[:, :, 0] = ((1.0 - alpha) * Jgzz[:, :, 0] + Jgzz[:, :, 1]) * invdzsq
+        if hi == VBC_NEUM:
+            D[:, :, kmax - 1] = Jgzz[:, :, kmax - 1] * invdzsq
+        elif hi == VBC_DIRI:
+            D[:, :, kmax - 1] = (Jgzz[:, :, kmax - 1] + 2.0 * Jgzz[:, :, kmax]) * invdzsq
+        else:
+            D[:, :, kmax - 1] = (Jgzz[:, :, kmax - 1] + (1.0 - alpha) * Jgzz[:, :, kmax]) * invdzsq
+        dptsv(D, DL, B)
+        vertPhi[i].view(g)[..., 0] = B
+
     def vertical_line_solver(self, vertPhi, vertRhs, bcLo, bcHi):
-        """verticalLineSolver, Neumann-Neumann branch                                  :1248-1421"""
+        """verticalLineSolver                                                          :1248-1421"""
         dz = self.dx[2]
         L = so.lib()
+        if not self.doHorizSolve:
+            # no column is Neumann-Neumann; a Neumann end rolls in the boundary data, which stays zero without horizontal
+            # solves (bdryData.setVal(0.0), never touched again): rhs + 0 is rhs
+            for i in range(len(self.grids)):
+                self.lapack_vertical_solver(i, vertPhi, vertRhs)
+            return
         for i, g in enumerate(self.grids):
             Nz = g.size()[2]
             r = vertRhs[i].view(g)[..., 0]
@@ -297,8 +381,8 @@ class LevelLepticSolver:
         flatRhs = [np.zeros(s) for s in flat2]
         bcLo = [np.zeros(s) for s in flat2]
         bcHi = [np.zeros(s) for s in flat2]
-        horizPhi = so.LevelData(self.flatGrids, 1, (1, 1, 0))
-        horizRhs = so.LevelData(self.flatGrids, 1, (0, 0, 0))
+        horizPhi = so.LevelData(self.flatGrids, 1, (1, 1, 0)) if self.doHorizSolve else None
+        horizRhs = so.LevelData(self.flatGrids, 1, (0, 0, 0)) if self.doHorizSolve else None
         useExcess = useHorizPhi = self.doHorizSolve
 
         # J * residual

@@ -800,7 +800,11 @@ class LevelLepticSolver:
         _ck(lib().somar_solver_num_local_patches(lh, C.byref(n)))
         v.num_local_patches = n.value
         self.level = v
-        self.vert, self.horiz = self._view(1), self._view(2)
+        self.vert = self._view(1)
+        try:
+            self.horiz = self._view(2)
+        except SomarError:
+            self.horiz = None   # no column is Neumann-Neumann: no flat problem (gatherVerticalBCTypes)
 
     def _view(self, which):
         v = AMRPressureSolver()

@@ -1280,6 +1280,11 @@ void AMRSolver::heat_step(int l, int scheme, double dt, bool zeroPhi, double old
 void AMRSolver::tga_step(int l_max, int l_base, double dt, SolveStats& st)
 {
     SOMAR_CHECK(finalized_ && l_base >= 0 && l_base <= l_max && l_max < nlevels(), "tga_step: bad level range");
+    // createData allocates m_srct for l_base..l_max only (MappedAMRTGA.H:388-403); computeAMROperator on m_srct then reads
+    // *m_srct[l_base - 1] for the coarse-fine values of level l_base (MappedAMRMultiGrid.H:907-909) -- a null pointer when
+    // l_base > 0.  The reference has no defined behaviour there, so neither has this.
+    SOMAR_CHECK(l_base == 0, "tga_step: l_base > 0 is undefined in the reference (MappedAMRTGA::oneStep reads the source "
+                             "term of level l_base - 1, which createData never allocates)");
     SOMAR_CHECK(dt >= 0.0, "negative time step");
     const double tgaEpsilon = 1.e-12;
     const double a = 2.0 - std::sqrt(2.0) - tgaEpsilon;
@@ -1298,7 +1303,6 @@ void AMRSolver::tga_step(int l_max, int l_base, double dt, SolveStats& st)
         srct[l] = P.heat_field(2);
         zero[l] = P.field(0, 5);   // m_residual, set to zero: computeAMROperator's right-hand side
     }
-    // a level below l_base supplies the coarse-fine values of BOTH a_phiOld and a_phiNew from its own arrays
     auto apply_helm = [&](std::vector<double*>& ans, std::vector<double*>& phi, double mu, bool homogeneous) {
         set_alpha_beta(1.0, mu * dt);
         for (int l = l_base; l <= l_max; ++l) launch_set(st_, zero[l], n[l], 0.0);

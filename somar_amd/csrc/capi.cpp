@@ -1388,7 +1388,7 @@ int somar_leptic_create(somar_leptic_t** out, const int* domain_lo, const int* d
         SOMAR_HIP(hipEventCreate(&h->level->ev1));
         for (int q = 0; q < 2; ++q) {
             h->parts[q] = new somar_solver;
-            h->parts[q]->ps = q == 0 ? &h->lep->vert() : &h->lep->horiz();
+            h->parts[q]->ps = q == 0 ? &h->lep->vert() : h->lep->horiz_ptr();
             h->parts[q]->owned = false;
             SOMAR_HIP(hipEventCreate(&h->parts[q]->ev0));
             SOMAR_HIP(hipEventCreate(&h->parts[q]->ev1));
@@ -1433,6 +1433,8 @@ int somar_leptic_part(somar_leptic_t* h, int which, somar_solver_t** out)
 {
     API_BEGIN
     SOMAR_CHECK(h && out && (which == 1 || which == 2), "which: 1 (J-scaled 3-D solver) or 2 (flat solver)");
+    SOMAR_CHECK(h->parts[which - 1]->ps, "this layout has no flat problem: no column is Neumann-Neumann "
+                                         "(gatherVerticalBCTypes switched the horizontal solves off)");
     *out = h->parts[which - 1];
     API_END
 }

@@ -38,8 +38,10 @@ LepticSolver::LepticSolver(Comm* comm, hipStream_t shared) : comm_(comm)
 
 LepticSolver::~LepticSolver()
 {
-    for (double* f : {f_total, f_rhsA, f_rhsB, f_gam, h_excess, h_bcLo, h_bcHi, h_gx, h_gy}) Level::free_field(f);
+    for (double* f : {f_total, f_rhsA, f_rhsB, f_gam, f_efac, h_excess, h_bcLo, h_bcHi, h_gx, h_gy}) Level::free_field(f);
     hipFree(d_avg);
+    hipFree(d_vbc);
+    hipFree(d_bad);
     horiz_.reset();
     vert_.reset();
     own_orig_.reset();
@@ -80,12 +82,38 @@ void LepticSolver::define_inner(const IBox& domain, const bool periodic[3], cons
     for (int d = 0; d < 3; ++d)
         SOMAR_CHECK(!periodic[d], "the leptic solver does not support periodic directions (neither does the reference: "
                                   "LevelLepticSolver.cpp:997-1001, 1315)");
-    // columns that span the domain: every coarse-fine boundary is then a lateral one (the CF vertical ends of
-    // LepticLapackVerticalSolver, LevelLepticSolverF.ChF:161-283, cannot occur)
-    for (const IBox& b : boxes)
-        SOMAR_CHECK(b.lo[2] == domain.lo[2] && b.hi[2] == domain.hi[2],
-                    "the leptic solver wants vertically complete boxes (LepticBoxUtils::createVerticalSolverGrids layout)");
     hasCF_ = dxCrse != nullptr;
+    // gatherVerticalBCTypes (LevelLepticSolver.cpp:1523-1640): an end of a column is a physical boundary (Neumann or Dirichlet)
+    // or, inside the domain, a coarse-fine interface over the whole box end (anything else: "Vertical grids are ill-formed")
+    vbc_.assign(2 * boxes.size(), 0);
+    bool anyNN = false, allNN = true;
+    for (size_t bi = 0; bi < boxes.size(); ++bi) {
+        const IBox& b = boxes[bi];
+        SOMAR_CHECK(b.size(2) >= 2, "the vertical line solver wants at least two cells per column");
+        for (int s = 0; s < 2; ++s) {
+            const bool atDom = s == 0 ? b.lo[2] == domain.lo[2] : b.hi[2] == domain.hi[2];
+            int t;
+            if (atDom) {
+                t = bc_type[2][s] == 0 ? 0 : 1;
+            } else {
+                SOMAR_CHECK(hasCF_, "Vertical grids are ill-formed: a column ends inside the domain of a level without a coarser one");
+                IBox adj = b;
+                adj.lo[2] = adj.hi[2] = s == 0 ? b.lo[2] - 1 : b.hi[2] + 1;
+                for (const IBox& o : boxes)
+                    SOMAR_CHECK((o & adj).empty(), "Vertical grids are ill-formed: a box is split in the vertical");
+                t = 2;
+            }
+            vbc_[2 * bi + s] = t;
+        }
+        const bool nn = vbc_[2 * bi] == 0 && vbc_[2 * bi + 1] == 0;
+        anyNN = anyNN || nn;
+        allNN = allNN && nn;
+    }
+    doHorizSolve_ = anyNN;
+    // m_flatDI / m_flatDIComplement (columns that do not span the domain next to columns that do, :318-333) are not built
+    SOMAR_CHECK(!anyNN || allNN, "the leptic solver takes layouts whose columns are ALL Neumann-Neumann or none of them "
+                                 "(Dirichlet / coarse-fine ended): mixed layouts are not implemented");
+    dzCrse_ = dxCrse ? dxCrse[2] : 0.0;
     for (int d = 0; d < 3; ++d) dx_[d] = dx[d];
     H_ = prm.domainHeight > 0.0 ? prm.domainHeight : dx[2] * domain.size(2);
     // the J-scaled operator and the full multigrid on it (alpha 0, beta 1), with the level's CFRegion and dxCrse
@@ -95,6 +123,7 @@ void LepticSolver::define_inner(const IBox& domain, const bool periodic[3], cons
     vert_.reset(new PressureSolver(comm_, st_));
     vert_->define(domain, periodic, dx, bc_type, boxes, owner, 0.0, 1.0, pf, dxCrse);
     vert_->probe_eps = probeEps;
+    if (!doHorizSolve_) return;   // no Neumann-Neumann column: no excess, no flat problem (:304)
     // flat grids: the same boxes, one cell thick at the domain's lowest vertical index           :304-432
     IBox flatDom = domain;
     flatDom.hi[2] = flatDom.lo[2];
@@ -119,14 +148,41 @@ void LepticSolver::finalize()
     if (full_) {
         // the J-scaled operator and the flat problem inherit LevelGeometry::isDiagonal() == false: 19-point / 9-point kernels
         vert_->make_full();
-        horiz_->make_full();
+        if (horiz_) horiz_->make_full();
     }
     if (own_orig_) orig_->finalize();
     Level& O = orig_->level(0);
     Level& V = vert_->level(0);
+    SOMAR_CHECK(O.field_elems == V.field_elems && O.npatches() == V.npatches(), "internal: layouts differ");
+    if (!doHorizSolve_) {
+        // columns ending at Dirichlet walls / coarse-fine interfaces: the J-scaled operator, two factor fields, the end codes
+        if (full_) {
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) launch_copy(st_, V.dev.jgf[a][b], O.dev.jgf[a][b], V.field_elems);
+        } else {
+            for (int d = 0; d < 3; ++d) launch_copy(st_, V.dev.jg[d], O.dev.jg[d], V.field_elems);
+        }
+        launch_set(st_, V.dev.jinv, V.field_elems, 1.0);
+        sync();
+        vert_->finalize();
+        f_total = V.alloc_field();
+        f_rhsA = V.alloc_field();
+        f_rhsB = V.alloc_field();
+        f_gam = V.alloc_field();
+        f_efac = V.alloc_field();
+        std::vector<int> local(2 * (size_t)std::max(1, V.npatches()), 0);
+        for (int pi = 0; pi < V.npatches(); ++pi)
+            for (int s2 = 0; s2 < 2; ++s2) local[2 * pi + s2] = vbc_[2 * V.local[pi] + s2];
+        SOMAR_HIP(hipMalloc(&d_vbc, local.size() * sizeof(int)));
+        SOMAR_HIP(hipMemcpy(d_vbc, local.data(), local.size() * sizeof(int), hipMemcpyHostToDevice));
+        SOMAR_HIP(hipMalloc(&d_bad, sizeof(int)));
+        SOMAR_HIP(hipMemset(d_bad, 0, sizeof(int)));
+        SOMAR_HIP(hipDeviceSynchronize());
+        finalized_ = true;
+        return;
+    }
     Level& F = horiz_->level(0);
-    SOMAR_CHECK(O.field_elems == V.field_elems && O.npatches() == V.npatches() && V.npatches() == F.npatches(),
-                "internal: layouts differ");
+    SOMAR_CHECK(V.npatches() == F.npatches(), "internal: layouts differ");
     // metric of the J-scaled operator: the level's J g^{ab}, J^{-1} := 1
     if (full_) {
         for (int a = 0; a < 3; ++a)
@@ -169,13 +225,79 @@ void LepticSolver::set_zero_avg(double* hphi)
 
 void LepticSolver::solve(bool homogeneous, LepticStats& S)
 {
-    (void)homogeneous;  // physical BCs are homogeneous Neumann, CF values homogeneous (m_crsePhiPtr == NULL): nothing differs
-    solve_fields(orig_->phi(), orig_->rhs(), S);
+    // Neumann walls are homogeneous either way; a Dirichlet wall's values enter the first residual unless homogeneous
+    solve_fields(orig_->phi(), orig_->rhs(), S, homogeneous);
 }
 
-void LepticSolver::solve_fields(double* a_phi, const double* a_rhs, LepticStats& S)
+// no column is Neumann-Neumann (gatherVerticalBCTypes, :1615-1627): m_doHorizSolve is false, every order is one
+// LepticLapackVerticalSolver pass, the residual test and the full-multigrid fallback (LevelLepticSolver.cpp:762-933)
+void LepticSolver::solve_fields_no_horiz(double* a_phi, const double* a_rhs, LepticStats& S, bool homogeneous)
+{
+    PressureSolver &Os = *orig_, &Vs = *vert_;
+    Level& V = Vs.level(0);
+    const Tile* ct = V.d_ctiles;
+    const int nct = V.nctiles, tj = V.ctile_j;
+    const long long n = V.field_elems;
+    const int maxOrder = prm.maxOrder;
+    double* vertPhi = Vs.phi();
+    double* rhsP = f_rhsA;
+    double* tmpP = f_rhsB;
+    S = LepticStats();
+    Os.residual(0, rhsP, a_phi, a_rhs, homogeneous);
+    launch_lep_divide(st_, ct, nct, tj, V.dev, rhsP, rhsP, Os.level(0).dev.jinv);
+    double resNorm = Vs.norm(0, rhsP, prm.normType);
+    S.resNorms.push_back(resNorm);
+    launch_set(st_, f_total, n, 0.0);
+    int exitStatus = -1;
+    for (int order = 0; order <= maxOrder; ++order) {
+        S.orders = order + 1;
+        // a Neumann end rolls in the boundary data, which stay zero without horizontal solves: rhs + 0
+        launch_lep_vsolve_lapack(st_, ct, nct, tj, V.dev, vertPhi, rhsP, f_gam, f_efac, d_vbc, dx_[2], dzCrse_, d_bad);
+        Vs.residual(0, tmpP, vertPhi, rhsP);
+        resNorm = Vs.norm(0, tmpP, prm.normType);
+        double relResNorm = resNorm / S.resNorms[0];
+        const double prevRelResNorm = S.resNorms.back() / S.resNorms[0];
+        double redu = prevRelResNorm - relResNorm;
+        if (redu <= prm.hang && order == maxOrder) {
+            launch_copy(st_, Vs.rhs(), rhsP, n);
+            Vs.solve(true, true, S.fullStats);
+            Vs.residual(0, tmpP, vertPhi, rhsP);
+            resNorm = Vs.norm(0, tmpP, prm.normType);
+            relResNorm = resNorm / S.resNorms[0];
+            S.usedFullSolver = 1;
+        }
+        std::swap(rhsP, tmpP);
+        S.resNorms.push_back(resNorm);
+        redu = prevRelResNorm - relResNorm;
+        if (redu > prm.hang || order < maxOrder) {
+            launch_lep_axpy(st_, ct, nct, tj, V.dev, f_total, vertPhi, 1.0);
+            exitStatus = (order < maxOrder - 1) ? 0 : 1;
+        } else if (-redu > prm.hang) {
+            exitStatus = (order == 0) ? 4 : 3;
+            break;
+        } else {
+            exitStatus = (order == 0) ? 4 : 2;
+            break;
+        }
+    }
+    if (exitStatus != 4) launch_lep_axpy(st_, ct, nct, tj, V.dev, a_phi, f_total, 1.0);
+    S.exitStatus = exitStatus;
+    int bad = 0;
+    SOMAR_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st_));
+    sync();
+    if (bad) {
+        SOMAR_HIP(hipMemset(d_bad, 0, sizeof(int)));
+        SOMAR_CHECK(false, "LepticLapackVerticalSolver: dptsv met a non-positive pivot (INFO != 0)");
+    }
+}
+
+void LepticSolver::solve_fields(double* a_phi, const double* a_rhs, LepticStats& S, bool homogeneous)
 {
     SOMAR_CHECK(finalized_, "solve before finalize");
+    if (!doHorizSolve_) {
+        solve_fields_no_horiz(a_phi, a_rhs, S, homogeneous);
+        return;
+    }
     PressureSolver &Os = *orig_, &Vs = *vert_, &Hs = *horiz_;
     Level& V = Vs.level(0);
     Level& F = Hs.level(0);
@@ -191,7 +313,7 @@ void LepticSolver::solve_fields(double* a_phi, const double* a_rhs, LepticStats&
     S = LepticStats();
 
     // J * residual of the level's own operator                                                   :697-715
-    Os.residual(0, rhsP, a_phi, a_rhs);
+    Os.residual(0, rhsP, a_phi, a_rhs, homogeneous);
     launch_lep_divide(st_, ct, nct, tj, V.dev, rhsP, rhsP, Os.level(0).dev.jinv);
     double resNorm = Vs.norm(0, rhsP, prm.normType);
     S.resNorms.push_back(resNorm);

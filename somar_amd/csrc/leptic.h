@@ -11,7 +11,9 @@
 // kernels (leptic_kernels.hip); the host sequences launches and reads back one norm per order.
 //
 // Scope: diagonal or non-diagonal metric; coarse-fine boundaries on the lateral sides of the columns (the level of an AMR
-// hierarchy refined by (r, r, 1): attach()); homogeneous-Neumann physical boundaries,
+// hierarchy refined by (r, r, 1): attach()); columns that are ALL Neumann-Neumann (horizontal solves) or ALL ended by a
+// Dirichlet wall / a coarse-fine interface (LepticLapackVerticalSolver + dptsv, no horizontal solves; layouts mixing the two
+// kinds raise); homogeneous-Neumann lateral boundaries,
 // non-periodic directions (the reference leaves the averaged gradient on a periodic horizontal boundary face
 // unset, LevelLepticSolver.cpp:997-1001, and refuses a periodic vertical, :1315).
 #pragma once
@@ -57,16 +59,19 @@ public:
     PressureSolver& orig() { return *orig_; }
     PressureSolver& vert() { return *vert_; }
     PressureSolver& horiz() { return *horiz_; }
+    PressureSolver* horiz_ptr() { return horiz_.get(); }   // null: no column is Neumann-Neumann, there is no flat problem
     void finalize();  // after the metric of orig() is set: finalizes all three solvers
     // LevelLepticSolver::solve(phi, rhs) on orig()'s resident phi / rhs: phi += leptic correction
     void solve(bool homogeneous, LepticStats& S);
     // the same on any two fields of the level's layout: phi += leptic correction for rhs - L[phi] (homogeneous CF / BC values)
-    void solve_fields(double* phi, const double* rhs, LepticStats& S);
+    void solve_fields(double* phi, const double* rhs, LepticStats& S, bool homogeneous = true);
+    bool do_horiz_solve() const { return doHorizSolve_; }
     void sync() { SOMAR_HIP(hipStreamSynchronize(st_)); }
     LepticParams prm;
 
 private:
     void set_zero_avg(double* hphi);
+    void solve_fields_no_horiz(double* phi, const double* rhs, LepticStats& S, bool homogeneous);
     Comm* comm_;
     hipStream_t st_ = nullptr;
     void define_inner(const IBox& domain, const bool periodic[3], const double dx[3], const int bc_type[3][2],
@@ -84,6 +89,13 @@ private:
     double *f_total = nullptr, *f_rhsA = nullptr, *f_rhsB = nullptr, *f_gam = nullptr;
     double *h_excess = nullptr, *h_bcLo = nullptr, *h_bcHi = nullptr, *h_gx = nullptr, *h_gy = nullptr;
     double* d_avg = nullptr;  // (sum, count) for setZeroAvg
+    // columns ending at Dirichlet walls / coarse-fine interfaces (gatherVerticalBCTypes): per box (lo, hi) 0 Neum, 1 Diri, 2 CF
+    std::vector<int> vbc_;
+    bool doHorizSolve_ = true;
+    double dzCrse_ = 0.0;
+    double* f_efac = nullptr;
+    int* d_vbc = nullptr;
+    int* d_bad = nullptr;
 };
 
 void launch_lep_avg_metric(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H);
@@ -97,6 +109,8 @@ void launch_lep_excess(hipStream_t st, const Tile* ct, int nct, int tj, const Le
                        const double* rhs, const double* bcLo, const double* bcHi, double* excess, double dzScale);
 void launch_lep_vsolve(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
                        double* phi, double* rhs, double* gam, const double* bcLo, const double* bcHi, double dz);
+void launch_lep_vsolve_lapack(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, double* phi,
+                              const double* rhs, double* dfac, double* efac, const int* vbc, double dz, double dzCrse, int* bad);
 void launch_lep_hgrad(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
                       const double* phi, double* gx, double* gy);
 void launch_lep_hrhs(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,

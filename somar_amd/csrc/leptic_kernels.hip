@@ -157,6 +157,69 @@ __global__ __launch_bounds__(512) void k_lep_vsolve(const Tile* __restrict__ til
     }
 }
 
+// verticalLineSolver on columns that END at a Dirichlet wall or a coarse-fine interface: LepticLapackVerticalSolver
+// (LevelLepticSolverF.ChF:161-283) -- the symmetric tridiagonal system D, DL (= dptsv's E), B = -rhs with the end rows of
+// BCType Neum / Diri / CF (linear interpolation against a zero coarse value, alpha = 1 - 2 dz / (dzCrse + dz)) -- and
+// LAPACK dptsv (EXTERNAL), restated as dpttrf's L D L^T loop fused with dptts2's forward substitution on the way up and
+// dptts2's back substitution on the way down.  dfac / efac: scratch fields for the factors.  vbc[2 patch + side]: 0 Neum,
+// 1 Diri, 2 CF.  A non-positive pivot (dptsv's INFO != 0) is counted in *bad.
+__global__ __launch_bounds__(512) void k_lep_vsolve_lapack(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ vp,
+                                                           double* __restrict__ phi, const double* __restrict__ rhs,
+                                                           const double* __restrict__ jgz, double* __restrict__ dfac,
+                                                           double* __restrict__ efac, const int* __restrict__ vbc,
+                                                           double dz, double dzCrse, int* __restrict__ bad)
+{
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = vp[t.patch];
+    const int N = p.n[2];
+    const long long sk = p.pk;
+    const double invdzsq = 1.0 / (dz * dz);
+    const int lo = vbc[2 * t.patch], hi = vbc[2 * t.patch + 1];
+    const double alpha = 1.0 - 2.0 * dz / (dzCrse + dz);
+    for (int q = 0; q < 2; ++q) {
+        const int li = t.i0 + threadIdx.x + 64 * q, lj = t.j0 + threadIdx.y;
+        if (li >= p.n[0] || lj >= p.n[1]) continue;
+        const long long c0 = p.off + li + (long long)p.pj * lj;
+        int info = 0;
+        // row k (1-based) sits in cell k-1; Jgzz(IDX(k)) is the low face of cell k
+        auto diag = [&](int k, long long c) {   // D(k), c = cell k-1
+            if (k == 1) {
+                if (lo == 0) return jgz[c + sk] * invdzsq;
+                if (lo == 1) return (2.0 * jgz[c] + jgz[c + sk]) * invdzsq;
+                return ((1.0 - alpha) * jgz[c] + jgz[c + sk]) * invdzsq;
+            }
+            if (k == N) {
+                if (hi == 0) return jgz[c] * invdzsq;
+                if (hi == 1) return (jgz[c] + 2.0 * jgz[c + sk]) * invdzsq;
+                return (jgz[c] + (1.0 - alpha) * jgz[c + sk]) * invdzsq;
+            }
+            return (jgz[c] + jgz[c + sk]) * invdzsq;
+        };
+        long long c = c0;
+        double d = diag(1, c);
+        double b = -rhs[c];
+        for (int k = 1; k <= N - 1; ++k, c += sk) {
+            if (!(d > 0.0)) info = 1;
+            const double ei = -jgz[c + sk] * invdzsq;          // DL(k)
+            const double e = ei / d;
+            dfac[c] = d;
+            efac[c] = e;
+            phi[c] = b;
+            d = diag(k + 1, c + sk) - e * ei;
+            b = -rhs[c + sk] - b * e;
+        }
+        if (!(d > 0.0)) info = 1;
+        double x = b / d;                                        // B(N) / D(N)
+        phi[c] = x;
+        c -= sk;
+        for (int k = N - 1; k >= 1; --k, c -= sk) {
+            x = phi[c] / dfac[c] - x * efac[c];
+            phi[c] = x;
+        }
+        if (info) atomicAdd(bad, 1);
+    }
+}
+
 // vertical average of the horizontal face gradients J g^{aa} d_a phi (MAPPEDMACGRADORTHO + UNMAPPEDVERTINTEGRAL);
 // faces on the physical boundary carry the boundary data, which are zero.  Every column fills its low faces, the
 // last column of a box also the high face (its phi ghost has been exchanged).
@@ -371,6 +434,12 @@ void launch_lep_vsolve(hipStream_t st, const Tile* ct, int nct, int tj, const Le
                        double* phi, double* rhs, double* gam, const double* bcLo, const double* bcHi, double dz)
 {
     if (nct) hipLaunchKernelGGL(k_lep_vsolve, LEP_GRID(nct, tj), ct, V.patches, H.patches, phi, rhs, V.jg[2], gam, bcLo, bcHi, dz);
+}
+void launch_lep_vsolve_lapack(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, double* phi,
+                              const double* rhs, double* dfac, double* efac, const int* vbc, double dz, double dzCrse, int* bad)
+{
+    if (nct) hipLaunchKernelGGL(k_lep_vsolve_lapack, LEP_GRID(nct, tj), ct, V.patches, phi, rhs, V.jg[2], dfac, efac, vbc, dz,
+                                dzCrse, bad);
 }
 void launch_lep_hgrad(hipStream_t st, const Tile* ct, int nct, int tj, const LevelDev& V, const LevelDev& H,
                       const double* phi, double* gx, double* gy)

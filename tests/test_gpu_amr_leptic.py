@@ -199,3 +199,43 @@ def test_c5_shaped_three_level_leptic_solve_matches_oracle():
                 np.testing.assert_allclose(g_, w_, rtol=0, atol=1e-7 * scale)
     finally:
         gpu.undefine()
+
+
+# ---- columns that end at a coarse-fine interface (LepticLapackVerticalSolver's BCType_CF row) ------------------------------
+def test_fine_level_whose_columns_end_under_the_coarse_level():
+    """level 1 = the lower half of the water column of the central block, refined by (2, 2, 2): Neumann bottom, coarse-fine
+    top and lateral sides; no column is Neumann-Neumann, so every order is one dptsv per column and there is no flat
+    problem.  l_base = l_max = 1 through the composite leptic solver, as AMRLepticSolver runs its level solver."""
+    from somar_amd import api as F
+    n, ratios = (16, 16, 8), [(2, 2, 2)]
+    fine = [[so.Box((8, 8, 0), (15, 23, 7)), so.Box((16, 8, 0), (23, 23, 7))]]
+    levels = make_amr_levels(so, sa, n, (1.0, 1.0, H), (False, False, False), ratios, fine, cbox=(8, 8, 8))
+    amr = sl.AMRLepticSolver(levels, ratios, so.BCHolder(), leptic=dict(maxOrder=3, domainHeight=H))
+    amr.iterMax = 2
+    rhs1 = so.random_field(levels[1].grids, 9, domainBox=levels[1].domain.box)
+    phi = [so.LevelData(Lv.grids, 1, (1, 1, 1)) for Lv in levels]
+    amr.solve(phi, [None, rhs1], 1, 1)
+    lep = amr.leptic[1]
+    assert not lep.doHorizSolve and all(t == (sl.VBC_NEUM, sl.VBC_CF) for t in lep.vertBCTypes)
+    gpu = make_gpu_amr(levels, ratios, imax=2)
+    lp = F.LepticParams()
+    F._ck(F.lib().somar_leptic_params_default(lp))
+    lp.max_order, lp.domain_height = 3, H
+    gpu.enableLeptic(lp)
+    try:
+        upload(gpu.levels[1], F.F_RHS, rhs1)
+        gpu.levels[0].setVal(F.F_PHI, 0.0)
+        st = gpu.solveAMRLeptic(1, 1)
+        ls = gpu.lepticStats(1)
+        assert st["iters"] == amr.iters and st["exitStatus"] == amr.exitStatus
+        assert ls["exitStatus"] == lep.exitStatus and ls["horizSolves"] == 0 and ls["usedFullSolver"] == lep.usedFullSolver
+        tol = 1e-6 if lep.usedFullSolver else 1e-10
+        np.testing.assert_allclose(st["history"], amr.history, rtol=0, atol=tol * amr.history[0])
+        np.testing.assert_allclose(ls["resNorms"], lep.resNorms, rtol=0, atol=tol * lep.resNorms[0])
+        got = download_valid(gpu.levels[1], F.F_PHI, levels[1].grids)
+        want = valid_of(phi[1])
+        scale = max(float(np.max(np.abs(w))) for w in want)
+        for g_, w_ in zip(got, want):
+            np.testing.assert_allclose(g_, w_, rtol=0, atol=max(tol, 1e-9) * scale)
+    finally:
+        gpu.undefine()

@@ -65,7 +65,7 @@ def _uncovered(comp, levels, fields):
     return out
 
 
-@pytest.mark.parametrize("full,layout,lbase", [(False, TWO, 0), (True, TWO, 0), (False, THREE, 0), (False, THREE, 1)])
+@pytest.mark.parametrize("full,layout,lbase", [(False, TWO, 0), (True, TWO, 0), (False, THREE, 0)])
 def test_composite_tga_step_matches_the_oracle(full, layout, lbase):
     from somar_amd import api as F
     levels, comp = _setup(full, layout)
@@ -93,6 +93,19 @@ def test_composite_tga_step_matches_the_oracle(full, layout, lbase):
             got.append(w)
         got = [None] * lbase + got
         assert max_rel_diff(_uncovered(comp, levels, got), _uncovered(comp, levels, want)) < 1e-9
+    finally:
+        gpu.undefine()
+
+
+def test_level_ranges_above_the_base_level_are_refused():
+    """MappedAMRTGA::oneStep reads *m_srct[l_base - 1], which createData never allocates (MappedAMRTGA.H:388-403): undefined
+    in the reference, refused here"""
+    from somar_amd import SomarError
+    levels, comp = _setup(False, THREE)
+    gpu = _gpu(levels, False, THREE[0])
+    try:
+        with pytest.raises(SomarError, match="l_base > 0 is undefined in the reference"):
+            gpu.tgaStepAMR(2, 1, 0.1)
     finally:
         gpu.undefine()
 

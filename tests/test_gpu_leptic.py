@@ -174,7 +174,7 @@ def test_leptic_full_multigrid_fallback_matches_oracle():
 def test_leptic_rejects_what_the_reference_cannot_do():
     from somar_amd import LevelLepticSolver, SomarError
     s = LevelLepticSolver()
-    with pytest.raises(SomarError, match="vertically complete"):
+    with pytest.raises(SomarError, match="Vertical grids are ill-formed"):
         s.define((0, 0, 0), (15, 15, 7), (False, False, False), (0.1, 0.1, 0.01),
                  [((0, 0, 0), (15, 15, 3)), ((0, 0, 4), (15, 15, 7))])
     s = LevelLepticSolver()
@@ -256,3 +256,60 @@ def test_leptic_two_ranks_sharing_one_gpu():
             if p.is_alive():
                 p.kill()
     assert out == {r: "ok" for r in range(nranks)}, "\n".join("rank %d: %s" % kv for kv in sorted(out.items()))
+
+
+# ---- columns that END at a Dirichlet wall or a coarse-fine interface: LepticLapackVerticalSolver + dptsv -------------------
+D_, N_ = 1, 0
+
+
+@pytest.mark.parametrize("variant,H,maxOrder", [("cartesian", 0.02, 1), ("stretched", 0.005, 3), ("stretched", 0.02, 2)])
+def test_dirichlet_topped_columns_match_the_oracle(variant, H, maxOrder):
+    """Neumann below, Dirichlet above with a non-zero value: gatherVerticalBCTypes switches the horizontal problem off and
+    every order is one dptsv per column (k_lep_vsolve_lapack).  Bit for bit unless the full multigrid takes over."""
+    from somar_amd import LevelLepticSolver
+    from somar_amd.api import F_PHI, F_RHS
+    n, box = (16, 16, 8), (8, 8, 8)
+    L = (1.0, 1.0, H)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, box)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_diagonal_metric(grids, dx, L, 3, variant, domain=dom)
+    types = [[N_, N_], [N_, N_], [N_, D_]]
+    values = [[0.0, 0.0], [0.0, 0.0], [0.0, 0.3]]
+    bc = so.BCHolder([list(t) for t in types], [list(v) for v in values])
+    fac = so.Factory(dom, grids, dx, bc, Jgup, Jinv)
+    op = so.AMRMultiGrid(fac, so.BiCGStab()).op
+    lep = sl.LevelLepticSolver(op, maxOrder=maxOrder, domainHeight=H)
+    assert not lep.doHorizSolve
+    rhs = so.random_field(grids, 9, domainBox=dom.box)
+    phi = so.random_field(grids, 11, ghost=(1, 1, 1), domainBox=dom.box)
+    for f in phi.fabs:
+        f.a[...] *= 1e-3
+    s = LevelLepticSolver()
+    s.params.max_order, s.params.domain_height = maxOrder, H
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids], bc_type=[t for q in types for t in q])
+    try:
+        assert s.horiz is None
+        lv = s.level
+        lv.setBCValues([x for q in values for x in q])
+        for p_ in range(lv.num_local_patches):
+            _, _, gi = lv.patch_box(p_)
+            jg = [np.asfortranarray(Jgup[gi][d].a[..., d]) for d in range(3)]
+            lv.setMetricOrtho(p_, jg[0], jg[1], jg[2], np.asfortranarray(Jinv[gi].a[..., 0]))
+        s.finalize()
+        upload(s.level, F_PHI, phi)
+        upload(s.level, F_RHS, rhs)
+        status = lep.solve(phi, rhs, False)
+        st = s.solve(False)
+        assert st["exitStatus"] == status and st["horizSolves"] == 0 and st["usedFullSolver"] == lep.usedFullSolver
+        got, want = download_valid(s.level, F_PHI, grids), valid_of(phi)
+        if not lep.usedFullSolver:
+            assert st["resNorms"] == lep.resNorms
+            for g_, w_ in zip(got, want):
+                np.testing.assert_array_equal(g_, w_)
+        else:
+            np.testing.assert_allclose(st["resNorms"], lep.resNorms, rtol=1e-9)
+            for g_, w_ in zip(got, want):
+                np.testing.assert_allclose(g_, w_, rtol=0, atol=1e-10 * float(np.max(np.abs(w_))))
+    finally:
+        s.undefine()

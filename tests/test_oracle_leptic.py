@@ -225,3 +225,110 @@ def test_amr_leptic_vcycle_as_written_and_with_the_base_level_fed_the_restricted
     fixed.solve(sol2, rhs, 1, 0)
     g = fixed.history
     assert g[1] < 1e-4 * g[0] and g[2] < 1e-2 * g[1]
+
+
+# ---- columns that END at Dirichlet walls or coarse-fine interfaces: LepticLapackVerticalSolver + dptsv ---------------------
+def test_dptsv_restatement_equals_scipys_lapack_bit_for_bit():
+    """the symmetric tridiagonal systems LepticLapackVerticalSolver assembles, through the restated
+    dpttrf + dptts2 loops and through SciPy's LAPACK dptsv"""
+    from scipy.linalg import lapack
+    rng = np.random.default_rng(11)
+    for n in (2, 3, 8, 17, 64):
+        J = rng.uniform(0.5, 2.0, (5, n + 1))
+        invdzsq = 1.0 / (0.37 * 0.37)
+        D = (J[:, :-1] + J[:, 1:]) * invdzsq
+        D[:, 0] = (2.0 * J[:, 0] + J[:, 1]) * invdzsq          # Dirichlet below
+        D[:, -1] = J[:, n - 1] * invdzsq                        # Neumann above
+        E = -J[:, 1:n] * invdzsq
+        B = rng.uniform(-1, 1, (5, n))
+        d2, e2, b2 = D.copy(), E.copy(), B.copy()
+        sl.dptsv(d2, e2, b2)
+        for c in range(5):
+            _, _, x, info = lapack.dptsv(D[c], E[c], B[c])
+            assert info == 0
+            np.testing.assert_array_equal(b2[c], x)
+
+
+def _dirichlet_top_problem(n=(16, 16, 8), box=(8, 8, 8), L=(1.0, 1.0, 0.02), variant="stretched"):
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, box)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_diagonal_metric(grids, dx, L, 3, variant=variant, domain=dom)
+    bc = so.BCHolder([[so.BC_NEUM, so.BC_NEUM], [so.BC_NEUM, so.BC_NEUM], [so.BC_NEUM, so.BC_DIRI]])
+    fac = so.Factory(dom, grids, dx, bc, Jgup, Jinv)
+    return dom, grids, dx, Jgup, Jinv, fac
+
+
+def test_dirichlet_topped_columns_need_no_horizontal_solve():
+    """Neumann below, Dirichlet above (a free surface): no column is Neumann-Neumann, so gatherVerticalBCTypes switches the
+    horizontal problem off and every order is ONE dptsv per column.  Known answers: (1) with a right-hand side that depends
+    on z only (Cartesian map) the vertical solve IS the solution -- order 0 leaves round-off; (2) on a thin stretched
+    domain every order gains about eps^2 and the reported norm is the true J-weighted residual."""
+    dom, grids, dx, Jgup, Jinv, fac = _dirichlet_top_problem(variant="cartesian")
+    op = so.AMRMultiGrid(fac, so.BiCGStab()).op
+    lep = sl.LevelLepticSolver(op, maxOrder=1)
+    assert not lep.doHorizSolve and lep.vertBCTypes[0] == (sl.VBC_NEUM, sl.VBC_DIRI)
+    rhs = so.LevelData(grids, 1)
+    for g, f in zip(grids, rhs.fabs):
+        k = np.arange(g.lo[2], g.hi[2] + 1)
+        f.view(g)[..., 0] = np.cos(0.7 * k)[None, None, :]
+    phi = so.LevelData(grids, 1, (1, 1, 1))
+    lep.solve(phi, rhs, True)
+    assert lep.resNorms[1] < 1e-11 * lep.resNorms[0]
+    # thin stretched domain, random data
+    dom, grids, dx, Jgup, Jinv, fac = _dirichlet_top_problem(L=(1.0, 1.0, 0.005))
+    op = so.AMRMultiGrid(fac, so.BiCGStab()).op
+    lep = sl.LevelLepticSolver(op, maxOrder=3)
+    rhs = so.random_field(grids, 9, domainBox=dom.box)
+    phi = so.LevelData(grids, 1, (1, 1, 1))
+    status = lep.solve(phi, rhs, True)
+    h = lep.resNorms
+    assert status == sl.EXIT_ITER and not lep.usedFullSolver and lep.horizSolves == 0
+    assert all(b < 0.2 * a for a, b in zip(h, h[1:])) and h[-1] < 1e-4 * h[0]
+    res = so.LevelData(grids, 1, (0, 0, 0))
+    op.residual(res, phi, rhs, True)
+    jres = max(float(np.max(np.abs(res[i].view(g) / Jinv[i].view(g)))) for i, g in enumerate(grids))
+    assert abs(jres - h[-1]) <= 1e-9 * h[0]
+
+
+def _bottom_half_refined(L=(1.0, 1.0, 0.005)):
+    """level 1 = the lower half of the water column of the central block, refined by (2, 2, 2): its columns start at the
+    Neumann bottom and END at a coarse-fine interface"""
+    from oracle import somar_amr as sa
+    from tests.helpers import make_amr_levels
+    n, ratios = (16, 16, 8), [(2, 2, 2)]
+    fine = [[so.Box((8, 8, 0), (15, 23, 7)), so.Box((16, 8, 0), (23, 23, 7))]]
+    levels = make_amr_levels(so, sa, n, L, (False, False, False), ratios, fine, cbox=(8, 8, 8))
+    return levels, ratios
+
+
+def test_columns_ending_at_a_coarse_fine_interface():
+    """LepticLapackVerticalSolver's BCType_CF row (linear interpolation against a zero coarse value, alpha =
+    1 - 2 dz / (dzCrse + dz)): on a refined level whose columns end under the coarse level the orders converge (the lateral
+    coarse-fine faces and the column ends both carry homogeneous values) and the reported norm is the true residual"""
+    from oracle import somar_amr as sa
+    levels, ratios = _bottom_half_refined()
+    comp = sa.AMRComposite(levels, ratios, so.BCHolder(), so.BiCGStab())
+    op = comp.ops[1]
+    lep = sl.LevelLepticSolver(op, maxOrder=4, domainHeight=0.005)
+    assert not lep.doHorizSolve and all(t == (sl.VBC_NEUM, sl.VBC_CF) for t in lep.vertBCTypes)
+    rhs = so.random_field(levels[1].grids, 9, domainBox=levels[1].domain.box)
+    phi = so.LevelData(levels[1].grids, 1, (1, 1, 1))
+    status = lep.solve(phi, rhs, True)
+    h = lep.resNorms
+    assert status in (sl.EXIT_ITER, sl.EXIT_CONVERGE) and h[-1] < 1e-3 * h[0] and all(b < 0.5 * a for a, b in zip(h, h[1:]))
+    res = so.LevelData(levels[1].grids, 1, (0, 0, 0))
+    op.residual(res, phi, rhs, True)
+    jres = max(float(np.max(np.abs(res[i].view(g) / op.Jinv[i].view(g)))) for i, g in enumerate(levels[1].grids))
+    assert abs(jres - h[-1]) <= 1e-9 * h[0]
+
+
+def test_mixed_column_kinds_are_refused():
+    from oracle import somar_amr as sa
+    from tests.helpers import make_amr_levels
+    n, ratios = (16, 16, 8), [(2, 2, 2)]
+    fine = [[so.Box((8, 8, 0), (15, 23, 15)), so.Box((16, 8, 0), (23, 23, 7))]]   # one full column box, one half
+    levels = make_amr_levels(so, sa, n, (1.0, 1.0, 0.02), (False, False, False), ratios, fine, cbox=(8, 8, 8))
+    comp = sa.AMRComposite(levels, ratios, so.BCHolder(), so.BiCGStab())
+    with pytest.raises(AssertionError, match="mixing"):
+        sl.LevelLepticSolver(comp.ops[1], maxOrder=2)
