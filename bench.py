@@ -214,11 +214,13 @@ def contraction_c2(gpu, F):
     return gpu.norm(F.F_SCRATCH, 0) / r0
 
 
-def bench_c4(api, torch, dist, comm, world, steps, warmup, scale):
-    """BASELINE C4: ms per AMR V-cycle on the 3-level 1024x1024x128 hierarchy, levels sharded in y-slabs"""
+def bench_c4(api, torch, dist, comm, world, steps, warmup, scale, config="c4"):
+    """BASELINE C4 (config "c4"): ms per AMR V-cycle on the 3-level 1024x1024x128 hierarchy, levels sharded in y-slabs;
+    config "c5": BASELINE C5's shape, 4 levels of 512x512x64 cells each, terrain-following NON-diagonal metric produced on
+    the device from the nodal depth (BathymetricBaseMap's own discretisation, somar_solver_set_metric_map)"""
     from bench_amr import build_hierarchy
     F = api
-    gpu, levels, cells_local, t_def, dx0, ratios = build_hierarchy("c4", scale, 128, comm=comm, nranks=world)
+    gpu, levels, cells_local, t_def, dx0, ratios = build_hierarchy(config, scale, 128, comm=comm, nranks=world)
     nlev = len(levels)
     try:
         # a COMPATIBLE composite residual (the hierarchy is all-Neumann / periodic: L has the constants in its null space):
@@ -262,11 +264,19 @@ def bench_c4(api, torch, dist, comm, world, steps, warmup, scale):
             gpu.zeroCovered(l, F.F_SCRATCH)
         r1 = max(v.norm(F.F_SCRATCH, 0) for v in gpu.levels)
         s = scale
-        cells = [1024 * 1024 * 128 // s ** 3, 1024 * 2048 * 128 // s ** 3, 1024 * 4096 * 128 // s ** 3]
+        cells = [sum((h[0] - a[0] + 1) * (h[1] - a[1] + 1) * (h[2] - a[2] + 1) for a, h in lev) for lev in levels]
         ms = 1e3 * dt / steps
-        return {"workload": "C4 LockExchange-shaped 3-level %dx%dx%d, (2,2,1) refinements of the central half / quarter in x, "
-                            "Cartesian metric, y periodic, 128^3 boxes, AMR V-cycle 4/4/2; every level's boxes in y-slabs over "
-                            "%d GPU(s)" % (1024 // s, 1024 // s, 128 // s, world),
+        if config == "c5":
+            what = ("C5-shaped 4-level hierarchy, %dx%dx%d cells on every level, (2,2,1) refinements nested around the "
+                    "topographic bump, terrain-following NON-diagonal metric (19-point kernels) produced on the device from "
+                    "the nodal depth (BathymetricBaseMap::fill_dxdXi + CONVERTFAB + GeoSourceInterface::fill_Jgup), no "
+                    "periodic direction, 64x64x%d boxes, AMR V-cycle 4/4/2, multigrid solver; every level's boxes in y-slabs "
+                    "over %d GPU(s)" % (512 // s, 512 // s, 64 // s, 64 // s, world))
+        else:
+            what = ("C4 LockExchange-shaped 3-level %dx%dx%d, (2,2,1) refinements of the central half / quarter in x, "
+                    "Cartesian metric, y periodic, 128^3 boxes, AMR V-cycle 4/4/2; every level's boxes in y-slabs over "
+                    "%d GPU(s)" % (1024 // s, 1024 // s, 128 // s, world))
+        return {"workload": what,
                 "ms_per_amr_vcycle": ms, "amr_vcycles_per_s": 1e3 / ms, "steps": steps, "warmup": warmup,
                 "cells_per_level": cells, "boxes_per_level": [len(b) for b in levels], "define_seconds": t_def,
                 "mg_depth_per_level": [v.depth() for v in gpu.levels],
@@ -285,6 +295,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the c4_amr sub-record")
     ap.add_argument("--no-cartesian", action="store_true", help="skip the c2_cartesian sub-record")
+    ap.add_argument("--no-c5", action="store_true", help="skip the c5_amr sub-record")
     ap.add_argument("--c4-steps", type=int, default=5)
     ap.add_argument("--c4-warmup", type=int, default=1)
     ap.add_argument("--c4-scale", type=int, default=1, help="divide every C4 extent (rehearsals on small boxes)")
@@ -426,6 +437,18 @@ def main():
         if not (0.0 < c4["amr_vcycle_contraction"] < 1.0):
             failures.append("C4 AMR V-cycle does not contract: %r" % c4["amr_vcycle_contraction"])
         out["c4_amr"] = c4
+
+    # ---------------- C5's shape: 4 levels, non-diagonal terrain-following metric (19-point kernels) ----------------
+    if not args.no_c5:
+        try:
+            c5 = bench_c4(api, torch, dist, comm, world, args.c4_steps, args.c4_warmup, args.c4_scale, config="c5")
+            if not (0.0 < c5["amr_vcycle_contraction"] < 1.0):
+                failures.append("C5 AMR V-cycle does not contract: %r" % c5["amr_vcycle_contraction"])
+            out["c5_amr"] = c5
+        except Exception as e:   # a sub-record must not take the headline down with it at N > 1
+            if world == 1:
+                raise
+            out["c5_amr"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n)

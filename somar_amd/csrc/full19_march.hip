@@ -29,7 +29,10 @@
 namespace somar {
 
 constexpr int FM_I = 128;  // region width (64 lanes x double2) = 124-cell tile + 2 low + 2 high
-constexpr int FM_J = 8;    // region rows = 6-row tile + 1 low + 1 high (512 threads: 256 VGPRs per lane, no spills; 64 KB LDS, two workgroups per CU)
+// region rows FM_J = tile rows + 1 low + 1 high, a template parameter: 8 (6-row tile, 512 threads, 64 KB LDS; at 160 VGPRs
+// a SIMD holds 3 waves, so ONE such workgroup fits a CU: 8 waves per CU) or 6 (4-row tile, 384 threads, 48 KB LDS: TWO
+// workgroups per CU = 12 waves, the occupancy limit, for 1.5 instead of 1.33 times the phi / psi halo traffic -- 1.4 B/cell
+// of about 106).  SOMAR_FULL_ROWS selects; the tile tables follow (Level::define).
 constexpr int FM_S = 4;    // plane slots: k-1, k, k+1 are read while k+2's slot is being written
 
 struct JgFullM { const double* c[3][3]; };  // c[faceDir][component]
@@ -50,7 +53,7 @@ __device__ __forceinline__ double2 fm_ld2(const double* __restrict__ a, long lon
 __device__ __forceinline__ double fm_pick(const double2& v, int s) { return s ? v.y : v.x; }
 
 // MODE 0: out = rhs - L[phi]   MODE 1: out = L[phi]   MODE 2: out = phi with the cells of `color` relaxed (one GSRB pass)
-template <int MODE>
+template <int MODE, int FM_J>
 __global__ __launch_bounds__(64 * FM_J) void k_full_march(const Tile* __restrict__ tiles,
                                                           const PatchDesc* __restrict__ patches,
                                                           double* __restrict__ out, const double* __restrict__ phi,
@@ -300,7 +303,15 @@ __global__ __launch_bounds__(64 * FM_J) void k_full_march(const Tile* __restrict
     }
 }
 
-int full_march_rows() { return FM_J; }
+int full_march_rows()
+{
+    static int rows = 0;
+    if (!rows) {
+        const char* e = getenv("SOMAR_FULL_ROWS");
+        rows = (e && atoi(e) == 6) ? 6 : 8;
+    }
+    return rows;
+}
 
 static JgFullM jgfullm(const LevelDev& L)
 {
@@ -315,12 +326,19 @@ void launch_full_march(hipStream_t st, const Tile* tiles, int ntiles, const Leve
                        const double* psi, const double* rhs, int mode)
 {
     if (ntiles == 0) return;
-    if (mode == 0)
-        hipLaunchKernelGGL(k_full_march<0>, dim3(ntiles), dim3(64, FM_J, 1), 0, st, tiles, L.patches, out, phi, psi, rhs,
-                           jgfullm(L), L.jinv, L.P, 0);
+    const bool six = full_march_rows() == 6;
+    if (mode == 0 && six)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<0, 6>), dim3(ntiles), dim3(64, 6, 1), 0, st, tiles, L.patches, out, phi, psi,
+                           rhs, jgfullm(L), L.jinv, L.P, 0);
+    else if (mode == 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<0, 8>), dim3(ntiles), dim3(64, 8, 1), 0, st, tiles, L.patches, out, phi, psi,
+                           rhs, jgfullm(L), L.jinv, L.P, 0);
+    else if (six)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<1, 6>), dim3(ntiles), dim3(64, 6, 1), 0, st, tiles, L.patches, out, phi, psi,
+                           rhs, jgfullm(L), L.jinv, L.P, 0);
     else
-        hipLaunchKernelGGL(k_full_march<1>, dim3(ntiles), dim3(64, FM_J, 1), 0, st, tiles, L.patches, out, phi, psi, rhs,
-                           jgfullm(L), L.jinv, L.P, 0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<1, 8>), dim3(ntiles), dim3(64, 8, 1), 0, st, tiles, L.patches, out, phi, psi,
+                           rhs, jgfullm(L), L.jinv, L.P, 0);
 }
 
 // one colour pass of the 19-point GSRB: out = phi with the cells of `color` relaxed (out != phi)
@@ -328,8 +346,12 @@ void launch_gsrb_full_march(hipStream_t st, const Tile* tiles, int ntiles, const
                             const double* phi, const double* psi, const double* rhs, int color)
 {
     if (ntiles == 0) return;
-    hipLaunchKernelGGL(k_full_march<2>, dim3(ntiles), dim3(64, FM_J, 1), 0, st, tiles, L.patches, out, phi, psi, rhs,
-                       jgfullm(L), L.jinv, L.P, color);
+    if (full_march_rows() == 6)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<2, 6>), dim3(ntiles), dim3(64, 6, 1), 0, st, tiles, L.patches, out, phi, psi,
+                           rhs, jgfullm(L), L.jinv, L.P, color);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<2, 8>), dim3(ntiles), dim3(64, 8, 1), 0, st, tiles, L.patches, out, phi, psi,
+                           rhs, jgfullm(L), L.jinv, L.P, color);
 }
 
 }  // namespace somar

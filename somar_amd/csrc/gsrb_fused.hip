@@ -150,24 +150,29 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
     const int wi = t.pad_[0] > 0 ? t.pad_[0] : FR_I - 4;
     const int lj = t.j0 - 2 + row;
     // INMODE 3/4: where this pair's coarse parents live (floor division: ghosts map to coarse ghosts)
-    long long cbase = 0, cpk = 0;
-    int cstep = 0;
+    long long cbase = 0, cpk = 0, coff = 0;
+    int cstep = 0, csh2 = 0;
     if (INMODE >= 3) {
         const PatchDesc cp = cpatches[t.patch];
         auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
         const int ci0 = fdiv(li, r0);
         cstep = fdiv(li + 1, r0) - ci0;  // 0 when both cells share a parent
+        coff = cp.off;
         cbase = cp.off + ci0 + (long long)cp.pj * fdiv(lj, r1);
         cpk = cp.pk;
+        csh2 = r2 >> 1;                  // multigrid ratios are 1 or 2 per direction (checked by the launcher)
     }
     auto ldphi = [&](int kp, bool ok0, bool ok1) {
         if (INMODE == 1) return make_double2(0.0, 0.0);
         double2 v = ld2(phi_in, p.off + li + (long long)p.pj * lj + p.pk * kp, ok0, ok1, p.off);
         if (INMODE >= 3) {
-            // floor(kp / r2); multigrid ratios are 1 or 2 per direction: a shift instead of an integer division per plane
-            const int ck = (r2 == 2) ? (kp >> 1) : (r2 == 1 ? kp : (kp >= 0 ? kp / r2 : -((-kp + r2 - 1) / r2)));
-            const long long c = (ok0 || ok1) ? cbase + cpk * ck : cbase - (cbase - cpatches[t.patch].off);
-            const double c0 = crse[c], c1 = crse[c + ((ok0 || ok1) ? cstep : 0)];
+            // floor(kp / r2) as an arithmetic shift; both coarse loads are unconditional loads from a safe address (no branch,
+            // no load that waits for another: a branch here made the compiler drain vmcnt(0) in every plane)
+            const bool any = ok0 || ok1;
+            const long long c = any ? cbase + cpk * (long long)(kp >> csh2) : coff;
+            const long long c2 = any ? c + cstep : coff;
+            const double c0 = crse[c];
+            const double c1 = crse[c2];
             v.x = ok0 ? v.x + c0 : 0.0;
             v.y = ok1 ? v.y + c1 : 0.0;
         }
@@ -387,6 +392,8 @@ void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const Leve
         case 4: SOMAR_LAUNCH_FUSED(ROWS, 4); break;    \
         default: SOMAR_LAUNCH_FUSED(ROWS, 0);          \
     }
+    SOMAR_CHECK(in_mode < 3 || ((r0 == 1 || r0 == 2) && (r1 == 1 || r1 == 2) && (r2 == 1 || r2 == 2)),
+                "internal: the prolongation folded into a sweep takes multigrid ratios of 1 or 2 per direction");
     bool diri = false;
     for (int d = 0; d < 3; ++d) diri = diri || L.P.diri[d][0] || L.P.diri[d][1];
     if (diri) {

@@ -586,7 +586,7 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     // ---- tiles of the k-marching kernels: (FT_I x FT_J) columns, k split into chunks so that the launch
     // fills the 256 CUs evenly (one 1024-thread workgroup per CU at a time); `halo` = planes a chunk reads
     // beyond its own (fused red-black sweep: 3, marching residual: 2) ----------------------------------
-    auto march_tiles = [&](int FT_I, int FT_J, double halo) {
+    auto march_tiles = [&](int FT_I, int FT_J, double halo, int slots = 256) {
         long long cols = 0;
         int maxn2 = 1;
         // tile columns of equal (even) width per box: 128 cells -> 2 x 64, 512 -> 5 x 104 (104,104,104,104,96), never
@@ -606,9 +606,9 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
         double best_eff = -1.0;
         for (int nch = 1; nch <= 64 && (nch == 1 || maxn2 / nch >= 4); ++nch) {  // small levels: short chunks, more workgroups
             const long long blocks = cols * nch;
-            const long long rounds = (blocks + 255) / 256;
+            const long long rounds = (blocks + slots - 1) / slots;
             const double nk = (double)maxn2 / nch;
-            const double eff = (double)blocks / (double)(rounds * 256) * nk / (nk + halo);
+            const double eff = (double)blocks / (double)(rounds * slots) * nk / (nk + halo);
             if (eff > best_eff + 1e-9) { best_eff = eff; best = nch; }
         }
         std::vector<Tile> fnat;
@@ -643,7 +643,7 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     hrtiles = march_tiles(124, 14, 2.0);
     d_rtiles = to_device(hrtiles);
     nrtiles = (int)hrtiles.size();
-    hqtiles = march_tiles(124, full_march_rows() - 2, 2.0);
+    hqtiles = march_tiles(124, full_march_rows() - 2, 2.0, full_march_rows() == 6 ? 512 : 256);   // 6 rows: two workgroups per CU
     d_qtiles = to_device(hqtiles);
     nqtiles = (int)hqtiles.size();
 

@@ -169,6 +169,17 @@ def terrain_metric(lo, hi, dx, L):
     return jg, np.asfortranarray(1.0 / s)
 
 
+def terrain_nodal_depth(nlo, nhi, dx, L):
+    """The NODAL depth field d(x, y) = H (1 - s) of terrain_metric's map, on nodes [nlo, nhi] (inclusive) of a level with
+    spacing dx: what a BathymetricBaseMap subclass's fill_bathymetry returns, the input of somar_solver_set_metric_map."""
+    H = L[2]
+    w = min(L[0], L[1]) / 4.0
+    x = (np.arange(nlo[0], nhi[0] + 1, dtype=np.float64) * dx[0])[:, None]
+    y = (np.arange(nlo[1], nhi[1] + 1, dtype=np.float64) * dx[1])[None, :]
+    s = 0.5 + 0.3 * np.exp(-((x - 0.5 * L[0]) ** 2 + (y - 0.5 * L[1]) ** 2) / (w * w))
+    return np.asfortranarray(H * (1.0 - s))
+
+
 def c5_hierarchy(scale=1, box=64, nranks=1, nlev=4):
     """BASELINE config C5's shape: terrain-following NON-diagonal metric (terrain_metric), 4 levels each
     refined by (2,2,1), nested around the topographic bump at the domain centre: level l covers the central 2^-l of the

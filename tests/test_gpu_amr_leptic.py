@@ -141,7 +141,7 @@ def test_leptic_cycle_needs_enable_and_column_boxes():
                          [[so.Box((8, 8, 0), (23, 23, 7))]], variant="cartesian", cbox=(8, 8, 4))
     gpu = make_gpu_amr(lv, [(2, 2, 1)])
     try:
-        with pytest.raises(SomarError, match="vertically complete"):
+        with pytest.raises(SomarError, match="Vertical grids are ill-formed"):
             gpu.enableLeptic()
     finally:
         gpu.undefine()

@@ -109,8 +109,11 @@ def test_c5_small_parity_with_the_oracle(oracle, am, path, monkeypatch):
         gpu.undefine()
 
 
-def test_c5_full_size_properties():
-    """512x512x64 per level x 4 levels, 19-point k-marching kernels everywhere"""
+def test_c5_full_size_properties(monkeypatch):
+    """512x512x64 per level x 4 levels, 19-point k-marching kernels everywhere.  The analytic metric arrays (uploaded): the
+    conservation check below weighs with the SAME J; bench.py's c5_amr record takes the device-produced bathymetric metric
+    (tests/test_gpu_metric_producers.py)."""
+    monkeypatch.setenv("SOMAR_BENCH_HOST_METRIC", "1")
     from bench_amr import build_hierarchy
     from somar_amd import api as F
     gpu, levels, cells, _, dx0, ratios = build_hierarchy("c5", 1, 64)

@@ -54,6 +54,8 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
             lo, hi, _ = v.patch_box(q)
             shp = [h - a + 1 for a, h in zip(lo, hi)]
             tot += shp[0] * shp[1] * shp[2]
+            if H.get("metric") == "terrain" and not os.environ.get("SOMAR_BENCH_HOST_METRIC"):
+                continue   # produced on the device below (setMetricMap) from the level's nodal depth
             if H.get("metric") == "terrain":
                 ta = time.perf_counter()
                 jg, jinv = synthetic.terrain_metric(lo, hi, dxl, H["L"])   # non-diagonal: the 19-point kernels
@@ -72,6 +74,18 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
             tm["host_metric_arrays"] += tb - ta
             tm["metric_upload"] += time.perf_counter() - tb
         cells.append(tot)
+        if H.get("metric") == "terrain" and not os.environ.get("SOMAR_BENCH_HOST_METRIC") and v.num_local_patches:
+            # BathymetricBaseMap on the device: only the NODAL depth d = H (1 - s) of the region this rank's boxes cover
+            # (nodes lo-1 .. hi+2) is evaluated on the host, a 2-D array
+            ta = time.perf_counter()
+            bx = [v.patch_box(q) for q in range(v.num_local_patches)]
+            nlo = [min(b[0][d] for b in bx) - 1 for d in range(2)]
+            nhi = [max(b[1][d] for b in bx) + 2 for d in range(2)]
+            depth = synthetic.terrain_nodal_depth(nlo, nhi, dxl, H["L"])
+            tb = time.perf_counter()
+            v.setMetricMap(F.MAP_BATHYMETRIC, H["L"], depth, nlo)
+            tm["host_metric_arrays"] += tb - ta
+            tm["metric_upload"] += time.perf_counter() - tb
         if H.get("metric") != "terrain" and not os.environ.get("SOMAR_BENCH_HOST_METRIC"):
             ta = time.perf_counter()
             v.setMetricUniform(1.0, 1.0, 1.0, 1.0)   # CartesianMap::fill_Jgup / fill_Jinv on the device

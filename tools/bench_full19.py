@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--path", default="march", choices=["march", "direct"])
+    ap.add_argument("--metric", default="sheared", choices=["sheared", "bathy"],
+                    help="bathy: BathymetricBaseMap of a bump, produced on the device (no host arrays)")
     args = ap.parse_args()
     if args.path == "direct":
         os.environ["SOMAR_MARCH_MIN_CELLS"] = "1000000000000"
@@ -65,15 +67,24 @@ def main():
     L = (1.0, 1.0, 1.0)
     dx = tuple(L[d] / n for d in range(3))
     t0 = time.perf_counter()
-    jg, jinv = sheared_metric(n, dx, L)
+    if args.metric == "sheared":
+        jg, jinv = sheared_metric(n, dx, L)
     t_metric = time.perf_counter() - t0
     s = F.AMRPressureSolver()
     p = s._p
     s.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg, p.hang,
                          p.norm_thresh, 0)
     s.define((0, 0, 0), (n - 1,) * 3, (False, False, False), dx, [((0, 0, 0), (n - 1,) * 3)])
-    s.setMetricFull(0, jg[0], jg[1], jg[2], jinv)
-    del jg, jinv
+    if args.metric == "sheared":
+        s.setMetricFull(0, jg[0], jg[1], jg[2], jinv)
+        del jg, jinv
+    else:
+        t0 = time.perf_counter()
+        x = (np.arange(-1, n + 3) * dx[0])[:, None]
+        y = (np.arange(-1, n + 3) * dx[1])[None, :]
+        depth = L[2] * (0.5 - 0.3 * np.exp(-((x - 0.5) ** 2 + (y - 0.5) ** 2) / 0.0625))
+        s.setMetricMap(F.MAP_BATHYMETRIC, L, depth, (-1, -1))
+        t_metric = time.perf_counter() - t0
     s.finalize()
     s.fillHash(F.F_RHS, 12345)
     s.removeMean(F.F_RHS)
@@ -105,7 +116,7 @@ def main():
     cells = n ** 3
     pass_ms = ms_g / max(n_g, 1)
     res_ms = ms_r / max(n_r, 1)
-    out = {"n": n, "path": args.path, "cells": cells, "metric_seconds": t_metric, "mg_depth": s.depth(),
+    out = {"n": n, "path": args.path, "metric": args.metric, "rows": os.environ.get("SOMAR_FULL_ROWS", "8"), "cells": cells, "metric_seconds": t_metric, "mg_depth": s.depth(),
            "gsrb_colour_pass_ms": pass_ms, "gsrb_sweep_kernel_ms": 2 * pass_ms, "residual_kernel_ms": res_ms,
            "gsrb_sweep_wall_ms": t_sweep * 1e3, "residual_wall_ms": t_res * 1e3,
            "gsrb_sweep_alg_GBs": 120.0 * cells / (2 * pass_ms * 1e-3) / 1e9,
