@@ -419,8 +419,14 @@ int somar_altered_jgup(long long n, double* dest, const double* nsq_fc, const do
 /* ---- leptic level solver -------------------------------------------------------------------------------------
  * Replaces LevelLepticSolver (calculus/LepticSolver/LevelLepticSolver.H:53-347): define(op) :147-437 and
  * solve(phi, rhs) :646-956, for an operator that offers what LepticOperator asks (LepticOperator.H:33-45).
- * The level's boxes must be vertically complete columns (the layout LepticBoxUtils::createVerticalSolverGrids makes);
- * diagonal metric, homogeneous-Neumann physical boundaries, no periodic direction, no coarse-fine boundary.
+ * The level's boxes must not be split in the vertical (the layout LepticBoxUtils::createVerticalSolverGrids makes): every
+ * column ends at a physical boundary or, on a level of a hierarchy, at a coarse-fine interface.  gatherVerticalBCTypes
+ * (:1523-1640) decides from the ends: columns that are Neumann at both ends take the Neumann-Neumann line solver and the
+ * horizontal (flat) problem; when NO column is Neumann-Neumann -- a Dirichlet (free-surface) top or bottom, or columns ending
+ * under the coarser level -- every order is one LepticLapackVerticalSolver + dptsv pass (LevelLepticSolverF.ChF:161-283) and
+ * there is no flat problem; a layout mixing the two kinds is refused.  Diagonal or non-diagonal metric
+ * (somar_solver_set_metric_full on the level handle), homogeneous-Neumann lateral boundaries, no periodic direction;
+ * coarse-fine boundaries through somar_amr_enable_leptic.
  * somar_leptic_params_t = setParameters / setHorizMGParameters / setHorizBottomParameters / setFullMGParameters /
  * setFullBottomParameters (:516-640); defaults = setDefaultParameters (:461-508). */
 typedef struct somar_leptic somar_leptic_t; /* opaque */
