@@ -126,14 +126,31 @@ struct TinyProgram {
 };
 void launch_tiny_program(hipStream_t st, const LevelDev& L, const CopyItem* items, int nitems, long long field_elems,
                          double* const* fields, int nfields, const TinyOp* ops, int nops);
+// where a reduction's result is also stored for the host: coherent host memory + a sequence number the host spins on
+// (PressureSolver::fetch_scalars); fused into the reduction's last kernel it saves the separate one-thread publish launch
+struct ScalarPublish { double* host_dst; unsigned long long* host_seq; unsigned long long seq; };
+// the whole BiCGStab bottom solve of a tiny level in one single-workgroup launch (k_tiny_bicgstab, kernels.hip); the caller
+// fills phi, rhs, w (r, r~, e, p, p~, s~, t, v), the parameters, info (device, 2 doubles: iterations, exit code) and pub
+struct TinyBicg {
+    const Tile* tiles; int ntiles; int tile_j;
+    const PatchDesc* patches; int npatches;
+    const CopyItem* items; int nitems;
+    long long field_elems;
+    const double* jg[3]; const double* jinv; const double* lapd;
+    StencilParams P;
+    double* phi; const double* rhs;
+    double* w[8];
+    int imax, numRestarts, normType, precondIters;
+    double eps, reps, hang, small, metric;
+    double* info;
+    ScalarPublish pub;
+};
+void launch_tiny_bicgstab(hipStream_t st, const LevelDev& L, const CopyItem* items, int nitems, long long field_elems, TinyBicg A);
 // streaming probe (diagnostics): kind 0 copy, 1 read, 2 six reads + one write; in6: six arrays of `cells` doubles
 void launch_stream_probe(hipStream_t st, int kind, int workgroups, double* const* in6, double* out, long long cells);
 // (min, max) per (patch, k-chunk) of a over the valid cells (dir < 0) or valid dir-faces: out[2 * npatches * MM_CH] (device)
 constexpr int MM_CH = 64;
 void launch_minmax_valid(hipStream_t st, const LevelDev& L, const double* a, int dir, double* out);
-// where a reduction's result is also stored for the host: coherent host memory + a sequence number the host spins on
-// (PressureSolver::fetch_scalars); fused into the reduction's last kernel it saves the separate one-thread publish launch
-struct ScalarPublish { double* host_dst; unsigned long long* host_seq; unsigned long long seq; };
 // mode 0: sum a*b, 1: max|a|, 2: sum|a|, 3: signed max a  -> out[0] (device)
 // ordered: reference-ordered serial sum (modes 0 and 2; meant for small levels, see k_reduce_ordered)
 void launch_reduce(hipStream_t st, const LevelDev& L, const double* a, const double* b, int mode, double* partials,

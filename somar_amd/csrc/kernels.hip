@@ -1234,6 +1234,255 @@ void launch_tiny_program(hipStream_t st, const LevelDev& L, const CopyItem* item
     }
 }
 
+// ---- the bottom solver of a tiny level in ONE launch -----------------------------------------------------------------------------
+// Chombo 3.1 BiCGStabSolver<T>::solve as PressureSolver::bottom_solve restates it (solver.cpp), run by one 1024-thread
+// workgroup: the same operations in the same order -- residual, DIAGPRECOND + point-GSRB sweeps, operator, the vector updates
+// (k_incr / k_incr2 / k_bicg_p's expressions), dot products and norms summed in the reference's serial order exactly as
+// k_reduce_ordered sums them -- with __syncthreads() where the kernel boundaries were and every scalar (rho, alpha, omega,
+// the stopping tests) computed redundantly by every thread from the same reduced values, so the control flow is uniform
+// without a broadcast.  On BASELINE C2 the eight iterations on the 4^3 bottom box were about 100 launches and 25 host round
+// trips per V-cycle; this is one launch and one round trip.  Bit-identical to the launch-by-launch path by construction
+// (tests run both).  w: r, r~, e, p, p~, s~, t, v.
+__global__ __launch_bounds__(1024) void k_tiny_bicgstab(TinyBicg A)
+{
+    __shared__ double X[512];
+    __shared__ double M[16];
+    const int tid = threadIdx.x;
+    const int vper = 64 * A.tile_j;
+    const int nvb = 1024 / vper;
+    const int vb = tid / vper, vt = tid - vb * vper;
+    const int tx = vt & 63, ty = vt >> 6;
+    const long long n = A.field_elems;
+    auto sync = [&]() { __threadfence_block(); __syncthreads(); };
+    auto exchange = [&](double* f) {
+        for (int it = vb; it < A.nitems; it += nvb) {
+            const CopyItem ci = A.items[it];
+            const PatchDesc sp = A.patches[ci.src_patch];
+            const PatchDesc dp = A.patches[ci.dst_patch];
+            const int n0 = ci.n[0], n01 = ci.n[0] * ci.n[1];
+            const int cells = n01 * ci.n[2];
+            for (int idx = vt; idx < cells; idx += vper) {
+                const int k = idx / n01;
+                const int r = idx - k * n01;
+                const int j = r / n0, i = r - j * n0;
+                f[cidx(dp, ci.dst_lo[0] + i, ci.dst_lo[1] + j, ci.dst_lo[2] + k)] =
+                    f[cidx(sp, ci.src_lo[0] + i, ci.src_lo[1] + j, ci.src_lo[2] + k)];
+            }
+        }
+        sync();
+    };
+    auto gsrb = [&](double* phi, const double* rhs, int color) {
+        for (int b = vb; b < A.ntiles; b += nvb)
+            gsrb_ortho_body(A.tiles, A.patches, phi, rhs, A.jg[0], A.jg[1], A.jg[2], A.jinv, A.lapd, A.P, color, 0, b, tx, ty);
+        sync();
+    };
+    auto op0 = [&](double* out, const double* phi, const double* rhs) {   // rhs - L[phi]
+        for (int b = vb; b < A.ntiles; b += nvb)
+            op_ortho_body<0>(A.tiles, A.patches, out, phi, rhs, A.jg[0], A.jg[1], A.jg[2], A.jinv, A.P, b, tx, ty);
+        sync();
+    };
+    auto op1 = [&](double* out, const double* phi) {                       // L[phi]
+        for (int b = vb; b < A.ntiles; b += nvb)
+            op_ortho_body<1>(A.tiles, A.patches, out, phi, phi, A.jg[0], A.jg[1], A.jg[2], A.jinv, A.P, b, tx, ty);
+        sync();
+    };
+    auto setv = [&](double* f, double a) { for (long long i = tid; i < n; i += 1024) f[i] = a; sync(); };
+    auto copy = [&](double* y, const double* x) { for (long long i = tid; i < n; i += 1024) y[i] = x[i]; sync(); };
+    auto incr = [&](double* y, const double* x, double a) { for (long long i = tid; i < n; i += 1024) y[i] = y[i] + a * x[i]; sync(); };
+    auto incr2 = [&](double* y1, const double* x1, double a1, double* y2, const double* x2, double a2) {
+        for (long long i = tid; i < n; i += 1024) {
+            y1[i] = y1[i] + a1 * x1[i];
+            y2[i] = y2[i] + a2 * x2[i];
+        }
+        sync();
+    };
+    // serial-order sum over the valid cells, box after box, Fortran order (k_reduce_ordered): mode 0 a*b, mode 2 |a|
+    auto ordsum = [&](const double* a, const double* b, int mode) {
+        double tot = 0.0;
+        for (int pi = 0; pi < A.npatches; ++pi) {
+            const PatchDesc p = A.patches[pi];
+            const long long cells = (long long)p.n[0] * p.n[1] * p.n[2];
+            double sbox = 0.0;
+            for (long long base = 0; base < cells; base += 512) {
+                const int cnt = (int)((cells - base) < 512 ? (cells - base) : 512);
+                __syncthreads();
+                for (int q = tid; q < cnt; q += 1024) {
+                    const long long idx = base + q;
+                    const int i = (int)(idx % p.n[0]);
+                    const long long r = idx / p.n[0];
+                    const int j = (int)(r % p.n[1]), k = (int)(r / p.n[1]);
+                    const long long c = cidx(p, i, j, k);
+                    X[q] = mode == 0 ? a[c] * b[c] : fabs(a[c]);
+                }
+                __syncthreads();
+                int q = 0;
+                if (base == 0) { sbox = X[0]; q = 1; }
+                for (; q + 16 <= cnt; q += 16) {
+                    double xv[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xv[j] = X[q + j];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) sbox = sbox + xv[j];
+                }
+                for (; q < cnt; ++q) sbox = sbox + X[q];
+            }
+            tot = tot + sbox;
+        }
+        __syncthreads();
+        return tot;
+    };
+    auto maxabs = [&](const double* a) {
+        double m = 0.0;
+        for (int pi = 0; pi < A.npatches; ++pi) {
+            const PatchDesc p = A.patches[pi];
+            const long long cells = (long long)p.n[0] * p.n[1] * p.n[2];
+            for (long long idx = tid; idx < cells; idx += 1024) {
+                const int i = (int)(idx % p.n[0]);
+                const long long r = idx / p.n[0];
+                const int j = (int)(r % p.n[1]), k = (int)(r / p.n[1]);
+                const double v = fabs(a[cidx(p, i, j, k)]);
+                m = v > m ? v : m;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double w = __shfl_down(m, o, 64);
+            m = w > m ? w : m;
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) M[tid >> 6] = m;
+        __syncthreads();
+        double r = M[0];
+        for (int w = 1; w < 16; ++w) r = M[w] > r ? M[w] : r;
+        __syncthreads();
+        return r;
+    };
+    auto norm = [&](const double* a) {
+        if (A.normType == 0) return maxabs(a);
+        if (A.normType == 1) return ordsum(a, a, 2);
+        return sqrt(ordsum(a, a, 0));
+    };
+    auto residual = [&](double* out, double* phi, const double* rhs) { exchange(phi); op0(out, phi, rhs); };
+    auto apply_op = [&](double* out, double* phi) { exchange(phi); op1(out, phi); };
+    auto pre_cond = [&](double* phi, const double* rhs) {
+        if (A.precondIters <= 0) { copy(phi, rhs); return; }
+        for (int b = vb; b < A.ntiles; b += nvb) diag_body<0>(A.tiles, A.patches, phi, rhs, A.lapd, A.P.alpha, A.P.beta, b, tx, ty);
+        sync();
+        for (int it = 0; it < A.precondIters; ++it)
+            for (int pass = 0; pass < 2; ++pass) { exchange(phi); gsrb(phi, rhs, pass); }
+    };
+    double *phi = A.phi, *r = A.w[0], *r_tilde = A.w[1], *e = A.w[2], *p = A.w[3], *p_tilde = A.w[4], *s_tilde = A.w[5],
+           *t = A.w[6], *v = A.w[7];
+    const double* rhs = A.rhs;
+    auto finish = [&](int iters, int exit_code) {
+        if (tid == 0) {
+            const double vals[2] = {(double)iters, (double)exit_code};
+            A.info[0] = vals[0];
+            A.info[1] = vals[1];
+            publish_scalars(vals, 2, A.pub);
+        }
+    };
+
+    int recount = 0;
+    residual(r, phi, rhs);
+    copy(r_tilde, r);
+    setv(e, 0.0);
+    setv(p_tilde, 0.0);
+    setv(s_tilde, 0.0);
+    int i = 0;
+    double rho[4] = {0, 0, 0, 0};
+    double nrm[2];
+    nrm[0] = norm(r);
+    double initial_norm = nrm[0];
+    const double initial_rnorm = nrm[0];
+    nrm[1] = nrm[0];
+    double alpha[2] = {0, 0}, beta[2] = {0, 0}, omega[2] = {0, 0};
+    bool init = true;
+    int restarts = 0;
+    if (A.metric > 0) initial_norm = A.metric;
+    const double eps = A.eps;
+    int bottom_exit = -1;
+    while ((i < A.imax && nrm[0] > eps * nrm[1]) && (nrm[1] > 0)) {
+        ++i;
+        nrm[1] = nrm[0];
+        alpha[1] = alpha[0]; beta[1] = beta[0]; omega[1] = omega[0];
+        rho[3] = rho[2]; rho[2] = rho[1];
+        rho[1] = ordsum(r_tilde, r, 0);
+        if (rho[1] == 0.0) {
+            incr(phi, e, 1.0);
+            finish(i, 2);
+            return;
+        }
+        if (init) {
+            copy(p, r);
+            init = false;
+        } else {
+            beta[1] = (rho[1] / rho[2]) * (alpha[1] / omega[1]);
+            const double bt = beta[1], bw = -beta[1] * omega[1];
+            for (long long q = tid; q < n; q += 1024) {
+                double u = p[q] * bt;
+                u = u + bw * v[q];
+                u = u + 1.0 * r[q];
+                p[q] = u;
+            }
+            sync();
+        }
+        pre_cond(p_tilde, p);
+        apply_op(v, p_tilde);
+        const double m = ordsum(r_tilde, v, 0);
+        alpha[0] = rho[1] / m;
+        if (fabs(m) > A.small * fabs(rho[1])) {
+            incr2(r, v, -alpha[0], e, p_tilde, alpha[0]);
+            nrm[0] = norm(r);
+        } else {
+            setv(r, 0.0);
+            nrm[0] = 0.0;
+        }
+        if (nrm[0] > eps * initial_norm && nrm[0] > A.reps * initial_rnorm) {
+            pre_cond(s_tilde, r);
+            apply_op(t, s_tilde);
+            const double tr = ordsum(t, r, 0), tt = ordsum(t, t, 0);
+            omega[0] = tr / tt;
+            incr2(e, s_tilde, omega[0], r, t, -omega[0]);
+            nrm[0] = norm(r);
+        }
+        if (nrm[0] <= eps * initial_norm || nrm[0] <= A.reps * initial_rnorm) {
+            bottom_exit = 1;
+            break;
+        }
+        if (omega[0] == 0.0 || nrm[0] > (1 - A.hang) * nrm[1]) {
+            if (recount == 0) {
+                recount = 1;
+            } else {
+                recount = 0;
+                incr(phi, e, 1.0);
+                if (restarts == A.numRestarts) {
+                    finish(i, 3);
+                    return;
+                }
+                residual(r, phi, rhs);
+                nrm[0] = norm(r);
+                rho[0] = rho[1] = rho[2] = rho[3] = 0.0;
+                alpha[0] = beta[0] = omega[0] = 0.0;
+                copy(r_tilde, r);
+                setv(e, 0.0);
+                ++restarts;
+                init = true;
+            }
+        }
+    }
+    incr(phi, e, 1.0);
+    finish(i, bottom_exit);
+}
+void launch_tiny_bicgstab(hipStream_t st, const LevelDev& L, const CopyItem* items, int nitems, long long field_elems,
+                          TinyBicg A)
+{
+    A.tiles = L.tiles; A.ntiles = L.ntiles; A.tile_j = L.tile_j; A.patches = L.patches; A.npatches = L.npatches;
+    A.items = items; A.nitems = nitems; A.field_elems = field_elems;
+    for (int d = 0; d < 3; ++d) A.jg[d] = L.jg[d];
+    A.jinv = L.jinv; A.lapd = L.lapdiag; A.P = L.P;
+    hipLaunchKernelGGL(k_tiny_bicgstab, dim3(1), dim3(1024), 0, st, A);
+}
+
 // ---- what this device streams (somar_diag_stream_probe) -----------------------------------------------------------------------
 // kind 0: copy (1 read + 1 write stream); 1: read only; 2: the fused sweep's mix, 6 read streams + 1 write stream, no stencil,
 // no halo -- the ceiling the sweep's achieved bandwidth is to be read against (tools/bw_probe.hip measures more variants)

@@ -1600,10 +1600,49 @@ bool PressureSolver::fold_prolong(int d) const
 // Chombo 3.1 BiCGStabSolver<T>::solve (EXTERNAL to the reference; restated from the published
 // algorithm, same variable names).  Runs on the coarsest MG depth.
 // ------------------------------------------------------------------------------------
+// A bottom level small enough for the one-launch BiCGStab (k_tiny_bicgstab): everything tiny() asks (all boxes on this rank,
+// the 7-point operator, Neumann / periodic sides, no coarse-fine faces, point GSRB) and serial-order sums.
+// SOMAR_FUSED_BOTTOM_MAX_CELLS (default 512, 0 = off) is the A/B switch.
+bool PressureSolver::fused_bottom(int d) const
+{
+    const char* env = getenv("SOMAR_FUSED_BOTTOM_MAX_CELLS");   // read per call (once per V-cycle): tests flip it
+    const long long maxc = env ? atoll(env) : 512;
+    static const bool poll = !(getenv("SOMAR_POLL_FETCH") && atoi(getenv("SOMAR_POLL_FETCH")) == 0);
+    const Level& L = *lev[d];
+    return maxc > 0 && poll && !full_ && !diri_ && L.ncf == 0 && L.plan.peers.empty() && !profiling_ && !capturing_ &&
+           comm_->size == 1 && L.valid_cells_global <= maxc && ordered(d) && !ord_sharded(d) && L.dev.ntiles > 0 &&
+           L.dev.tile_j >= 1 && L.dev.tile_j <= 16 && (1024 % (64 * L.dev.tile_j)) == 0 &&
+           prm.relaxMode == RELAX_LEVEL_GSRB && prm.precondMode != PRECOND_DIAG_LINE_RELAX && bicg[7] != nullptr;
+}
+
 void PressureSolver::bottom_solve(double* phi, const double* rhs)
 {
     const int d = (int)lev.size() - 1;
     const long long n = lev[d]->field_elems;
+    if (fused_bottom(d)) {
+        Level& L = *lev[d];
+        TinyBicg A;
+        std::memset(&A, 0, sizeof(A));
+        A.phi = phi;
+        A.rhs = rhs;
+        for (int q = 0; q < 8; ++q) A.w[q] = bicg[q];
+        A.imax = prm.bottom_imax;
+        A.numRestarts = prm.bottom_numRestarts;
+        A.normType = prm.bottom_normType;
+        A.precondIters = (prm.num_smooth_precond == 0 || prm.precondMode == PRECOND_NONE) ? 0 : prm.num_smooth_precond;
+        A.eps = bottom_eps_eff;
+        A.reps = prm.bottom_reps;
+        A.hang = prm.bottom_hang;
+        A.small = prm.bottom_small;
+        A.metric = bottom_metric;
+        A.info = d_scalars + SLOT_TMP;
+        A.pub = ScalarPublish{h_scalars + SLOT_TMP, h_seq_, ++fetch_seq_};
+        launch_tiny_bicgstab(st_, L.dev, L.d_local_items, (int)L.plan.local.size(), n, A);
+        wait_published(A.pub.seq);
+        bottom_iters = (int)h_scalars[SLOT_TMP];
+        bottom_exit = (int)h_scalars[SLOT_TMP + 1];
+        return;
+    }
     double *r = bicg[0], *r_tilde = bicg[1], *e = bicg[2], *p = bicg[3], *p_tilde = bicg[4], *s_tilde = bicg[5],
            *t = bicg[6], *v = bicg[7];
     const int nt = prm.bottom_normType;

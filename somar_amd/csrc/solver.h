@@ -245,6 +245,7 @@ private:
     // rounds that 64 CUs run at once.  The launch-bound tail needs flat per-cell work lists, not fewer launches of this shape.
     long long tiny_max_cells_ = 0;
     bool tiny(int d) const;
+    bool fused_bottom(int d) const;   // the whole BiCGStab bottom solve in one single-workgroup launch (k_tiny_bicgstab)
     void tiny_run(int d, double* const* fields, int nfields, const std::vector<TinyOp>& ops);
     long long fused_min_cells_ = 262144;
     long long march_min_cells_ = 262144;  // levels at least this big use the k-marching operator/residual

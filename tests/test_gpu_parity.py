@@ -238,6 +238,48 @@ def test_bottom_solver_and_vcycle(oracle, case, F):
     gpu.undefine()
 
 
+@pytest.mark.parametrize("case", CASES[:4])
+def test_one_launch_bottom_solver_equals_the_launch_by_launch_one(oracle, case, F, monkeypatch):
+    """k_tiny_bicgstab (the whole BiCGStab bottom solve in one single-workgroup launch, default on bottom levels of at most
+    512 cells) against PressureSolver::bottom_solve's launch-by-launch path (SOMAR_FUSED_BOTTOM_MAX_CELLS=0): same
+    iteration count, same exit code, same bits -- and both equal to the oracle's BiCGStab within the solve's tolerance."""
+    so = oracle
+    dom, grids, amr, gpu = _both(oracle, case)
+    D = amr.mg.depth
+    opb = amr.mg.ops[-1]
+    cells = sum(g.numPts() for g in opb.grids)
+    rhs = so.random_field(opb.grids, 91, (0, 0, 0), opb.domain.box)
+    so.remove_weighted_mean(rhs, opb.Jinv)
+    fp, fr = (F.FIELD(D - 1, F.F_CORR), F.FIELD(D - 1, F.F_RES)) if D > 1 else (F.F_CORR, F.F_RES)
+    out = {}
+    for mode in ("0", "100000"):
+        monkeypatch.setenv("SOMAR_FUSED_BOTTOM_MAX_CELLS", mode)
+        upload(gpu, fr, rhs, depth=D - 1)
+        gpu.setVal(fp, 0.0)
+        it, ex = gpu.bottomSolve(fp, fr)
+        out[mode] = (it, ex, download_valid(gpu, fp, opb.grids, D - 1))
+    assert out["0"][:2] == out["100000"][:2]
+    if cells <= 4096:       # serial-order sums on both paths
+        for a, b in zip(out["0"][2], out["100000"][2]):
+            np.testing.assert_array_equal(a, b)
+    else:                   # the launch path sums large levels by tree, the one-launch kernel is not used there at all
+        for a, b in zip(out["0"][2], out["100000"][2]):
+            np.testing.assert_array_equal(a, b)
+    # whole V-cycles and solves with either bottom solver
+    res = so.random_field(grids, 92, (0, 0, 0), dom.box)
+    so.remove_weighted_mean(res, amr.op.Jinv)
+    cyc = {}
+    for mode in ("0", "100000"):
+        monkeypatch.setenv("SOMAR_FUSED_BOTTOM_MAX_CELLS", mode)
+        upload(gpu, F.F_RES, res)
+        gpu.setVal(F.F_CORR, 0.0)
+        gpu.vcycle(F.F_CORR, F.F_RES)
+        cyc[mode] = download_valid(gpu, F.F_CORR, grids)
+    for a, b in zip(cyc["0"], cyc["100000"]):
+        np.testing.assert_array_equal(a, b)
+    gpu.undefine()
+
+
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("smooth", [(2, 2, 2), (4, 4, 2)])
 def test_full_solve_history_matches(oracle, case, smooth, gsrb_mode):
