@@ -74,3 +74,46 @@ def test_composite_operator_conserves_and_solve_converges(config):
             assert all(b < a for a, b in zip(h[:3], h[1:4]))
     finally:
         gpu.undefine()
+
+
+def test_composite_tga_step_conserves_the_heat_content_at_c3_size():
+    """MappedAMRTGA::oneStep (somar_amr_tga_step) on BASELINE C3 at full size (50 M cells, two levels, Neumann / periodic):
+    the refluxed composite operator integrates to zero, so the composite integral of phi grows by dt x the integral of the
+    source -- which holds only if the flux-register scales follow beta through the step's four coefficient changes.  The
+    solves stop at the solver's eps (1e-6 of their initial residual), which bounds the defect."""
+    from bench_amr import build_hierarchy
+    from somar_amd import api as F
+    nu, dt, S = 0.05, 0.2, 0.5
+    gpu, levels, cells, _, dx0, ratios = build_hierarchy("c3", 1, alpha=1.0, beta=nu)
+    try:
+        nlev = len(levels)
+        dV = []
+        dx = list(dx0)
+        for l in range(nlev):
+            if l > 0:
+                dx = [a / b for a, b in zip(dx, ratios[l - 1])]
+            dV.append(float(np.prod(dx)))
+        for l, v in enumerate(gpu.levels):
+            v.fillHash(F.F_HEAT_OLD, 31 + l)
+            v.setVal(F.F_HEAT_SRC, S)
+            v.setVal(F.F_PHI, 0.0)
+            v.setVal(F.F_SCRATCH, 1.0)
+
+        def integral(field):
+            for l in range(nlev - 1):
+                gpu.zeroCovered(l, field)
+            return sum(v.dotProduct(field, F.F_SCRATCH) * dV[l] for l, v in enumerate(gpu.levels))
+
+        i_old = integral(F.F_HEAT_OLD)      # covered coarse cells never reach an uncovered result (the reflux replaces their fluxes)
+        volume = 15.0 * 3.0 * 2.0
+        st = gpu.tgaStepAMR(nlev - 1, 0, dt)
+        assert st["exitStatus"] == 1
+        h = st["history"]
+        assert h[-1] <= 1e-6 * h[0]
+        i_new = integral(F.F_PHI)
+        assert abs(i_new - (i_old + dt * S * volume)) < 2e-5 * volume
+        assert abs(i_new - i_old) > 0.5 * dt * S * volume
+        # the coefficients are still the last solve's (1, -mu1 dt nu): a composite residual with them works as well
+        gpu.setAlphaAndBetaAMR(1.0, 1.0)
+    finally:
+        gpu.undefine()

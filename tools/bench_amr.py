@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult=4, comm=None, nranks=1):
+def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult=4, comm=None, nranks=1, alpha=0.0, beta=1.0):
     """-> (AMRPressureSolver (finalized), levels' boxes, LOCAL cells per level, define seconds, dx0, ratios)"""
     from somar_amd import api as F
     from somar_amd import synthetic
@@ -42,7 +42,7 @@ def build_hierarchy(config="c3", scale=1, box=128, pre=4, post=4, bottom=2, mult
     t0 = time.perf_counter()
     tm = {"host_metric_arrays": 0.0, "metric_upload": 0.0}
     gpu.defineAMR((0, 0, 0), tuple(a - 1 for a in n0), H["periodic"], dx0, ratios, levels,
-                  owners_per_level=H["owners"], comm=comm)
+                  owners_per_level=H["owners"], comm=comm, alpha=alpha, beta=beta)
     tm["define_tables"] = time.perf_counter() - t0
     cells = []
     dxl = list(dx0)
