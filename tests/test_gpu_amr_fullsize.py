@@ -97,11 +97,12 @@ def test_composite_tga_step_conserves_the_heat_content_at_c3_size():
             v.fillHash(F.F_HEAT_OLD, 31 + l)
             v.setVal(F.F_HEAT_SRC, S)
             v.setVal(F.F_PHI, 0.0)
-            v.setVal(F.F_SCRATCH, 1.0)
 
         def integral(field):
             for l in range(nlev - 1):
                 gpu.zeroCovered(l, field)
+            for v in gpu.levels:
+                v.setVal(F.F_SCRATCH, 1.0)      # the step uses the scratch field (computeAMROperator's zero right-hand side)
             return sum(v.dotProduct(field, F.F_SCRATCH) * dV[l] for l, v in enumerate(gpu.levels))
 
         i_old = integral(F.F_HEAT_OLD)      # covered coarse cells never reach an uncovered result (the reflux replaces their fluxes)
