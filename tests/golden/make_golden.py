@@ -129,6 +129,67 @@ def compute():
     out["tga_history"] = np.array(amr.history)
     out["tga_iters_exit"] = np.array([amr.iters, amr.exitStatus])
     out["tga_phi_box0"] = new[0].view(grids[0])[..., 0].copy()
+    # 9. (round 2) BathymetricBaseMap from a nodal depth: J g^{zeta b} on the zeta-faces and 1/J of box 0, and the 19-point
+    #    operator applied with that metric
+    from oracle import somar_maps as sm
+    n, L, bs = (16, 16, 8), (4.0, 2.0, 1.0), (8, 8, 8)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, bs)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    dlo, dn = (-1, -1), (n[0] + 4, n[1] + 4)
+    x = (np.arange(dlo[0], dlo[0] + dn[0]) * dx[0])[:, None]
+    y = (np.arange(dlo[1], dlo[1] + dn[1]) * dx[1])[None, :]
+    depth = 0.15 + 0.02 * x - 0.03 * y + 0.25 * np.exp(-((x - 1.7) ** 2 + (y - 0.9) ** 2) / 0.5)
+    m = sm.BathymetricMap(dx, L, depth, dlo)
+    out["bathy_depth_nodes"] = depth
+    out["bathy_jgup_zeta_box0"] = sm.fill_jgup(m, grids[0], 2)
+    out["bathy_jinv_box0"] = sm.fill_jinv(m, grids[0])
+    Jgup = so.FluxData(grids, 3, 3)
+    Jinv = so.LevelData(grids, 1, (0, 0, 0))
+    for i, g in enumerate(grids):
+        for mu in range(3):
+            Jgup[i][mu].a[...] = sm.fill_jgup(m, g, mu)
+        Jinv[i].a[..., 0] = sm.fill_jinv(m, g)
+    fac = so.Factory(dom, grids, dx, so.BCHolder(), Jgup, Jinv, isDiagonal=False)
+    mg = so.MultiGrid(fac, so.BiCGStab())
+    phi = so.random_field(grids, 7, (1, 1, 1), dom.box)
+    lph = so.LevelData(grids, 1)
+    mg.ops[0].apply_op(lph, phi, True)
+    out["bathy_applyop_box0"] = lph[0].view(grids[0])[..., 0].copy()
+    # 10. (round 2) leptic columns with a Dirichlet top: LepticLapackVerticalSolver + dptsv, no horizontal solves
+    n, L = (16, 16, 8), (1.0, 1.0, 0.005)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, (8, 8, 8))
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_diagonal_metric(grids, dx, L, 3, "stretched", domain=dom)
+    bc = so.BCHolder([[0, 0], [0, 0], [0, 1]], [[0.0, 0.0], [0.0, 0.0], [0.0, 0.3]])
+    op = so.AMRMultiGrid(so.Factory(dom, grids, dx, bc, Jgup, Jinv), so.BiCGStab()).op
+    lep = sl.LevelLepticSolver(op, maxOrder=3, domainHeight=L[2])
+    rhs = so.random_field(grids, 9, domainBox=dom.box)
+    phi = so.LevelData(grids, 1, (1, 1, 1))
+    status = lep.solve(phi, rhs, False)
+    out["leptic_diri_res_norms"] = np.array(lep.resNorms)
+    out["leptic_diri_status_full"] = np.array([status, int(lep.usedFullSolver)])
+    out["leptic_diri_phi_box0"] = phi[0].view(grids[0])[..., 0].copy()
+    # 11. (round 2) inflow / outflow sides of BasicVelocityBCGhostClass in the cell-centred divergence
+    dom, grids, dx, Jgup, Jinv = make_problem(so, (16, 16, 8), 8, "stretched", (False, True, False), (2.0, 1.0, 0.5))
+    vel = smooth_cc_velocity(so, dom, grids, (1, 1, 1))
+    div = so.LevelData(grids, 1)
+    so.level_divergence_cc(div, vel, Jinv, grids, dom, dx, velbc=([1, 2, 0, 0, 2, 1], [0.7, 0.0, 0.0, 0.0, 0.0, -0.3]))
+    out["cc_div_inflow_outflow_box0"] = div[0].a[..., 0].copy()
+    # 12. (round 2) MappedAMRTGA::oneStep over two levels: history of the last solve, fine-level solution
+    ratios = [(2, 2, 2)]
+    fine = [[so.Box((8, 8, 4), (23, 15, 11)), so.Box((8, 16, 4), (23, 23, 11))]]
+    levels = make_amr_levels(so, am, (16, 16, 8), (1.0, 1.0, 0.5), (False, False, False), ratios, fine, cbox=8)
+    bc = so.BCHolder([[1, 1], [1, 0], [1, 1]], [[0.1, 0.0], [0.0, 0.0], [0.0, -0.2]])
+    comp = am.AMRComposite(levels, ratios, bc, so.BiCGStab(), alpha=1.0, beta=0.05)
+    old = [so.random_field(Lv.grids, 3 + l, (1, 1, 1), Lv.domain.box) for l, Lv in enumerate(levels)]
+    src = [so.random_field(Lv.grids, 13 + l, (1, 1, 1), Lv.domain.box) for l, Lv in enumerate(levels)]
+    new = [so.random_field(Lv.grids, 23 + l, (1, 1, 1), Lv.domain.box) for l, Lv in enumerate(levels)]
+    am.amr_tga_one_step(comp, new, old, src, 0.2, 0, 1)
+    out["amr_tga_history"] = np.array(comp.history)
+    out["amr_tga_iters_exit"] = np.array([comp.iters, comp.exitStatus])
+    out["amr_tga_fine_phi_box0"] = new[1][0].view(levels[1].grids[0])[..., 0].copy()
     return out
 
 

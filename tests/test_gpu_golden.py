@@ -195,3 +195,102 @@ def test_cc_projection_and_helmholtz_match_golden(oracle):
         np.testing.assert_allclose(download_valid(gpu, F.F_PHI, grids)[0], GOLD["tga_phi_box0"], rtol=0, atol=1e-9)
     finally:
         gpu.undefine()
+
+
+def test_round2_features_match_golden(oracle):
+    """the device-produced bathymetric metric (seen through the 19-point operator), the Dirichlet-topped leptic solve, the
+    inflow / outflow sides of the cell-centred divergence and the composite TGA step against the committed vectors"""
+    from somar_amd import AMRPressureSolver, LevelLepticSolver
+    from somar_amd import api as F
+    from helpers import smooth_cc_velocity
+    so = oracle
+    from oracle import somar_amr as sa
+    # 9. bathymetric map on the device
+    n, L, bs = (16, 16, 8), (4.0, 2.0, 1.0), (8, 8, 8)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, bs)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    s = AMRPressureSolver()
+    p = s._p
+    s.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg, p.hang,
+                         p.norm_thresh, 0)
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids])
+    s.setMetricMap(F.MAP_BATHYMETRIC, L, GOLD["bathy_depth_nodes"], (-1, -1))
+    s.finalize()
+    try:
+        upload(s, F.F_PHI, so.random_field(grids, 7, (1, 1, 1), dom.box))
+        s.applyOp(0, F.F_RES, F.F_PHI)
+        np.testing.assert_array_equal(download_valid(s, F.F_RES, grids)[0], GOLD["bathy_applyop_box0"])
+    finally:
+        s.undefine()
+    # 10. leptic columns with a Dirichlet top
+    n, L = (16, 16, 8), (1.0, 1.0, 0.005)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, (8, 8, 8))
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_diagonal_metric(grids, dx, L, 3, "stretched", domain=dom)
+    lep = LevelLepticSolver()
+    lep.params.max_order, lep.params.domain_height = 3, L[2]
+    lep.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids], bc_type=[0, 0, 0, 0, 0, 1])
+    try:
+        lv = lep.level
+        lv.setBCValues([0.0, 0.0, 0.0, 0.0, 0.0, 0.3])
+        for q in range(lv.num_local_patches):
+            _, _, gi = lv.patch_box(q)
+            jg = [np.asfortranarray(Jgup[gi][d].a[..., d]) for d in range(3)]
+            lv.setMetricOrtho(q, jg[0], jg[1], jg[2], np.asfortranarray(Jinv[gi].a[..., 0]))
+        lep.finalize()
+        lv.setVal(F.F_PHI, 0.0)
+        upload(lv, F.F_RHS, so.random_field(grids, 9, domainBox=dom.box))
+        st = lep.solve(False)
+        assert [st["exitStatus"], int(st["usedFullSolver"])] == list(GOLD["leptic_diri_status_full"])
+        if not st["usedFullSolver"]:
+            assert st["resNorms"] == list(GOLD["leptic_diri_res_norms"])
+            np.testing.assert_array_equal(download_valid(lv, F.F_PHI, grids)[0], GOLD["leptic_diri_phi_box0"])
+        else:
+            np.testing.assert_allclose(st["resNorms"], GOLD["leptic_diri_res_norms"], rtol=1e-9)
+    finally:
+        lep.undefine()
+    # 11. inflow / outflow sides in the cell-centred divergence
+    dom, grids, dx, Jgup, Jinv = make_problem(so, (16, 16, 8), 8, "stretched", (False, True, False), (2.0, 1.0, 0.5))
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv)
+    try:
+        gpu.setVelBC([1, 2, 0, 0, 2, 1], [0.7, 0.0, 0.0, 0.0, 0.0, -0.3])
+        vel = smooth_cc_velocity(so, dom, grids, (1, 1, 1))
+        for q in range(gpu.num_local_patches):
+            gpu.uploadCCVel(q, vel[gpu.patch_box(q)[2]].a, (1, 1, 1))
+        gpu.divergenceCC(F.F_RHS, 1.0, True)
+        np.testing.assert_array_equal(download_valid(gpu, F.F_RHS, grids)[0], GOLD["cc_div_inflow_outflow_box0"])
+    finally:
+        gpu.undefine()
+    # 12. composite TGA step
+    ratios = [(2, 2, 2)]
+    fine = [[so.Box((8, 8, 4), (23, 15, 11)), so.Box((8, 16, 4), (23, 23, 11))]]
+    levels = make_amr_levels(so, sa, (16, 16, 8), (1.0, 1.0, 0.5), (False, False, False), ratios, fine, cbox=8)
+    a = AMRPressureSolver()
+    p = a._p
+    a.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg, p.hang,
+                         p.norm_thresh, 0)
+    L0 = levels[0]
+    a.defineAMR(L0.domain.box.lo, L0.domain.box.hi, L0.domain.periodic, L0.dx, ratios,
+                [[(g.lo, g.hi) for g in Lv.grids] for Lv in levels], alpha=1.0, beta=0.05, bc_type=[1, 1, 1, 0, 1, 1])
+    for v in a.levels:
+        v.setBCValues([0.1, 0.0, 0.0, 0.0, 0.0, -0.2])
+    for Lv, v in zip(levels, a.levels):
+        for q in range(v.num_local_patches):
+            _, _, gi = v.patch_box(q)
+            jg = [np.asfortranarray(Lv.Jgup[gi][d].a[..., d]) for d in range(3)]
+            v.setMetricOrtho(q, jg[0], jg[1], jg[2], np.asfortranarray(Lv.Jinv[gi].a[..., 0]))
+    a.finalize()
+    try:
+        for l, Lv in enumerate(levels):
+            upload(a.levels[l], F.F_HEAT_OLD, so.random_field(Lv.grids, 3 + l, (1, 1, 1), Lv.domain.box))
+            upload(a.levels[l], F.F_HEAT_SRC, so.random_field(Lv.grids, 13 + l, (1, 1, 1), Lv.domain.box))
+            upload(a.levels[l], F.F_PHI, so.random_field(Lv.grids, 23 + l, (1, 1, 1), Lv.domain.box))
+        st = a.tgaStepAMR(1, 0, 0.2)
+        assert [st["iters"], st["exitStatus"]] == list(GOLD["amr_tga_iters_exit"])
+        np.testing.assert_allclose(st["history"], GOLD["amr_tga_history"], rtol=1e-10)
+        got = download_valid(a.levels[1], F.F_PHI, levels[1].grids)[0]
+        np.testing.assert_allclose(got, GOLD["amr_tga_fine_phi_box0"], rtol=0, atol=1e-9)
+    finally:
+        a.undefine()
