@@ -40,4 +40,7 @@ def test_two_rank_bench_line():
     # coarsenable test works per box), so the cycles differ slightly -- but both contract alike
     assert two["config"]["mg_depth"] == one["config"]["mg_depth"] - 1
     assert two["vcycle_contraction"] == pytest.approx(one["vcycle_contraction"], rel=1e-2)
+    # what a sharded run has to reproduce is the SAME two-box layout held by one process (rank 0 computes it in the same run)
+    assert one["vcycle_contraction_single_process_same_layout"] is None
+    assert two["vcycle_contraction"] == pytest.approx(two["vcycle_contraction_single_process_same_layout"], rel=1e-9)
     assert 0.0 < one["vcycle_contraction"] < 1.0
