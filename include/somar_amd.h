@@ -48,7 +48,7 @@ extern "C" {
  * 5: + somar_amr_solve_host (multi-level host boundary), somar_k_gsrbiter3dortho (box-by-box kernel hook); additions only
  * 6: + somar_amr_tga_step (composite MappedAMRTGA::oneStep); composite operations with heat coefficients installed no
  *    longer fail (the flux-register scales follow beta); somar_solver_set_vel_bc (inflow / outflow sides); somar_solver_set_metric_map (cylindrical and bathymetric
- *    metric producers on the device); additions only */
+ *    metric producers on the device); somar_k_fillmappedlapdiag3d, somar_k_mappedaverage2 (kernel-level hooks); additions only */
 #define SOMAR_AMD_ABI_VERSION 6
 
 /* BCType codes, calculus/BCInterface/BCDescriptor.H:34-39 */
@@ -296,6 +296,34 @@ int somar_k_gsrbiter3dortho(double* phi, const int* iphilo0, const int* iphilo1,
                             const int* ilapDiaghi1, const int* ilapDiaghi2, const int* iregionlo0, const int* iregionlo1,
                             const int* iregionlo2, const int* iregionhi0, const int* iregionhi1, const int* iregionhi2,
                             const double* dx, const double* alpha, const double* beta, const int* redBlack);
+/* Two more of the Fortran exports, same conventions (parity-test hooks): FILLMAPPEDLAPDIAG3D (AMRElliptic/
+ * MappedAMRPoissonOpF.ChF:233-274, prototype MappedAMRPoissonOpF_F.H:139-146: lapDiag on `region` from component d of the
+ * direction-d FluxBox FAB and 1/J) and MAPPEDAVERAGE2 (MappedChombo/MappedCoarseAverageF.ChF:132-167, prototype
+ * MappedCoarseAverageF_F.H:111-117: the J-weighted restriction coarse = sum(fine / Jinv) / sum(1 / Jinv) over the refRatio
+ * block of every cell of `box`; bref = [0, refRatio - 1]). */
+int somar_k_fillmappedlapdiag3d(double* lapDiag, const int* ilapDiaglo0, const int* ilapDiaglo1, const int* ilapDiaglo2,
+                                const int* ilapDiaghi0, const int* ilapDiaghi1, const int* ilapDiaghi2, const double* Jg0,
+                                const int* iJg0lo0, const int* iJg0lo1, const int* iJg0lo2, const int* iJg0hi0,
+                                const int* iJg0hi1, const int* iJg0hi2, const int* nJg0comp, const double* Jg1,
+                                const int* iJg1lo0, const int* iJg1lo1, const int* iJg1lo2, const int* iJg1hi0,
+                                const int* iJg1hi1, const int* iJg1hi2, const int* nJg1comp, const double* Jg2,
+                                const int* iJg2lo0, const int* iJg2lo1, const int* iJg2lo2, const int* iJg2hi0,
+                                const int* iJg2hi1, const int* iJg2hi2, const int* nJg2comp, const double* Jinv,
+                                const int* iJinvlo0, const int* iJinvlo1, const int* iJinvlo2, const int* iJinvhi0,
+                                const int* iJinvhi1, const int* iJinvhi2, const int* iregionlo0, const int* iregionlo1,
+                                const int* iregionlo2, const int* iregionhi0, const int* iregionhi1, const int* iregionhi2,
+                                const double* dx);
+int somar_k_mappedaverage2(double* coarse, const int* icoarselo0, const int* icoarselo1, const int* icoarselo2,
+                           const int* icoarsehi0, const int* icoarsehi1, const int* icoarsehi2, const int* ncoarsecomp,
+                           const double* fine, const int* ifinelo0, const int* ifinelo1, const int* ifinelo2,
+                           const int* ifinehi0, const int* ifinehi1, const int* ifinehi2, const int* nfinecomp,
+                           const double* fineCCJinv, const int* ifineCCJinvlo0, const int* ifineCCJinvlo1,
+                           const int* ifineCCJinvlo2, const int* ifineCCJinvhi0, const int* ifineCCJinvhi1,
+                           const int* ifineCCJinvhi2, const int* iboxlo0, const int* iboxlo1, const int* iboxlo2,
+                           const int* iboxhi0, const int* iboxhi1, const int* iboxhi2, const int* refRatio,
+                           const int* ibreflo0, const int* ibreflo1, const int* ibreflo2, const int* ibrefhi0,
+                           const int* ibrefhi1, const int* ibrefhi2);
+
 
 /* stream control + HIP-event timing on the solver's own stream */
 int somar_sync(somar_solver_t* s);

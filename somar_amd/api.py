@@ -124,6 +124,10 @@ _SIGS = {
     # FORT_PROTO shapes: FRA = data, 3 lo, 3 hi, ncomp; FRA1 = data, 3 lo, 3 hi; BOX = 3 lo, 3 hi; then dx, alpha, beta, redBlack
     "somar_k_gsrbiter3dortho": ([_PD] + [_PI] * 7 + [_PD] + [_PI] * 7 + ([_PD] + [_PI] * 6) * 5 + [_PI] * 6
                                 + [_PD, _PD, _PD, _PI]),
+    # FILLMAPPEDLAPDIAG3D: FRA1 lapDiag, 3 x FRA Jg, FRA1 Jinv, BOX region, REALVECT dx
+    "somar_k_fillmappedlapdiag3d": ([_PD] + [_PI] * 6 + ([_PD] + [_PI] * 7) * 3 + [_PD] + [_PI] * 6 + [_PI] * 6 + [_PD]),
+    # MAPPEDAVERAGE2: FRA coarse, FRA fine, FRA1 fineCCJinv, BOX box, INTVECT refRatio, BOX bref
+    "somar_k_mappedaverage2": ([_PD] + [_PI] * 7 + [_PD] + [_PI] * 7 + [_PD] + [_PI] * 6 + [_PI] * 6 + [_PI] + [_PI] * 6),
     "somar_sync": [_H],
     "somar_timer_start": [_H],
     "somar_timer_stop": [_H, _PD],
@@ -749,6 +753,37 @@ def k_gsrbiter3dortho(phi, phi_lo, rhs, rhs_lo, jg, jg_lo, jinv, jinv_lo, lapdia
     args += ip(region[0]) + ip(region[1])
     args += [_da(dx), C.byref(C.c_double(alpha)), C.byref(C.c_double(beta)), C.byref(C.c_int(redBlack))]
     _ck(lib().somar_k_gsrbiter3dortho(*args))
+
+
+def _fort_ip(v):
+    return [C.byref(C.c_int(int(x))) for x in v]
+
+
+def _fort_fab(a, lo, ncomp):
+    """CHFp_FRA / CHFp_FRA1 argument group of a Fortran-ordered numpy array placed at lo"""
+    shp = a.shape[:3]
+    hi = [l + n - 1 for l, n in zip(lo, shp)]
+    out = [_dp(a)] + _fort_ip(lo) + _fort_ip(hi)
+    if ncomp:
+        out.append(C.byref(C.c_int(a.shape[3] if a.ndim == 4 else 1)))
+    return out
+
+
+def k_fillmappedlapdiag3d(lapdiag, lap_lo, jg, jg_lo, jinv, jinv_lo, region, dx):
+    """FILLMAPPEDLAPDIAG3D through the Fortran-shaped C entry; jg[d]: (faces..., 3) Fortran-ordered FluxBox FABs"""
+    args = _fort_fab(lapdiag, lap_lo, False)
+    for d in range(3):
+        args += _fort_fab(jg[d], jg_lo[d], True)
+    args += _fort_fab(jinv, jinv_lo, False) + _fort_ip(region[0]) + _fort_ip(region[1]) + [_da(dx)]
+    _ck(lib().somar_k_fillmappedlapdiag3d(*args))
+
+
+def k_mappedaverage2(coarse, coarse_lo, fine, fine_lo, fjinv, fjinv_lo, box, refRatio):
+    """MAPPEDAVERAGE2 through the Fortran-shaped C entry; coarse is written on `box`"""
+    args = _fort_fab(coarse, coarse_lo, True) + _fort_fab(fine, fine_lo, True) + _fort_fab(fjinv, fjinv_lo, False)
+    args += _fort_ip(box[0]) + _fort_ip(box[1]) + [(C.c_int * 3)(*[int(x) for x in refRatio])]
+    args += _fort_ip((0, 0, 0)) + _fort_ip([r - 1 for r in refRatio])
+    _ck(lib().somar_k_mappedaverage2(*args))
 
 
 def altered_jgup(nsq_fc, dximu_dz, dxinu_dz, gup, J, dt_theta, coriolis_f, hjac=None):

@@ -963,6 +963,108 @@ int somar_k_gsrbiter3dortho(double* phi, const int* iphilo0, const int* iphilo1,
     API_END
 }
 
+// FILLMAPPEDLAPDIAG3D (AMRElliptic/MappedAMRPoissonOpF.ChF:233-274; prototype MappedAMRPoissonOpF_F.H:139-146) on host FABs
+int somar_k_fillmappedlapdiag3d(double* lapDiag, const int* ilapDiaglo0, const int* ilapDiaglo1, const int* ilapDiaglo2,
+                                const int* ilapDiaghi0, const int* ilapDiaghi1, const int* ilapDiaghi2, const double* Jg0,
+                                const int* iJg0lo0, const int* iJg0lo1, const int* iJg0lo2, const int* iJg0hi0,
+                                const int* iJg0hi1, const int* iJg0hi2, const int* nJg0comp, const double* Jg1,
+                                const int* iJg1lo0, const int* iJg1lo1, const int* iJg1lo2, const int* iJg1hi0,
+                                const int* iJg1hi1, const int* iJg1hi2, const int* nJg1comp, const double* Jg2,
+                                const int* iJg2lo0, const int* iJg2lo1, const int* iJg2lo2, const int* iJg2hi0,
+                                const int* iJg2hi1, const int* iJg2hi2, const int* nJg2comp, const double* Jinv,
+                                const int* iJinvlo0, const int* iJinvlo1, const int* iJinvlo2, const int* iJinvhi0,
+                                const int* iJinvhi1, const int* iJinvhi2, const int* iregionlo0, const int* iregionlo1,
+                                const int* iregionlo2, const int* iregionhi0, const int* iregionhi1, const int* iregionhi2,
+                                const double* dx)
+{
+    API_BEGIN
+    HostFab fld = mkfab(lapDiag, ilapDiaglo0, ilapDiaglo1, ilapDiaglo2, ilapDiaghi0, ilapDiaghi1, ilapDiaghi2, nullptr);
+    HostFab fjg[3] = {mkfab(Jg0, iJg0lo0, iJg0lo1, iJg0lo2, iJg0hi0, iJg0hi1, iJg0hi2, nJg0comp),
+                      mkfab(Jg1, iJg1lo0, iJg1lo1, iJg1lo2, iJg1hi0, iJg1hi1, iJg1hi2, nJg1comp),
+                      mkfab(Jg2, iJg2lo0, iJg2lo1, iJg2lo2, iJg2hi0, iJg2hi1, iJg2hi2, nJg2comp)};
+    HostFab fji = mkfab(Jinv, iJinvlo0, iJinvlo1, iJinvlo2, iJinvhi0, iJinvhi1, iJinvhi2, nullptr);
+    const int rlo[3] = {*iregionlo0, *iregionlo1, *iregionlo2}, rhi[3] = {*iregionhi0, *iregionhi1, *iregionhi2};
+    const IBox region(rlo, rhi);
+    if (region.empty()) return 0;
+    const int four[3] = {4, 4, 4};
+    const bool per[3] = {false, false, false};
+    const int bct[3][2] = {{BC_NEUM, BC_NEUM}, {BC_NEUM, BC_NEUM}, {BC_NEUM, BC_NEUM}};
+    Level L;
+    Comm self;
+    L.define(region.grow(four), per, dx, bct, std::vector<IBox>{region}, std::vector<int>{0}, &self);
+    L.alloc_metric();
+    L.refresh_params();
+    hipStream_t st = nullptr;
+    for (int d = 0; d < 3; ++d) {
+        SOMAR_CHECK(fjg[d].ncomp > d, "Jg FAB of direction d must carry component d (the FluxBox layout)");
+        IBox fr = region;
+        fr.hi[d] += 1;
+        L.upload(L.dev.jg[d], 0, fjg[d].p + (size_t)d * fjg[d].box.numPts(), fjg[d].box, fr, st);   // component d = J g^{dd}
+    }
+    L.upload(L.dev.jinv, 0, fji.p, fji.box, region, st);
+    launch_lapdiag(st, L.dev);
+    L.download(L.dev.lapdiag, 0, lapDiag, fld.box, region, st);
+    SOMAR_HIP(hipStreamSynchronize(st));
+    API_END
+}
+
+// MAPPEDAVERAGE2 (MappedChombo/MappedCoarseAverageF.ChF:132-167; prototype MappedCoarseAverageF_F.H:111-117) on host FABs:
+// the J-weighted restriction of restrictResidual, coarse(ic) = sum(fine / Jinv) / sum(1 / Jinv) over the refRatio block
+int somar_k_mappedaverage2(double* coarse, const int* icoarselo0, const int* icoarselo1, const int* icoarselo2,
+                           const int* icoarsehi0, const int* icoarsehi1, const int* icoarsehi2, const int* ncoarsecomp,
+                           const double* fine, const int* ifinelo0, const int* ifinelo1, const int* ifinelo2,
+                           const int* ifinehi0, const int* ifinehi1, const int* ifinehi2, const int* nfinecomp,
+                           const double* fineCCJinv, const int* ifineCCJinvlo0, const int* ifineCCJinvlo1,
+                           const int* ifineCCJinvlo2, const int* ifineCCJinvhi0, const int* ifineCCJinvhi1,
+                           const int* ifineCCJinvhi2, const int* iboxlo0, const int* iboxlo1, const int* iboxlo2,
+                           const int* iboxhi0, const int* iboxhi1, const int* iboxhi2, const int* refRatio,
+                           const int* ibreflo0, const int* ibreflo1, const int* ibreflo2, const int* ibrefhi0,
+                           const int* ibrefhi1, const int* ibrefhi2)
+{
+    API_BEGIN
+    HostFab fc = mkfab(coarse, icoarselo0, icoarselo1, icoarselo2, icoarsehi0, icoarsehi1, icoarsehi2, ncoarsecomp);
+    HostFab ff = mkfab(fine, ifinelo0, ifinelo1, ifinelo2, ifinehi0, ifinehi1, ifinehi2, nfinecomp);
+    HostFab fj = mkfab(fineCCJinv, ifineCCJinvlo0, ifineCCJinvlo1, ifineCCJinvlo2, ifineCCJinvhi0, ifineCCJinvhi1,
+                       ifineCCJinvhi2, nullptr);
+    const int blo[3] = {*iboxlo0, *iboxlo1, *iboxlo2}, bhi[3] = {*iboxhi0, *iboxhi1, *iboxhi2};
+    const IBox cbox(blo, bhi);
+    if (cbox.empty()) return 0;
+    const int r[3] = {refRatio[0], refRatio[1], refRatio[2]};
+    const int brl[3] = {*ibreflo0, *ibreflo1, *ibreflo2}, brh[3] = {*ibrefhi0, *ibrefhi1, *ibrefhi2};
+    for (int d = 0; d < 3; ++d) {
+        SOMAR_CHECK(r[d] == 1 || r[d] == 2 || r[d] == 4, "refinement ratios are 1, 2 or 4 per direction");
+        SOMAR_CHECK(brl[d] == 0 && brh[d] == r[d] - 1, "bref must be the refRatio block [0, refRatio - 1]");
+    }
+    SOMAR_CHECK(fc.ncomp == ff.ncomp, "coarse and fine must carry the same number of components");
+    int flo[3], fhi[3];
+    for (int d = 0; d < 3; ++d) { flo[d] = cbox.lo[d] * r[d]; fhi[d] = (cbox.hi[d] + 1) * r[d] - 1; }
+    const IBox fbox(flo, fhi);
+    const int four[3] = {4, 4, 4};
+    const bool per[3] = {false, false, false};
+    const int bct[3][2] = {{BC_NEUM, BC_NEUM}, {BC_NEUM, BC_NEUM}, {BC_NEUM, BC_NEUM}};
+    const double dx1[3] = {1.0, 1.0, 1.0};
+    Level LF, LC;
+    Comm self;
+    int g4r[3] = {4 * r[0], 4 * r[1], 4 * r[2]};
+    LF.define(fbox.grow(g4r), per, dx1, bct, std::vector<IBox>{fbox}, std::vector<int>{0}, &self);
+    LC.define(cbox.grow(four), per, dx1, bct, std::vector<IBox>{cbox}, std::vector<int>{0}, &self);
+    LF.alloc_metric();
+    LC.alloc_metric();
+    hipStream_t st = nullptr;
+    LF.upload(LF.dev.jinv, 0, fj.p, fj.box, fbox, st);
+    double* dfine = LF.alloc_field();
+    double* dcrse = LC.alloc_field();
+    for (int n = 0; n < fc.ncomp; ++n) {
+        LF.upload(dfine, 0, fine + (size_t)n * ff.box.numPts(), ff.box, fbox, st);
+        launch_restrict(st, LC.dev, LF.dev, dcrse, dfine, r);
+        LC.download(dcrse, 0, coarse + (size_t)n * fc.box.numPts(), fc.box, cbox, st);
+    }
+    SOMAR_HIP(hipStreamSynchronize(st));
+    Level::free_field(dfine);
+    Level::free_field(dcrse);
+    API_END
+}
+
 int somar_solver_set_cc_j(somar_solver_t* s, int patch, const double* J, const double* Jinv, const int* ghost)
 {
     API_BEGIN

@@ -124,3 +124,45 @@ def test_fortran_shaped_gsrb_kernel_hook_bit_exact(oracle, redBlack):
     F.k_gsrbiter3dortho(got, plo, rhs, lo, jg, [lo, lo, lo], jinv, lo, lapd, lo, region, dx, 0.3, 1.7, redBlack)
     assert not np.array_equal(got, phi)
     np.testing.assert_array_equal(got, want)
+
+
+def test_fortran_shaped_lapdiag_and_average_hooks_bit_exact(oracle):
+    """FILLMAPPEDLAPDIAG3D and MAPPEDAVERAGE2 with the Fortran exports' own argument shapes (MappedAMRPoissonOpF_F.H:139-146,
+    MappedCoarseAverageF_F.H:111-117), on host FABs placed anywhere, against the C restatement on the same buffers"""
+    so = oracle
+    from somar_amd import api as F
+    rng = np.random.default_rng(5)
+    L = so.lib()
+    iv = lambda v: (C.c_int * 3)(*v)      # noqa: E731
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
+    # lapDiag
+    lo, n = (3, -2, 5), (20, 13, 9)
+    hi = tuple(a + b - 1 for a, b in zip(lo, n))
+    fhi = [tuple(h + (d == q) for q, h in enumerate(hi)) for d in range(3)]
+    jg3 = [np.asfortranarray(rng.uniform(0.5, 1.5, tuple(a + (d == q) for q, a in enumerate(n)) + (3,))) for d in range(3)]
+    jinv = np.asfortranarray(rng.uniform(0.5, 1.5, n))
+    dx = (0.1, 0.07, 0.2)
+    region = ((lo[0] + 2, lo[1], lo[2] + 1), (hi[0], hi[1] - 3, hi[2]))
+    want = np.full(n, -7.0, order="F")
+    L.orc_fillmappedlapdiag3d(dp(want), iv(lo), iv(hi), dp(jg3[0]), iv(lo), iv(fhi[0]), dp(jg3[1]), iv(lo), iv(fhi[1]),
+                              dp(jg3[2]), iv(lo), iv(fhi[2]), dp(jinv), iv(lo), iv(hi), iv(region[0]), iv(region[1]),
+                              (C.c_double * 3)(*dx))
+    got = np.full(n, -7.0, order="F")
+    F.k_fillmappedlapdiag3d(got, lo, jg3, [lo, lo, lo], jinv, lo, region, dx)
+    np.testing.assert_array_equal(got, want)
+    assert np.any(got != -7.0) and np.any(got == -7.0)          # written on the region only
+    # J-weighted average, two components, semicoarsening ratio (2, 1, 2)
+    r = (2, 1, 2)
+    cbox = ((2, -1, 3), (9, 6, 6))
+    flo = tuple(a * q for a, q in zip(cbox[0], r))
+    fn = tuple((h - a + 1) * q for a, h, q in zip(cbox[0], cbox[1], r))
+    fhi_ = tuple(a + b - 1 for a, b in zip(flo, fn))
+    fine = np.asfortranarray(rng.uniform(-1, 1, fn + (2,)))
+    fjinv = np.asfortranarray(rng.uniform(0.5, 1.5, fn))
+    cn = tuple(h - a + 1 for a, h in zip(cbox[0], cbox[1]))
+    want = np.zeros(cn + (2,), order="F")
+    L.orc_mappedaverage2(dp(want), iv(cbox[0]), iv(cbox[1]), 2, dp(fine), iv(flo), iv(fhi_), dp(fjinv), iv(flo), iv(fhi_),
+                         iv(cbox[0]), iv(cbox[1]), iv(r))
+    got = np.zeros(cn + (2,), order="F")
+    F.k_mappedaverage2(got, cbox[0], fine, flo, fjinv, flo, cbox, r)
+    np.testing.assert_array_equal(got, want)
