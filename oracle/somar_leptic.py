@@ -47,14 +47,16 @@ def flatten_box(b, pos):
     return so.Box((b.lo[0], b.lo[1], pos), (b.hi[0], b.hi[1], pos))
 
 
-def vert_avg_metric(grids, Jgup, domBox, isDiagonal=True):
+def vert_avg_metric(grids, Jgup, domBox, isDiagonal=True, which=None):
     """The horizontal problem's metric: vertical average of the horizontal block J g^{ab}, a, b < 2 (diagonal metric:
     only a == b is non-zero), J^{-1} := 1.  createVertAvgFCJgupPtr (geometry/LevelGeometryBasics.cpp:500-569):
     UNMAPPEDVERTINTEGRAL, levelSum += func * (1/Nz), k ascending."""
     pos = domBox.lo[2]
-    flat = [flatten_box(g, pos) for g in grids]
+    which = list(range(len(grids))) if which is None else list(which)   # the grids that get a flat twin (m_flatDI)
+    flat = [flatten_box(grids[i], pos) for i in which]
     hJg = so.FluxData(flat, 2, ndim=2)
-    for i, g in enumerate(grids):
+    for h, i in enumerate(which):
+        g = grids[i]
         scale = 1.0 / float(g.size()[2])
         for d in range(2):
             for b in range(2):
@@ -64,7 +66,7 @@ def vert_avg_metric(grids, Jgup, domBox, isDiagonal=True):
                 acc = np.zeros(src.shape[:2])
                 for k in range(src.shape[2]):
                     acc = acc + src[:, :, k] * scale
-                hJg[i][d].a[:, :, 0, b] = acc
+                hJg[h][d].a[:, :, 0, b] = acc
     hJinv = so.LevelData(flat, 1, (0, 0, 0), fill=1.0)
     return flat, hJg, hJinv
 
@@ -127,11 +129,16 @@ class LevelLepticSolver:
                     t.append(VBC_CF)
             self.vertBCTypes.append(tuple(t))
         self.doHorizSolve = any(t == (VBC_NEUM, VBC_NEUM) for t in self.vertBCTypes)
+        # m_flatDI: the grids that span the domain vertically (vertSpanCheck, :318-333); with Neumann walls these are the
+        # Neumann-Neumann columns.  m_flatDIComplement: the rest -- they take no part in the horizontal problem.
+        self.flatDI = [i for i, g in enumerate(grids) if g.lo[2] == domBox.lo[2] and g.hi[2] == domBox.hi[2]]
         if self.doHorizSolve:
-            # m_flatDI / m_flatDIComplement (columns that do not span the domain next to columns that do, :318-333) are
-            # not restated: either every column is Neumann-Neumann or none is
-            assert all(t == (VBC_NEUM, VBC_NEUM) for t in self.vertBCTypes), \
-                "layouts mixing Neumann-Neumann columns with Dirichlet / coarse-fine ended ones are not restated"
+            assert all((self.vertBCTypes[i] == (VBC_NEUM, VBC_NEUM)) == (i in self.flatDI) for i in range(len(grids))), \
+                "a column that spans the domain without being Neumann-Neumann next to Neumann-Neumann ones is not restated"
+            if len(self.flatDI) != len(grids):
+                # levelVertHorizGradient hands the non-spanning columns' Neumann ends boundary data as well (non-zero only
+                # with cross terms): restated for the diagonal metric, where it vanishes
+                assert op.isDiagonal, "mixed column kinds are restated for diagonal metrics"
         self.H = dx[2] * domBox.size()[2] if domainHeight is None else domainHeight
         # vertical grids == original grids; Jgup is shared, Jinv := 1 (the residual equation is scaled by J)
         self.Jgup = op.Jgup
@@ -154,10 +161,11 @@ class LevelLepticSolver:
         if not self.doHorizSolve:
             return
         # horizontal structures                                                   :304-432
-        self.flatGrids, hJg, hJinv = vert_avg_metric(grids, self.Jgup, domBox, op.isDiagonal)
+        # createHorizontalSolverGrids: the flattened spanning boxes (LepticBoxUtils.cpp:100-117)
+        self.horizGrids, hJg, hJinv = vert_avg_metric(grids, self.Jgup, domBox, op.isDiagonal, self.flatDI)
         self.horizDomain = so.Domain(flatten_box(domBox, domBox.lo[2]), dom.periodic)
-        hcf = sa.CFRegion(self.flatGrids, self.horizDomain) if self.cf is not None else None
-        hfac = so.Factory(self.horizDomain, self.flatGrids, dx, so.BCHolder(), hJg, hJinv, alpha=0.0, beta=1.0,
+        hcf = sa.CFRegion(self.horizGrids, self.horizDomain) if self.cf is not None else None
+        hfac = so.Factory(self.horizDomain, self.horizGrids, dx, so.BCHolder(), hJg, hJinv, alpha=0.0, beta=1.0,
                           isDiagonal=op.isDiagonal, ndim=2, maxDepth=hz["maxDepth"], precondIters=hz["precond"],
                           relaxMode=hz["relaxMode"], dxCrse=self.dxCrse, cf=hcf)   # forceDxCrse(m_dxCrse), :381
         hbot = so.BiCGStab(imax=hzb["imax"], eps=hzb["eps"], numRestarts=hzb["numRestarts"], hang=hzb["hang"],
@@ -166,7 +174,7 @@ class LevelLepticSolver:
         self.horizSolver.imin = hz["imin"]
         self.horizSolver.set_solver_parameters(hz["pre"], hz["post"], hz["bottom"], 1, hz["imax"], hz["eps"],
                                                hz["hang"], hz["normThresh"])
-        npts = sum(g.numPts() for g in self.flatGrids)
+        npts = sum(g.numPts() for g in self.horizGrids)
         self.horizRemoveAvg = npts == self.horizDomain.box.numPts()
         self.exitStatus = EXIT_NONE
         self.resNorms = []
@@ -178,6 +186,9 @@ class LevelLepticSolver:
         """excess = hiNeumBC - loNeumBC - Integral[rhs]                                :1183-1240"""
         dzScale = -1.0 * self.dx[2]
         for i, g in enumerate(self.grids):
+            if i not in self.flatDI:
+                excess[i][...] = 0.0                  # setToZero(a_excess, m_flatDIComplement), :1203
+                continue
             e = bcHi[i].copy()
             e = e + (-1.0) * bcLo[i]
             r = rhs[i].view(g)[..., 0]
@@ -233,6 +244,10 @@ class LevelLepticSolver:
                 self.lapack_vertical_solver(i, vertPhi, vertRhs)
             return
         for i, g in enumerate(self.grids):
+            if self.vertBCTypes[i] != (VBC_NEUM, VBC_NEUM):
+                # a column of the complement (mixed layout): its boundary data are zero for a diagonal metric
+                self.lapack_vertical_solver(i, vertPhi, vertRhs)
+                continue
             Nz = g.size()[2]
             r = vertRhs[i].view(g)[..., 0]
             # roll the BC values in: rhs -/+ NeumBCVal/dz (rollInFAB := 0; plus(bc, scale); rhs.plus(rollIn, 1))
@@ -261,6 +276,9 @@ class LevelLepticSolver:
             self.cf.homogeneous_cf_interp(phi, self.dx, self.dxCrse, (1, 1, 1))   # :1005
         so.exchange(phi, dom, phi.ghost)
         for i, g in enumerate(self.grids):
+            if i not in self.flatDI:
+                flatRhs[i][...] = 0.0                 # setValLevel(a_rhs, 0.0); only m_flatDI is filled (:1019-1021)
+                continue
             Nz = g.size()[2]
             dzScale = 1.0 / float(Nz)
             acc_rhs = np.zeros(g.size()[:2])
@@ -381,8 +399,8 @@ class LevelLepticSolver:
         flatRhs = [np.zeros(s) for s in flat2]
         bcLo = [np.zeros(s) for s in flat2]
         bcHi = [np.zeros(s) for s in flat2]
-        horizPhi = so.LevelData(self.flatGrids, 1, (1, 1, 0)) if self.doHorizSolve else None
-        horizRhs = so.LevelData(self.flatGrids, 1, (0, 0, 0)) if self.doHorizSolve else None
+        horizPhi = so.LevelData(self.horizGrids, 1, (1, 1, 0)) if self.doHorizSolve else None
+        horizRhs = so.LevelData(self.horizGrids, 1, (0, 0, 0)) if self.doHorizSolve else None
         useExcess = useHorizPhi = self.doHorizSolve
 
         # J * residual
@@ -420,11 +438,11 @@ class LevelLepticSolver:
             if useHorizPhi:
                 self.compute_horiz_rhs(flatRhs, vertPhi)
                 if useExcess:
-                    for i in range(len(grids)):
+                    for i in self.flatDI:
                         flatRhs[i][...] = flatRhs[i] + excess[i] * (-1.0 / H)
                 so.ld_set(horizRhs, 0.0)
-                for i, g in enumerate(self.flatGrids):
-                    horizRhs[i].view(g)[:, :, 0, 0] += flatRhs[i]
+                for h, i in enumerate(self.flatDI):      # flatRhs.addTo(horizRhs) through m_flatToHorizCopier
+                    horizRhs[h].view(self.horizGrids[h])[:, :, 0, 0] += flatRhs[i]
                 horizRhsNorm = so.ld_norm(horizRhs, self.normType)
                 if self.horizRhsTol * self.resNorms[0] > horizRhsNorm:
                     useHorizPhi = False
@@ -434,8 +452,9 @@ class LevelLepticSolver:
                 if self.horizRemoveAvg:
                     self.set_zero_avg(horizPhi)
                 self.horizSolves += 1
-                for i, g in enumerate(grids):   # ADDEXTRUSION
-                    vertPhi[i].view(g)[..., 0] += horizPhi[i].view(self.flatGrids[i])[:, :, 0, 0][:, :, None]
+                for h, i in enumerate(self.flatDI):   # ADDEXTRUSION on the spanning grids (addHorizontalCorrection, :1504)
+                    g = grids[i]
+                    vertPhi[i].view(g)[..., 0] += horizPhi[h].view(self.horizGrids[h])[:, :, 0, 0][:, :, None]
 
             op.residual(tmpRhs, vertPhi, rhs, True)
             resNorm = so.ld_norm(tmpRhs, self.normType)

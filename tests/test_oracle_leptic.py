@@ -323,12 +323,40 @@ def test_columns_ending_at_a_coarse_fine_interface():
     assert abs(jres - h[-1]) <= 1e-9 * h[0]
 
 
-def test_mixed_column_kinds_are_refused():
+def _mixed_levels():
+    """level 1, refined by (2, 2, 2): one box spanning the whole depth (Neumann-Neumann, part of the horizontal problem) next
+    to one that covers the lower half only (Neumann bottom, coarse-fine top: LAPACK line solves, no horizontal part)"""
     from oracle import somar_amr as sa
     from tests.helpers import make_amr_levels
     n, ratios = (16, 16, 8), [(2, 2, 2)]
-    fine = [[so.Box((8, 8, 0), (15, 23, 15)), so.Box((16, 8, 0), (23, 23, 7))]]   # one full column box, one half
-    levels = make_amr_levels(so, sa, n, (1.0, 1.0, 0.02), (False, False, False), ratios, fine, cbox=(8, 8, 8))
+    fine = [[so.Box((8, 8, 0), (15, 23, 15)), so.Box((16, 8, 0), (23, 23, 7))]]
+    levels = make_amr_levels(so, sa, n, (1.0, 1.0, 0.005), (False, False, False), ratios, fine, cbox=(8, 8, 8))
+    return levels, ratios
+
+
+def test_mixed_column_kinds_share_one_level_and_stall():
+    """m_flatDI / m_flatDIComplement (LevelLepticSolver.cpp:318-333): the spanning box alone carries the excess, the flat
+    problem and the extrusion; the half-depth box is solved column by column with dptsv.  As restated, the horizontal
+    correction is added to the spanning columns only (addHorizontalCorrection loops m_flatDI, :1504), which leaves a jump
+    across the fine-fine face to the non-spanning neighbour: the first order RAISES the residual and the later, purely
+    vertical orders cannot remove it -- the solve stalls near a quarter of the initial residual on the spanning box while
+    the half-depth box converges.  (Unpinned like everything here; the GPU path refuses such layouts.)  What must hold:
+    the reported norm is the true J-weighted residual of the level operator."""
+    from oracle import somar_amr as sa
+    levels, ratios = _mixed_levels()
     comp = sa.AMRComposite(levels, ratios, so.BCHolder(), so.BiCGStab())
-    with pytest.raises(AssertionError, match="mixing"):
-        sl.LevelLepticSolver(comp.ops[1], maxOrder=2)
+    op = comp.ops[1]
+    lep = sl.LevelLepticSolver(op, maxOrder=4, domainHeight=0.005)
+    assert lep.doHorizSolve and lep.flatDI == [0]
+    assert lep.vertBCTypes == [(sl.VBC_NEUM, sl.VBC_NEUM), (sl.VBC_NEUM, sl.VBC_CF)]
+    assert len(lep.horizGrids) == 1 and not lep.horizRemoveAvg
+    rhs = so.random_field(levels[1].grids, 9, domainBox=levels[1].domain.box)
+    phi = so.LevelData(levels[1].grids, 1, (1, 1, 1))
+    lep.solve(phi, rhs, True)
+    h = lep.resNorms
+    assert lep.horizSolves == 1 and h[1] > h[0] and 0.1 * h[0] < h[-1] < h[0]
+    res = so.LevelData(levels[1].grids, 1, (0, 0, 0))
+    op.residual(res, phi, rhs, True)
+    per_box = [float(np.max(np.abs(res[i].view(g) / op.Jinv[i].view(g)))) for i, g in enumerate(levels[1].grids)]
+    assert abs(max(per_box) - h[-1]) <= 1e-9 * h[0]
+    assert per_box[1] < 1e-3 * h[0] < per_box[0]          # the dptsv columns converge, the spanning box does not
