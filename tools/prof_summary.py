@@ -2,7 +2,7 @@
 """Condense rocprofv3 CSV output into the small summaries kept under profiles/.
 
   python tools/prof_summary.py stats  <dir-with-*_kernel_stats.csv/_kernel_trace.csv>  <out.md>
-  python tools/prof_summary.py pmc    <fetch-dir> <write-dir> <out.json> [cells]
+  python tools/prof_summary.py pmc    <fetch-dir> <write-dir> <out.json> [cells [kernel-substring,kernel-substring,...]]
 
 PMC recipe (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE come from separate passes;
 both are in KiB; on gfx950 FETCH_SIZE counts 128-B fills as 64 B, so read bytes are calibrated on a kernel
@@ -76,7 +76,7 @@ def _pmc_rows(d, counter):
     return out
 
 
-def pmc(fd, wd, out, cells):
+def pmc(fd, wd, out, cells, keys=None):
     fetch = _pmc_rows(fd, "FETCH_SIZE")
     write = _pmc_rows(wd, "WRITE_SIZE")
 
@@ -103,7 +103,7 @@ def pmc(fd, wd, out, cells):
         res["fetch_correction_from_mix_probe"] = 48.0 * 512 ** 3 / p2f[0]
         res["write_check_from_mix_probe"] = p2w[0] / (8.0 * 512 ** 3)
     res["raw"] = {}
-    for key in ("k_gsrb_ortho", "k_gsrb_fused", "k_op_ortho<0>", "k_resid_march<0", "k_resid_march<2", "k_restrict", "k_prolong"):
+    for key in (keys or ("k_gsrb_ortho", "k_gsrb_fused", "k_op_ortho<0>", "k_resid_march<0", "k_resid_march<2", "k_restrict", "k_prolong")):
         f, w = biggest(fetch, key), biggest(write, key)
         if f and w:
             res["raw"][key] = {"fetch_bytes_raw": f[0], "write_bytes": w[0], "launches": f[1]}
@@ -118,4 +118,5 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 512 ** 3)
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 512 ** 3,
+            sys.argv[6].split(",") if len(sys.argv) > 6 else None)
