@@ -313,3 +313,49 @@ def test_dirichlet_topped_columns_match_the_oracle(variant, H, maxOrder):
                 np.testing.assert_allclose(g_, w_, rtol=0, atol=1e-10 * float(np.max(np.abs(w_))))
     finally:
         s.undefine()
+
+
+def test_dirichlet_topped_columns_with_a_nondiagonal_metric():
+    """the same column mode on a terrain-following (19-point) operator: the tridiagonal systems take J g^{zeta zeta} alone
+    (LepticLapackVerticalSolver knows no cross terms), the residual test runs on the full operator"""
+    from somar_amd import LevelLepticSolver
+    from somar_amd.api import F_PHI, F_RHS
+    n, box, L, maxOrder = (32, 32, 8), (16, 16, 8), (64.0, 64.0, 1.0), 3
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, box)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_terrain_metric(grids, dx, L, dom)
+    types = [[N_, N_], [N_, N_], [N_, D_]]
+    bc = so.BCHolder([list(t) for t in types], [[0.0, 0.0], [0.0, 0.0], [0.0, 0.0]])
+    fac = so.Factory(dom, grids, dx, bc, Jgup, Jinv, isDiagonal=False)
+    op = so.AMRMultiGrid(fac, so.BiCGStab()).op
+    lep = sl.LevelLepticSolver(op, maxOrder=maxOrder, domainHeight=L[2])
+    assert not lep.doHorizSolve
+    rhs = so.random_field(grids, 9, domainBox=dom.box)
+    phi = so.LevelData(grids, 1, (1, 1, 1))
+    s = LevelLepticSolver()
+    s.params.max_order, s.params.domain_height = maxOrder, L[2]
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids], bc_type=[t for q in types for t in q])
+    try:
+        lv = s.level
+        for p_ in range(lv.num_local_patches):
+            _, _, gi = lv.patch_box(p_)
+            lv.setMetricFull(p_, *[np.asfortranarray(Jgup[gi][d].a) for d in range(3)], np.asfortranarray(Jinv[gi].a[..., 0]))
+        s.finalize()
+        lv.setVal(F_PHI, 0.0)
+        upload(lv, F_RHS, rhs)
+        status = lep.solve(phi, rhs, True)
+        st = s.solve(True)
+        assert st["exitStatus"] == status and st["horizSolves"] == 0 and st["usedFullSolver"] == lep.usedFullSolver
+        got, want = download_valid(lv, F_PHI, grids), valid_of(phi)
+        if not lep.usedFullSolver:
+            assert st["resNorms"] == lep.resNorms
+            for g_, w_ in zip(got, want):
+                np.testing.assert_array_equal(g_, w_)
+        else:
+            np.testing.assert_allclose(st["resNorms"], lep.resNorms, rtol=1e-8)
+            scale = max(float(np.max(np.abs(w_))) for w_ in want)
+            for g_, w_ in zip(got, want):
+                np.testing.assert_allclose(g_, w_, rtol=0, atol=1e-9 * scale)
+    finally:
+        s.undefine()
