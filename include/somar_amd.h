@@ -49,7 +49,7 @@ extern "C" {
  * 6: + somar_amr_tga_step (composite MappedAMRTGA::oneStep); composite operations with heat coefficients installed no
  *    longer fail (the flux-register scales follow beta); somar_solver_set_vel_bc (inflow / outflow sides); somar_solver_set_metric_map (cylindrical and bathymetric
  *    metric producers on the device); somar_k_fillmappedlapdiag3d, somar_k_mappedaverage2 (kernel-level hooks); additions only */
-#define SOMAR_AMD_ABI_VERSION 6
+#define SOMAR_AMD_ABI_VERSION 7
 
 /* BCType codes, calculus/BCInterface/BCDescriptor.H:34-39 */
 #define SOMAR_BC_NONE (-1)
@@ -186,6 +186,10 @@ int somar_vcycle_from_zero(somar_solver_t* s, int corr_field, int res_field);
  * such a level of a somar_amr hierarchy. */
 int somar_mini_vcycle(somar_solver_t* s, int corr_field, int res_field);
 int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* iters, int* exit_code);
+/* how the LAST bottom solve ran (Chombo BiCGStabSolver as AMRPressureSolver.cpp:253-265 configures it): 0 = launch by launch,
+ * 1 = one single-workgroup launch (bottoms of at most 512 cells), 2 = one persistent launch with one workgroup per box and
+ * device-wide barriers (multi-box bottoms; SOMAR_BOX_BOTTOM=0 switches it off).  Same iterates on every path. */
+int somar_bottom_kind(somar_solver_t* s, int* kind);
 
 /* MAC level projection of a face-centred velocity given in flux form (J u^a on a-faces, one host array per
  * local patch spanning faces(valid, a)):  rhs = div(U)/dt ; solve ; U -= dt * Jg^{aa} d_a(phi).

@@ -101,6 +101,7 @@ _SIGS = {
     "somar_vcycle_from_zero": [_H, C.c_int, C.c_int],
     "somar_mini_vcycle": [_H, C.c_int, C.c_int],
     "somar_bottom_solve": [_H, C.c_int, C.c_int, _PI, _PI],
+    "somar_bottom_kind": [_H, _PI],
     "somar_vel_upload": [_H, C.c_int, C.c_int, _PD],
     "somar_vel_download": [_H, C.c_int, C.c_int, _PD],
     "somar_vel_wall_bc": [_H],
@@ -627,6 +628,12 @@ class AMRPressureSolver:
         it, ex = C.c_int(), C.c_int()
         _ck(lib().somar_bottom_solve(self._h, phi_field, rhs_field, C.byref(it), C.byref(ex)))
         return it.value, ex.value
+
+    def bottomKind(self):
+        """how the last bottom solve ran: 0 launch by launch, 1 one single-workgroup launch, 2 one persistent launch, a workgroup per box"""
+        k = C.c_int()
+        _ck(lib().somar_bottom_kind(self._h, C.byref(k)))
+        return k.value
 
     # -- MAC level projection (LevelMACProjector / BaseProjector::project, velocity in flux form) -------
     def uploadVel(self, d, patch, host):

@@ -519,6 +519,13 @@ int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* ite
     API_END
 }
 
+int somar_bottom_kind(somar_solver_t* s, int* kind)
+{
+    API_BEGIN
+    *kind = s->ps->bottom_kind;
+    API_END
+}
+
 int somar_vel_upload(somar_solver_t* s, int dir, int patch, const double* host)
 {
     API_BEGIN

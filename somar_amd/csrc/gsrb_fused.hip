@@ -64,17 +64,20 @@ __device__ __forceinline__ double2 uni2(double c, bool, bool) { return make_doub
 // One GSRB point update of cell (gi,gj,gk): interior form = GSRBITER3DORTHO, cells touching a domain
 // face = GSRBBOUNDARYITER3DORTHO (a Neumann face contributes neither flux nor diagonal; a Dirichlet face contributes
 // both, its ghost being -own).  own = the cell's value before this update.
-template <bool DIRI>
+// INT: the caller's tile (its red ring included) touches no domain face and no seam in x and y, so only the plane's position
+// in z -- the same for every lane -- decides between the two forms: the per-lane classification (periodic wrap, six
+// compares, a divergent branch) collapses into one scalar test per plane.
+template <bool DIRI, bool INT = false>
 __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS, double yyS, double zzS, int gi,
                                              int gj, int gk, double pxl, double pxh, double pyl, double pyh,
                                              double pzl, double pzh, double gxl, double gxh, double gyl, double gyh,
                                              double gzl, double gzh, double Ji, double rhs, double own)
 {
     // a ring cell may be the periodic image of a cell on the far side: classify the REAL cell
-    if (P.periodic[0]) { const int n = P.dom_hi[0] - P.dom_lo[0] + 1; gi = gi < P.dom_lo[0] ? gi + n : (gi > P.dom_hi[0] ? gi - n : gi); }
-    if (P.periodic[1]) { const int n = P.dom_hi[1] - P.dom_lo[1] + 1; gj = gj < P.dom_lo[1] ? gj + n : (gj > P.dom_hi[1] ? gj - n : gj); }
+    if (!INT && P.periodic[0]) { const int n = P.dom_hi[0] - P.dom_lo[0] + 1; gi = gi < P.dom_lo[0] ? gi + n : (gi > P.dom_hi[0] ? gi - n : gi); }
+    if (!INT && P.periodic[1]) { const int n = P.dom_hi[1] - P.dom_lo[1] + 1; gj = gj < P.dom_lo[1] ? gj + n : (gj > P.dom_hi[1] ? gj - n : gj); }
     if (P.periodic[2]) { const int n = P.dom_hi[2] - P.dom_lo[2] + 1; gk = gk < P.dom_lo[2] ? gk + n : (gk > P.dom_hi[2] ? gk - n : gk); }
-    const bool onb = (gi == P.dom_lo[0]) || (gi == P.dom_hi[0]) || (gj == P.dom_lo[1]) || (gj == P.dom_hi[1]) ||
+    const bool onb = (!INT && ((gi == P.dom_lo[0]) || (gi == P.dom_hi[0]) || (gj == P.dom_lo[1]) || (gj == P.dom_hi[1]))) ||
                      (gk == P.dom_lo[2]) || (gk == P.dom_hi[2]);
     if (!onb) {
         const double JDxx = xxS * (gxh * pxh + gxl * pxl);
@@ -85,17 +88,17 @@ __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS,
         const double lapd = -Ji * ((gxh + gxl) * xxS + (gyh + gyl) * yyS + (gzh + gzl) * zzS);
         return (rhs - lphi) / (P.alpha + P.beta * lapd);
     }
-    const bool nxl = (gi == P.dom_lo[0]) && P.neum[0][0];
-    const bool nxh = (gi == P.dom_hi[0]) && P.neum[0][1];
-    const bool nyl = (gj == P.dom_lo[1]) && P.neum[1][0];
-    const bool nyh = (gj == P.dom_hi[1]) && P.neum[1][1];
+    const bool nxl = !INT && (gi == P.dom_lo[0]) && P.neum[0][0];
+    const bool nxh = !INT && (gi == P.dom_hi[0]) && P.neum[0][1];
+    const bool nyl = !INT && (gj == P.dom_lo[1]) && P.neum[1][0];
+    const bool nyh = !INT && (gj == P.dom_hi[1]) && P.neum[1][1];
     const bool nzl = (gk == P.dom_lo[2]) && P.neum[2][0];
     const bool nzh = (gk == P.dom_hi[2]) && P.neum[2][1];
     // A Dirichlet face: the neighbour beyond it is the ghost ELLIPTICCONSTDIRIBCGHOST (order 1, homogeneous inside the
     // smoother) derives from this very cell, -phi(cell).  The cell keeps its value through the other colour's pass, so
     // the ghost LevelGSRB refills before each pass is -own in both; it never has to exist in memory.
     // (DIRI is a template parameter: the Neumann / periodic instantiations carry none of this.)
-    if (DIRI) {
+    if (DIRI) {   // (never together with INT)
         if ((gi == P.dom_lo[0]) && P.diri[0][0]) pxl = -own;
         if ((gi == P.dom_hi[0]) && P.diri[0][1]) pxh = -own;
         if ((gj == P.dom_lo[1]) && P.diri[1][0]) pyl = -own;
@@ -124,23 +127,23 @@ __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS,
 //    post-smoothing sweep instead of a separate 16 B/cell pass.
 // 3: phi_in is read as value + crse(i / r): the prolongation (CONSTINTERPPS) folded into the first post-smoothing
 //    sweep -- ghosts included, which needs crse exchanged one cell deep.  4: as 3, minus sums[0]/sums[1].
-template <int FR_J, int INMODE, bool DIRI = false, bool UNI = false>
-__global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict__ tiles,
-                                                     const PatchDesc* __restrict__ patches,
-                                                     double* __restrict__ phi_out,
-                                                     const double* __restrict__ phi_in,
-                                                     const double* __restrict__ rhs,
-                                                     const double* __restrict__ jgx,
-                                                     const double* __restrict__ jgy,
-                                                     const double* __restrict__ jgz,
-                                                     const double* __restrict__ jinv, StencilParams P,
-                                                     const double* __restrict__ sums,
-                                                     const PatchDesc* __restrict__ cpatches,
-                                                     const double* __restrict__ crse, int r0, int r1, int r2)
+// INT (uniform-metric instantiations only): this tile and its red ring touch no domain face, periodic seam or coarse-fine face
+// in x and y -- over 90 % of the tiles of a large level -- so everything that classifies a cell against those per lane
+// is compiled out (gsrb_point<.., INT>, the ring's existence tests, the coarse-fine ghosts of x and y).  Same arithmetic on
+// the same values: same bits.
+template <int FR_J, int INMODE, bool DIRI, bool UNI, bool INT>
+__device__ __forceinline__ void gsrb_fused_body(double (&S)[3][FR_J][FR_I], const Tile& t, const PatchDesc& p,
+                                                double* __restrict__ phi_out,
+                                                const double* __restrict__ phi_in,
+                                                const double* __restrict__ rhs,
+                                                const double* __restrict__ jgx,
+                                                const double* __restrict__ jgy,
+                                                const double* __restrict__ jgz,
+                                                const double* __restrict__ jinv, const StencilParams& P,
+                                                const double* __restrict__ sums,
+                                                const PatchDesc* __restrict__ cpatches,
+                                                const double* __restrict__ crse, int r0, int r1, int r2)
 {
-    __shared__ __attribute__((aligned(16))) double S[3][FR_J][FR_I];
-    const Tile t = tiles[blockIdx.x];
-    const PatchDesc p = patches[t.patch];
     const double avg = (INMODE == 2 || INMODE == 4) ? sums[0] / sums[1] : 0.0;
     const int lane = threadIdx.x, row = threadIdx.y;
     const int ri = 2 * lane;       // region column of the pair's first cell
@@ -201,16 +204,18 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
         const int l = li + s, g = p.lo[0] + l, r = ri + s;
         bool cmp = (l >= -1) && (l <= p.n[0]) && (r >= 1) && (r <= wi + 2) && (lj >= -1) && (lj <= p.n[1]) &&
                    (row >= 1) && (row <= FR_J - 2);
-        if ((g < P.dom_lo[0] && (P.neum[0][0] || (DIRI && P.diri[0][0]))) ||
-            (g > P.dom_hi[0] && (P.neum[0][1] || (DIRI && P.diri[0][1]))))
-            cmp = false;
-        if ((gj < P.dom_lo[1] && (P.neum[1][0] || (DIRI && P.diri[1][0]))) ||
-            (gj > P.dom_hi[1] && (P.neum[1][1] || (DIRI && P.diri[1][1]))))
-            cmp = false;
-        // beyond a coarse-fine face of this box there is no cell of this level either: the ghost there is an
-        // interpolated value (filled before the sweep for the red phase, recomputed below for the black one)
-        if ((l < 0 && (p.cf & 1)) || (l >= p.n[0] && (p.cf & 2))) cmp = false;
-        if ((lj < 0 && (p.cf & 4)) || (lj >= p.n[1] && (p.cf & 8))) cmp = false;
+        if (!INT) {
+            if ((g < P.dom_lo[0] && (P.neum[0][0] || (DIRI && P.diri[0][0]))) ||
+                (g > P.dom_hi[0] && (P.neum[0][1] || (DIRI && P.diri[0][1]))))
+                cmp = false;
+            if ((gj < P.dom_lo[1] && (P.neum[1][0] || (DIRI && P.diri[1][0]))) ||
+                (gj > P.dom_hi[1] && (P.neum[1][1] || (DIRI && P.diri[1][1]))))
+                cmp = false;
+            // beyond a coarse-fine face of this box there is no cell of this level either: the ghost there is an
+            // interpolated value (filled before the sweep for the red phase, recomputed below for the black one)
+            if ((l < 0 && (p.cf & 1)) || (l >= p.n[0] && (p.cf & 2))) cmp = false;
+            if ((lj < 0 && (p.cf & 4)) || (lj >= p.n[1] && (p.cf & 8))) cmp = false;
+        }
         comp_ij[s] = cmp;
         out_ij[s] = (l >= 0) && (l < p.n[0]) && (lj >= 0) && (lj < p.n[1]) && (r >= 2) && (r < wi + 2) &&
                     (row >= 2) && (row < FR_J - 2);
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
             if (comp) {
                 const double pxl = S[slot][row][rc - 1], pxh = S[slot][row][rc + 1];
                 const double pyl = S[slot][row - 1][rc], pyh = S[slot][row + 1][rc];
-                red = gsrb_point<DIRI>(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, gk, pxl, pxh, pyl, pyh, pick(Pm, c),
+                red = gsrb_point<DIRI, INT>(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, gk, pxl, pxh, pyl, pyh, pick(Pm, c),
                                  pick(Pp, c), c ? Gx.y : Gx.x, c ? gx_next : Gx.y, pick(Gy, c), pick(Gyh, c),
                                  pick(Gzc, c), pick(Gzp, c), pick(Ji, c), pick(Rh, c), red);
                 S[slot][row][rc] = red;  // visible to the black phase of the NEXT step (after its barrier)
@@ -308,21 +313,23 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
                     double pxl = S[sb][row][rc - 1], pxh = S[sb][row][rc + 1];
                     double pyl = S[sb][row - 1][rc], pyh = S[sb][row + 1][rc];
                     double pzl = redPrev2, pzh = red;
-                    if (p.cf) {
+                    if (INT ? (p.cf & 48) != 0 : p.cf != 0) {
                         // homogeneousCFInterp between the colours (LevelGSRB refills the CF ghosts before the
                         // black pass): ghost = c1 * first valid cell (this black cell, old value) + c2 * second
                         // valid cell (its opposite neighbour, a NEW red value)
                         const double own = S[sb][row][rc];
                         const int l = li + c;
                         const double xl = pxl, xh = pxh, yl = pyl, yh = pyh, zl = pzl, zh = pzh;
-                        if ((p.cf & 1) && l == 0) pxl = P.cf_c1[0] * own + P.cf_c2[0] * xh;
-                        if ((p.cf & 2) && l == p.n[0] - 1) pxh = P.cf_c1[0] * own + P.cf_c2[0] * xl;
-                        if ((p.cf & 4) && lj == 0) pyl = P.cf_c1[1] * own + P.cf_c2[1] * yh;
-                        if ((p.cf & 8) && lj == p.n[1] - 1) pyh = P.cf_c1[1] * own + P.cf_c2[1] * yl;
+                        if (!INT) {
+                            if ((p.cf & 1) && l == 0) pxl = P.cf_c1[0] * own + P.cf_c2[0] * xh;
+                            if ((p.cf & 2) && l == p.n[0] - 1) pxh = P.cf_c1[0] * own + P.cf_c2[0] * xl;
+                            if ((p.cf & 4) && lj == 0) pyl = P.cf_c1[1] * own + P.cf_c2[1] * yh;
+                            if ((p.cf & 8) && lj == p.n[1] - 1) pyh = P.cf_c1[1] * own + P.cf_c2[1] * yl;
+                        }
                         if ((p.cf & 16) && kb == 0) pzl = P.cf_c1[2] * own + P.cf_c2[2] * zh;
                         if ((p.cf & 32) && kb == p.n[2] - 1) pzh = P.cf_c1[2] * own + P.cf_c2[2] * zl;
                     }
-                    black = gsrb_point<DIRI>(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, p.lo[2] + kb, pxl, pxh, pyl, pyh,
+                    black = gsrb_point<DIRI, INT>(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, p.lo[2] + kb, pxl, pxh, pyl, pyh,
                                        pzl, pzh, b_gxl, b_gxh, b_gyl, b_gyh, b_gzl, pick(Gzc, c), b_ji, b_rhs,
                                        S[sb][row][rc]);
                 }
@@ -374,6 +381,41 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
     }
 }
 
+template <int FR_J, int INMODE, bool DIRI = false, bool UNI = false>
+__global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict__ tiles,
+                                                     const PatchDesc* __restrict__ patches,
+                                                     double* __restrict__ phi_out,
+                                                     const double* __restrict__ phi_in,
+                                                     const double* __restrict__ rhs,
+                                                     const double* __restrict__ jgx,
+                                                     const double* __restrict__ jgy,
+                                                     const double* __restrict__ jgz,
+                                                     const double* __restrict__ jinv, StencilParams P,
+                                                     const double* __restrict__ sums,
+                                                     const PatchDesc* __restrict__ cpatches,
+                                                     const double* __restrict__ crse, int r0, int r1, int r2, int lean_ok)
+{
+    __shared__ __attribute__((aligned(16))) double S[3][FR_J][FR_I];
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    if (UNI && !DIRI) {
+        // does the tile grown by its red ring stay clear of every domain face (periodic seams included: the boundary form of
+        // the update applies there too) and of every coarse-fine face, in x and y?  One scalar test per workgroup.
+        const int wi = t.pad_[0] > 0 ? t.pad_[0] : FR_I - 4;
+        const int ilo = t.i0 - 1, ihi = min(t.i0 + wi, p.n[0]), jlo = t.j0 - 1, jhi = min(t.j0 + FR_J - 4, p.n[1]);
+        const bool lean = lean_ok && p.lo[0] + ilo > P.dom_lo[0] && p.lo[0] + ihi < P.dom_hi[0] && p.lo[1] + jlo > P.dom_lo[1] &&
+                          p.lo[1] + jhi < P.dom_hi[1] && !((p.cf & 1) && ilo < 0) && !((p.cf & 2) && ihi >= p.n[0]) &&
+                          !((p.cf & 4) && jlo < 0) && !((p.cf & 8) && jhi >= p.n[1]);
+        if (lean) {
+            gsrb_fused_body<FR_J, INMODE, DIRI, UNI, UNI && !DIRI>(S, t, p, phi_out, phi_in, rhs, jgx, jgy, jgz, jinv, P, sums,
+                                                                  cpatches, crse, r0, r1, r2);
+            return;
+        }
+    }
+    gsrb_fused_body<FR_J, INMODE, DIRI, UNI, false>(S, t, p, phi_out, phi_in, rhs, jgx, jgy, jgz, jinv, P, sums, cpatches, crse,
+                                                    r0, r1, r2);
+}
+
 void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* phi_out,
                        const double* phi_in, const double* rhs, int in_mode, const double* sums,
                        const LevelDev* C, const double* crse, const int* r)
@@ -381,9 +423,10 @@ void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const Leve
     if (ntiles == 0) return;
     const PatchDesc* cpatches = C ? C->patches : nullptr;
     const int r0 = r ? r[0] : 1, r1 = r ? r[1] : 1, r2 = r ? r[2] : 1;
+    static const int lean_ok = getenv("SOMAR_NO_LEAN_TILES") == nullptr;   // A/B switch: interior tiles take the general path too
 #define SOMAR_LAUNCH_FUSED(ROWS, M)                                                                                  \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gsrb_fused<ROWS, M>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
-                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2)
+                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2, lean_ok)
 #define SOMAR_LAUNCH_FUSED_MODES(ROWS)                 \
     switch (in_mode) {                                 \
         case 1: SOMAR_LAUNCH_FUSED(ROWS, 1); break;    \
@@ -400,7 +443,7 @@ void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const Leve
         // Dirichlet sides: no null space, hence never a mean removal (modes 2 / 4)
 #define SOMAR_LAUNCH_FUSED_D(ROWS, M)                                                                                       \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gsrb_fused<ROWS, M, true>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
-                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2)
+                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2, lean_ok)
         SOMAR_CHECK(in_mode == 0 || in_mode == 1 || in_mode == 3, "internal: mean removal on a level with Dirichlet sides");
         if (fused_rows() == 8) {
             if (in_mode == 1) SOMAR_LAUNCH_FUSED_D(8, 1); else if (in_mode == 3) SOMAR_LAUNCH_FUSED_D(8, 3); else SOMAR_LAUNCH_FUSED_D(8, 0);
@@ -414,7 +457,7 @@ void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const Leve
         // uniform metric: the four coefficient streams come from StencilParams
 #define SOMAR_LAUNCH_FUSED_U(M)                                                                                                 \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gsrb_fused<16, M, false, true>), dim3(ntiles), dim3(64, 16, 1), 0, st, tiles, L.patches, \
-                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2)
+                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2, lean_ok)
         switch (in_mode) {
             case 1: SOMAR_LAUNCH_FUSED_U(1); break;
             case 2: SOMAR_LAUNCH_FUSED_U(2); break;

@@ -146,6 +146,28 @@ struct TinyBicg {
     ScalarPublish pub;
 };
 void launch_tiny_bicgstab(hipStream_t st, const LevelDev& L, const CopyItem* items, int nitems, long long field_elems, TinyBicg A);
+// the BiCGStab bottom solve of a level of up to BOX_MAX_WG boxes of up to BOX_MAX_CELLS cells as ONE persistent launch, one
+// workgroup per box (k_box_bicgstab, kernels.hip): device-wide barriers where the launch-by-launch path has kernel boundaries.
+// nb: for every valid cell (boxes back to back, Fortran order inside a box; box b starts at cstart[b]) the field offsets of the
+// six cells its stencil reads (x-, x+, y-, y+, z-, z+): the neighbour itself, or -- across a box edge -- the valid cell the ghost
+// exchange would have copied from (built on the host from the level's exchange plan), so no ghost cell is ever filled.
+constexpr int BOX_MAX_WG = 128, BOX_MAX_CELLS = 2048;
+struct BoxBicg {
+    const PatchDesc* patches; int npatches;
+    const int* nb; const int* cstart;
+    const double* jg[3]; const double* jinv; const double* lapd;
+    StencilParams P;
+    double* phi; const double* rhs;
+    double* z[2];        // p~ and s~ in the level's layout: the only fields a workgroup reads outside its own box
+    int imax, numRestarts, normType, precondIters;
+    double eps, reps, hang, small, metric;
+    double* sums;        // 4 * BOX_MAX_WG doubles: per-box partial results of the running reduction(s), double-buffered
+    unsigned* sync;      // BOX_MAX_WG + 1: per workgroup the number of the last barrier it reached; abort flag (a barrier gave up); zeroed per launch
+    int serial;          // sums in the reference's serial order (levels of at most ordered_max cells) or by a fixed tree per box
+    double* info;        // device: iterations, exit code
+    ScalarPublish pub;
+};
+void launch_box_bicgstab(hipStream_t st, const LevelDev& L, int max_box_cells, BoxBicg A);
 // streaming probe (diagnostics): kind 0 copy, 1 read, 2 six reads + one write; in6: six arrays of `cells` doubles
 void launch_stream_probe(hipStream_t st, int kind, int workgroups, double* const* in6, double* out, long long cells);
 // (min, max) per (patch, k-chunk) of a over the valid cells (dir < 0) or valid dir-faces: out[2 * npatches * MM_CH] (device)

@@ -32,6 +32,8 @@ PressureSolver::PressureSolver(Comm* comm, hipStream_t shared) : comm_(comm ? co
     // levels up to this many cells sum in the reference's serial order (k_reduce_ordered); tests raise it to
     // make whole solves reproduce the oracle's histories to the last bits
     if (const char* e = getenv("SOMAR_ORDERED_REDUCE_MAX")) ordered_max_cells_ = atoll(e);
+    if (const char* e = getenv("SOMAR_BOX_BOTTOM")) box_bottom_on_ = atoi(e) != 0;
+    if (const char* e = getenv("SOMAR_BOX_BOTTOM_MIN_CELLS")) box_min_cells_ = atoll(e);
     if (const char* e = getenv("SOMAR_AGGLOM_CELLS")) agglom_cells_ = atoll(e);
     if (const char* e = getenv("SOMAR_GRAPH_CELLS")) graph_cells_ = atoll(e);
 }
@@ -65,6 +67,7 @@ PressureSolver::~PressureSolver()
                 if (c != d && L->dev.jgf[d][c]) { hipFree(L->dev.jgf[d][c]); L->dev.jgf[d][c] = nullptr; }
     hipFree(f_phi); hipFree(f_rhs); hipFree(f_uberRes); hipFree(f_uberCorr); hipFree(f_best);
     for (double* f : bicg) hipFree(f);
+    hipFree(d_box_nb_); hipFree(d_box_cstart_); hipFree(d_box_sums_); hipFree(d_box_sync_);
     hipFree(d_partials);
     hipFree(d_scalars);
     for (Prof& p : prof_) {
@@ -1615,10 +1618,104 @@ bool PressureSolver::fused_bottom(int d) const
            prm.relaxMode == RELAX_LEVEL_GSRB && prm.precondMode != PRECOND_DIAG_LINE_RELAX && bicg[7] != nullptr;
 }
 
+// A bottom level for the persistent one-workgroup-per-box BiCGStab (k_box_bicgstab): every box on this rank, the boxes cover
+// the whole domain (no coarse-fine faces), the 7-point operator with Neumann / periodic sides, point GSRB, at most BOX_MAX_WG
+// boxes of at most BOX_MAX_CELLS cells.
+bool PressureSolver::box_bottom(int d) const
+{
+    static const bool poll = !(getenv("SOMAR_POLL_FETCH") && atoi(getenv("SOMAR_POLL_FETCH")) == 0);
+    const Level& L = *lev[d];
+    if (!box_bottom_on_ || !poll || full_ || diri_ || L.ncf != 0 || !L.plan.peers.empty() || profiling_ || capturing_ ||
+        comm_->size != 1 || prm.relaxMode != RELAX_LEVEL_GSRB || prm.precondMode == PRECOND_DIAG_LINE_RELAX || !bicg[7])
+        return false;
+    if (L.valid_cells_global < box_min_cells_ || L.valid_cells_global != L.domain.numPts()) return false;
+    if (L.npatches() < 1 || L.npatches() > BOX_MAX_WG || L.field_elems > 0x7fffffffll) return false;
+    for (const PatchDesc& p : L.hpatches)
+        if ((long long)p.n[0] * p.n[1] * p.n[2] > BOX_MAX_CELLS) return false;
+    return true;
+}
+
+// For every valid cell of depth d (boxes back to back, Fortran order inside a box) the field offsets of the six cells its
+// stencil reads: the neighbour itself, or the valid cell the level's ghost exchange copies into that ghost cell (the exchange
+// plan applied to an identity map) -- k_box_bicgstab reads neighbouring boxes directly and never fills a ghost cell.
+void PressureSolver::build_box_tables(int d)
+{
+    if (box_depth_ == d) return;
+    SOMAR_CHECK(box_depth_ < 0, "box bottom solver tables built for another depth");
+    const Level& L = *lev[d];
+    std::vector<int> G((size_t)L.field_elems);
+    for (size_t q = 0; q < G.size(); ++q) G[q] = (int)q;
+    auto at = [](const PatchDesc& p, int i, int j, int k) { return p.off + i + (long long)p.pj * j + p.pk * k; };
+    for (const CopyItem& it : L.plan.local) {
+        const PatchDesc& sp = L.hpatches[it.src_patch];
+        const PatchDesc& dp = L.hpatches[it.dst_patch];
+        for (int k = 0; k < it.n[2]; ++k)
+            for (int j = 0; j < it.n[1]; ++j)
+                for (int i = 0; i < it.n[0]; ++i)
+                    G[(size_t)at(dp, it.dst_lo[0] + i, it.dst_lo[1] + j, it.dst_lo[2] + k)] =
+                        (int)at(sp, it.src_lo[0] + i, it.src_lo[1] + j, it.src_lo[2] + k);
+    }
+    std::vector<int> cstart(L.hpatches.size() + 1, 0), nb;
+    box_max_cells_ = 0;
+    for (size_t b = 0; b < L.hpatches.size(); ++b) {
+        const PatchDesc& p = L.hpatches[b];
+        const int cells = p.n[0] * p.n[1] * p.n[2];
+        cstart[b + 1] = cstart[b] + cells;
+        box_max_cells_ = std::max(box_max_cells_, cells);
+        for (int k = 0; k < p.n[2]; ++k)
+            for (int j = 0; j < p.n[1]; ++j)
+                for (int i = 0; i < p.n[0]; ++i) {
+                    const long long c = at(p, i, j, k);
+                    const long long off[6] = {c - 1, c + 1, c - p.pj, c + p.pj, c - p.pk, c + p.pk};
+                    for (int s = 0; s < 6; ++s)   // (a flat level has no z frame: those two entries are never read)
+                        nb.push_back(off[s] >= 0 && off[s] < L.field_elems ? G[(size_t)off[s]] : (int)c);
+                }
+    }
+    SOMAR_HIP(hipMalloc(&d_box_nb_, nb.size() * sizeof(int)));
+    SOMAR_HIP(hipMalloc(&d_box_cstart_, cstart.size() * sizeof(int)));
+    SOMAR_HIP(hipMalloc(&d_box_sums_, (size_t)4 * BOX_MAX_WG * sizeof(double)));
+    SOMAR_HIP(hipMalloc(&d_box_sync_, (BOX_MAX_WG + 1) * sizeof(unsigned)));
+    SOMAR_HIP(hipMemcpy(d_box_nb_, nb.data(), nb.size() * sizeof(int), hipMemcpyHostToDevice));
+    SOMAR_HIP(hipMemcpy(d_box_cstart_, cstart.data(), cstart.size() * sizeof(int), hipMemcpyHostToDevice));
+    box_depth_ = d;
+}
+
 void PressureSolver::bottom_solve(double* phi, const double* rhs)
 {
     const int d = (int)lev.size() - 1;
     const long long n = lev[d]->field_elems;
+    if (!fused_bottom(d) && box_bottom(d)) {
+        build_box_tables(d);
+        Level& L = *lev[d];
+        BoxBicg A;
+        std::memset(&A, 0, sizeof(A));
+        A.nb = d_box_nb_;
+        A.cstart = d_box_cstart_;
+        A.phi = phi;
+        A.rhs = rhs;
+        A.z[0] = bicg[4];
+        A.z[1] = bicg[5];
+        A.imax = prm.bottom_imax;
+        A.numRestarts = prm.bottom_numRestarts;
+        A.normType = prm.bottom_normType;
+        A.precondIters = (prm.num_smooth_precond == 0 || prm.precondMode == PRECOND_NONE) ? 0 : prm.num_smooth_precond;
+        A.eps = bottom_eps_eff;
+        A.reps = prm.bottom_reps;
+        A.hang = prm.bottom_hang;
+        A.small = prm.bottom_small;
+        A.metric = bottom_metric;
+        A.sums = d_box_sums_;
+        A.sync = d_box_sync_;
+        A.serial = ordered(d) ? 1 : 0;
+        A.info = d_scalars + SLOT_TMP;
+        A.pub = ScalarPublish{h_scalars + SLOT_TMP, h_seq_, ++fetch_seq_};
+        launch_box_bicgstab(st_, L.dev, box_max_cells_, A);
+        wait_published(A.pub.seq);
+        bottom_iters = (int)h_scalars[SLOT_TMP];
+        bottom_exit = (int)h_scalars[SLOT_TMP + 1];
+        bottom_kind = 2;
+        return;
+    }
     if (fused_bottom(d)) {
         Level& L = *lev[d];
         TinyBicg A;
@@ -1641,12 +1738,14 @@ void PressureSolver::bottom_solve(double* phi, const double* rhs)
         wait_published(A.pub.seq);
         bottom_iters = (int)h_scalars[SLOT_TMP];
         bottom_exit = (int)h_scalars[SLOT_TMP + 1];
+        bottom_kind = 1;
         return;
     }
     double *r = bicg[0], *r_tilde = bicg[1], *e = bicg[2], *p = bicg[3], *p_tilde = bicg[4], *s_tilde = bicg[5],
            *t = bicg[6], *v = bicg[7];
     const int nt = prm.bottom_normType;
     int recount = 0;
+    bottom_kind = 0;
     residual(d, r, phi, rhs);
     launch_copy(st_, r_tilde, r, n);
     launch_set(st_, e, n, 0.0);

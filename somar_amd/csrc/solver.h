@@ -208,6 +208,7 @@ public:
     // bottom-solver state shared with MappedAMRMultiGrid (setConvergenceMetrics)
     double bottom_metric = -1.0, bottom_eps_eff = 1e-6;
     int bottom_iters = 0, bottom_exit = 0;
+    int bottom_kind = 0;   // how the last bottom solve ran: 0 launch by launch, 1 k_tiny_bicgstab, 2 k_box_bicgstab
     std::vector<std::array<int, 3>> mgRefRatios;
 
 private:
@@ -247,6 +248,16 @@ private:
     bool tiny(int d) const;
     bool fused_bottom(int d) const;   // the whole BiCGStab bottom solve in one single-workgroup launch (k_tiny_bicgstab)
     void tiny_run(int d, double* const* fields, int nfields, const std::vector<TinyOp>& ops);
+    // the BiCGStab bottom solve of a multi-box bottom level as one persistent launch, one workgroup per box (k_box_bicgstab);
+    // SOMAR_BOX_BOTTOM=0 is the A/B switch (read once, at construction).  The neighbour table is built at the first use.
+    bool box_bottom(int d) const;
+    void build_box_tables(int d);
+    bool box_bottom_on_ = true;
+    long long box_min_cells_ = 513;      // smaller single-workgroup bottoms stay with k_tiny_bicgstab
+    int box_depth_ = -1, box_max_cells_ = 0;
+    int *d_box_nb_ = nullptr, *d_box_cstart_ = nullptr;
+    double* d_box_sums_ = nullptr;
+    unsigned* d_box_sync_ = nullptr;
     long long fused_min_cells_ = 262144;
     long long march_min_cells_ = 262144;  // levels at least this big use the k-marching operator/residual
     long long ordered_max_cells_ = 4096;

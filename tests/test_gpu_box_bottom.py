@@ -1,0 +1,160 @@
+"""k_box_bicgstab -- the BiCGStab bottom solve of a multi-box bottom level as ONE persistent launch, one workgroup per box,
+device-wide barriers where the launch-by-launch path has kernel boundaries (the path BASELINE C3 / C4 take: 16 boxes of 512
+cells / 64 boxes of 1024 cells) -- against PressureSolver::bottom_solve's launch-by-launch path (SOMAR_BOX_BOTTOM=0) and the
+oracle's restatement of Chombo's BiCGStabSolver (EXTERNAL to the reference; parity with SOMAR unpinned).
+
+Both GPU paths add their dot products in the reference's serial order here (SOMAR_ORDERED_REDUCE_MAX covers the level), so
+they must agree BIT FOR BIT: iteration count, exit code, solution.  Layouts: 64 / 288 / 512-cell boxes (one cell per thread),
+960-cell boxes (two), 2048-cell boxes (four); periodic wraps incl. a box that is its own neighbour; Neumann walls."""
+import numpy as np
+import pytest
+
+from helpers import download_valid, make_gpu_solver, make_oracle_solver, make_problem, max_rel_diff, upload, valid_of
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (n, boxsz, variant, periodic, L, maxDepth)
+    ((32, 32, 32), 16, "stretched", (False, False, False), (1.0, 1.0, 1.0), -1),        # 8 boxes of 4^3
+    ((64, 32, 16), 16, "stretched", (False, True, False), (4.0, 1.0, 0.5), 1),
+    ((48, 24, 24), (24, 12, 8), "stretched", (True, True, True), (1.0, 2.0, 1.0), 1),
+    ((36, 20, 12), (12, 20, 4), "stretched", (False, False, True), (1.0, 1.0, 3.0), 0),    # 960-cell boxes, y: one box wide
+    ((32, 32, 16), (16, 16, 8), "cartesian", (False, True, False), (1.0, 1.0, 1.0), 0),    # 2048-cell boxes
+    ((16, 16, 64), (16, 16, 8), "stretched", (True, True, False), (1.0, 1.0, 1.0), 0),     # periodic: a box is its own neighbour
+]
+
+
+@pytest.fixture(scope="module")
+def F():
+    from somar_amd import api
+    return api
+
+
+def _gpu(case, box_on, monkeypatch):
+    n, boxsz, variant, periodic, L, maxDepth = case
+    monkeypatch.setenv("SOMAR_BOX_BOTTOM", "1" if box_on else "0")
+    monkeypatch.setenv("SOMAR_BOX_BOTTOM_MIN_CELLS", "1")
+    monkeypatch.setenv("SOMAR_FUSED_BOTTOM_MAX_CELLS", "0")       # not the single-workgroup kernel
+    monkeypatch.setenv("SOMAR_ORDERED_REDUCE_MAX", "1000000")     # serial-order sums on the launch path at these sizes too
+    return n, boxsz, variant, periodic, L, maxDepth
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_box_bottom_solver_equals_the_launch_path_and_the_oracle(oracle, case, F, monkeypatch):
+    so = oracle
+    n, boxsz, variant, periodic, L, maxDepth = case
+    dom, grids, dx, Jgup, Jinv = make_problem(so, n, boxsz, variant, periodic, L)
+    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv, maxDepth=maxDepth)
+    D = amr.mg.depth
+    opb = amr.mg.ops[-1]
+    rhs = so.random_field(opb.grids, 91, (0, 0, 0), opb.domain.box)
+    so.remove_weighted_mean(rhs, opb.Jinv)
+    fp, fr = (F.FIELD(D - 1, F.F_CORR), F.FIELD(D - 1, F.F_RES)) if D > 1 else (F.F_CORR, F.F_RES)
+    res = so.random_field(grids, 92, (0, 0, 0), dom.box)
+    so.remove_weighted_mean(res, amr.op.Jinv)
+    out, cyc = {}, {}
+    for on in (False, True):
+        _gpu(case, on, monkeypatch)
+        gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv, maxDepth=maxDepth)
+        assert gpu.depth() == D
+        upload(gpu, fr, rhs, depth=D - 1)
+        gpu.setVal(fp, 0.0)
+        it, ex = gpu.bottomSolve(fp, fr)
+        assert gpu.bottomKind() == (2 if on else 0)
+        out[on] = (it, ex, download_valid(gpu, fp, opb.grids, D - 1))
+        # a second solve from the first one's answer (non-zero initial guess) and a whole V-cycle through it
+        it2, ex2 = gpu.bottomSolve(fp, fr)
+        upload(gpu, F.F_RES, res)
+        gpu.setVal(F.F_CORR, 0.0)
+        gpu.vcycle(F.F_CORR, F.F_RES)
+        cyc[on] = (it2, ex2, download_valid(gpu, F.F_CORR, grids))
+        gpu.undefine()
+    assert out[False][:2] == out[True][:2]
+    for a, b in zip(out[False][2], out[True][2]):
+        np.testing.assert_array_equal(a, b)
+    assert cyc[False][:2] == cyc[True][:2]
+    for a, b in zip(cyc[False][2], cyc[True][2]):
+        np.testing.assert_array_equal(a, b)
+    # the oracle's BiCGStab on the same level
+    phi = so.LevelData(opb.grids, 1, (1, 1, 1))
+    bs = so.BiCGStab()
+    bs.define(opb, True)
+    bs.solve(phi, rhs)
+    assert out[True][:2] == (bs.iters, bs.exitStatus)
+    for a, b in zip(out[True][2], valid_of(phi)):   # the oracle's sums and the kernel's run in the same order: same bits
+        np.testing.assert_array_equal(a, b)
+    assert max_rel_diff(out[True][2], valid_of(phi)) < 1e-9
+
+
+def test_max_norm_and_one_norm_variants(oracle, F, monkeypatch):
+    """bottom.normType 0 / 1 take the max / abs-sum reductions of the kernel"""
+    so = oracle
+    case = CASES[1]
+    n, boxsz, variant, periodic, L, maxDepth = case
+    dom, grids, dx, Jgup, Jinv = make_problem(so, n, boxsz, variant, periodic, L)
+    for nt in (0, 1):
+        got = {}
+        for on in (False, True):
+            _gpu(case, on, monkeypatch)
+            from somar_amd import AMRPressureSolver
+            s = AMRPressureSolver()
+            p = s._p
+            s.setAMRMGParameters(p.imin, p.imax, p.eps, maxDepth, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg,
+                                 p.hang, p.norm_thresh, 0)
+            s.setBottomParameters(p.bottom_imax, p.bottom_num_restarts, p.bottom_eps, p.bottom_reps, p.bottom_hang,
+                                  p.bottom_small, nt, 0)
+            s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids])
+            for q in range(s.num_local_patches):
+                _, _, gi = s.patch_box(q)
+                jg = [np.asfortranarray(Jgup[gi][d].a[..., d]) for d in range(3)]
+                s.setMetricOrtho(q, jg[0], jg[1], jg[2], np.asfortranarray(Jinv[gi].a[..., 0]))
+            s.finalize()
+            D = s.depth()
+            fp, fr = F.FIELD(D - 1, F.F_CORR), F.FIELD(D - 1, F.F_RES)
+            s.fillHash(fr, 77)
+            s.setVal(fp, 0.0)
+            it, ex = s.bottomSolve(fp, fr)
+            assert s.bottomKind() == (2 if on else 0)
+            got[on] = (it, ex, [s.download(fp, q, (0, 0, 0), D - 1) for q in range(s.num_local_patches)])
+            s.undefine()
+        assert got[False][:2] == got[True][:2], nt
+        for a, b in zip(got[False][2], got[True][2]):
+            np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("case", [CASES[4], ((64, 64, 16), (16, 8, 4), "stretched", (False, True, False), (2.0, 1.0, 0.5), 0)])
+def test_tree_sums_above_the_ordered_limit(oracle, case, F, monkeypatch):
+    """Above SOMAR_ORDERED_REDUCE_MAX cells (default 4096; BASELINE C3 / C4's bottoms have 8 192 / 65 536) the kernel adds each
+    box's terms by a fixed tree, as the launch path does on such levels: the same solve as the oracle's up to the rounding of
+    the dot products (BiCGStab amplifies a last-bit difference: the iterates drift apart, both solves stop at the same
+    relative residual 1e-6 within an iteration of each other, the solutions agree to a few 1e-5)."""
+    so = oracle
+    n, boxsz, variant, periodic, L, maxDepth = case
+    dom, grids, dx, Jgup, Jinv = make_problem(so, n, boxsz, variant, periodic, L)
+    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv, maxDepth=maxDepth)
+    opb = amr.mg.ops[-1]
+    assert sum(g.numPts() for g in opb.grids) > 4096
+    rhs = so.random_field(opb.grids, 91, (0, 0, 0), opb.domain.box)
+    so.remove_weighted_mean(rhs, opb.Jinv)
+    phi = so.LevelData(opb.grids, 1, (1, 1, 1))
+    bs = so.BiCGStab()
+    bs.define(opb, True)
+    bs.solve(phi, rhs)
+    monkeypatch.setenv("SOMAR_BOX_BOTTOM_MIN_CELLS", "1")
+    monkeypatch.delenv("SOMAR_ORDERED_REDUCE_MAX", raising=False)
+    got = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("SOMAR_BOX_BOTTOM", on)
+        gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv, maxDepth=maxDepth)
+        D = gpu.depth()
+        fp, fr = (F.FIELD(D - 1, F.F_CORR), F.FIELD(D - 1, F.F_RES)) if D > 1 else (F.F_CORR, F.F_RES)
+        upload(gpu, fr, rhs, depth=D - 1)
+        gpu.setVal(fp, 0.0)
+        it, ex = gpu.bottomSolve(fp, fr)
+        assert gpu.bottomKind() == (2 if on == "1" else 0)
+        got[on] = (it, ex, download_valid(gpu, fp, opb.grids, D - 1))
+        gpu.undefine()
+    for on in ("0", "1"):
+        it, ex, sol = got[on]
+        assert ex == bs.exitStatus and abs(it - bs.iters) <= 1, (on, it, ex, bs.iters, bs.exitStatus)
+        assert max_rel_diff(sol, valid_of(phi)) < 2e-4, on   # two converged (eps 1e-6) solves of the same system
