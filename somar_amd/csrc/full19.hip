@@ -33,18 +33,17 @@ struct JgFull { const double* c[3][3]; };  // c[faceDir][component]
 // ------------------------------------------------------------------------------------
 // REDIRECT: psi is kept in the boxes' frames only (its copy inside the valid region is never made): a read of psi at a
 // cell INSIDE the box's valid region returns phi there -- the value the full copy psi := phi would have put.
+// one op over the threads [t0, t0 + nt, ...) of the caller
 template <bool REDIRECT>
-__global__ void k_ghost_ops(const GhostOp* __restrict__ ops, const PatchDesc* __restrict__ patches,
-                            double* __restrict__ phi, double* __restrict__ psi, JgFull J, StencilParams P)
+__device__ __forceinline__ void ghost_op_body(const GhostOp& op, const PatchDesc& p, double* phi, double* psi,   // may alias
+                                              const JgFull& J, const StencilParams& P, int t0, int nt)
 {
-    const GhostOp op = ops[blockIdx.x];
-    const PatchDesc p = patches[op.patch];
     const int n0 = op.n[0], n01 = op.n[0] * op.n[1];
     const int cells = n01 * op.n[2];   // a ghost region of one box: far below 2^31 (32-bit index arithmetic: no 64-bit divisions)
     double* dst = op.dstf ? psi : phi;
     const double* src = op.srcf ? psi : phi;
     const long long st[3] = {1, (long long)p.pj, p.pk};
-    for (int idx = (int)(blockIdx.y * blockDim.x + threadIdx.x); idx < cells; idx += (int)(gridDim.y * blockDim.x)) {
+    for (int idx = t0; idx < cells; idx += nt) {
         const int k = idx / n01;
         const int r = idx - k * n01;
         const int j = r / n0, i = r - j * n0;
@@ -88,6 +87,51 @@ __global__ void k_ghost_ops(const GhostOp* __restrict__ ops, const PatchDesc* __
                                  (rd(psi, true, cc, 1) - rd(psi, true, cc, -1) + rd(psi, true, a, bk, cc, 1) - rd(psi, true, a, bk, cc, -1)) * J.c[a][cc][f] * idxc;
             phi[g] = phi[v] + (0.0 - cross) * P.dx[a] / J.c[a][a][f];
         }
+    }
+}
+
+template <bool REDIRECT>
+__global__ void k_ghost_ops(const GhostOp* __restrict__ ops, const PatchDesc* __restrict__ patches,
+                            double* phi, double* psi, JgFull J, StencilParams P)
+{
+    const GhostOp op = ops[blockIdx.x];
+    const PatchDesc p = patches[op.patch];
+    ghost_op_body<REDIRECT>(op, p, phi, psi, J, P, (int)(blockIdx.y * blockDim.x + threadIdx.x), (int)(gridDim.y * blockDim.x));
+}
+
+// A whole ghost program in ONE launch, one workgroup per box.  Every op of a program reads and writes the storage of its own
+// box only (the exchange that feeds it has already run), so the stage boundaries of the dependence schedule -- kernel boundaries
+// in the staged form, 12-20 launches per application -- need only a workgroup barrier.  box_ops: the ops of box b, sorted by
+// stage (GhostOp::pad_), are box_ops[box_first[b] .. box_first[b + 1]).  For the SMALL levels (boxes of at most a few thousand
+// cells: a face is a few hundred cells, one 256-thread workgroup is plenty): on BASELINE C5 5 500 of the 7 700 dispatches of an
+// AMR V-cycle were staged ghost ops of such levels, three quarters of them inside the bottom solver.
+template <bool REDIRECT>
+__global__ __launch_bounds__(256) void k_ghost_program(const GhostOp* __restrict__ box_ops, const int* __restrict__ box_first,
+                                                       const PatchDesc* __restrict__ patches, double* phi, double* psi,
+                                                       JgFull J, StencilParams P, int copy_all)
+{
+    const int b = blockIdx.x;
+    const PatchDesc p = patches[b];
+    if (copy_all) {
+        // the leading psi := phi of the full-copy programs (run_full_program), on the box grown by its one-cell frame: all a
+        // program of this box and the stencil kernel behind it read of psi
+        const int m0 = p.n[0] + 2, m1 = p.n[1] + 2, m2 = P.active[2] ? p.n[2] + 2 : 1, z0 = P.active[2] ? -1 : 0;
+        for (int idx = threadIdx.x; idx < m0 * m1 * m2; idx += blockDim.x) {
+            const int k = idx / (m0 * m1), r = idx - k * (m0 * m1);
+            const long long c = fidx(p, r % m0 - 1, r / m0 - 1, k + z0);
+            psi[c] = phi[c];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    int cur = -1;
+    for (int q = box_first[b]; q < box_first[b + 1]; ++q) {
+        const GhostOp op = box_ops[q];
+        if (op.pad_ != cur) {
+            if (cur >= 0) { __threadfence_block(); __syncthreads(); }
+            cur = op.pad_;
+        }
+        ghost_op_body<REDIRECT>(op, p, phi, psi, J, P, (int)threadIdx.x, (int)blockDim.x);
     }
 }
 
@@ -318,6 +362,16 @@ void launch_ghost_ops(hipStream_t st, const LevelDev& L, const GhostOp* ops, int
     P.bc_homog = bc_homog ? 1 : 0;
     if (redirect) hipLaunchKernelGGL(k_ghost_ops<true>, dim3(nops, L.ghost_gy), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
     else hipLaunchKernelGGL(k_ghost_ops<false>, dim3(nops, L.ghost_gy), dim3(256), 0, st, ops, L.patches, phi, psi, jgfull(L), P);
+}
+
+void launch_ghost_program(hipStream_t st, const LevelDev& L, const GhostOp* box_ops, const int* box_first, double* phi,
+                          double* psi, bool bc_homog, bool redirect, bool copy_all)
+{
+    if (L.npatches == 0) return;
+    StencilParams P = L.P;
+    P.bc_homog = bc_homog ? 1 : 0;
+    if (redirect) hipLaunchKernelGGL(k_ghost_program<true>, dim3(L.npatches), dim3(256), 0, st, box_ops, box_first, L.patches, phi, psi, jgfull(L), P, copy_all ? 1 : 0);
+    else hipLaunchKernelGGL(k_ghost_program<false>, dim3(L.npatches), dim3(256), 0, st, box_ops, box_first, L.patches, phi, psi, jgfull(L), P, copy_all ? 1 : 0);
 }
 
 void launch_flux_full(hipStream_t st, const LevelDev& L, double* const out[3], const double* phi, const double* psi)

@@ -30,6 +30,10 @@ struct LevelDev {
 // boxes' frames only -- the frame-only programs of the marching 19-point kernels, full19_march.hip)
 void launch_ghost_ops(hipStream_t st, const LevelDev& L, const GhostOp* ops, int nops, double* phi, double* psi,
                       bool bc_homog = true, bool redirect = false);
+// a whole ghost program in one launch, one workgroup per box (ops sorted by box, then stage = GhostOp::pad_; box b owns
+// box_ops[box_first[b] .. box_first[b + 1])); copy_all: psi := phi on every box grown by one cell first
+void launch_ghost_program(hipStream_t st, const LevelDev& L, const GhostOp* box_ops, const int* box_first, double* phi,
+                          double* psi, bool bc_homog, bool redirect, bool copy_all);
 // k-marching 19-point operator / residual (mode 0: out = rhs - L[phi], 1: out = L[phi]) and one GSRB colour pass
 // (out = phi with the colour's cells relaxed; out != phi); psi valid in the one-cell frames only (full19_march.hip)
 void launch_full_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out, const double* phi,

@@ -33,6 +33,7 @@ PressureSolver::PressureSolver(Comm* comm, hipStream_t shared) : comm_(comm ? co
     // make whole solves reproduce the oracle's histories to the last bits
     if (const char* e = getenv("SOMAR_ORDERED_REDUCE_MAX")) ordered_max_cells_ = atoll(e);
     if (const char* e = getenv("SOMAR_BOX_BOTTOM")) box_bottom_on_ = atoi(e) != 0;
+    if (const char* e = getenv("SOMAR_GHOST_STAGED")) ghost_box_on_ = atoi(e) == 0;
     if (const char* e = getenv("SOMAR_BOX_BOTTOM_MIN_CELLS")) box_min_cells_ = atoll(e);
     if (const char* e = getenv("SOMAR_AGGLOM_CELLS")) agglom_cells_ = atoll(e);
     if (const char* e = getenv("SOMAR_GRAPH_CELLS")) graph_cells_ = atoll(e);
@@ -57,10 +58,10 @@ PressureSolver::~PressureSolver()
     for (double* f : f_psi) hipFree(f);
     for (double* f : f_W) hipFree(f);
     hipFree(d_fold);
-    for (FullProgram& q : aux_prog_) hipFree(q.d_ops);
+    for (FullProgram& q : aux_prog_) free_program(q);
     for (double* f : f_heatflux) Level::free_field(f);
     for (auto& pr : full_prog_)
-        for (auto& q : pr) hipFree(q.d_ops);
+        for (auto& q : pr) free_program(q);
     for (auto& L : lev)
         for (int d = 0; d < 3; ++d)
             for (int c = 0; c < 3; ++c)

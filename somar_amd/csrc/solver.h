@@ -293,7 +293,15 @@ private:
     std::vector<char> sf_valid_;
     bool fold_prolong(int d) const;
     // ---- non-diagonal metric (19-point) path, solver_full.cpp ----
-    struct FullProgram { GhostOp* d_ops = nullptr; std::vector<int> first, count; };
+    // d_ops: the ops stage by stage (first / count per stage) for the staged form, one launch per stage; d_box_ops / d_box_first:
+    // the same ops sorted by box, then stage (GhostOp::pad_), for the one-launch form (k_ghost_program, small levels)
+    struct FullProgram { GhostOp* d_ops = nullptr; std::vector<int> first, count; GhostOp* d_box_ops = nullptr; int* d_box_first = nullptr; };
+    void upload_program(FullProgram& P, const std::vector<std::vector<GhostOp>>& stages, int npatches);
+    static void free_program(FullProgram& P);
+    // small levels run a ghost program as ONE launch, one workgroup per box (SOMAR_GHOST_STAGED=1: always stage by stage)
+    bool box_program(int d) const { return ghost_box_on_ && !full_march(d) && lev[d]->npatches() > 0; }
+    bool ghost_box_on_ = true;
+    void run_program(int d, const FullProgram& P, double* phi, double* psi, bool homogeneous, bool redirect, bool copy_all);
     bool full_ = false;
     std::vector<double*> f_psi;                            // per depth: the extrapolated copy of phi
     // per depth: [0] operator, [1] smoother, [2] fillExtrap alone (getFlux of the flux register), [3] ExtrapolateCFEV

@@ -286,6 +286,65 @@ static std::vector<GhostOp> frame_copy_stage(const Level& L)
     return out;
 }
 
+void PressureSolver::free_program(FullProgram& P)
+{
+    hipFree(P.d_ops);
+    hipFree(P.d_box_ops);
+    hipFree(P.d_box_first);
+    P.d_ops = nullptr;
+    P.d_box_ops = nullptr;
+    P.d_box_first = nullptr;
+}
+
+// stages (the ops of stage s may run together, stage s + 1 after them) -> the device tables of both forms
+void PressureSolver::upload_program(FullProgram& P, const std::vector<std::vector<GhostOp>>& stages, int npatches)
+{
+    free_program(P);
+    std::vector<GhostOp> flat;
+    P.first.clear();
+    P.count.clear();
+    std::vector<std::vector<GhostOp>> byBox(npatches);
+    for (size_t s = 0; s < stages.size(); ++s) {
+        P.first.push_back((int)flat.size());
+        P.count.push_back((int)stages[s].size());
+        for (GhostOp op : stages[s]) {
+            op.pad_ = (int)s;
+            flat.push_back(op);
+            byBox[op.patch].push_back(op);
+        }
+    }
+    if (flat.empty()) return;
+    std::vector<GhostOp> sorted;
+    std::vector<int> first(npatches + 1, 0);
+    for (int b = 0; b < npatches; ++b) {
+        first[b] = (int)sorted.size();
+        sorted.insert(sorted.end(), byBox[b].begin(), byBox[b].end());   // stage order is kept: stages were walked in order
+    }
+    first[npatches] = (int)sorted.size();
+    SOMAR_HIP(hipMalloc(&P.d_ops, flat.size() * sizeof(GhostOp)));
+    SOMAR_HIP(hipMemcpy(P.d_ops, flat.data(), flat.size() * sizeof(GhostOp), hipMemcpyHostToDevice));
+    SOMAR_HIP(hipMalloc(&P.d_box_ops, sorted.size() * sizeof(GhostOp)));
+    SOMAR_HIP(hipMemcpy(P.d_box_ops, sorted.data(), sorted.size() * sizeof(GhostOp), hipMemcpyHostToDevice));
+    SOMAR_HIP(hipMalloc(&P.d_box_first, first.size() * sizeof(int)));
+    SOMAR_HIP(hipMemcpy(P.d_box_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+}
+
+// One application of a ghost program: on small levels ONE launch (a workgroup per box walks the box's ops, a workgroup barrier
+// at every stage boundary), on large ones a launch per stage.  copy_all: psi := phi first.
+void PressureSolver::run_program(int d, const FullProgram& P, double* phi, double* psi, bool homogeneous, bool redirect,
+                                 bool copy_all)
+{
+    Level& L = *lev[d];
+    if (box_program(d) && (P.d_box_ops || copy_all)) {
+        if (!P.d_box_ops) { launch_copy(st_, psi, phi, L.field_elems); return; }
+        launch_ghost_program(st_, L.dev, P.d_box_ops, P.d_box_first, phi, psi, homogeneous, redirect, copy_all);
+        return;
+    }
+    if (copy_all) launch_copy(st_, psi, phi, L.field_elems);  // psi := phi (valid cells and exchanged ghosts)
+    for (size_t s = 0; s < P.first.size(); ++s)
+        launch_ghost_ops(st_, L.dev, P.d_ops + P.first[s], P.count[s], phi, psi, homogeneous, redirect);
+}
+
 void PressureSolver::build_full_programs(int d)
 {
     Level& L = *lev[d];
@@ -296,31 +355,14 @@ void PressureSolver::build_full_programs(int d)
         FullProgram& P = full_prog_[d][which];
         auto stages = build_program(L, which >= 4 ? which - 4 : which, bc_value_);
         if (which >= 4) stages.insert(stages.begin(), frame_copy_stage(L));
-        std::vector<GhostOp> flat;
-        P.first.clear();
-        P.count.clear();
-        for (const auto& s : stages) {
-            P.first.push_back((int)flat.size());
-            P.count.push_back((int)s.size());
-            flat.insert(flat.end(), s.begin(), s.end());
-        }
-        hipFree(P.d_ops);
-        P.d_ops = nullptr;
-        if (!flat.empty()) {
-            SOMAR_HIP(hipMalloc(&P.d_ops, flat.size() * sizeof(GhostOp)));
-            SOMAR_HIP(hipMemcpy(P.d_ops, flat.data(), flat.size() * sizeof(GhostOp), hipMemcpyHostToDevice));
-        }
+        upload_program(P, stages, L.npatches());
     }
     SOMAR_HIP(hipDeviceSynchronize());
 }
 
 void PressureSolver::run_full_program(int d, int which, double* phi, bool homogeneous)
 {
-    Level& L = *lev[d];
-    launch_copy(st_, f_psi[d], phi, L.field_elems);  // psi := phi (valid cells and exchanged ghosts)
-    const FullProgram& P = full_prog_[d][which];
-    for (size_t s = 0; s < P.first.size(); ++s)
-        launch_ghost_ops(st_, L.dev, P.d_ops + P.first[s], P.count[s], phi, f_psi[d], homogeneous);
+    run_program(d, full_prog_[d][which], phi, f_psi[d], homogeneous, false, true);
 }
 
 // The same call sequences for the marching kernels (full19_march.hip): psi is written in the boxes' one-cell frames
@@ -328,10 +370,7 @@ void PressureSolver::run_full_program(int d, int which, double* phi, bool homoge
 // so the whole-field copy psi := phi (16 B/cell per application) is gone.  which: 0 operator, 1 smoother.
 void PressureSolver::run_full_program_frames(int d, int which, double* phi, bool homogeneous)
 {
-    Level& L = *lev[d];
-    const FullProgram& P = full_prog_[d][which + 4];
-    for (size_t s = 0; s < P.first.size(); ++s)
-        launch_ghost_ops(st_, L.dev, P.d_ops + P.first[s], P.count[s], phi, f_psi[d], homogeneous, true);
+    run_program(d, full_prog_[d][which + 4], phi, f_psi[d], homogeneous, true, false);
 }
 
 // stage 0 of the frame-only programs with (src, dst) in the roles of (phi, psi)
@@ -378,31 +417,18 @@ void PressureSolver::run_aux_program(int which, double* phi)
                 B.face_and_copy(0, 0, domValid, vd, 1, 2, L.active);
             }
         }
-        const auto stages = schedule_stages(perPatch);
-        std::vector<GhostOp> flat;
-        for (const auto& sgs : stages) {
-            P.first.push_back((int)flat.size());
-            P.count.push_back((int)sgs.size());
-            flat.insert(flat.end(), sgs.begin(), sgs.end());
-        }
-        if (!flat.empty()) {
-            SOMAR_HIP(hipMalloc(&P.d_ops, flat.size() * sizeof(GhostOp)));
-            SOMAR_HIP(hipMemcpy(P.d_ops, flat.data(), flat.size() * sizeof(GhostOp), hipMemcpyHostToDevice));
-            SOMAR_HIP(hipDeviceSynchronize());
-        }
+        upload_program(P, schedule_stages(perPatch), L.npatches());
+        SOMAR_HIP(hipDeviceSynchronize());
         aux_built_[which] = true;
     }
     // these ops only use phi (dst = src = field 0); the metric planes are not read (no NEUM op)
-    for (size_t q = 0; q < P.first.size(); ++q) launch_ghost_ops(st_, L.dev, P.d_ops + P.first[q], P.count[q], phi, phi);
+    run_program(0, P, phi, phi, true, false, false);
 }
 
 void PressureSolver::cf_ev(int d, double* phi)
 {
     if (!full_ || !hasCF_) return;
-    Level& L = *lev[d];
-    const FullProgram& P = full_prog_[d][3];
-    for (size_t q = 0; q < P.first.size(); ++q)
-        launch_ghost_ops(st_, L.dev, P.d_ops + P.first[q], P.count[q], phi, phi);
+    run_program(d, full_prog_[d][3], phi, phi, true, false, false);
 }
 
 double* const* PressureSolver::flux_fields(double* phi)
@@ -411,10 +437,7 @@ double* const* PressureSolver::flux_fields(double* phi)
     Level& L = *lev[0];
     for (int a = 0; a < prm.spaceDim; ++a)
         if (!f_flux[a]) f_flux[a] = L.alloc_field();
-    launch_copy(st_, f_psi[0], phi, L.field_elems);
-    const FullProgram& P = full_prog_[0][2];
-    for (size_t q = 0; q < P.first.size(); ++q)
-        launch_ghost_ops(st_, L.dev, P.d_ops + P.first[q], P.count[q], phi, f_psi[0]);
+    run_program(0, full_prog_[0][2], phi, f_psi[0], true, false, true);
     launch_flux_full(st_, L.dev, f_flux, phi, f_psi[0]);
     return f_flux;
 }
@@ -458,10 +481,7 @@ void PressureSolver::mac_grad_full(double* phi)
     }
     for (int a = 0; a < prm.spaceDim; ++a)
         if (!f_flux[a]) f_flux[a] = L.alloc_field();
-    launch_copy(st_, f_psi[0], phi, L.field_elems);
-    const FullProgram& P = full_prog_[0][2];
-    for (size_t q = 0; q < P.first.size(); ++q)
-        launch_ghost_ops(st_, L.dev, P.d_ops + P.first[q], P.count[q], phi, f_psi[0]);
+    run_program(0, full_prog_[0][2], phi, f_psi[0], true, false, true);
     // one op per (box, side): different sides of a box write different cells and read only valid ones
     launch_ghost_ops(st_, L.dev, d_extrapbc_ops_, n_extrapbc_ops_, phi, phi);
     launch_flux_full(st_, L.dev, f_flux, phi, f_psi[0]);
