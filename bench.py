@@ -51,6 +51,9 @@ N_FINE = 512
 # single-GPU first-cycle contraction |r1|/|r0| of the timed problems (driver BENCH_r01 / profiles/): the N > 1 runs
 # must reproduce them (same arithmetic; only the large-level mean sums associate differently)
 SINGLE_RANK_CONTRACTION = {("stretched", 512): 0.46093832950371805}
+# one AMR V-cycle of the full-size C4 / C5 hierarchies on their compatible composite residual (profiles/r03_*): the box layout
+# -- hence the hierarchy and the arithmetic -- is the same at every N, only owners change
+AMR_CONTRACTION = {"c4": 0.0244679, "c5": 0.0033342}
 
 
 def host_cores():
@@ -87,17 +90,34 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(n=N_FINE):
+def c2_random_field(n):
+    """BASELINE C2's residual before its mean is removed: std::mt19937_64(12345), uniform(-1, 1), drawn in Fortran order over
+    the n^3 domain (SURVEY.md 8d / BASELINE.md 4).  Generated ONCE on the host; the same array is uploaded to the GPU
+    (before anything is timed) and handed to the CPU baseline."""
+    from somar_amd import api
+    return api.host_random_field((n, n, n), 12345)
+
+
+def upload_c2_residual(gpu, F, field):
+    """the local boxes' part of `field` -> F_RES, then the J-weighted mean is removed on the device"""
+    import numpy as np
+    for q in range(gpu.num_local_patches):
+        lo, hi, _ = gpu.patch_box(q)
+        gpu.upload(F.F_RES, q, np.asfortranarray(field[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1]), (0, 0, 0))
+    gpu.removeMean(F.F_RES)
+
+
+def cpu_baseline(n=N_FINE, field=None):
     """The reference's V-cycle on the host: C orchestration + restated Fortran kernels + OpenMP (oracle/cpu_vcycle.c),
-    the real n^3 problem.  Bounded: 1 timed cycle on one core, 3 on all cores (~20-40 s of CPU work at 512^3)."""
+    the real n^3 problem on the SAME random residual as the GPU run.  Bounded: 1 timed cycle on one core, 3 on all cores
+    (~20-40 s of CPU work at 512^3)."""
     import numpy as np
     from oracle import cpu_vcycle as cv
     from somar_amd import synthetic
     cores = host_cores()
     dx = (1.0 / n,) * 3
     jg, jinv = synthetic.stretched_diagonal_metric((0, 0, 0), (n - 1,) * 3, dx, (1.0, 1.0, 1.0))
-    rng = np.random.default_rng(12345)
-    res = np.asfortranarray(rng.uniform(-1.0, 1.0, (n,) * 3))
+    res = np.array(field if field is not None else c2_random_field(n), order="F")
     res -= float((res / jinv).sum() / (1.0 / jinv).sum())
     corr = np.zeros((n + 2,) * 3, order="F")
     h = cv.CpuVCycle((n,) * 3, dx, jg, jinv, pre=2, post=2, bottom=2, nthreads=cores)
@@ -349,9 +369,10 @@ def main():
     ratios = [list(r) for r in gpu.mgRefRatios()]
     cells_total = n ** 3
     cells_local = cells_total // world
-    # the residual of a solve from phi = 0: uniform(-1,1) (seed 12345) minus its J-weighted mean
-    gpu.fillHash(F.F_RES, 12345)
-    gpu.removeMean(F.F_RES)
+    # the residual of a solve from phi = 0: std::mt19937_64(12345), uniform(-1,1), minus its J-weighted mean; generated on the host,
+    # resident in HBM before the timed region; the CPU baseline below gets the same array
+    res_host = c2_random_field(n)
+    upload_c2_residual(gpu, F, res_host)
     dt = time_c2(gpu, F, torch, dist, args.steps, args.warmup)
     ms_per_step = 1e3 * dt / args.steps
     value = args.steps / dt
@@ -390,8 +411,7 @@ def main():
         ok = 1
         if rank == 0:
             twin, _, _ = build_c2(api, synthetic, n, world, 0, None, "stretched", all_on_this_rank=True)
-            twin.fillHash(F.F_RES, 12345)
-            twin.removeMean(F.F_RES)
+            upload_c2_residual(twin, F, res_host)
             contraction_twin = contraction_c2(twin, api)
             twin.undefine()
             del twin
@@ -426,6 +446,9 @@ def main():
                    "mg_depth": depth, "mg_ref_ratios": ratios, "cells": cells_total, "define_seconds": t_def},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/traffic.json: HBM bytes per launch of this kernel from separate rocprofv3 --pmc "
+                                       "FETCH_SIZE / WRITE_SIZE passes of an EARLIER run (round 2, same kernel source); cited, "
+                                       "not measured in this run",
                      "algorithmic_bytes_per_launch": b_launch * cells_local, "launches": n_gsrb,
                      "avg_launch_ms": t_gsrb * 1e3, "measured_copy_GBs": copy_gbs,
                      "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
@@ -449,8 +472,7 @@ def main():
     # ---------------- SURVEY 8d variant (i): true Cartesian metric, the converging case ----------------
     if not args.no_cartesian:
         g2, _, t_def2 = build_c2(api, synthetic, n, world, rank, comm, "cartesian")
-        g2.fillHash(F.F_RES, 12345)
-        g2.removeMean(F.F_RES)
+        upload_c2_residual(g2, F, res_host)
         dt2 = time_c2(g2, F, torch, dist, args.steps, args.warmup)
         c2 = contraction_c2(g2, F)
         if not (0.0 < c2 < 1.0):
@@ -466,6 +488,9 @@ def main():
         c4 = bench_c4(api, torch, dist, comm, world, args.c4_steps, args.c4_warmup, args.c4_scale)
         if not (0.0 < c4["amr_vcycle_contraction"] < 1.0):
             failures.append("C4 AMR V-cycle does not contract: %r" % c4["amr_vcycle_contraction"])
+        elif args.c4_scale == 1 and abs(c4["amr_vcycle_contraction"] - AMR_CONTRACTION["c4"]) > 5e-3 * AMR_CONTRACTION["c4"]:
+            failures.append("C4 AMR V-cycle contraction %.7f departs from the recorded %.7f"
+                            % (c4["amr_vcycle_contraction"], AMR_CONTRACTION["c4"]))
         out["c4_amr"] = c4
 
     # ---------------- C5's shape: 4 levels, non-diagonal terrain-following metric (19-point kernels) ----------------
@@ -474,6 +499,9 @@ def main():
             c5 = bench_c4(api, torch, dist, comm, world, args.c4_steps, args.c4_warmup, args.c4_scale, config="c5")
             if not (0.0 < c5["amr_vcycle_contraction"] < 1.0):
                 failures.append("C5 AMR V-cycle does not contract: %r" % c5["amr_vcycle_contraction"])
+            elif args.c4_scale == 1 and abs(c5["amr_vcycle_contraction"] - AMR_CONTRACTION["c5"]) > 5e-3 * AMR_CONTRACTION["c5"]:
+                failures.append("C5 AMR V-cycle contraction %.7f departs from the recorded %.7f"
+                                % (c5["amr_vcycle_contraction"], AMR_CONTRACTION["c5"]))
             out["c5_amr"] = c5
         except Exception as e:   # a sub-record must not take the headline down with it at N > 1
             if world == 1:
@@ -481,7 +509,7 @@ def main():
             out["c5_amr"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(n)
+        out["cpu_baseline"] = cpu_baseline(n, res_host)
     elif rank == 0:
         out["cpu_baseline"] = None
     if comm is not None:

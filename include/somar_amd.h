@@ -105,6 +105,10 @@ typedef struct somar_stats {
 int somar_abi_version(void);
 const char* somar_last_error(void);
 int somar_device_count(int* count);
+/* Synthetic inputs of the benchmark configurations: out[0 .. n) = successive draws of
+ * std::uniform_real_distribution<double>(lo, hi) from std::mt19937_64(seed).  Host memory, host arithmetic (no GPU): the
+ * SAME array then goes to the GPU path and to the CPU baseline of bench.py. */
+int somar_host_fill_mt19937_64(double* out, long long n, unsigned long long seed, double lo, double hi);
 int somar_params_default(somar_params_t* p);
 
 /* boxes: nboxes*6 ints {lo0,lo1,lo2,hi0,hi1,hi2}; owner: rank per box or NULL (all rank 0);

@@ -102,6 +102,7 @@ _SIGS = {
     "somar_mini_vcycle": [_H, C.c_int, C.c_int],
     "somar_bottom_solve": [_H, C.c_int, C.c_int, _PI, _PI],
     "somar_bottom_kind": [_H, _PI],
+    "somar_host_fill_mt19937_64": [_PD, C.c_longlong, C.c_ulonglong, C.c_double, C.c_double],
     "somar_vel_upload": [_H, C.c_int, C.c_int, _PD],
     "somar_vel_download": [_H, C.c_int, C.c_int, _PD],
     "somar_vel_wall_bc": [_H],
@@ -909,6 +910,14 @@ def plan_exchange(domain_lo, domain_hi, periodic, boxes, owner, rank, ghost=2, m
                           "peer": o[11]})
         out.append(items)
     return tuple(out)
+
+
+def host_random_field(shape, seed, lo=-1.0, hi=1.0):
+    """std::mt19937_64(seed) + uniform_real_distribution(lo, hi), drawn in Fortran order over `shape` (SURVEY.md 8d): the
+    benchmark configurations' random fields, generated on the host"""
+    a = np.empty(shape, order="F")
+    _ck(lib().somar_host_fill_mt19937_64(a.ctypes.data_as(_PD), a.size, seed, lo, hi))
+    return a
 
 
 def device_count():

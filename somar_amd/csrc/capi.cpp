@@ -1,4 +1,5 @@
 // somar_amd/csrc/capi.cpp -- extern "C" boundary of libsomar_amd.so (include/somar_amd.h).
+#include <random>
 #include <cstring>
 #include <string>
 
@@ -64,6 +65,16 @@ extern "C" {
 
 int somar_abi_version(void) { return SOMAR_AMD_ABI_VERSION; }
 const char* somar_last_error(void) { return g_err.c_str(); }
+
+int somar_host_fill_mt19937_64(double* out, long long n, unsigned long long seed, double lo, double hi)
+{
+    API_BEGIN
+    SOMAR_CHECK(out && n >= 0 && lo < hi, "somar_host_fill_mt19937_64: bad arguments");
+    std::mt19937_64 gen(seed);
+    std::uniform_real_distribution<double> dist(lo, hi);
+    for (long long i = 0; i < n; ++i) out[i] = dist(gen);
+    API_END
+}
 
 int somar_device_count(int* count)
 {

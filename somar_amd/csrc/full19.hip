@@ -105,33 +105,50 @@ __global__ void k_ghost_ops(const GhostOp* __restrict__ ops, const PatchDesc* __
 // stage (GhostOp::pad_), are box_ops[box_first[b] .. box_first[b + 1]).  For the SMALL levels (boxes of at most a few thousand
 // cells: a face is a few hundred cells, one 256-thread workgroup is plenty): on BASELINE C5 5 500 of the 7 700 dispatches of an
 // AMR V-cycle were staged ghost ops of such levels, three quarters of them inside the bottom solver.
+constexpr int GP_MAX_OPS = 160;   // ops of one box staged in LDS (10 KB); a longer program walks the rest from global memory
 template <bool REDIRECT>
-__global__ __launch_bounds__(256) void k_ghost_program(const GhostOp* __restrict__ box_ops, const int* __restrict__ box_first,
+__global__ __launch_bounds__(512) void k_ghost_program(const GhostOp* __restrict__ box_ops, const int* __restrict__ box_first,
                                                        const PatchDesc* __restrict__ patches, double* phi, double* psi,
                                                        JgFull J, StencilParams P, int copy_all)
 {
-    const int b = blockIdx.x;
+    __shared__ GhostOp sops[GP_MAX_OPS];
+    const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     const PatchDesc p = patches[b];
+    const int first = box_first[b], nops = box_first[b + 1] - first;
+    // the box's op list: one coalesced copy, every load in flight at once (walking it from global memory cost a load
+    // latency per op: 100-odd ops per box)
+    {
+        const int4* src = reinterpret_cast<const int4*>(box_ops + first);
+        int4* dst = reinterpret_cast<int4*>(sops);
+        const int n16 = min(nops, GP_MAX_OPS) * (int)(sizeof(GhostOp) / 16);
+        for (int q = tid; q < n16; q += nth) dst[q] = src[q];
+    }
     if (copy_all) {
         // the leading psi := phi of the full-copy programs (run_full_program), on the box grown by its one-cell frame: all a
         // program of this box and the stencil kernel behind it read of psi
         const int m0 = p.n[0] + 2, m1 = p.n[1] + 2, m2 = P.active[2] ? p.n[2] + 2 : 1, z0 = P.active[2] ? -1 : 0;
-        for (int idx = threadIdx.x; idx < m0 * m1 * m2; idx += blockDim.x) {
+        for (int idx = tid; idx < m0 * m1 * m2; idx += nth) {
             const int k = idx / (m0 * m1), r = idx - k * (m0 * m1);
             const long long c = fidx(p, r % m0 - 1, r / m0 - 1, k + z0);
             psi[c] = phi[c];
         }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // stage by stage; the ops of a stage are independent of each other: one wavefront per op, side by side
+    const int wave = tid >> 6, lane = tid & 63, nwaves = nth >> 6;
+    int q = 0;
+    while (q < nops) {
+        const int stage = q < GP_MAX_OPS ? sops[q].pad_ : box_ops[first + q].pad_;
+        int e = q + 1;
+        while (e < nops && (e < GP_MAX_OPS ? sops[e].pad_ : box_ops[first + e].pad_) == stage) ++e;
+        for (int o = q + wave; o < e; o += nwaves) {
+            const GhostOp op = o < GP_MAX_OPS ? sops[o] : box_ops[first + o];
+            ghost_op_body<REDIRECT>(op, p, phi, psi, J, P, lane, 64);
+        }
         __threadfence_block();
         __syncthreads();
-    }
-    int cur = -1;
-    for (int q = box_first[b]; q < box_first[b + 1]; ++q) {
-        const GhostOp op = box_ops[q];
-        if (op.pad_ != cur) {
-            if (cur >= 0) { __threadfence_block(); __syncthreads(); }
-            cur = op.pad_;
-        }
-        ghost_op_body<REDIRECT>(op, p, phi, psi, J, P, (int)threadIdx.x, (int)blockDim.x);
+        q = e;
     }
 }
 
@@ -370,8 +387,8 @@ void launch_ghost_program(hipStream_t st, const LevelDev& L, const GhostOp* box_
     if (L.npatches == 0) return;
     StencilParams P = L.P;
     P.bc_homog = bc_homog ? 1 : 0;
-    if (redirect) hipLaunchKernelGGL(k_ghost_program<true>, dim3(L.npatches), dim3(256), 0, st, box_ops, box_first, L.patches, phi, psi, jgfull(L), P, copy_all ? 1 : 0);
-    else hipLaunchKernelGGL(k_ghost_program<false>, dim3(L.npatches), dim3(256), 0, st, box_ops, box_first, L.patches, phi, psi, jgfull(L), P, copy_all ? 1 : 0);
+    if (redirect) hipLaunchKernelGGL(k_ghost_program<true>, dim3(L.npatches), dim3(512), 0, st, box_ops, box_first, L.patches, phi, psi, jgfull(L), P, copy_all ? 1 : 0);
+    else hipLaunchKernelGGL(k_ghost_program<false>, dim3(L.npatches), dim3(512), 0, st, box_ops, box_first, L.patches, phi, psi, jgfull(L), P, copy_all ? 1 : 0);
 }
 
 void launch_flux_full(hipStream_t st, const LevelDev& L, double* const out[3], const double* phi, const double* psi)

@@ -156,6 +156,7 @@ void launch_tiny_bicgstab(hipStream_t st, const LevelDev& L, const CopyItem* ite
 // six cells its stencil reads (x-, x+, y-, y+, z-, z+): the neighbour itself, or -- across a box edge -- the valid cell the ghost
 // exchange would have copied from (built on the host from the level's exchange plan), so no ghost cell is ever filled.
 constexpr int BOX_MAX_WG = 128, BOX_MAX_CELLS = 2048;
+constexpr int BOX_FAB_MAX = 2048, BOX_MAX_OPS = 320;   // 19-point variant: cells of a box grown by one cell; ops of one of its ghost programs
 struct BoxBicg {
     const PatchDesc* patches; int npatches;
     const int* nb; const int* cstart;
@@ -167,6 +168,14 @@ struct BoxBicg {
     double eps, reps, hang, small, metric;
     double* sums;        // 4 * BOX_MAX_WG doubles: per-box partial results of the running reduction(s), double-buffered
     unsigned* sync;      // BOX_MAX_WG + 1: per workgroup the number of the last barrier it reached; abort flag (a barrier gave up); zeroed per launch
+    // 19-point variant (non-diagonal metric, 3-D, boxes of at most 256 cells): all J g^{ab}; for every cell of box b grown by one
+    // cell (x fastest, box b starts at fab_start[b]) the field offset its value comes from -- the cell itself, the valid cell
+    // the ghost exchange copies there, or -1 (a ghost beyond a wall: the program fills it); the box-sorted ghost programs
+    // [0] operator, [1] smoother (GhostOp::pad_ = stage; box b owns ops[w][ops_first[w][b] .. ops_first[w][b + 1]))
+    int full;
+    const double* jgf[3][3];
+    const int* fab_src; const int* fab_start;
+    const GhostOp* ops[2]; const int* ops_first[2];
     int serial;          // sums in the reference's serial order (levels of at most ordered_max cells) or by a fixed tree per box
     double* info;        // device: iterations, exit code
     ScalarPublish pub;

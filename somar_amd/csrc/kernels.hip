@@ -842,12 +842,21 @@ __global__ __launch_bounds__(1024) void k_reduce_ordered_par(const PatchDesc* __
         for (; q < cnt; ++q) s = s + x[q];
         return s;
     };
+    __shared__ int CNT[1024];              // cells of the next (up to) 1024 boxes: the patch table is read once, all loads in flight
     double tot = 0.0;
     int pi = 0;
     while (pi < npatches) {
-        const PatchDesc p0 = patches[pi];
-        const long long n0 = (long long)p0.n[0] * p0.n[1] * p0.n[2];
-        if (n0 > ORD_CAP) {   // one large box: chunks of ORD_CAP cells, one chain
+        const int nb = min(npatches - pi, 1024);
+        __syncthreads();   // X, S and CNT of the previous group have been consumed
+        if (tid < nb) {
+            const PatchDesc q = patches[pi + tid];
+            const long long nq = (long long)q.n[0] * q.n[1] * q.n[2];
+            CNT[tid] = nq > ORD_CAP ? ORD_CAP + 1 : (int)nq;
+        }
+        __syncthreads();
+        if (CNT[0] > ORD_CAP) {   // one large box: chunks of ORD_CAP cells, one chain
+            const PatchDesc p0 = patches[pi];
+            const long long n0 = (long long)p0.n[0] * p0.n[1] * p0.n[2];
             double sbox = 0.0;
             for (long long base = 0; base < n0; base += ORD_CAP) {
                 const int cnt = (int)((n0 - base) < ORD_CAP ? (n0 - base) : ORD_CAP);
@@ -860,40 +869,30 @@ __global__ __launch_bounds__(1024) void k_reduce_ordered_par(const PatchDesc* __
             ++pi;
             continue;
         }
-        // a group of consecutive boxes that fits: [pi, pe)
-        int pe = pi;
-        long long cells = 0;
-        while (pe < npatches && pe - pi < 1024) {
-            const PatchDesc q = patches[pe];
-            const long long nq = (long long)q.n[0] * q.n[1] * q.n[2];
-            if (cells + nq > ORD_CAP) break;
-            cells += nq;
-            ++pe;
-        }
-        const int G = pe - pi;
+        // a group of consecutive boxes that fits: [pi, pi + G)
+        int G = 0, cells = 0;
+        while (G < nb && cells + CNT[G] <= ORD_CAP) { cells += CNT[G]; ++G; }
         const int tpb = 1024 / G;                 // threads staging one box
         const int mb = tid / tpb, sub = tid - mb * tpb;
-        __syncthreads();   // X and S of the previous group have been consumed
-        int myoff = 0, mycnt = 0;
+        int myoff = 0, mycnt = 0, stoff = 0;
         {
-            // offsets: every thread needs its own box's (staging) and, for tid < G, box tid's (chain); G <= 1024 boxes of a
-            // tiny level -- the prefix is a short uniform loop over the patch table (L1-resident)
             int off = 0;
-            for (int q = 0; q < G; ++q) {
-                const PatchDesc pq = patches[pi + q];
-                const int nq = pq.n[0] * pq.n[1] * pq.n[2];
-                if (q == mb && mb < G) {
-                    for (int idx = sub; idx < nq; idx += tpb) X[off + q + idx] = term(pq, idx);
-                }
-                if (q == tid) { myoff = off + q; mycnt = nq; }
-                off += nq;
+            for (int q = 0; q < G; ++q) {         // uniform LDS reads
+                if (q == mb) stoff = off + q;
+                if (q == tid) { myoff = off + q; mycnt = CNT[q]; }
+                off += CNT[q];
             }
+        }
+        if (mb < G) {
+            const PatchDesc pq = patches[pi + mb];
+            const int nq = CNT[mb];
+            for (int idx = sub; idx < nq; idx += tpb) X[stoff + idx] = term(pq, idx);
         }
         __syncthreads();
         if (tid < G) S[tid] = chain(X + myoff, mycnt, 0.0, true);
         __syncthreads();
         for (int q = 0; q < G; ++q) tot = tot + S[q];
-        pi = pe;
+        pi += G;
     }
     if (tid == 0) {
         out[0] = tot;
@@ -1583,465 +1582,6 @@ void launch_tiny_bicgstab(hipStream_t st, const LevelDev& L, const CopyItem* ite
     for (int d = 0; d < 3; ++d) A.jg[d] = L.jg[d];
     A.jinv = L.jinv; A.lapd = L.lapdiag; A.P = L.P;
     hipLaunchKernelGGL(k_tiny_bicgstab, dim3(1), dim3(1024), 0, st, A);
-}
-
-// ---- the bottom solver of a multi-box level as ONE persistent launch, one workgroup per box --------------------------------
-// BASELINE C3 / C4 end their base level's V-cycle on 8 192 / 65 536 cells in 16 / 64 boxes, where BiCGStab runs 50-70 iterations
-// of ~27 launches each: 12 of C3's 20 ms, 27 of C4's 147 ms per AMR V-cycle, none of which shards.  Here the whole solve is one
-// launch: workgroup b owns box b, a thread owns CPT cells of it for the whole solve and keeps their coefficients and the
-// BiCGStab vectors (r, r~, e, p, v, t) in registers; the only data another workgroup reads are the preconditioned vectors p~ / s~
-// (fields in the level's layout, written with write-through stores, read with cache-bypassing loads -- agent-scope relaxed
-// atomics -- straight from the neighbouring box's valid cells through a host-built neighbour table, so there is no ghost
-// exchange at all) and the per-box partial sums.  Kernel boundaries become device-wide barriers (1.2-1.9 us for 16-64
-// workgroups with one arrival counter, tools/gridsync_probe.hip; per-workgroup flags here); every workgroup computes every scalar from the same partial sums in the
-// same order, so the control flow is uniform across the grid.  On levels of at most ordered_max cells the sums follow the
-// reference's SERIAL order (box after box, Fortran order inside a box): one thread walks its box's terms staged in LDS, then
-// the box totals are added in layout order -- bit-identical to the launch-by-launch path and to the oracle.  Above that
-// (where the launch path sums by tree as well) each box's terms go through a fixed tree: the 1024-add chain of a C4 box cost
-// 20 us per iteration.  Every spin loop is bounded: a barrier that gives up raises the abort flag, every workgroup leaves,
-// the host reports the failure (no fallback).
-// Control flow: Chombo 3.1 BiCGStabSolver<T>::solve as PressureSolver::bottom_solve restates it (solver.cpp).
-constexpr unsigned BOX_SPIN_MAX = 1u << 26;
-template <int CPT, int MAXT>
-__global__ __launch_bounds__(MAXT) void k_box_bicgstab(BoxBicg A)
-{
-    __shared__ double X[BOX_MAX_CELLS], Y[BOX_MAX_CELLS];
-    __shared__ double S[2][BOX_MAX_WG];
-    __shared__ double M[16];
-    __shared__ int s_ok;
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const int b = blockIdx.x, nwg = gridDim.x;
-    const PatchDesc p = A.patches[b];
-    const StencilParams& P = A.P;
-    const int cells = p.n[0] * p.n[1] * p.n[2];
-    const bool three = P.active[2] != 0;
-    const double xxScale = 1.0 / (P.dx[0] * P.dx[0]), yyScale = 1.0 / (P.dx[1] * P.dx[1]), zzScale = 1.0 / (P.dx[2] * P.dx[2]);
-    const double sx = 1.0 / P.dx[0], sy = 1.0 / P.dx[1], sz = 1.0 / P.dx[2];
-
-    // ---- this thread's cells: position, coefficients, neighbour table, boundary classification, denominators ----
-    bool act[CPT];
-    int c[CPT], nbo[CPT][6], col[CPT];
-    unsigned flg[CPT];   // bits 0-5: Neumann face at x-, x+, y-, y+, z-, z+; bit 6: the boundary form of the sweep applies
-    double jl[CPT][3], jh[CPT][3], Ji[CPT], dd[CPT], dg[CPT];
-#pragma unroll
-    for (int q = 0; q < CPT; ++q) {
-        const int idx = tid + q * nth;
-        act[q] = idx < cells;
-        const int ii = act[q] ? idx : 0;
-        const int li = ii % p.n[0], r = ii / p.n[0];
-        const int lj = r % p.n[1], lk = r / p.n[1];
-        const long long cc = cidx(p, li, lj, lk);
-        c[q] = (int)cc;
-        const int gi = p.lo[0] + li, gj = p.lo[1] + lj, gk = p.lo[2] + lk;
-        col[q] = (gi + gj + gk) & 1;
-        const int* nbp = A.nb + 6ll * (A.cstart[b] + ii);
-#pragma unroll
-        for (int s = 0; s < 6; ++s) nbo[q][s] = nbp[s];
-        jl[q][0] = A.jg[0][cc]; jh[q][0] = A.jg[0][cc + 1];
-        jl[q][1] = A.jg[1][cc]; jh[q][1] = A.jg[1][cc + p.pj];
-        jl[q][2] = three ? A.jg[2][cc] : 0.0; jh[q][2] = three ? A.jg[2][cc + p.pk] : 0.0;
-        Ji[q] = A.jinv[cc];
-        const double lap = A.lapd[cc];
-        dd[q] = P.alpha + P.beta * lap;
-        const bool xl = gi == P.dom_lo[0], xh = gi == P.dom_hi[0], yl = gj == P.dom_lo[1], yh = gj == P.dom_hi[1];
-        const bool zl = three && gk == P.dom_lo[2], zh = three && gk == P.dom_hi[2];
-        const bool onb = xl || xh || yl || yh || zl || zh;
-        const bool nxl = xl && P.neum[0][0], nxh = xh && P.neum[0][1], nyl = yl && P.neum[1][0], nyh = yh && P.neum[1][1];
-        const bool nzl = zl && P.neum[2][0], nzh = zh && P.neum[2][1];
-        flg[q] = (nxl ? 1u : 0u) | (nxh ? 2u : 0u) | (nyl ? 4u : 0u) | (nyh ? 8u : 0u) | (nzl ? 16u : 0u) | (nzh ? 32u : 0u) |
-                 (onb ? 64u : 0u);
-        if (!onb) {
-            dg[q] = dd[q];
-        } else {   // GSRBBOUNDARYITER's diagonal: the faces that carry a flux, in its order (3-D: lo sides, then hi sides)
-            double ld = 0.0;
-            if (three) {
-                if (!nxl) ld = ld - xxScale * jl[q][0];
-                if (!nyl) ld = ld - yyScale * jl[q][1];
-                if (!nzl) ld = ld - zzScale * jl[q][2];
-                if (!nxh) ld = ld - xxScale * jh[q][0];
-                if (!nyh) ld = ld - yyScale * jh[q][1];
-                if (!nzh) ld = ld - zzScale * jh[q][2];
-            } else {
-                if (!nxl) ld = ld - xxScale * jl[q][0];
-                if (!nxh) ld = ld - xxScale * jh[q][0];
-                if (!nyl) ld = ld - yyScale * jl[q][1];
-                if (!nyh) ld = ld - yyScale * jh[q][1];
-            }
-            ld = ld * Ji[q];
-            dg[q] = P.alpha + P.beta * ld;
-        }
-    }
-
-    // ---- device-wide barrier: every workgroup stamps its own flag with the barrier's number (a plain write-through store, no
-    // read-modify-write on a shared counter), the first wavefront polls all flags at once, one or two per lane ----
-    unsigned epoch = 0;
-    auto gsync = [&]() -> bool {
-        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's write-through stores have been acknowledged
-        __syncthreads();
-        if (nwg == 1) return true;
-        ++epoch;
-        if (tid < 64) {
-            if (tid == 0) __hip_atomic_store(A.sync + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int ok = 1;
-            unsigned spins = 0;
-            for (;;) {
-                bool here = true;
-                for (int q = tid; q < nwg; q += 64)
-                    here = here && __hip_atomic_load(A.sync + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
-                if (__all(here)) break;
-                if (++spins > BOX_SPIN_MAX || __hip_atomic_load(A.sync + BOX_MAX_WG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    ok = 0;
-                    break;
-                }
-            }
-            if (tid == 0) {
-                if (!ok) __hip_atomic_store(A.sync + BOX_MAX_WG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_ok = ok;
-            }
-        }
-        __syncthreads();
-        return s_ok != 0;
-    };
-    auto ld_shared = [](const double* f, int off) { return __hip_atomic_load(f + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto st_shared = [](double* f, int off, double v) { __hip_atomic_store(f + off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-
-    // ---- stencil pieces on one of this thread's cells (operation order of gsrb_ortho_body / op_ortho_body) ----
-    auto relax_cell = [&](int q, const double* zf, double rhsv) {
-        double v[6];
-#pragma unroll
-        for (int s = 0; s < 6; ++s) v[s] = (s < 4 || three) ? ld_shared(zf, nbo[q][s]) : 0.0;
-        const unsigned f = flg[q];
-        double lphi;
-        if (!three) {
-            if (!(f & 64u)) {
-                const double JDxx = xxScale * (jh[q][0] * v[1] + jl[q][0] * v[0]);
-                const double JDyy = yyScale * (jh[q][1] * v[3] + jl[q][1] * v[2]);
-                lphi = P.beta * (JDxx + JDyy) * Ji[q];
-            } else {
-                double JDloX = 0, JDhiX = 0, JDloY = 0, JDhiY = 0;
-                if (!(f & 1u)) JDloX = jl[q][0] * v[0];
-                if (!(f & 2u)) JDhiX = jh[q][0] * v[1];
-                if (!(f & 4u)) JDloY = jl[q][1] * v[2];
-                if (!(f & 8u)) JDhiY = jh[q][1] * v[3];
-                lphi = P.beta * Ji[q] * ((JDloX + JDhiX) * xxScale + (JDloY + JDhiY) * yyScale);
-            }
-        } else if (!(f & 64u)) {
-            const double JDxx = xxScale * (jh[q][0] * v[1] + jl[q][0] * v[0]);
-            const double JDyy = yyScale * (jh[q][1] * v[3] + jl[q][1] * v[2]);
-            const double JDzz = zzScale * (jh[q][2] * v[5] + jl[q][2] * v[4]);
-            lphi = P.beta * Ji[q] * (JDxx + JDyy + JDzz);
-        } else {
-            double JDloX = 0, JDhiX = 0, JDloY = 0, JDhiY = 0, JDloZ = 0, JDhiZ = 0;
-            if (!(f & 1u)) JDloX = jl[q][0] * v[0];
-            if (!(f & 4u)) JDloY = jl[q][1] * v[2];
-            if (!(f & 16u)) JDloZ = jl[q][2] * v[4];
-            if (!(f & 2u)) JDhiX = jh[q][0] * v[1];
-            if (!(f & 8u)) JDhiY = jh[q][1] * v[3];
-            if (!(f & 32u)) JDhiZ = jh[q][2] * v[5];
-            lphi = P.beta * Ji[q] * ((JDloX + JDhiX) * xxScale + (JDloY + JDhiY) * yyScale + (JDloZ + JDhiZ) * zzScale);
-        }
-        return (rhsv - lphi) / dg[q];
-    };
-    auto op_cell = [&](int q, const double* zf, double pc) {   // L[z] at the cell whose own value is pc
-        double v[6];
-#pragma unroll
-        for (int s = 0; s < 6; ++s) v[s] = (s < 4 || three) ? ld_shared(zf, nbo[q][s]) : 0.0;
-        const unsigned f = flg[q];
-        double fxl = jl[q][0] * sx * (pc - v[0]);
-        double fxh = jh[q][0] * sx * (v[1] - pc);
-        double fyl = jl[q][1] * sy * (pc - v[2]);
-        double fyh = jh[q][1] * sy * (v[3] - pc);
-        double fzl = 0.0, fzh = 0.0;
-        if (three) {
-            fzl = jl[q][2] * sz * (pc - v[4]);
-            fzh = jh[q][2] * sz * (v[5] - pc);
-        }
-        if (f & 1u) fxl = 0.0;
-        if (f & 2u) fxh = 0.0;
-        if (f & 4u) fyl = 0.0;
-        if (f & 8u) fyh = 0.0;
-        if (f & 16u) fzl = 0.0;
-        if (f & 32u) fzh = 0.0;
-        fxl *= P.beta; fxh *= P.beta; fyl *= P.beta; fyh *= P.beta; fzl *= P.beta; fzh *= P.beta;
-        double l = three ? Ji[q] * ((fxh - fxl) * sx + (fyh - fyl) * sy + (fzh - fzl) * sz)
-                         : Ji[q] * ((fxh - fxl) * sx + (fyh - fyl) * sy);
-        if (P.alpha != 0.0) l = P.alpha * pc + 1.0 * l;
-        return l;
-    };
-
-    // ---- reductions: per-box serial chain(s), then the box totals in layout order ----
-    int nred = 0;
-    auto chain = [&](const double* x) {
-        double s = x[0];
-        int q = 1;
-        for (; q + 16 <= cells; q += 16) {
-            double xv[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) xv[j] = x[q + j];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) s = s + xv[j];
-        }
-        for (; q < cells; ++q) s = s + x[q];
-        return s;
-    };
-    // the terms of up to two sums are in X (and Y); -> the two totals.  false: the barrier gave up
-    auto finish_sums = [&](bool two, double& ra, double& rb) -> bool {
-        __syncthreads();
-        double* mine = A.sums + (nred & 1) * 2 * BOX_MAX_WG;
-        ++nred;
-        if (A.serial) {
-            if (tid == 0) st_shared(mine, b, chain(X));
-            if (two && tid == (nth > 64 ? 64 : 0)) st_shared(mine, BOX_MAX_WG + b, chain(Y));   // on another wavefront, side by side
-        } else {
-            // levels above ordered_max cells (where the launch-by-launch path sums by tree too): a fixed tree per box -- a
-            // thread's terms in order, the wavefront's 64 partial sums by shuffles, the wavefronts' results in order
-            double sa = 0.0, sb = 0.0;
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) if (act[q]) { sa = sa + X[tid + q * nth]; if (two) sb = sb + Y[tid + q * nth]; }
-            sa = wave_sum(sa);
-            if (two) sb = wave_sum(sb);
-            if ((tid & 63) == 0) { M[tid >> 6] = sa; M[8 + (tid >> 6)] = sb; }
-            __syncthreads();
-            if (tid == 0) {
-                double ta = M[0], tb = M[8];
-                for (int w = 1; w < (nth + 63) / 64; ++w) { ta = ta + M[w]; tb = tb + M[8 + w]; }
-                st_shared(mine, b, ta);
-                if (two) st_shared(mine, BOX_MAX_WG + b, tb);
-            }
-        }
-        if (!gsync()) return false;
-        for (int q = tid; q < nwg; q += nth) {
-            S[0][q] = ld_shared(mine, q);
-            if (two) S[1][q] = ld_shared(mine, BOX_MAX_WG + q);
-        }
-        __syncthreads();
-        double ta = 0.0, tb = 0.0;
-        for (int q = 0; q < nwg; ++q) ta = ta + S[0][q];
-        if (two) for (int q = 0; q < nwg; ++q) tb = tb + S[1][q];
-        ra = ta;
-        rb = tb;
-        return true;
-    };
-    auto finish_max = [&](double m, double& out) -> bool {
-        for (int o = 32; o > 0; o >>= 1) {
-            const double w = __shfl_down(m, o, 64);
-            m = w > m ? w : m;
-        }
-        __syncthreads();
-        if ((tid & 63) == 0) M[tid >> 6] = m;
-        __syncthreads();
-        double* mine = A.sums + (nred & 1) * 2 * BOX_MAX_WG;
-        ++nred;
-        if (tid == 0) {
-            double r = M[0];
-            for (int w = 1; w < (nth + 63) / 64; ++w) r = M[w] > r ? M[w] : r;
-            st_shared(mine, b, r);
-        }
-        if (!gsync()) return false;
-        for (int q = tid; q < nwg; q += nth) S[0][q] = ld_shared(mine, q);
-        __syncthreads();
-        double r = S[0][0];
-        for (int q = 1; q < nwg; ++q) r = S[0][q] > r ? S[0][q] : r;
-        out = r;
-        return true;
-    };
-
-    double r[CPT], rt[CPT], e[CPT], pv[CPT], v[CPT], t[CPT], zo[CPT], pt[CPT];
-    auto dot = [&](const double* a, const double* bb, double& out) -> bool {
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) if (act[q]) X[tid + q * nth] = a[q] * bb[q];
-        double dummy;
-        return finish_sums(false, out, dummy);
-    };
-    auto norm = [&](const double* a, double& out) -> bool {
-        if (A.normType == 0) {
-            double m = 0.0;
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) if (act[q]) { const double w = fabs(a[q]); m = w > m ? w : m; }
-            return finish_max(m, out);
-        }
-        double dummy, sres;
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) if (act[q]) X[tid + q * nth] = A.normType == 1 ? fabs(a[q]) : a[q] * a[q];
-        if (!finish_sums(false, sres, dummy)) return false;
-        out = A.normType == 1 ? sres : sqrt(sres);
-        return true;
-    };
-    // DIAGPRECOND + point-GSRB sweeps on zf with right-hand side w (registers): the result is in zf and, for this thread's own
-    // cells, in zo; the last barrier leaves zf readable by everybody
-    auto pre_cond = [&](double* zf, const double* w) -> bool {
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) if (act[q]) {
-            zo[q] = A.precondIters <= 0 ? w[q] : w[q] / dd[q];
-            st_shared(zf, c[q], zo[q]);
-        }
-        if (!gsync()) return false;
-        for (int it = 0; it < A.precondIters; ++it)
-            for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                for (int q = 0; q < CPT; ++q) if (act[q] && col[q] == pass) {
-                    zo[q] = relax_cell(q, zf, w[q]);
-                    st_shared(zf, c[q], zo[q]);
-                }
-                if (!gsync()) return false;
-            }
-        return true;
-    };
-    // r = rhs - L[phi]: phi goes through z[0] (shared reads of the neighbours)
-    auto residual = [&](const double* phiv) -> bool {
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) if (act[q]) st_shared(A.z[0], c[q], phiv[q]);
-        if (!gsync()) return false;
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) if (act[q]) r[q] = A.rhs[c[q]] - op_cell(q, A.z[0], phiv[q]);
-        if (!gsync()) return false;   // z[0] is rewritten by the next pre_cond: everybody has read it
-        return true;
-    };
-    auto finish = [&](int iters, int exit_code) {
-        if (b == 0 && tid == 0) {
-            const double vals[2] = {(double)iters, (double)exit_code};
-            A.info[0] = vals[0];
-            A.info[1] = vals[1];
-            publish_scalars(vals, 2, A.pub);
-        }
-    };
-
-    double phv[CPT];
-#pragma unroll
-    for (int q = 0; q < CPT; ++q) {
-        phv[q] = act[q] ? A.phi[c[q]] : 0.0;
-        r[q] = rt[q] = e[q] = pv[q] = v[q] = t[q] = zo[q] = pt[q] = 0.0;
-    }
-    int recount = 0;
-    if (!residual(phv)) return;
-#pragma unroll
-    for (int q = 0; q < CPT; ++q) rt[q] = r[q];
-    int i = 0;
-    double rho[4] = {0, 0, 0, 0};
-    double nrm[2];
-    if (!norm(r, nrm[0])) return;
-    double initial_norm = nrm[0];
-    const double initial_rnorm = nrm[0];
-    nrm[1] = nrm[0];
-    double alpha[2] = {0, 0}, beta[2] = {0, 0}, omega[2] = {0, 0};
-    bool init = true;
-    int restarts = 0;
-    if (A.metric > 0) initial_norm = A.metric;
-    const double eps = A.eps;
-    int bottom_exit = -1;
-    auto add_e_to_phi = [&]() {
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) phv[q] = phv[q] + 1.0 * e[q];
-    };
-    auto store_phi = [&]() {
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) if (act[q]) A.phi[c[q]] = phv[q];
-    };
-    while ((i < A.imax && nrm[0] > eps * nrm[1]) && (nrm[1] > 0)) {
-        ++i;
-        nrm[1] = nrm[0];
-        alpha[1] = alpha[0]; beta[1] = beta[0]; omega[1] = omega[0];
-        rho[3] = rho[2]; rho[2] = rho[1];
-        if (!dot(rt, r, rho[1])) return;
-        if (rho[1] == 0.0) {
-            add_e_to_phi();
-            store_phi();
-            finish(i, 2);
-            return;
-        }
-        if (init) {
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) pv[q] = r[q];
-            init = false;
-        } else {
-            beta[1] = (rho[1] / rho[2]) * (alpha[1] / omega[1]);
-            const double bt = beta[1], bw = -beta[1] * omega[1];
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) {
-                double u = pv[q] * bt;
-                u = u + bw * v[q];
-                u = u + 1.0 * r[q];
-                pv[q] = u;
-            }
-        }
-        if (!pre_cond(A.z[0], pv)) return;
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) { pt[q] = zo[q]; v[q] = act[q] ? op_cell(q, A.z[0], zo[q]) : 0.0; }
-        double m;
-        if (!dot(rt, v, m)) return;
-        alpha[0] = rho[1] / m;
-        if (fabs(m) > A.small * fabs(rho[1])) {
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) {
-                r[q] = r[q] + (-alpha[0]) * v[q];
-                e[q] = e[q] + alpha[0] * pt[q];
-            }
-            if (!norm(r, nrm[0])) return;
-        } else {
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) r[q] = 0.0;
-            nrm[0] = 0.0;
-        }
-        if (nrm[0] > eps * initial_norm && nrm[0] > A.reps * initial_rnorm) {
-            if (!pre_cond(A.z[1], r)) return;
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) t[q] = act[q] ? op_cell(q, A.z[1], zo[q]) : 0.0;
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) if (act[q]) { X[tid + q * nth] = t[q] * r[q]; Y[tid + q * nth] = t[q] * t[q]; }
-            double tr, tt;
-            if (!finish_sums(true, tr, tt)) return;
-            omega[0] = tr / tt;
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) {
-                e[q] = e[q] + omega[0] * zo[q];
-                r[q] = r[q] + (-omega[0]) * t[q];
-            }
-            if (!norm(r, nrm[0])) return;
-        }
-        if (nrm[0] <= eps * initial_norm || nrm[0] <= A.reps * initial_rnorm) {
-            bottom_exit = 1;
-            break;
-        }
-        if (omega[0] == 0.0 || nrm[0] > (1 - A.hang) * nrm[1]) {
-            if (recount == 0) {
-                recount = 1;
-            } else {
-                recount = 0;
-                add_e_to_phi();
-                if (restarts == A.numRestarts) {
-                    store_phi();
-                    finish(i, 3);
-                    return;
-                }
-                if (!residual(phv)) return;
-                if (!norm(r, nrm[0])) return;
-                rho[0] = rho[1] = rho[2] = rho[3] = 0.0;
-                alpha[0] = beta[0] = omega[0] = 0.0;
-#pragma unroll
-                for (int q = 0; q < CPT; ++q) { rt[q] = r[q]; e[q] = 0.0; }
-                ++restarts;
-                init = true;
-            }
-        }
-    }
-    add_e_to_phi();
-    store_phi();
-    finish(i, bottom_exit);
-}
-void launch_box_bicgstab(hipStream_t st, const LevelDev& L, int max_box_cells, BoxBicg A)
-{
-    A.patches = L.patches; A.npatches = L.npatches;
-    for (int d = 0; d < 3; ++d) A.jg[d] = L.jg[d];
-    A.jinv = L.jinv; A.lapd = L.lapdiag; A.P = L.P;
-    SOMAR_CHECK(L.npatches >= 1 && L.npatches <= BOX_MAX_WG && max_box_cells >= 1 && max_box_cells <= BOX_MAX_CELLS,
-                "k_box_bicgstab: level outside the kernel's limits");
-    SOMAR_HIP(hipMemsetAsync(A.sync, 0, (BOX_MAX_WG + 1) * sizeof(unsigned), st));
-    // 512-thread workgroups (256 VGPRs each: a thread's cells, their coefficients and vectors stay in registers), 1 / 2 / 4 cells
-    // per thread
-    const int nth = std::min(512, (max_box_cells + 63) / 64 * 64);
-    if (max_box_cells <= 512) hipLaunchKernelGGL((k_box_bicgstab<1, 512>), dim3(L.npatches), dim3(nth), 0, st, A);
-    else if (max_box_cells <= 1024) hipLaunchKernelGGL((k_box_bicgstab<2, 512>), dim3(L.npatches), dim3(nth), 0, st, A);
-    else hipLaunchKernelGGL((k_box_bicgstab<4, 512>), dim3(L.npatches), dim3(nth), 0, st, A);
 }
 
 // ---- what this device streams (somar_diag_stream_probe) -----------------------------------------------------------------------

@@ -68,7 +68,7 @@ PressureSolver::~PressureSolver()
                 if (c != d && L->dev.jgf[d][c]) { hipFree(L->dev.jgf[d][c]); L->dev.jgf[d][c] = nullptr; }
     hipFree(f_phi); hipFree(f_rhs); hipFree(f_uberRes); hipFree(f_uberCorr); hipFree(f_best);
     for (double* f : bicg) hipFree(f);
-    hipFree(d_box_nb_); hipFree(d_box_cstart_); hipFree(d_box_sums_); hipFree(d_box_sync_);
+    hipFree(d_box_nb_); hipFree(d_box_cstart_); hipFree(d_box_sums_); hipFree(d_box_sync_); hipFree(d_box_fab_); hipFree(d_box_fabstart_);
     hipFree(d_partials);
     hipFree(d_scalars);
     for (Prof& p : prof_) {
@@ -1626,13 +1626,30 @@ bool PressureSolver::box_bottom(int d) const
 {
     static const bool poll = !(getenv("SOMAR_POLL_FETCH") && atoi(getenv("SOMAR_POLL_FETCH")) == 0);
     const Level& L = *lev[d];
-    if (!box_bottom_on_ || !poll || full_ || diri_ || L.ncf != 0 || !L.plan.peers.empty() || profiling_ || capturing_ ||
+    if (!box_bottom_on_ || !poll || diri_ || L.ncf != 0 || !L.plan.peers.empty() || profiling_ || capturing_ ||
         comm_->size != 1 || prm.relaxMode != RELAX_LEVEL_GSRB || prm.precondMode == PRECOND_DIAG_LINE_RELAX || !bicg[7])
         return false;
-    if (L.valid_cells_global < box_min_cells_ || L.valid_cells_global != L.domain.numPts()) return false;
+    // (the 19-point operator has no single-workgroup kernel: its bottoms come here whatever their size)
+    if ((!full_ && L.valid_cells_global < box_min_cells_) || L.valid_cells_global != L.domain.numPts()) return false;
     if (L.npatches() < 1 || L.npatches() > BOX_MAX_WG || L.field_elems > 0x7fffffffll) return false;
     for (const PatchDesc& p : L.hpatches)
         if ((long long)p.n[0] * p.n[1] * p.n[2] > BOX_MAX_CELLS) return false;
+    if (full_) {
+        // the 19-point variant: 3-D, boxes of at most 256 cells and at least 2 wide (order-2 extrapolation reads three cells
+        // back from a ghost), the box grown by one cell and its two ghost programs within the kernel's LDS arrays
+        if (!L.active[2] || hasCF_) return false;
+        const int d0 = (int)lev.size() - 1;
+        if (d != d0 || (int)full_prog_.size() <= d) return false;
+        for (const PatchDesc& p : L.hpatches) {
+            if ((long long)p.n[0] * p.n[1] * p.n[2] > 256 || p.n[0] < 2 || p.n[1] < 2 || p.n[2] < 2) return false;
+            if ((long long)(p.n[0] + 2) * (p.n[1] + 2) * (p.n[2] + 2) > BOX_FAB_MAX) return false;
+        }
+        for (int w = 0; w < 2; ++w) {
+            const FullProgram& Pg = full_prog_[d][w];
+            if (!Pg.d_box_ops && !Pg.first.empty()) return false;
+            if (Pg.max_box_ops > BOX_MAX_OPS) return false;
+        }
+    }
     return true;
 }
 
@@ -1676,6 +1693,26 @@ void PressureSolver::build_box_tables(int d)
     SOMAR_HIP(hipMalloc(&d_box_cstart_, cstart.size() * sizeof(int)));
     SOMAR_HIP(hipMalloc(&d_box_sums_, (size_t)4 * BOX_MAX_WG * sizeof(double)));
     SOMAR_HIP(hipMalloc(&d_box_sync_, (BOX_MAX_WG + 1) * sizeof(unsigned)));
+    if (full_) {
+        // the box grown by one cell: where each of its cells' values comes from
+        std::vector<int> fab, fstart(L.hpatches.size() + 1, 0);
+        for (size_t b = 0; b < L.hpatches.size(); ++b) {
+            const PatchDesc& p = L.hpatches[b];
+            fstart[b] = (int)fab.size();
+            for (int k = -1; k <= p.n[2]; ++k)
+                for (int j = -1; j <= p.n[1]; ++j)
+                    for (int i = -1; i <= p.n[0]; ++i) {
+                        const long long c = at(p, i, j, k);
+                        const bool inside = i >= 0 && i < p.n[0] && j >= 0 && j < p.n[1] && k >= 0 && k < p.n[2];
+                        fab.push_back(inside ? (int)c : (G[(size_t)c] != (int)c ? G[(size_t)c] : -1));
+                    }
+        }
+        fstart[L.hpatches.size()] = (int)fab.size();
+        SOMAR_HIP(hipMalloc(&d_box_fab_, fab.size() * sizeof(int)));
+        SOMAR_HIP(hipMalloc(&d_box_fabstart_, fstart.size() * sizeof(int)));
+        SOMAR_HIP(hipMemcpy(d_box_fab_, fab.data(), fab.size() * sizeof(int), hipMemcpyHostToDevice));
+        SOMAR_HIP(hipMemcpy(d_box_fabstart_, fstart.data(), fstart.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     SOMAR_HIP(hipMemcpy(d_box_nb_, nb.data(), nb.size() * sizeof(int), hipMemcpyHostToDevice));
     SOMAR_HIP(hipMemcpy(d_box_cstart_, cstart.data(), cstart.size() * sizeof(int), hipMemcpyHostToDevice));
     box_depth_ = d;
@@ -1708,6 +1745,12 @@ void PressureSolver::bottom_solve(double* phi, const double* rhs)
         A.sums = d_box_sums_;
         A.sync = d_box_sync_;
         A.serial = ordered(d) ? 1 : 0;
+        A.full = full_ ? 1 : 0;
+        if (full_) {
+            A.fab_src = d_box_fab_;
+            A.fab_start = d_box_fabstart_;
+            for (int w = 0; w < 2; ++w) { A.ops[w] = full_prog_[d][w].d_box_ops; A.ops_first[w] = full_prog_[d][w].d_box_first; }
+        }
         A.info = d_scalars + SLOT_TMP;
         A.pub = ScalarPublish{h_scalars + SLOT_TMP, h_seq_, ++fetch_seq_};
         launch_box_bicgstab(st_, L.dev, box_max_cells_, A);

@@ -321,6 +321,8 @@ void PressureSolver::upload_program(FullProgram& P, const std::vector<std::vecto
         sorted.insert(sorted.end(), byBox[b].begin(), byBox[b].end());   // stage order is kept: stages were walked in order
     }
     first[npatches] = (int)sorted.size();
+    P.max_box_ops = 0;
+    for (int b = 0; b < npatches; ++b) P.max_box_ops = std::max(P.max_box_ops, first[b + 1] - first[b]);
     SOMAR_HIP(hipMalloc(&P.d_ops, flat.size() * sizeof(GhostOp)));
     SOMAR_HIP(hipMemcpy(P.d_ops, flat.data(), flat.size() * sizeof(GhostOp), hipMemcpyHostToDevice));
     SOMAR_HIP(hipMalloc(&P.d_box_ops, sorted.size() * sizeof(GhostOp)));

@@ -158,3 +158,69 @@ def test_tree_sums_above_the_ordered_limit(oracle, case, F, monkeypatch):
         it, ex, sol = got[on]
         assert ex == bs.exitStatus and abs(it - bs.iters) <= 1, (on, it, ex, bs.iters, bs.exitStatus)
         assert max_rel_diff(sol, valid_of(phi)) < 2e-4, on   # two converged (eps 1e-6) solves of the same system
+
+
+FULL_CASES = [
+    # (n, boxsz, periodic, L): non-diagonal (sheared) metric, the bottom level's boxes 4^3 ... 8x4x4
+    ((16, 16, 16), 8, (True, True, True), (1.0, 1.0, 1.0)),
+    ((16, 16, 8), 8, (False, True, False), (2.0, 1.0, 0.5)),
+    ((24, 16, 8), (12, 8, 8), (False, False, False), (1.5, 1.0, 0.5)),
+    ((32, 32, 16), 16, (False, False, False), (1.0, 1.0, 0.5)),
+]
+
+
+@pytest.mark.parametrize("case", FULL_CASES)
+def test_nineteen_point_box_bottom_solver_equals_the_launch_path_and_the_oracle(oracle, case, F, monkeypatch):
+    """the 19-point variant (k_box_bicgstab<.., FULL>): exchange, psi snapshot and the box's ghost programs in LDS instead of
+    12-20 staged launches per colour pass / operator application.  Bit for bit the launch path's iterates and the oracle's."""
+    from somar_amd import AMRPressureSolver
+    so = oracle
+    n, bs, per, L = case
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), per)
+    grids = so.split_domain(dom.box, bs)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    Jgup, Jinv = so.make_full_metric(grids, dx, L, dom)
+    fac = so.Factory(dom, grids, dx, so.BCHolder(), Jgup, Jinv, isDiagonal=False)
+    mg = so.MultiGrid(fac, so.BiCGStab())
+    D = mg.depth
+    opb = mg.ops[-1]
+    rhs = so.random_field(opb.grids, 91, (0, 0, 0), opb.domain.box)
+    so.remove_weighted_mean(rhs, opb.Jinv)
+    res = so.random_field(grids, 92, (0, 0, 0), dom.box)
+    so.remove_weighted_mean(res, mg.ops[0].Jinv)
+    fp, fr = (F.FIELD(D - 1, F.F_CORR), F.FIELD(D - 1, F.F_RES)) if D > 1 else (F.F_CORR, F.F_RES)
+    out, cyc = {}, {}
+    for on in (False, True):
+        monkeypatch.setenv("SOMAR_BOX_BOTTOM", "1" if on else "0")
+        s = AMRPressureSolver()
+        p = s._p
+        s.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg, p.hang,
+                             p.norm_thresh, 0)
+        s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids])
+        for q in range(s.num_local_patches):
+            _, _, gi = s.patch_box(q)
+            s.setMetricFull(q, *[np.asfortranarray(Jgup[gi][d].a) for d in range(3)], np.asfortranarray(Jinv[gi].a[..., 0]))
+        s.finalize()
+        assert s.depth() == D
+        upload(s, fr, rhs, depth=D - 1)
+        s.setVal(fp, 0.0)
+        it, ex = s.bottomSolve(fp, fr)
+        assert s.bottomKind() == (2 if on else 0)
+        out[on] = (it, ex, download_valid(s, fp, opb.grids, D - 1))
+        upload(s, F.F_RES, res)
+        s.setVal(F.F_CORR, 0.0)
+        s.vcycle(F.F_CORR, F.F_RES)
+        cyc[on] = download_valid(s, F.F_CORR, grids)
+        s.undefine()
+    assert out[False][:2] == out[True][:2]
+    for a, b in zip(out[False][2], out[True][2]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(cyc[False], cyc[True]):
+        np.testing.assert_array_equal(a, b)
+    phi = so.LevelData(opb.grids, 1, (1, 1, 1))
+    bsol = so.BiCGStab()
+    bsol.define(opb, True)
+    bsol.solve(phi, rhs)
+    assert out[True][:2] == (bsol.iters, bsol.exitStatus)
+    for a, b in zip(out[True][2], valid_of(phi)):
+        np.testing.assert_array_equal(a, b)
