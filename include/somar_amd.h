@@ -93,6 +93,11 @@ typedef struct somar_stats {
                                         * final_rnorm are exact whatever imax is */
 } somar_stats_t;
 
+/* The COMPLETE residual history of the calling thread's last solve (any entry point that fills a somar_stats_t), for callers
+ * whose AMRMG.imax exceeds SOMAR_MAX_HISTORY - 1: copies min(capacity, n) entries into out (may be NULL with capacity 0) and
+ * stores the full length in *n.  (MappedAMRMultiGrid keeps no history at all; it prints each norm, MappedAMRMultiGrid.H:1150-1157.) */
+int somar_last_history(double* out, int capacity, int* n);
+
 /* resident field handles: which | (depth << 8) */
 #define SOMAR_F_PHI 0     /* depth 0: the solution        */
 #define SOMAR_F_RHS 1     /* depth 0: the right-hand side */
@@ -194,6 +199,10 @@ int somar_bottom_solve(somar_solver_t* s, int phi_field, int rhs_field, int* ite
  * 1 = one single-workgroup launch (bottoms of at most 512 cells), 2 = one persistent launch with one workgroup per box and
  * device-wide barriers (multi-box bottoms; SOMAR_BOX_BOTTOM=0 switches it off).  Same iterates on every path. */
 int somar_bottom_kind(somar_solver_t* s, int* kind);
+/* which of the library's alternative execution paths have run on this solver so far (tests assert that the path under test
+ * is the one that ran): out4 = {fused sweeps whose ghost exchange travelled on the second stream under their interior tiles,
+ * ghost programs executed as one launch (a workgroup per box), ghost programs executed stage by stage, bottom solves} */
+int somar_solver_counters(somar_solver_t* s, long long* out4);
 
 /* MAC level projection of a face-centred velocity given in flux form (J u^a on a-faces, one host array per
  * local patch spanning faces(valid, a)):  rhs = div(U)/dt ; solve ; U -= dt * Jg^{aa} d_a(phi).
@@ -337,7 +346,9 @@ int somar_k_mappedaverage2(double* coarse, const int* icoarselo0, const int* ico
 int somar_sync(somar_solver_t* s);
 int somar_timer_start(somar_solver_t* s);
 int somar_timer_stop(somar_solver_t* s, double* milliseconds);
-/* per-launch HIP events around the depth-0 hot kernels: kernel 0 = GSRB colour pass, 1 = residual */
+/* per-launch HIP events: kernel 0 = the depth-0 GSRB launches, 1 = the depth-0 operator / residual launches, 2 = ghost exchanges
+ * with other ranks on any depth (pack + grouped send/recv + unpack; LevelData::exchange, MappedAMRPoissonOp.cpp:2222-2238),
+ * 3 = the replicated coarse tail of a sharded hierarchy.  While profiling nothing is overlapped or graph-replayed. */
 int somar_profile_enable(somar_solver_t* s, int on);
 int somar_profile_get(somar_solver_t* s, int kernel, int* launches, double* total_ms);
 
@@ -559,11 +570,16 @@ int somar_solver_set_metric_uniform(somar_solver_t* s, const double* c4);
  *          fill_bathymetry returns (DEMMap, LedgeMap, BeamGeneratorMap ...), host array over nodes
  *          [depth_lo, depth_lo + depth_n) of this level's index space, i fastest, covering nodes lo-1 .. hi+2 of every
  *          local box in both horizontal directions.  AVG3IX's misprinted eighth term (AddlFortranMacros.H:88) is reproduced.
- *    Both run GeoSourceInterface::fill_Jgup / fill_Jinv's generic algebra per point at the point's own centring, as
- *    LevelGeometry does.  Maps not listed (Twisted, NewBeamGenerator's spline, DEM interpolation itself) stay with the caller
- *    through somar_solver_set_metric_full or somar_metric_jgup_from_dxdxi. */
+ *      SOMAR_MAP_TWISTED      TwistedMap with m_twistType 0 (geometry/maps/TwistedMap.cpp:160-260, TwistedMapF.ChF:
+ *          TWISTED0_FILL_DXDXI, TWISTED0_FILL_J), non-diagonal: x^mu = xi^mu + pert_mu sin(2 pi xi^nu) sin(2 pi xi^sigma);
+ *          L = the three amplitudes m_pert, depth unused.
+ *    All run GeoSourceInterface::fill_Jgup / fill_Jinv's generic algebra per point at the point's own centring, as
+ *    LevelGeometry does.  Maps not listed (TwistedMap's m_twistType 1, which goes through the generic finite differences of
+ *    GeoSourceInterface, NewBeamGenerator's spline, the DEM interpolation itself) stay with the caller through
+ *    somar_solver_set_metric_full or somar_metric_jgup_from_dxdxi. */
 #define SOMAR_MAP_CYLINDRICAL 1
 #define SOMAR_MAP_BATHYMETRIC 2
+#define SOMAR_MAP_TWISTED 3
 int somar_solver_set_metric_map(somar_solver_t* s, int kind, const double* L, const double* depth, const int* depth_lo,
                                 const int* depth_n);
 

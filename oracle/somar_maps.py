@@ -22,7 +22,7 @@ import numpy as np
 
 from . import somar_oracle as so
 
-CYLINDRICAL, BATHYMETRIC = 1, 2
+CYLINDRICAL, BATHYMETRIC, TWISTED = 1, 2, 3
 
 
 def _idx(lo, hi):
@@ -136,6 +136,48 @@ class BathymetricMap:
         d = d * self.dxdXi(0, 0, T, I, J, K, 1.0)
         d = d * self.dxdXi(1, 1, T, I, J, K, 1.0)
         return d
+
+
+class TwistedMap:
+    """TwistedMap with m_twistType 0 (geometry/maps/TwistedMap.cpp:160-260): x^mu = xi^mu + pert_mu sin(2 pi xi^nu) sin(2 pi xi^o);
+    fill_dxdXi = setVal(scale) on the diagonal and TWISTED0_FILL_DXDXI off it (TwistedMapF.ChF:181-262), fill_J =
+    TWISTED0_FILL_J (TwistedMapF.ChF:270-340), one statement per Fortran statement"""
+    diagonal = False
+
+    def __init__(self, dXi, pert):
+        self.dXi, self.pert = tuple(float(x) for x in dXi), tuple(float(x) for x in pert)
+
+    def dxdXi(self, mu, nu, T, I, J, K, scale=1.0):
+        shape = np.broadcast(I, J, K).shape
+        if mu == nu:
+            return np.full(shape, scale)
+        twoPi = 2.0 * np.pi
+        o = 3 - mu - nu
+        x = (I, J, K)
+        offn, offo = (1.0 - T[nu]) * 0.5, (1.0 - T[o]) * 0.5
+        scaledPert = twoPi * scale * self.pert[mu]
+        v = scaledPert * np.cos(twoPi * self.dXi[nu] * (x[nu] + offn)) * np.sin(twoPi * self.dXi[o] * (x[o] + offo))
+        return np.broadcast_to(v, shape).copy()
+
+    def J(self, T, I, J, K, scale=1.0):
+        Pi = np.pi
+        twoPi = 2.0 * Pi
+        twoPiPi = twoPi * Pi
+        p = self.pert
+        pertProd = Pi * p[0] * p[1] * p[2]
+        Xi0 = twoPi * self.dXi[0] * (I + (1.0 - T[0]) * 0.5)
+        Xi1 = twoPi * self.dXi[1] * (J + (1.0 - T[1]) * 0.5)
+        Xi2 = twoPi * self.dXi[2] * (K + (1.0 - T[2]) * 0.5)
+        cCos2 = p[2] * np.cos(Xi2)
+        SinXi2, Sin2Xi2 = np.sin(Xi2), np.sin(2.0 * Xi2)
+        aSin22 = p[0] * SinXi2 ** 2
+        CosXi1, SinXi1, Sin2Xi1 = np.cos(Xi1), np.sin(Xi1), np.sin(2.0 * Xi1)
+        SinProd = pertProd * Sin2Xi1 * Sin2Xi2
+        CosProd = -2.0 * p[0] * cCos2 * SinXi1 ** 2
+        twobCos1 = -2.0 * p[1] * CosXi1
+        CosXi0, SinXi0, Sin2Xi0 = np.cos(Xi0), np.sin(Xi0), np.sin(2.0 * Xi0)
+        v = scale * (1.0 + twoPiPi * (twobCos1 * (cCos2 * SinXi0 ** 2 + CosXi0 * aSin22) + (CosXi0 * CosProd + Sin2Xi0 * SinProd)))
+        return np.broadcast_to(v, np.broadcast(I, J, K).shape).copy()
 
 
 def fill_jgup(m, valid, mu):

@@ -14,7 +14,7 @@ _LIB = None
 
 BC_NONE, BC_NEUM, BC_DIRI = -1, 0, 1
 F_PHI, F_RHS, F_RES, F_CORR, F_BEST, F_SCRATCH, F_AMR_CORR, F_AMR_RES, F_HEAT_OLD, F_HEAT_SRC = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
-MAP_CYLINDRICAL, MAP_BATHYMETRIC = 1, 2   # SOMAR_MAP_* of include/somar_amd.h
+MAP_CYLINDRICAL, MAP_BATHYMETRIC, MAP_TWISTED = 1, 2, 3   # SOMAR_MAP_* of include/somar_amd.h
 MAX_HISTORY = 64
 COMM_ID_BYTES = 128
 
@@ -102,6 +102,8 @@ _SIGS = {
     "somar_mini_vcycle": [_H, C.c_int, C.c_int],
     "somar_bottom_solve": [_H, C.c_int, C.c_int, _PI, _PI],
     "somar_bottom_kind": [_H, _PI],
+    "somar_solver_counters": [_H, C.POINTER(C.c_longlong)],
+    "somar_last_history": [_PD, C.c_int, _PI],
     "somar_host_fill_mt19937_64": [_PD, C.c_longlong, C.c_ulonglong, C.c_double, C.c_double],
     "somar_vel_upload": [_H, C.c_int, C.c_int, _PD],
     "somar_vel_download": [_H, C.c_int, C.c_int, _PD],
@@ -630,6 +632,12 @@ class AMRPressureSolver:
         _ck(lib().somar_bottom_solve(self._h, phi_field, rhs_field, C.byref(it), C.byref(ex)))
         return it.value, ex.value
 
+    def counters(self):
+        """{overlapped_sweeps, ghost_programs_one_launch, ghost_programs_staged, bottom_solves} so far"""
+        c = (C.c_longlong * 4)()
+        _ck(lib().somar_solver_counters(self._h, c))
+        return {"overlapped_sweeps": c[0], "ghost_programs_one_launch": c[1], "ghost_programs_staged": c[2], "bottom_solves": c[3]}
+
     def bottomKind(self):
         """how the last bottom solve ran: 0 launch by launch, 1 one single-workgroup launch, 2 one persistent launch, a workgroup per box"""
         k = C.c_int()
@@ -918,6 +926,15 @@ def host_random_field(shape, seed, lo=-1.0, hi=1.0):
     a = np.empty(shape, order="F")
     _ck(lib().somar_host_fill_mt19937_64(a.ctypes.data_as(_PD), a.size, seed, lo, hi))
     return a
+
+
+def last_history():
+    """the complete residual history of this thread's last solve (somar_stats_t.history holds at most 64 entries)"""
+    n = C.c_int()
+    _ck(lib().somar_last_history(None, 0, C.byref(n)))
+    out = np.zeros(max(n.value, 1))
+    _ck(lib().somar_last_history(out.ctypes.data_as(_PD), n.value, C.byref(n)))
+    return out[:n.value]
 
 
 def device_count():

@@ -348,8 +348,11 @@ int somar_field_dot(somar_solver_t* s, int field_a, int field_b, double* out)
     API_END
 }
 
+static thread_local std::vector<double> g_history;   // the last solve's whole history (somar_last_history)
+
 static void fill_stats(const SolveStats& st, somar_stats_t* o)
 {
+    g_history = st.history;
     if (!o) return;
     std::memset(o, 0, sizeof(*o));
     o->iters = st.iters;
@@ -361,6 +364,15 @@ static void fill_stats(const SolveStats& st, somar_stats_t* o)
     o->final_rnorm = st.final_rnorm;
     o->nhistory = (int)std::min<size_t>(st.history.size(), SOMAR_MAX_HISTORY);
     for (int i = 0; i < o->nhistory; ++i) o->history[i] = st.history[i];
+}
+
+int somar_last_history(double* out, int capacity, int* n)
+{
+    API_BEGIN
+    SOMAR_CHECK(n && capacity >= 0 && (out || capacity == 0), "somar_last_history: bad arguments");
+    *n = (int)g_history.size();
+    for (int i = 0; i < capacity && i < *n; ++i) out[i] = g_history[i];
+    API_END
 }
 
 int somar_solver_solve(somar_solver_t* s, int zero_phi, int force_homogeneous, somar_stats_t* stats)
@@ -534,6 +546,13 @@ int somar_bottom_kind(somar_solver_t* s, int* kind)
 {
     API_BEGIN
     *kind = s->ps->bottom_kind;
+    API_END
+}
+
+int somar_solver_counters(somar_solver_t* s, long long* out4)
+{
+    API_BEGIN
+    for (int q = 0; q < 4; ++q) out4[q] = s->ps->counters[q];
     API_END
 }
 

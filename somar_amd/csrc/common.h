@@ -107,7 +107,10 @@ struct StencilParams {
     // J^{-1} == uc[3] in every cell of this depth, found by PressureSolver::detect_uniform_metric.  The k-marching kernels
     // then take the four values from here instead of streaming four arrays of them (56 -> 24 B/cell on a sweep).
     int uniform = 0;
-    int pad3_ = 0;
+    // non-diagonal metric: J g^{xy} on x-faces and J g^{yx} on y-faces are zero everywhere on this depth (any map with x = xi,
+    // y = eta: BathymetricBaseMap and its DEM / Ledge / BeamGenerator subclasses); the marching 19-point kernels then stream
+    // seven coefficient planes instead of nine (PressureSolver::detect_zero_planes)
+    int zero_xy = 0;
     double uc[4] = {0.0, 0.0, 0.0, 0.0};
 };
 

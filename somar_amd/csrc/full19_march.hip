@@ -53,7 +53,10 @@ __device__ __forceinline__ double2 fm_ld2(const double* __restrict__ a, long lon
 __device__ __forceinline__ double fm_pick(const double2& v, int s) { return s ? v.y : v.x; }
 
 // MODE 0: out = rhs - L[phi]   MODE 1: out = L[phi]   MODE 2: out = phi with the cells of `color` relaxed (one GSRB pass)
-template <int MODE, int FM_J>
+// ZXY: J g^{xy} on x-faces and J g^{yx} on y-faces are identically zero (StencilParams::zero_xy): those two planes are not
+// streamed -- three of the pass's thirteen coefficient loads per plane -- and zeros stand in for them; the products are the
+// zeros the stored planes would give (up to the sign of zero).
+template <int MODE, int FM_J, bool ZXY = false>
 __global__ __launch_bounds__(64 * FM_J) void k_full_march(const Tile* __restrict__ tiles,
                                                           const PatchDesc* __restrict__ patches,
                                                           double* __restrict__ out, const double* __restrict__ phi,
@@ -146,12 +149,12 @@ __global__ __launch_bounds__(64 * FM_J) void k_full_march(const Tile* __restrict
         if (MODE != 1) Rh = fm_ld2(rhs, ck, o[0], o[1], p.off);
         const double2 Ji = fm_ld2(jinv, ck, o[0], o[1], p.off);
         const double2 Jx0 = fm_ld2(J.c[0][0], ck, gxo0, any, p.off);
-        const double2 Jx1 = fm_ld2(J.c[0][1], ck, gxo0, any, p.off);
+        const double2 Jx1 = ZXY ? make_double2(0.0, 0.0) : fm_ld2(J.c[0][1], ck, gxo0, any, p.off);
         const double2 Jx2 = fm_ld2(J.c[0][2], ck, gxo0, any, p.off);
-        const double2 Jy0 = fm_ld2(J.c[1][0], ck, o[0], o[1], p.off);
+        const double2 Jy0 = ZXY ? make_double2(0.0, 0.0) : fm_ld2(J.c[1][0], ck, o[0], o[1], p.off);
         const double2 Jy1 = fm_ld2(J.c[1][1], ck, o[0], o[1], p.off);
         const double2 Jy2 = fm_ld2(J.c[1][2], ck, o[0], o[1], p.off);
-        const double2 Jy0h = fm_ld2(J.c[1][0], ck + sj, o[0], o[1], p.off);
+        const double2 Jy0h = ZXY ? make_double2(0.0, 0.0) : fm_ld2(J.c[1][0], ck + sj, o[0], o[1], p.off);
         const double2 Jy1h = fm_ld2(J.c[1][1], ck + sj, o[0], o[1], p.off);
         const double2 Jy2h = fm_ld2(J.c[1][2], ck + sj, o[0], o[1], p.off);
         const double jx0n = __shfl_down(Jx0.x, 1, 64), jx1n = __shfl_down(Jx1.x, 1, 64), jx2n = __shfl_down(Jx2.x, 1, 64);
@@ -321,24 +324,26 @@ static JgFullM jgfullm(const LevelDev& L)
     return J;
 }
 
-// mode 0: out = rhs - L[phi], 1: out = L[phi].  psi needs to be right only in the one-cell frame of every box.
+// mode 0: out = rhs - L[phi], 1: out = L[phi], 2: one GSRB colour pass.  psi needs to be right only in the one-cell frame of every box.
+template <int MODE>
+static void launch_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out, const double* phi,
+                         const double* psi, const double* rhs, int color)
+{
+    const bool six = full_march_rows() == 6, z = L.P.zero_xy != 0;
+#define SOMAR_FM(ROWS, Z)                                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<MODE, ROWS, Z>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
+                       out, phi, psi, rhs, jgfullm(L), L.jinv, L.P, color)
+    if (six) { if (z) SOMAR_FM(6, true); else SOMAR_FM(6, false); }
+    else { if (z) SOMAR_FM(8, true); else SOMAR_FM(8, false); }
+#undef SOMAR_FM
+}
+
 void launch_full_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out, const double* phi,
                        const double* psi, const double* rhs, int mode)
 {
     if (ntiles == 0) return;
-    const bool six = full_march_rows() == 6;
-    if (mode == 0 && six)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<0, 6>), dim3(ntiles), dim3(64, 6, 1), 0, st, tiles, L.patches, out, phi, psi,
-                           rhs, jgfullm(L), L.jinv, L.P, 0);
-    else if (mode == 0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<0, 8>), dim3(ntiles), dim3(64, 8, 1), 0, st, tiles, L.patches, out, phi, psi,
-                           rhs, jgfullm(L), L.jinv, L.P, 0);
-    else if (six)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<1, 6>), dim3(ntiles), dim3(64, 6, 1), 0, st, tiles, L.patches, out, phi, psi,
-                           rhs, jgfullm(L), L.jinv, L.P, 0);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<1, 8>), dim3(ntiles), dim3(64, 8, 1), 0, st, tiles, L.patches, out, phi, psi,
-                           rhs, jgfullm(L), L.jinv, L.P, 0);
+    if (mode == 0) launch_march<0>(st, tiles, ntiles, L, out, phi, psi, rhs, 0);
+    else launch_march<1>(st, tiles, ntiles, L, out, phi, psi, rhs, 0);
 }
 
 // one colour pass of the 19-point GSRB: out = phi with the cells of `color` relaxed (out != phi)
@@ -346,12 +351,7 @@ void launch_gsrb_full_march(hipStream_t st, const Tile* tiles, int ntiles, const
                             const double* phi, const double* psi, const double* rhs, int color)
 {
     if (ntiles == 0) return;
-    if (full_march_rows() == 6)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<2, 6>), dim3(ntiles), dim3(64, 6, 1), 0, st, tiles, L.patches, out, phi, psi,
-                           rhs, jgfullm(L), L.jinv, L.P, color);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<2, 8>), dim3(ntiles), dim3(64, 8, 1), 0, st, tiles, L.patches, out, phi, psi,
-                           rhs, jgfullm(L), L.jinv, L.P, color);
+    launch_march<2>(st, tiles, ntiles, L, out, phi, psi, rhs, color);
 }
 
 }  // namespace somar

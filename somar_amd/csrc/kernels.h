@@ -156,7 +156,7 @@ void launch_tiny_bicgstab(hipStream_t st, const LevelDev& L, const CopyItem* ite
 // six cells its stencil reads (x-, x+, y-, y+, z-, z+): the neighbour itself, or -- across a box edge -- the valid cell the ghost
 // exchange would have copied from (built on the host from the level's exchange plan), so no ghost cell is ever filled.
 constexpr int BOX_MAX_WG = 128, BOX_MAX_CELLS = 2048;
-constexpr int BOX_FAB_MAX = 2048, BOX_MAX_OPS = 320;   // 19-point variant: cells of a box grown by one cell; ops of one of its ghost programs
+constexpr int BOX_FAB_MAX = 2048, BOX_MAX_OPS = 512;   // 19-point variant: cells of a box grown by one cell; ops of one of its ghost programs
 struct BoxBicg {
     const PatchDesc* patches; int npatches;
     const int* nb; const int* cstart;

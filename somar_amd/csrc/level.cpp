@@ -487,6 +487,8 @@ Level::~Level()
     hipFree(d_patches);
     hipFree(d_tiles);
     hipFree(d_ftiles);
+    hipFree(d_ftiles_own);
+    hipFree(d_ftiles_rem);
     hipFree(d_rtiles);
     hipFree(d_qtiles);
     hipFree(d_ctiles);
@@ -685,6 +687,32 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     d_recv_items = to_device(plan.recv_items);
     d_send_off = to_device(plan.send_itemoff);
     d_recv_off = to_device(plan.recv_itemoff);
+    if (!plan.peers.empty() && !hftiles.empty()) {
+        // which fused-sweep tiles read a ghost cell that arrives from another rank?  A tile reads phi two cells around its
+        // columns and planes (the recomputed red ring) -- FRAME deep, as deep as the exchange fills.
+        std::vector<std::vector<const CopyItem*>> byDst(hpatches.size());
+        for (const CopyItem& it : plan.recv_items) byDst[it.dst_patch].push_back(&it);
+        std::vector<Tile> own, rem;
+        const int rows = fused_rows() - 4;
+        for (const Tile& t : hftiles) {
+            const PatchDesc& p = hpatches[t.patch];
+            const int w = t.pad_[0] > 0 ? t.pad_[0] : 124;
+            const int lo[3] = {t.i0 - FRAME, t.j0 - FRAME, t.k0 - FRAME};
+            const int hi[3] = {std::min(t.i0 + w, p.n[0]) - 1 + FRAME, std::min(t.j0 + rows, p.n[1]) - 1 + FRAME, t.k0 + t.nk - 1 + FRAME};
+            bool hit = false;
+            for (const CopyItem* it : byDst[t.patch]) {
+                bool ov = true;
+                for (int d = 0; d < 3; ++d)
+                    ov = ov && std::max(lo[d], it->dst_lo[d]) <= std::min(hi[d], it->dst_lo[d] + it->n[d] - 1);
+                if (ov) { hit = true; break; }
+            }
+            (hit ? rem : own).push_back(t);
+        }
+        nftiles_own = (int)own.size();
+        nftiles_rem = (int)rem.size();
+        d_ftiles_own = to_device(own);
+        d_ftiles_rem = to_device(rem);
+    }
     if (plan.send_total) SOMAR_HIP(hipMalloc(&d_sendbuf, plan.send_total * sizeof(double)));
     if (plan.recv_total) SOMAR_HIP(hipMalloc(&d_recvbuf, plan.recv_total * sizeof(double)));
 
@@ -798,6 +826,19 @@ void Level::alloc_metric()
         if (!dev.jg[d]) dev.jg[d] = alloc_field();
     if (!dev.jinv) dev.jinv = alloc_field();
     if (!dev.lapdiag) dev.lapdiag = alloc_field();
+}
+
+void Level::exchange_remote(double* f, hipStream_t st) const
+{
+    if (plan.peers.empty()) return;
+    launch_pack(st, dev, d_send_items, d_send_off, (int)plan.send_items.size(), f, d_sendbuf, true);
+    comm->neighbor_exchange(d_sendbuf, d_recvbuf, plan.peers, plan.soff, plan.scount, plan.roff, plan.rcount, st);
+    launch_pack(st, dev, d_recv_items, d_recv_off, (int)plan.recv_items.size(), f, d_recvbuf, false);
+}
+
+void Level::exchange_local(double* f, hipStream_t st) const
+{
+    launch_copy_items(st, dev, d_local_items, (int)plan.local.size(), f);
 }
 
 void Level::exchange(double* f, hipStream_t st) const

@@ -97,6 +97,11 @@ public:
     std::vector<Tile> hftiles;   // tiles of the fused red-black sweep (gsrb_fused.hip)
     Tile* d_ftiles = nullptr;
     int nftiles = 0;
+    // sharded levels: hftiles split into the tiles that read no ghost cell another rank fills (they may run while the
+    // messages are in flight) and the rest (fused_overlap in solver.cpp); both lists keep the XCD-contiguous order
+    Tile* d_ftiles_own = nullptr;
+    Tile* d_ftiles_rem = nullptr;
+    int nftiles_own = 0, nftiles_rem = 0;
     std::vector<Tile> hrtiles;   // tiles of the k-marching operator/residual (resid_march.hip): 124 x 14 columns
     Tile* d_rtiles = nullptr;
     int nrtiles = 0;
@@ -178,6 +183,10 @@ public:
 
     // ghost exchange of one field (faces, edges and corners, 1 cell deep in active dirs)
     void exchange(double* f, hipStream_t st) const;
+    // its two halves: what other ranks send (pack, one grouped send / receive per neighbour, unpack) and the box-to-box
+    // copies inside this rank; they write disjoint ghost cells and may run on different streams
+    void exchange_remote(double* f, hipStream_t st) const;
+    void exchange_local(double* f, hipStream_t st) const;
 
     // host<->device transfer of one patch in Chombo FRA layout.  `hostbox` is the box the host
     // array is defined on (valid grown by the caller's ghosts, or a face box); `region` is

@@ -7,6 +7,9 @@
 //   BathymetricBaseMap::fill_dxdXi / fill_J    geometry/maps/BathymetricBaseMap.cpp:133-313 (the !isDiagonal() branches),
 //                                              BathymetricBaseMapF.ChF: FILL_BATHYDXDXI, FILL_BATHYDZDXI, FILL_BATHYDZDZETA
 //                                              with VERTPHI(f) = f, DVERTPHI(f) = one, HORIZPHI(f) = f
+//   TwistedMap (m_twistType 0)::fill_dxdXi / fill_J   geometry/maps/TwistedMap.cpp:160-260, TwistedMapF.ChF:181-262, 270-340
+//                                              (TWISTED0_FILL_DXDXI, TWISTED0_FILL_J); isDiagonal() = false:
+//                                              x^mu = xi^mu + pert_mu sin(2 pi xi^nu) sin(2 pi xi^sigma)
 //   CONVERTFAB                                 calculus/interpolation/ConvertFABF.ChF:32-150, AVG1IX / AVG2IX / AVG3IX of
 //                                              utils/AddlFortranMacros.H:74-88
 //   GeoSourceInterface::fill_dXidx / fill_gup / fill_Jgup / fill_Jinv   geometry/GeoSourceInterface.cpp:200-450
@@ -23,9 +26,9 @@
 namespace somar {
 
 struct MapParams {
-    int kind;            // 1 cylindrical, 2 bathymetric
+    int kind;            // 1 cylindrical, 2 bathymetric, 3 twisted (type 0)
     double dXi[3];
-    double L[3];
+    double L[3];         // bathymetric: domain lengths; twisted: the perturbation amplitudes m_pert
     const double* depth; // nodes [dlo, dlo + dn), i fastest
     int dlo[2], dn[2];
 };
@@ -73,6 +76,17 @@ struct MapEval {
             if (mu == 0) return nu == 0 ? scale * cos(Xi1) : -scale * Xi0 * sin(Xi1);
             return nu == 0 ? scale * sin(Xi1) : scale * Xi0 * cos(Xi1);
         }
+        if (M.kind == 3) {
+            // TwistedMap::fill_dxdXi: setVal(scale) on the diagonal, TWISTED0_FILL_DXDXI off it: the derivative of
+            // pert_mu sin(2 pi xi^nu) sin(2 pi xi^o) in direction nu, o the third direction
+            if (mu == nu) return scale;
+            const double twoPi = 2.0 * M_PI;
+            const int o = 3 - mu - nu;
+            const int x[3] = {i, j, k};
+            const double offn = (1.0 - T[nu]) * 0.5, offo = (1.0 - T[o]) * 0.5;
+            const double scaledPert = twoPi * scale * M.L[mu];
+            return scaledPert * cos(twoPi * M.dXi[nu] * (x[nu] + offn)) * sin(twoPi * M.dXi[o] * (x[o] + offo));
+        }
         if (mu != 2) {
             if (nu == 2 || mu != nu) return 0.0;
             const double offsetF = 0.5 * (1.0 - (double)T[nu]) + 0.5;
@@ -111,6 +125,22 @@ struct MapEval {
             const double off0 = (1.0 - T[0]) * 0.5;
             const double scaleDXi0 = 1.0 * M.dXi[0];
             return scaleDXi0 * (i + off0);
+        }
+        if (M.kind == 3) {   // TWISTED0_FILL_J, statement by statement (mult = 1)
+            const double Pi = M_PI, twoPi = 2.0 * Pi, twoPiPi = twoPi * Pi;
+            const double pertProd = Pi * M.L[0] * M.L[1] * M.L[2];
+            const double Xi0 = twoPi * M.dXi[0] * (i + (1.0 - T[0]) * 0.5);
+            const double Xi1 = twoPi * M.dXi[1] * (j + (1.0 - T[1]) * 0.5);
+            const double Xi2 = twoPi * M.dXi[2] * (k + (1.0 - T[2]) * 0.5);
+            const double cCos2 = M.L[2] * cos(Xi2);
+            const double SinXi2 = sin(Xi2), Sin2Xi2 = sin(2.0 * Xi2);
+            const double aSin22 = M.L[0] * (SinXi2 * SinXi2);
+            const double CosXi1 = cos(Xi1), SinXi1 = sin(Xi1), Sin2Xi1 = sin(2.0 * Xi1);
+            const double SinProd = pertProd * Sin2Xi1 * Sin2Xi2;
+            const double CosProd = -2.0 * M.L[0] * cCos2 * (SinXi1 * SinXi1);
+            const double twobCos1 = -2.0 * M.L[1] * CosXi1;
+            const double CosXi0 = cos(Xi0), SinXi0 = sin(Xi0), Sin2Xi0 = sin(2.0 * Xi0);
+            return 1.0 * (1.0 + twoPiPi * (twobCos1 * (cCos2 * (SinXi0 * SinXi0) + CosXi0 * aSin22) + (CosXi0 * CosProd + Sin2Xi0 * SinProd)));
         }
         double d = dxdXi(2, 2, T, i, j, k, 1.0);
         d = d * dxdXi(0, 0, T, i, j, k, 1.0);

@@ -32,8 +32,10 @@ PressureSolver::PressureSolver(Comm* comm, hipStream_t shared) : comm_(comm ? co
     // levels up to this many cells sum in the reference's serial order (k_reduce_ordered); tests raise it to
     // make whole solves reproduce the oracle's histories to the last bits
     if (const char* e = getenv("SOMAR_ORDERED_REDUCE_MAX")) ordered_max_cells_ = atoll(e);
+    if (const char* e = getenv("SOMAR_FUSED_BOTTOM_MAX_CELLS")) fused_bottom_max_ = atoll(e);
     if (const char* e = getenv("SOMAR_BOX_BOTTOM")) box_bottom_on_ = atoi(e) != 0;
     if (const char* e = getenv("SOMAR_GHOST_STAGED")) ghost_box_on_ = atoi(e) == 0;
+    if (const char* e = getenv("SOMAR_NO_OVERLAP")) overlap_on_ = atoi(e) == 0;
     if (const char* e = getenv("SOMAR_BOX_BOTTOM_MIN_CELLS")) box_min_cells_ = atoll(e);
     if (const char* e = getenv("SOMAR_AGGLOM_CELLS")) agglom_cells_ = atoll(e);
     if (const char* e = getenv("SOMAR_GRAPH_CELLS")) graph_cells_ = atoll(e);
@@ -48,6 +50,9 @@ PressureSolver::~PressureSolver()
     for (double* q : f_heat) Level::free_field(q);
     hipFree(d_extrapbc_ops_);
     if (st_) hipStreamSynchronize(st_);
+    if (st_comm_) { hipStreamSynchronize(st_comm_); hipStreamDestroy(st_comm_); }
+    if (ev_ready_) hipEventDestroy(ev_ready_);
+    if (ev_done_) hipEventDestroy(ev_done_);
     for (int w = 0; w < 2; ++w) { hipFree(f_sc_cc[w]); for (int d = 0; d < 3; ++d) hipFree(f_sc_face[w][d]); }
     for (double* f : f_res) hipFree(f);
     for (double* f : f_corr) hipFree(f);
@@ -112,7 +117,7 @@ void PressureSolver::prof_end(int k)
 }
 void PressureSolver::profile_get(int kernel, int* count, double* total_ms)
 {
-    SOMAR_CHECK(kernel == 0 || kernel == 1, "profile kernel id must be 0 or 1");
+    SOMAR_CHECK(kernel >= 0 && kernel < 4, "profile id: 0 GSRB, 1 operator / residual, 2 remote ghost exchanges, 3 replicated tail");
     sync();
     Prof& p = prof_[kernel];
     double tot = 0.0;
@@ -124,6 +129,14 @@ void PressureSolver::profile_get(int kernel, int* count, double* total_ms)
     *count = p.used;
     *total_ms = tot;
     p.used = 0;
+}
+
+void PressureSolver::xchg(const Level& L, double* f)
+{
+    const bool timed = profiling_ && !L.plan.peers.empty();
+    if (timed) prof_begin(2);
+    L.exchange(f, st_);
+    if (timed) prof_end(2);
 }
 
 double PressureSolver::fetch_scalar(int slot)
@@ -350,12 +363,12 @@ void PressureSolver::fill_metric_ghosts(Level& L)
     // that no box owns as a low face (see Copier::define_faces); the ordinary exchange then has the last word
     for (int d = 0; d < 3; ++d)
         if (L.cf_faces[d]) L.cf_faces[d]->run(L.dev.jg[d], L.dev.jg[d], st_);
-    for (int d = 0; d < 3; ++d) L.exchange(L.dev.jg[d], st_);
+    for (int d = 0; d < 3; ++d) xchg(L, L.dev.jg[d]);
     if (full_)
         for (int d = 0; d < 3; ++d)
             for (int c = 0; c < 3; ++c)
-                if (c != d && L.dev.jgf[d][c]) L.exchange(L.dev.jgf[d][c], st_);
-    L.exchange(L.dev.jinv, st_);
+                if (c != d && L.dev.jgf[d][c]) xchg(L, L.dev.jgf[d][c]);
+    xchg(L, L.dev.jinv);
 }
 
 // null-space probe, MappedAMRPoissonOpFactory.cpp:659-693
@@ -388,6 +401,17 @@ void PressureSolver::detect_uniform_metric()
     const bool off = e && atoi(e) != 0;
     for (auto& Lp : lev) Lp->dev.P.uniform = 0;
     if (off || full_ || prm.spaceDim != 3) return;
+    // one scratch buffer for the deepest patch table, released whatever happens below
+    size_t nmax = 1;
+    for (auto& Lp : lev) nmax = std::max(nmax, (size_t)std::max(Lp->npatches(), 1));
+    const size_t cap = 2 * nmax * MM_CH;
+    struct Scratch {
+        double* p = nullptr;
+        ~Scratch() { hipFree(p); }
+    } scratch;
+    SOMAR_HIP(hipMalloc(&scratch.p, sizeof(double) * (cap + 8)));
+    double* d_mm = scratch.p;
+    std::vector<double> mm(cap);
     for (auto& Lp : lev) {
         Level& L = *Lp;
         if (!(L.active[0] && L.active[1] && L.active[2])) continue;
@@ -395,10 +419,7 @@ void PressureSolver::detect_uniform_metric()
         // (max, -min) of the four arrays; a rank without boxes on this depth contributes -inf
         double h[8];
         for (double& v : h) v = -HUGE_VAL;
-        double* d_mm = nullptr;
         const size_t nmm = 2 * (size_t)std::max(np, 1) * MM_CH;
-        SOMAR_HIP(hipMalloc(&d_mm, sizeof(double) * (nmm + 8)));
-        std::vector<double> mm(nmm);
         for (int a = 0; a < 4; ++a) {
             if (!np) break;
             launch_minmax_valid(st_, L.dev, a < 3 ? L.dev.jg[a] : L.dev.jinv, a < 3 ? a : -1, d_mm);
@@ -410,18 +431,63 @@ void PressureSolver::detect_uniform_metric()
             }
         }
         if (comm_->size > 1) {
-            double* d8 = d_mm + nmm;
+            double* d8 = d_mm + cap;
             SOMAR_HIP(hipMemcpyAsync(d8, h, sizeof(h), hipMemcpyHostToDevice, st_));
             comm_->allreduce(d8, 8, 1, st_);
             SOMAR_HIP(hipMemcpyAsync(h, d8, sizeof(h), hipMemcpyDeviceToHost, st_));
             SOMAR_HIP(hipStreamSynchronize(st_));
         }
-        hipFree(d_mm);
         bool uni = true;
         for (int a = 0; a < 4; ++a) uni = uni && std::isfinite(h[2 * a]) && h[2 * a] == -h[2 * a + 1];
         if (!uni) continue;
         L.dev.P.uniform = 1;
         for (int a = 0; a < 4; ++a) L.dev.P.uc[a] = h[2 * a];
+    }
+}
+
+// Non-diagonal metric: are J g^{xy} (x-faces) and J g^{yx} (y-faces) identically zero on a depth?  True for every map of the
+// form x = xi, y = eta, z = z(xi, eta, zeta) -- BathymetricBaseMap (geometry/maps/BathymetricBaseMap.cpp:133-313) and all its
+// subclasses: the x-face normal has no eta component.  Coarse depths inherit it (averages of zeros).  SOMAR_NO_ZERO_PLANES=1
+// switches the detection off (A/B; the kernels then multiply the stored zeros, same values).
+void PressureSolver::detect_zero_planes()
+{
+    for (auto& Lp : lev) Lp->dev.P.zero_xy = 0;
+    const char* e = getenv("SOMAR_NO_ZERO_PLANES");
+    if ((e && atoi(e) != 0) || !full_ || prm.spaceDim != 3) return;
+    size_t nmax = 1;
+    for (auto& Lp : lev) nmax = std::max(nmax, (size_t)std::max(Lp->npatches(), 1));
+    const size_t cap = 2 * nmax * MM_CH;
+    struct Scratch {
+        double* p = nullptr;
+        ~Scratch() { hipFree(p); }
+    } scratch;
+    SOMAR_HIP(hipMalloc(&scratch.p, sizeof(double) * (cap + 1)));
+    std::vector<double> mm(cap);
+    for (auto& Lp : lev) {
+        Level& L = *Lp;
+        if (!(L.active[0] && L.active[1] && L.active[2])) continue;
+        const int np = L.npatches();
+        double nonzero = 0.0;   // max |value| over both planes
+        const int pl[2][2] = {{0, 1}, {1, 0}};
+        for (int w = 0; w < 2 && np; ++w) {
+            const double* a = L.dev.jgf[pl[w][0]][pl[w][1]];
+            if (!a) { nonzero = 1.0; break; }
+            launch_minmax_valid(st_, L.dev, a, pl[w][0], scratch.p);
+            SOMAR_HIP(hipMemcpyAsync(mm.data(), scratch.p, sizeof(double) * 2 * (size_t)np * MM_CH, hipMemcpyDeviceToHost, st_));
+            SOMAR_HIP(hipStreamSynchronize(st_));
+            for (size_t q = 0; q < (size_t)np * MM_CH; ++q) {
+                if (std::isfinite(mm[2 * q])) nonzero = std::max(nonzero, std::fabs(mm[2 * q]));
+                if (std::isfinite(mm[2 * q + 1])) nonzero = std::max(nonzero, std::fabs(mm[2 * q + 1]));
+            }
+        }
+        if (comm_->size > 1) {
+            double* d1 = scratch.p + cap;
+            SOMAR_HIP(hipMemcpyAsync(d1, &nonzero, sizeof(double), hipMemcpyHostToDevice, st_));
+            comm_->allreduce(d1, 1, 1, st_);
+            SOMAR_HIP(hipMemcpyAsync(&nonzero, d1, sizeof(double), hipMemcpyDeviceToHost, st_));
+            SOMAR_HIP(hipStreamSynchronize(st_));
+        }
+        L.dev.P.zero_xy = nonzero == 0.0 ? 1 : 0;
     }
 }
 
@@ -447,6 +513,7 @@ void PressureSolver::finalize()
     }
     const auto t1 = now();
     detect_uniform_metric();
+    detect_zero_planes();
     const auto t2 = now();
     struct Report {
         bool on; std::chrono::steady_clock::time_point t0, t1, t2; long long cells;
@@ -568,6 +635,7 @@ void PressureSolver::agglom_cycle(double* corr, const double* res, bool corr_zer
     PressureSolver& C = *coarse_;
     double* rC = C.work(0);
     double* cC = C.work(1);
+    if (profiling_) prof_begin(3);
     agglom_gather_.run(res, rC, st_);
     if (!corr_zero) agglom_gather_.run(corr, cC, st_);
     C.bottom_metric = bottom_metric;
@@ -582,6 +650,7 @@ void PressureSolver::agglom_cycle(double* corr, const double* res, bool corr_zer
     bottom_iters = C.bottom_iters;
     bottom_exit = C.bottom_exit;
     launch_copy_items2(st_, C.lev[0]->dev.patches, T.dev.patches, d_agglom_back_, n_agglom_back_, cC, corr);
+    if (profiling_) prof_end(3);
 }
 
 // ------------------------------------------------------------------------------------
@@ -683,20 +752,42 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
     if (fused_path) {
         // LevelGSRB::relax (GSRB.cpp:58-98) as ONE fused red+black launch per sweep (gsrb_fused.hip):
         // same values bit for bit, one ghost exchange per sweep instead of two, ping-pong buffers.
-        L.exchange(const_cast<double*>(res), st_);  // rhs ghosts: constant over the sweeps
+        xchg(L, const_cast<double*>(res));  // rhs ghosts: constant over the sweeps
         double* cur = e;
         double* alt = f_pp[d];
         for (int it = 0; it < iters; ++it) {
             const bool zin = e_zero && it == 0;  // zeros need neither an exchange nor a read
-            if (!zin) {
-                L.exchange(cur, st_);
-                L.cf_homog_ext(cur, st_);  // CF ghosts (faces + the edge ghosts the red ring reads), pre-sweep values
-            }
-            if (profiling_ && d == 0) prof_begin(0);
             int mode = 0;
             if (zin) mode = 1;
             else if (it == 0 && e_plus) mode = e_shift ? 4 : 3;
             else if (it == 0 && e_shift) mode = 2;
+            if (!zin && fused_overlap(L)) {
+                // the sweep's one exchange in flight on the second stream while the tiles that read none of its cells are swept
+                if (!st_comm_) {
+                    SOMAR_HIP(hipStreamCreateWithFlags(&st_comm_, hipStreamNonBlocking));
+                    SOMAR_HIP(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
+                    SOMAR_HIP(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
+                }
+                SOMAR_HIP(hipEventRecord(ev_ready_, st_));             // cur is final (and alt, which the sweep rewrites, is free)
+                SOMAR_HIP(hipStreamWaitEvent(st_comm_, ev_ready_, 0));
+                L.exchange_local(cur, st_);
+                L.cf_homog_ext(cur, st_);
+                launch_gsrb_fused(st_, L.d_ftiles_own, L.nftiles_own, L.dev, alt, cur, res, mode, e_shift,
+                                  e_plus_level ? &e_plus_level->dev : nullptr, e_plus, L.mgCrseRefRatio);
+                L.exchange_remote(cur, st_comm_);                      // (a host-staged transport may block here: the tiles above are already queued)
+                SOMAR_HIP(hipEventRecord(ev_done_, st_comm_));
+                SOMAR_HIP(hipStreamWaitEvent(st_, ev_done_, 0));
+                launch_gsrb_fused(st_, L.d_ftiles_rem, L.nftiles_rem, L.dev, alt, cur, res, mode, e_shift,
+                                  e_plus_level ? &e_plus_level->dev : nullptr, e_plus, L.mgCrseRefRatio);
+                ++counters[0];
+                std::swap(cur, alt);
+                continue;
+            }
+            if (!zin) {
+                xchg(L, cur);
+                L.cf_homog_ext(cur, st_);  // CF ghosts (faces + the edge ghosts the red ring reads), pre-sweep values
+            }
+            if (profiling_ && d == 0) prof_begin(0);
             launch_gsrb_fused(st_, L.d_ftiles, L.nftiles, L.dev, alt, cur, res, mode, e_shift,
                               e_plus_level ? &e_plus_level->dev : nullptr, e_plus, L.mgCrseRefRatio);
             if (profiling_ && d == 0) prof_end(0);
@@ -714,7 +805,7 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
         for (int it = 0; it < iters; ++it)
             for (int pass = 0; pass < 2; ++pass) {
                 L.cf_homog(cur, st_);
-                L.exchange(cur, st_);
+                xchg(L, cur);
                 run_full_program_frames(d, 1, cur);
                 // the pass rewrites the valid cells only; the ghost frame travels with them (edge / vertex ghosts at
                 // coarse-fine corners keep whatever the last ExtrapolateCFEV left there, as in the reference's in-place sweep)
@@ -737,7 +828,7 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
                 // other cells, computed from valid cells only: their order against the exchange does not matter)
                 const bool pull = !full_ && L.pull_ready();
                 L.cf_homog(e, st_);  // homogeneousCFInterp (Relaxer::fillGhostsAndExtrapolate)
-                if (!pull) L.exchange(e, st_);
+                if (!pull) xchg(L, e);
                 if (diri_ && !full_) apply_diri(d, e, true);  // ... and its physical ghosts (doBCs); non-diagonal: in the program
                 if (full_) run_full_program(d, 1, e);  // psi snapshot + extrapolation (order 1) + Neumann ghosts
                 if (profiling_ && d == 0) prof_begin(0);
@@ -750,7 +841,7 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
             // each box, then red+black on the box shells.  (The exchange "begun" before the interior phase only
             // carries shell cells, which that phase does not touch: completing it first changes nothing.)
             L.cf_homog(e, st_);
-            L.exchange(e, st_);
+            xchg(L, e);
             if (diri_) apply_diri(d, e, true);
             launch_gsrb_ortho(st_, L.dev, e, res, 0, 1);
             launch_gsrb_ortho(st_, L.dev, e, res, 1, 1);
@@ -772,7 +863,7 @@ void PressureSolver::line_relax(int d, double* e, const double* res)
 {
     Level& L = *lev[d];
     for (int pass = 0; pass < 2; ++pass) {
-        L.exchange(e, st_);
+        xchg(L, e);
         L.cf_homog(e, st_);  // fillGhostsAndExtrapolate: homogeneous CF values in the lateral ghost cells
         if (diri_ && !full_) apply_diri(d, e, true);  // ... and the ghosts of lateral Dirichlet sides (the vertical ends are folded in)
         if (full_) run_full_program(d, 1, e);  // extrap copy (order 1) + physical ghosts: the cross terms are explicit
@@ -811,7 +902,7 @@ void PressureSolver::residual_i(int d, double* out, double* phi, const double* r
     }
     // small levels (direct-load operator): the kernel pulls the ghosts it reads, no copy launch
     const bool pull = !full_ && L.pull_ready() && !(L.valid_cells_global >= march_min_cells_ && L.active[2]);
-    if (!pull) L.exchange(phi, st_);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
+    if (!pull) xchg(L, phi);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
     if (diri_ && !full_) apply_diri(d, phi, homogeneous);  // m_bc.setGhosts, :822 (non-diagonal: inside the program)
     if (profiling_ && d == 0) prof_begin(1);
     if (full_march(d)) {
@@ -836,7 +927,7 @@ void PressureSolver::apply_op_i(int d, double* out, double* phi, bool homogeneou
         return;
     }
     const bool pull = !full_ && L.pull_ready() && !(L.valid_cells_global >= march_min_cells_ && L.active[2]);
-    if (!pull) L.exchange(phi, st_);
+    if (!pull) xchg(L, phi);
     if (diri_ && !full_) apply_diri(d, phi, homogeneous);
     if (full_march(d)) {
         run_full_program_frames(d, 0, phi, homogeneous);
@@ -874,7 +965,7 @@ bool PressureSolver::residual_restrict_i(const LevelDev& C, double* crse, double
     for (int d = 0; d < 3; ++d)
         if (r[d] != 1 && r[d] != 2) return false;
     if (!(F.valid_cells_global >= march_min_cells_ && F.active[2] && !full_)) return false;
-    F.exchange(phi, st_);  // exchangeComplete, as residual_i
+    xchg(F, phi);  // exchangeComplete, as residual_i
     if (diri_) apply_diri(0, phi, true);
     launch_resid_restrict(st_, F.d_rtiles, F.nrtiles, F.dev, C, crse, phi, rhs, r, F.dxProduct, nullptr);
     return true;
@@ -887,7 +978,7 @@ void PressureSolver::restrict_residual(int d, double* resCoarse, double* phiFine
     if (F.valid_cells_global >= march_min_cells_ && F.active[2] && !full_) {
         // large level: residual and J-weighted average in one marching pass, the fine residual is never stored
         F.cf_homog(phiFine, st_);
-        F.exchange(phiFine, st_);
+        xchg(F, phiFine);
         if (diri_) apply_diri(d, phiFine, true);  // homogeneous Dirichlet ghosts, as residual() fills them
         if (profiling_ && d == 0) prof_begin(1);
         const bool want = F.zeroAvg && !ordered(d);  // the fine half of the folded prolongation's mean
@@ -1078,7 +1169,7 @@ void PressureSolver::divergence_mac(double* out, double dt)
 void PressureSolver::mac_correct(double* phi, double dt)
 {
     Level& L = *lev[0];
-    L.exchange(phi, st_);  // Copier excp(grids, grids, domain, ghost, true); a_phi.exchange(excp)  (Gradient.cpp:118-121)
+    xchg(L, phi);  // Copier excp(grids, grids, domain, ghost, true); a_phi.exchange(excp)  (Gradient.cpp:118-121)
     double* v[3] = {vel(0), vel(1), prm.spaceDim == 3 ? vel(2) : nullptr};
     if (full_) {
         // singleBoxMacGrad with a non-diagonal metric (Gradient.cpp:946-1101): extrap from the exchanged phi first, then
@@ -1339,7 +1430,7 @@ void PressureSolver::divergence_cc(double* out, double dt, bool wall)
 void PressureSolver::cc_correct(double* phi, double dt)
 {
     Level& L = *lev[0];
-    L.exchange(phi, st_);
+    xchg(L, phi);
     double* c[3] = {cc_vel(0), cc_vel(1), prm.spaceDim == 3 ? cc_vel(2) : nullptr};
     const double dtScale = dt == 0.0 ? -1.0 : -dt;
     if (full_) {
@@ -1399,7 +1490,7 @@ void PressureSolver::cycle_up(int d, double* corr, const double* res)
         // association of the (already tree-ordered) sum.
         Level& F = *lev[d];
         Level& C = *lev[d + 1];
-        C.exchange(f_corr[d + 1], st_);
+        xchg(C, f_corr[d + 1]);
         const double* shift = nullptr;
         if (F.zeroAvg) {
             double* s = d_fold + 8 * d;
@@ -1609,8 +1700,7 @@ bool PressureSolver::fold_prolong(int d) const
 // SOMAR_FUSED_BOTTOM_MAX_CELLS (default 512, 0 = off) is the A/B switch.
 bool PressureSolver::fused_bottom(int d) const
 {
-    const char* env = getenv("SOMAR_FUSED_BOTTOM_MAX_CELLS");   // read per call (once per V-cycle): tests flip it
-    const long long maxc = env ? atoll(env) : 512;
+    const long long maxc = fused_bottom_max_;   // SOMAR_FUSED_BOTTOM_MAX_CELLS, read once at construction
     static const bool poll = !(getenv("SOMAR_POLL_FETCH") && atoi(getenv("SOMAR_POLL_FETCH")) == 0);
     const Level& L = *lev[d];
     return maxc > 0 && poll && !full_ && !diri_ && L.ncf == 0 && L.plan.peers.empty() && !profiling_ && !capturing_ &&
@@ -1720,6 +1810,7 @@ void PressureSolver::build_box_tables(int d)
 
 void PressureSolver::bottom_solve(double* phi, const double* rhs)
 {
+    ++counters[3];
     const int d = (int)lev.size() - 1;
     const long long n = lev[d]->field_elems;
     if (!fused_bottom(d) && box_bottom(d)) {

@@ -208,6 +208,7 @@ public:
     // bottom-solver state shared with MappedAMRMultiGrid (setConvergenceMetrics)
     double bottom_metric = -1.0, bottom_eps_eff = 1e-6;
     int bottom_iters = 0, bottom_exit = 0;
+    long long counters[4] = {0, 0, 0, 0};   // overlapped sweeps, one-launch ghost programs, staged ghost programs, bottom solves
     int bottom_kind = 0;   // how the last bottom solve ran: 0 launch by launch, 1 k_tiny_bicgstab, 2 k_box_bicgstab
     std::vector<std::array<int, 3>> mgRefRatios;
 
@@ -220,6 +221,7 @@ private:
     bool build_coarser(int depth);
     void probe_null_space(int d);
     void fill_metric_ghosts(Level& L);
+    void detect_zero_planes();     // sets StencilParams::zero_xy per depth (non-diagonal metric, 3-D)
     void detect_uniform_metric();  // sets StencilParams::uniform / uc per depth (diagonal metric, 3-D)
     void line_relax(int d, double* e, const double* res);
     double* f_vel[3] = {nullptr, nullptr, nullptr};
@@ -253,6 +255,7 @@ private:
     bool box_bottom(int d) const;
     void build_box_tables(int d);
     bool box_bottom_on_ = true;
+    long long fused_bottom_max_ = 512;   // k_tiny_bicgstab takes bottoms of at most this many cells (0: off)
     long long box_min_cells_ = 513;      // smaller single-workgroup bottoms stay with k_tiny_bicgstab
     int box_depth_ = -1, box_max_cells_ = 0;
     int *d_box_nb_ = nullptr, *d_box_cstart_ = nullptr, *d_box_fab_ = nullptr, *d_box_fabstart_ = nullptr;
@@ -357,7 +360,20 @@ private:
     bool graph_cycle(int d, double* corr, const double* res, bool corr_zero);
     void drop_graphs();
     struct Prof { std::vector<hipEvent_t> a, b; int used = 0; };
-    Prof prof_[2];
+    Prof prof_[4];   // 0: GSRB launches of depth 0, 1: its operator / residual launches, 2: ghost exchanges with other ranks (any
+                     // depth), 3: the replicated tail of a sharded hierarchy (agglom_cycle)
+    // ghost exchange of a level of this solver (timed in a profiled pass when other ranks take part)
+    void xchg(const Level& L, double* f);
+    // Sharded large levels: the messages of a sweep's one ghost exchange travel on a second stream while the tiles that read no
+    // remote ghost cell are swept (the LooseGSRB idea, GSRB.cpp:122-140, without its change of the iteration: the fused sweep's
+    // tiles are independent, so this is the same sweep bit for bit).  SOMAR_NO_OVERLAP=1 is the A/B switch.
+    bool overlap_on_ = true;
+    hipStream_t st_comm_ = nullptr;
+    hipEvent_t ev_ready_ = nullptr, ev_done_ = nullptr;
+    bool fused_overlap(const Level& L) const
+    {
+        return overlap_on_ && !L.plan.peers.empty() && L.nftiles_own > 0 && !capturing_ && !profiling_;
+    }
     bool profiling_ = false;
     void prof_begin(int k);
     void prof_end(int k);

@@ -340,9 +340,11 @@ void PressureSolver::run_program(int d, const FullProgram& P, double* phi, doubl
     if (box_program(d) && (P.d_box_ops || copy_all)) {
         if (!P.d_box_ops) { launch_copy(st_, psi, phi, L.field_elems); return; }
         launch_ghost_program(st_, L.dev, P.d_box_ops, P.d_box_first, phi, psi, homogeneous, redirect, copy_all);
+        ++counters[1];
         return;
     }
     if (copy_all) launch_copy(st_, psi, phi, L.field_elems);  // psi := phi (valid cells and exchanged ghosts)
+    ++counters[2];
     for (size_t s = 0; s < P.first.size(); ++s)
         launch_ghost_ops(st_, L.dev, P.d_ops + P.first[s], P.count[s], phi, psi, homogeneous, redirect);
 }
@@ -518,7 +520,7 @@ void PressureSolver::set_metric_map(int kind, const double Lc[3], const double* 
 {
     SOMAR_CHECK(!lev.empty() && !finalized, "set_metric before define / after finalize");
     SOMAR_CHECK(prm.spaceDim == 3, "the map producers restate the CH_SPACEDIM = 3 algebra (GeoSourceInterface.cpp:236-291)");
-    SOMAR_CHECK(kind == 1 || kind == 2, "map kind: 1 cylindrical, 2 bathymetric");
+    SOMAR_CHECK(kind >= 1 && kind <= 3, "map kind: 1 cylindrical, 2 bathymetric, 3 twisted");
     Level& L = *lev[0];
     SOMAR_CHECK(L.npatches() < 65536, "too many local patches for one launch");
     double* d_depth = nullptr;
@@ -537,6 +539,10 @@ void PressureSolver::set_metric_map(int kind, const double Lc[3], const double* 
         SOMAR_HIP(hipMalloc(&d_depth, bytes));
         SOMAR_HIP(hipMemcpy(d_depth, depth, bytes, hipMemcpyHostToDevice));
         for (int d = 0; d < 2; ++d) { lo[d] = dlo[d]; n[d] = dn[d]; }
+        full_ = true;
+        alloc_full_metric(L);
+    } else if (kind == 3) {
+        // TwistedMap, m_twistType 0: Lc = the amplitudes m_pert; 2 pi |pert| < 1 keeps the Jacobian positive
         full_ = true;
         alloc_full_metric(L);
     } else {

@@ -45,10 +45,20 @@ def stretched_diagonal_metric(lo, hi, dx, L, ndim=3):
     return jg, jinv
 
 
-def slab_partition(n, nparts):
-    """One box per GPU for the 512^3 problem: split z, then y; x is never split (x rows stay long: coalescing, and
-    the marching kernels' tile columns divide a 512-wide box evenly).  -> [(lo, hi)] in rank order."""
-    split = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (1, 2, 4)}.get(nparts)
+def slab_partition(n, nparts, mode=None):
+    """One box per GPU for the 512^3 problem.  mode "yz" (default; SOMAR_BENCH_PARTITION overrides): split z, then y; x is
+    never split (x rows stay long: coalescing, and the marching kernels' tile columns divide a 512-wide box evenly).
+    mode "xy": the horizontal-only 2-D grid of SURVEY.md 8(e) -- 1x2, 2x2, 2x4 boxes in (x, y), vertical columns whole (what a
+    layout that also runs vertical line relaxation or the leptic solver needs).  Same halo surface per rank at N = 8
+    (393 K cells) either way.  -> [(lo, hi)] in rank order."""
+    import os
+    mode = mode or os.environ.get("SOMAR_BENCH_PARTITION", "yz")
+    if mode == "xy":
+        split = {1: (1, 1, 1), 2: (1, 2, 1), 4: (2, 2, 1), 8: (2, 4, 1)}.get(nparts)
+    elif mode == "yz":
+        split = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (1, 2, 4)}.get(nparts)
+    else:
+        raise ValueError("partition mode must be 'yz' or 'xy'")
     if split is None:
         raise ValueError("number of parts must be 1, 2, 4 or 8")
     sz = [n // s for s in split]
@@ -81,6 +91,35 @@ def y_slab_owners(boxes, nranks):
     ys = sorted({b[0][1] for b in boxes})
     rank_of_y = {y: min(q * nranks // len(ys), nranks - 1) for q, y in enumerate(ys)}
     return [rank_of_y[b[0][1]] for b in boxes]
+
+
+def xy_block_owners(boxes, nranks):
+    """Horizontal 2-D sharding of one level: the level's bounding rectangle in (x, y) is cut into a px x py grid of blocks
+    (1x2, 2x2, 2x4 for 2, 4, 8 ranks; y gets the larger factor, x rows stay as long as possible) and a box belongs to the block
+    its low corner falls in.  Against y-slabs at N = 8 a rank's halo shrinks (C4's finest level: 262 K -> 196 K cells per
+    exchange) and it gains x-neighbours.  Vertical columns stay whole."""
+    if nranks == 1:
+        return [0] * len(boxes)
+    px, py = {2: (1, 2), 4: (2, 2), 8: (2, 4)}.get(nranks, (1, nranks))
+    x0, x1 = min(b[0][0] for b in boxes), max(b[1][0] for b in boxes) + 1
+    y0, y1 = min(b[0][1] for b in boxes), max(b[1][1] for b in boxes) + 1
+    out = []
+    for lo, hi in boxes:
+        bx = min((lo[0] - x0) * px // (x1 - x0), px - 1)
+        by = min((lo[1] - y0) * py // (y1 - y0), py - 1)
+        out.append(by * px + bx)
+    return out
+
+
+def level_owners(boxes, nranks, mode=None):
+    """owners of one level's boxes: "slab" (y-slabs, default; SOMAR_BENCH_OWNERS overrides) or "block" (x-y blocks)"""
+    import os
+    mode = mode or os.environ.get("SOMAR_BENCH_OWNERS", "slab")
+    if mode == "block":
+        return xy_block_owners(boxes, nranks)
+    if mode != "slab":
+        raise ValueError("owners mode must be 'slab' or 'block'")
+    return y_slab_owners(boxes, nranks)
 
 
 def lockexchange_hierarchy(config="c3", scale=1, box=128, mult=4, nranks=1):
@@ -121,7 +160,7 @@ def lockexchange_hierarchy(config="c3", scale=1, box=128, mult=4, nranks=1):
         levels.append(boxes_of((lo_x, 0, 0), (lo_x + w - 1, n[1] - 1, n[2] - 1), bs))
         frac *= 2
     return {"n0": n0, "L": L, "periodic": (False, False, False) if flat else (False, True, False), "ratios": ratios,
-            "levels": levels, "owners": [y_slab_owners(b, nranks) for b in levels], "flat": flat,
+            "levels": levels, "owners": [level_owners(b, nranks) for b in levels], "flat": flat,
             "dx0": tuple(L[d] / n0[d] for d in range(3))}
 
 
@@ -200,5 +239,5 @@ def c5_hierarchy(scale=1, box=64, nranks=1, nlev=4):
         lo = [a - a % (2 * bs[0]) for a in lo]
         levels.append(boxes_of((lo[0], lo[1], 0), (lo[0] + w[0] - 1, lo[1] + w[1] - 1, n[2] - 1), bs))
     return {"n0": n0, "L": L, "periodic": (False, False, False), "ratios": ratios, "levels": levels,
-            "owners": [y_slab_owners(b, nranks) for b in levels], "flat": False, "metric": "terrain",
+            "owners": [level_owners(b, nranks) for b in levels], "flat": False, "metric": "terrain",
             "dx0": tuple(L[d] / n0[d] for d in range(3))}

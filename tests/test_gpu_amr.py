@@ -170,13 +170,20 @@ def test_mini_vcycle_bit_exact(oracle, am, layout):
         gpu.undefine()
 
 
+_ORACLE_SOLVES = {}   # layout -> the oracle's composite solve, shared by the two sweep-kernel variants
+
+
 @pytest.mark.parametrize("layout", LAYOUTS[:4] + RATIO4)
 def test_composite_solve_history_matches(oracle, am, layout, sweep_kernel):
     from somar_amd import api as F
     so = oracle
-    levels, comp, gpu = _setup(so, am, layout)
-    try:
-        lmax = len(levels) - 1
+    periodic, ratios, boxes = layout
+    fb = [[so.Box(lo, hi) for lo, hi in lev] for lev in boxes]
+    levels = make_amr_levels(so, am, (16, 16, 8), (2.0, 1.0, 0.5), periodic, ratios, fb)
+    lmax = len(levels) - 1
+    key = repr(layout)
+    if key not in _ORACLE_SOLVES:
+        comp = am.AMRComposite(levels, ratios, so.BCHolder(), so.BiCGStab())
         # a compatible right-hand side: rhs = L_composite[random phi]
         phi = [so.random_field(L.grids, 5 + l, (1, 1, 1), L.domain.box) for l, L in enumerate(levels)]
         zero = [so.LevelData(L.grids, 1) for L in levels]
@@ -187,14 +194,19 @@ def test_composite_solve_history_matches(oracle, am, layout, sweep_kernel):
             so.ld_scale(r, -1.0)
         sol = [so.LevelData(L.grids, 1, (1, 1, 1)) for L in levels]
         comp.solve(sol, rhs, lmax, 0)
+        _ORACLE_SOLVES[key] = {"rhs": rhs, "sol": [[np.array(x) for x in valid_of(s_)] for s_ in sol], "iters": comp.iters,
+                               "exitStatus": comp.exitStatus, "history": list(comp.history)}
+    o = _ORACLE_SOLVES[key]
+    gpu = make_gpu_amr(levels, ratios)
+    try:
         for l, v in enumerate(gpu.levels):
-            upload(v, F.F_RHS, rhs[l])
+            upload(v, F.F_RHS, o["rhs"][l])
         st = gpu.solveAMR(lmax, 0)
-        assert st["iters"] == comp.iters and st["exitStatus"] == comp.exitStatus
-        np.testing.assert_allclose(st["history"], comp.history, rtol=1e-12, atol=0.0)
+        assert st["iters"] == o["iters"] and st["exitStatus"] == o["exitStatus"]
+        np.testing.assert_allclose(st["history"], o["history"], rtol=1e-12, atol=0.0)
         for l in range(lmax + 1):
             got = download_valid(gpu.levels[l], F.F_PHI, levels[l].grids)
-            assert max_rel_diff(got, valid_of(sol[l])) < 1e-8
+            assert max_rel_diff(got, o["sol"][l]) < 1e-8
     finally:
         gpu.undefine()
 

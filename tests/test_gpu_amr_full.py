@@ -70,27 +70,27 @@ def test_full_metric_composite_residual_bit_exact(oracle, am, layout):
         gpu.undefine()
 
 
+_ORACLE_CYCLES = {}   # layout -> what the oracle computed: shared by the two kernel paths (the numpy oracle is the slow half)
+
+
 @pytest.mark.parametrize("layout", [LAYOUTS[0], LAYOUTS[1], LAYOUTS[2], LAYOUTS[4], LAYOUTS[5]])
 def test_full_metric_amr_vcycle_and_solve(oracle, am, layout):
     from somar_amd import api as F
     so = oracle
-    ndim, levels, comp, gpu = _setup(so, am, layout)
+    ndim, n, L_, cbox, periodic, ratios, boxes = layout
+    fb = [[so.Box(lo, hi) for lo, hi in lev] for lev in boxes]
+    levels = make_full_amr_levels(so, am, n, L_, periodic, ratios, fb, cbox=cbox, ndim=ndim)
     G = (1, 1, 1) if ndim == 3 else (1, 1, 0)
-    try:
+    key = repr(layout)
+    if key not in _ORACLE_CYCLES:
+        comp = am.AMRComposite(levels, ratios, so.BCHolder(), so.BiCGStab(), ndim=ndim, isDiagonal=False)
         zero = [so.LevelData(L.grids, 1, G) for L in levels]
         res = [so.random_field(L.grids, 70 + l, (0, 0, 0), L.domain.box) for l, L in enumerate(levels)]
         comp.zero_covered(0, res[0])
         comp.init(zero, res, 1, 0)
         comp.set_bottom_solver(1, 0)
         corr = [so.LevelData(L.grids, 1, G) for L in levels]
-        for l, v in enumerate(gpu.levels):
-            upload(v, F.F_RES, res[l])
-            v.setVal(F.F_CORR, 0.0)
         comp.amr_vcycle(corr, res, 1, 1, 0)
-        gpu.vcycleAMR(1, 0)
-        for l in (0, 1):
-            for g_, w_ in zip(download_valid(gpu.levels[l], F.F_CORR, levels[l].grids), valid_of(corr[l])):
-                np.testing.assert_array_equal(g_, w_)
         # composite solve: same iteration count / exit status / history whatever the layout quirk does to convergence
         phi = [so.random_field(L.grids, 5 + l, G, L.domain.box) for l, L in enumerate(levels)]
         z0 = [so.LevelData(L.grids, 1) for L in levels]
@@ -101,13 +101,25 @@ def test_full_metric_amr_vcycle_and_solve(oracle, am, layout):
             so.ld_scale(r, -1.0)
         sol = [so.LevelData(L.grids, 1, G) for L in levels]
         comp.solve(sol, rhs, 1, 0)
+        _ORACLE_CYCLES[key] = {"res": res, "corr": [[np.array(x) for x in valid_of(c)] for c in corr], "rhs": rhs,
+                               "iters": comp.iters, "exitStatus": comp.exitStatus, "history": list(comp.history)}
+    o = _ORACLE_CYCLES[key]
+    gpu = make_gpu_amr(levels, ratios, ndim=ndim, full=True)
+    try:
         for l, v in enumerate(gpu.levels):
-            upload(v, F.F_RHS, rhs[l])
+            upload(v, F.F_RES, o["res"][l])
+            v.setVal(F.F_CORR, 0.0)
+        gpu.vcycleAMR(1, 0)
+        for l in (0, 1):
+            for g_, w_ in zip(download_valid(gpu.levels[l], F.F_CORR, levels[l].grids), o["corr"][l]):
+                np.testing.assert_array_equal(g_, w_)
+        for l, v in enumerate(gpu.levels):
+            upload(v, F.F_RHS, o["rhs"][l])
         try:
             st = gpu.solveAMR(1, 0)
         except Exception:
             st = gpu.stats
-        assert st["iters"] == comp.iters and st["exitStatus"] == comp.exitStatus
-        np.testing.assert_allclose(st["history"], comp.history, rtol=1e-8, atol=0.0)
+        assert st["iters"] == o["iters"] and st["exitStatus"] == o["exitStatus"]
+        np.testing.assert_allclose(st["history"], o["history"], rtol=1e-8, atol=0.0)
     finally:
         gpu.undefine()

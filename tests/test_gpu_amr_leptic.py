@@ -91,7 +91,7 @@ def test_composite_leptic_solve_matches_oracle(metric, fixed):
     from somar_amd import api as F
     full = metric == "sheared"
     levels, height = _levels(metric)
-    iters = 3
+    iters = 2 if metric == "sheared" else 3   # (the sheared case's oracle run is the slowest test of the suite; its checks need h[0..2])
     # as written (fixed False) the base level is handed the composite residual with the covered cells zeroed, which is not a
     # compatible right-hand side; if its last order hangs, the full 3-D multigrid is turned loose on that singular,
     # inconsistent problem and its BiCGStab bottom solver amplifies round-off chaotically (both sides take that branch at

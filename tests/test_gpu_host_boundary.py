@@ -166,3 +166,29 @@ def test_fortran_shaped_lapdiag_and_average_hooks_bit_exact(oracle):
     got = np.zeros(cn + (2,), order="F")
     F.k_mappedaverage2(got, cbox[0], fine, flo, fjinv, flo, cbox, r)
     np.testing.assert_array_equal(got, want)
+
+
+def test_history_longer_than_the_stats_block(oracle):
+    """somar_stats_t.history holds SOMAR_MAX_HISTORY = 64 entries; an adapter whose AMRMG.imax is larger reads the whole history
+    of its last solve through somar_last_history (imin = imax = 80 forces 80 V-cycles whatever the residual does)"""
+    from helpers import make_problem
+    from somar_amd import AMRPressureSolver, api
+    so = oracle
+    dom, grids, dx, Jgup, Jinv = make_problem(so, (16, 16, 16), 8, "cartesian", (False, False, False), (1.0, 1.0, 1.0))
+    s = AMRPressureSolver()
+    p = s._p
+    s.setAMRMGParameters(80, 80, 1e-300, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg, p.hang, 0.0, 0)
+    s.define(dom.box.lo, dom.box.hi, dom.periodic, dx, [(g.lo, g.hi) for g in grids])
+    for q in range(s.num_local_patches):
+        _, _, gi = s.patch_box(q)
+        s.setMetricOrtho(q, *[np.asfortranarray(Jgup[gi][d].a[..., d]) for d in range(3)], np.asfortranarray(Jinv[gi].a[..., 0]))
+    s.finalize()
+    s.fillHash(api.F_RHS, 5)
+    s.removeMean(api.F_RHS)
+    st = s.solveResident(True, False)
+    assert st["iters"] == 80 and len(st["history"]) == 64
+    h = api.last_history()
+    assert len(h) == 81
+    np.testing.assert_array_equal(h[:64], st["history"])
+    assert h[-1] == st["final_rnorm"] or st["final_rnorm"] <= h[-1]     # (best-phi rollback may report an earlier, smaller norm)
+    s.undefine()

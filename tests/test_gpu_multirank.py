@@ -95,6 +95,32 @@ def _worker(rank, nranks, name, mode, q):
         np.testing.assert_allclose(st["history"], amr.history, rtol=1e-10, atol=1e-10 * amr.history[0])
         gpu.undefine()
 
+        if mode == "fused":
+            # ---- exchange / compute overlap: boxes large enough to have tiles that read no remote ghost cell; the sweeps'
+            #      exchanges travel on the second stream under those tiles (fused_overlap, solver.cpp).  Same bits.
+            dom, grids, dx, Jgup, Jinv = make_problem(so, (64, 32 * nranks, 32), (64, 32, 32), "stretched", (False, True, False),
+                                                      (2.0, 1.0, 1.0))
+            assert len(grids) == nranks
+            owner = list(range(nranks))
+            op = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv).mg.ops[0]
+            phi = so.random_field(grids, 13, (1, 1, 1), dom.box)
+            rhs = so.random_field(grids, 14, (0, 0, 0), dom.box)
+            op.relax(phi, rhs, 3)
+            for overlap in (True, False):
+                if overlap:
+                    os.environ.pop("SOMAR_NO_OVERLAP", None)
+                else:
+                    os.environ["SOMAR_NO_OVERLAP"] = "1"
+                g2 = make_gpu_solver(dom, grids, dx, Mine(Jgup), Mine(Jinv), owner=owner, comm=comm)
+                p0 = so.random_field(grids, 13, (1, 1, 1), dom.box)
+                upload(g2, F.F_PHI, p0)
+                upload(g2, F.F_RHS, rhs)
+                g2.relax(0, F.F_PHI, F.F_RHS, 3)
+                assert (g2.counters()["overlapped_sweeps"] == 3) == overlap, g2.counters()
+                mine(download_valid(g2, F.F_PHI, grids), valid_of(phi), "overlapped relax" if overlap else "serial relax")
+                g2.undefine()
+            os.environ.pop("SOMAR_NO_OVERLAP", None)
+
         if nranks != 2:
             F.comm_destroy(comm)
             q.put((rank, "ok"))

@@ -241,43 +241,42 @@ def test_bottom_solver_and_vcycle(oracle, case, F):
 @pytest.mark.parametrize("case", CASES[:4])
 def test_one_launch_bottom_solver_equals_the_launch_by_launch_one(oracle, case, F, monkeypatch):
     """k_tiny_bicgstab (the whole BiCGStab bottom solve in one single-workgroup launch, default on bottom levels of at most
-    512 cells) against PressureSolver::bottom_solve's launch-by-launch path (SOMAR_FUSED_BOTTOM_MAX_CELLS=0): same
-    iteration count, same exit code, same bits -- and both equal to the oracle's BiCGStab within the solve's tolerance."""
+    512 cells) against PressureSolver::bottom_solve's launch-by-launch path (SOMAR_FUSED_BOTTOM_MAX_CELLS=0, read when the
+    solver is created): same iteration count, same exit code, same bits -- bottom solves and whole V-cycles."""
     so = oracle
-    dom, grids, amr, gpu = _both(oracle, case)
+    n, boxsz, variant, periodic, L = case
+    dom, grids, dx, Jgup, Jinv = make_problem(so, n, boxsz, variant, periodic, L)
+    amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv)
     D = amr.mg.depth
     opb = amr.mg.ops[-1]
-    cells = sum(g.numPts() for g in opb.grids)
     rhs = so.random_field(opb.grids, 91, (0, 0, 0), opb.domain.box)
     so.remove_weighted_mean(rhs, opb.Jinv)
+    res = so.random_field(grids, 92, (0, 0, 0), dom.box)
+    so.remove_weighted_mean(res, amr.op.Jinv)
     fp, fr = (F.FIELD(D - 1, F.F_CORR), F.FIELD(D - 1, F.F_RES)) if D > 1 else (F.F_CORR, F.F_RES)
-    out = {}
+    out, cyc = {}, {}
     for mode in ("0", "100000"):
         monkeypatch.setenv("SOMAR_FUSED_BOTTOM_MAX_CELLS", mode)
+        monkeypatch.setenv("SOMAR_BOX_BOTTOM", "0")
+        gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv)
         upload(gpu, fr, rhs, depth=D - 1)
         gpu.setVal(fp, 0.0)
         it, ex = gpu.bottomSolve(fp, fr)
+        assert gpu.bottomKind() == 0 if mode == "0" else gpu.bottomKind() in (0, 1)   # (case3's tiles do not fit the kernel: launch path)
         out[mode] = (it, ex, download_valid(gpu, fp, opb.grids, D - 1))
-    assert out["0"][:2] == out["100000"][:2]
-    if cells <= 4096:       # serial-order sums on both paths
-        for a, b in zip(out["0"][2], out["100000"][2]):
-            np.testing.assert_array_equal(a, b)
-    else:                   # the launch path sums large levels by tree, the one-launch kernel is not used there at all
-        for a, b in zip(out["0"][2], out["100000"][2]):
-            np.testing.assert_array_equal(a, b)
-    # whole V-cycles and solves with either bottom solver
-    res = so.random_field(grids, 92, (0, 0, 0), dom.box)
-    so.remove_weighted_mean(res, amr.op.Jinv)
-    cyc = {}
-    for mode in ("0", "100000"):
-        monkeypatch.setenv("SOMAR_FUSED_BOTTOM_MAX_CELLS", mode)
         upload(gpu, F.F_RES, res)
         gpu.setVal(F.F_CORR, 0.0)
         gpu.vcycle(F.F_CORR, F.F_RES)
         cyc[mode] = download_valid(gpu, F.F_CORR, grids)
+        gpu.undefine()
+    assert out["0"][:2] == out["100000"][:2]
+    for a, b in zip(out["0"][2], out["100000"][2]):
+        np.testing.assert_array_equal(a, b)
     for a, b in zip(cyc["0"], cyc["100000"]):
         np.testing.assert_array_equal(a, b)
-    gpu.undefine()
+
+
+_ORACLE_SOLVES = {}   # (case, smooth) -> the oracle's solve: shared by the two sweep-kernel variants of the test below
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -285,18 +284,27 @@ def test_one_launch_bottom_solver_equals_the_launch_by_launch_one(oracle, case, 
 def test_full_solve_history_matches(oracle, case, smooth, gsrb_mode):
     so = oracle
     pre, post, bottom = smooth
-    dom, grids, amr, gpu = _both(oracle, case, pre=pre, post=post, bottom=bottom)
-    rhs = so.random_field(grids, 12345, (0, 0, 0), dom.box)
-    so.remove_weighted_mean(rhs, amr.op.Jinv)
-    phi = so.LevelData(grids, 1, (1, 1, 1))
-    amr.solve(phi, rhs)
-    gphi = [np.zeros(f.a.shape[:3], order="F") for f in phi.fabs]
-    grhs = [np.asfortranarray(f.a[..., 0]) for f in rhs.fabs]
-    st = gpu.solve(gphi, grhs, 0, 0, True, False)
-    assert st["iters"] == amr.iters
-    assert st["exitStatus"] == amr.exitStatus
-    h_g, h_o = np.array(st["history"]), np.array(amr.history)
-    if amr.mg.depth == 1:
+    n, boxsz, variant, periodic, L = case
+    dom, grids, dx, Jgup, Jinv = make_problem(so, n, boxsz, variant, periodic, L)
+    key = (case, smooth)
+    if key not in _ORACLE_SOLVES:   # the numpy oracle is the slow half of this test: once per problem
+        amr = make_oracle_solver(so, dom, grids, dx, Jgup, Jinv, pre=pre, post=post, bottom=bottom)
+        rhs = so.random_field(grids, 12345, (0, 0, 0), dom.box)
+        so.remove_weighted_mean(rhs, amr.op.Jinv)
+        phi = so.LevelData(grids, 1, (1, 1, 1))
+        amr.solve(phi, rhs)
+        _ORACLE_SOLVES[key] = {"iters": amr.iters, "exitStatus": amr.exitStatus, "history": list(amr.history),
+                               "depth": amr.mg.depth, "phi": [np.array(v) for v in valid_of(phi)],
+                               "rhs": [np.asfortranarray(f.a[..., 0]) for f in rhs.fabs],
+                               "shape": [f.a.shape[:3] for f in phi.fabs]}
+    o = _ORACLE_SOLVES[key]
+    gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv, pre=pre, post=post, bottom=bottom)
+    gphi = [np.zeros(shp, order="F") for shp in o["shape"]]
+    st = gpu.solve(gphi, o["rhs"], 0, 0, True, False)
+    assert st["iters"] == o["iters"]
+    assert st["exitStatus"] == o["exitStatus"]
+    h_g, h_o = np.array(st["history"]), np.array(o["history"])
+    if o["depth"] == 1:
         # boxes too thin to coarsen: the "V-cycle" is ONE long BiCGStab solve on the full grid, whose
         # iterates amplify the summation-order difference of the dot products (tree vs sequential).
         # Both must converge below eps; the histories are only comparable at that level.
@@ -307,7 +315,7 @@ def test_full_solve_history_matches(oracle, case, smooth, gsrb_mode):
     np.testing.assert_allclose(h_g, h_o, rtol=1e-10, atol=1e-10 * h_o[0])
     # solution agrees (up to the same tolerance scaled by the condition of the last V-cycles)
     got = [a[1:-1, 1:-1, 1:-1] for a in gphi]
-    assert max_rel_diff(got, valid_of(phi)) < 1e-8
+    assert max_rel_diff(got, o["phi"]) < 1e-8
     gpu.undefine()
 
 

@@ -74,3 +74,53 @@ def test_one_odd_face_value_turns_the_fast_path_off():
     Jgup[1][2].a[3, 4, 5, 2] *= 1.0 + 2.0 ** -52    # one ulp on one z-face of the second box
     gpu = make_gpu_solver(dom, grids, dx, Jgup, Jinv)
     assert gpu.metricUniform(0) is None
+
+
+@pytest.mark.parametrize("layout_id", [0, 1, 3])
+def test_uniform_metric_kernels_on_amr_levels_bit_exact(oracle, layout_id, monkeypatch):
+    """The combination the C3 / C4 benches run: the uniform-metric instantiations (k_gsrb_fused<.., UNI>, k_resid_march<.., UNI>,
+    lean interior tiles included) on REFINED levels -- coarse-fine ghosts between the colours, the prolongation folded into the
+    first post-sweep, the lean AMRVCycle, residual + restriction in one pass -- forced onto small hierarchies
+    (SOMAR_FUSED_MIN_CELLS=0, SOMAR_MARCH_MIN_CELLS=1).  One AMR V-cycle must equal the oracle's and the SOMAR_NO_UNIFORM=1
+    twin's bit for bit."""
+    from oracle import somar_amr as am
+    from somar_amd import api as F
+    from helpers import download_valid, make_amr_levels, make_gpu_amr, upload, valid_of
+    from test_gpu_amr import LAYOUTS
+    so = oracle
+    periodic, ratios, boxes = LAYOUTS[layout_id]
+    fb = [[so.Box(lo, hi) for lo, hi in lev] for lev in boxes]
+    levels = make_amr_levels(so, am, (16, 16, 8), (2.0, 1.0, 0.5), periodic, ratios, fb, variant="cartesian")
+    comp = am.AMRComposite(levels, ratios, so.BCHolder(), so.BiCGStab())
+    lmax = len(levels) - 1
+    phi = [so.LevelData(L.grids, 1, (1, 1, 1)) for L in levels]
+    res = [so.random_field(L.grids, 70 + l, (0, 0, 0), L.domain.box) for l, L in enumerate(levels)]
+    for l in range(lmax):
+        comp.zero_covered(l, res[l])
+    comp.init(phi, res, lmax, 0)
+    comp.set_bottom_solver(lmax, 0)
+    corr = [so.LevelData(L.grids, 1, (1, 1, 1)) for L in levels]
+    comp.amr_vcycle(corr, res, lmax, lmax, 0)
+    monkeypatch.setenv("SOMAR_FUSED_MIN_CELLS", "0")
+    monkeypatch.setenv("SOMAR_MARCH_MIN_CELLS", "1")
+    got = {}
+    for uni in (True, False):
+        if uni:
+            monkeypatch.delenv("SOMAR_NO_UNIFORM", raising=False)
+        else:
+            monkeypatch.setenv("SOMAR_NO_UNIFORM", "1")
+        gpu = make_gpu_amr(levels, ratios)
+        try:
+            for v in gpu.levels:
+                assert (v.metricUniform(0) is not None) == uni
+            for l, v in enumerate(gpu.levels):
+                upload(v, F.F_RES, res[l])
+                v.setVal(F.F_CORR, 0.0)
+            gpu.vcycleAMR(lmax, 0)
+            got[uni] = [download_valid(gpu.levels[l], F.F_CORR, levels[l].grids) for l in range(lmax + 1)]
+        finally:
+            gpu.undefine()
+    for l in range(lmax + 1):
+        for a, b, w in zip(got[True][l], got[False][l], valid_of(corr[l])):
+            np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(a, w)

@@ -112,3 +112,39 @@ def test_bathymetric_cell_centred_j_carries_the_misprint(oracle, sm):
     my = sm.BathymetricMap(dXi, L, _plane_depth(dXi, dlo, dn, 0.2, 0.0, -0.08), dlo)
     d = 0.2 - 0.08 * (J + 0.375) * dXi[1]
     np.testing.assert_allclose(sm.fill_jinv(my, valid), 1.0 / (1.0 - d / L[2]), rtol=1e-13)
+
+
+def test_twisted_map_jacobian_is_the_determinant_of_its_dxdxi(oracle, sm):
+    """TWISTED0_FILL_J is the closed form of det(dx/dXi) of TWISTED0_FILL_DXDXI's entries (TwistedMap.cpp:204-207: "without the
+    analytic version machine-epsilon sized noise is introduced"); and dx/dXi are the derivatives of the map's coordinates
+    (TWISTED0_FILL_PHYSCOOR) to second order in the spacing"""
+    so = oracle
+    n = 24
+    dXi = (1.0 / n,) * 3
+    pert = (0.05, -0.04, 0.03)
+    m = sm.TwistedMap(dXi, pert)
+    valid = so.Box((0, 0, 0), (n - 1, n - 1, n - 1))
+    I, J, K = np.meshgrid(*[np.arange(n)] * 3, indexing="ij")
+    for T in ((0, 0, 0), (1, 0, 0), (0, 0, 1)):
+        D = np.empty(I.shape + (3, 3))
+        for mu in range(3):
+            for nu in range(3):
+                D[..., mu, nu] = m.dxdXi(mu, nu, T, I, J, K)
+        np.testing.assert_allclose(m.J(T, I, J, K), np.linalg.det(D), rtol=1e-13)
+    assert m.J((0, 0, 0), I, J, K).min() > 0.5
+
+    def x(mu, xi):   # TWISTED0_FILL_PHYSCOOR
+        nu, o = (mu + 1) % 3, (mu + 2) % 3
+        return xi[mu] + pert[mu] * np.sin(2 * np.pi * xi[nu]) * np.sin(2 * np.pi * xi[o])
+    xi = [(I + 0.5) * dXi[0], (J + 0.5) * dXi[1], (K + 0.5) * dXi[2]]
+    h = 1e-5
+    for mu in range(3):
+        for nu in range(3):
+            xp = [a + (h if d == nu else 0.0) for d, a in enumerate(xi)]
+            xm = [a - (h if d == nu else 0.0) for d, a in enumerate(xi)]
+            fd = (x(mu, xp) - x(mu, xm)) / (2 * h)
+            np.testing.assert_allclose(m.dxdXi(mu, nu, (0, 0, 0), I, J, K), fd, atol=1e-8)
+    # the metric it feeds: symmetric positive J g^{ab} at a common point would need a common centring; on each face family
+    # the diagonal component is positive
+    for mu in range(3):
+        assert sm.fill_jgup(m, valid, mu)[..., mu].min() > 0.0

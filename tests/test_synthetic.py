@@ -55,6 +55,39 @@ def test_slab_partition_tiles_the_domain():
         assert len({b for b in boxes}) == parts
 
 
+def test_xy_partition_and_block_owners():
+    """the horizontal-only 2-D alternatives: whole vertical columns, every rank the same number of cells"""
+    from somar_amd import synthetic
+    for parts in (1, 2, 4, 8):
+        boxes = synthetic.slab_partition(512, parts, mode="xy")
+        assert len(boxes) == parts and len(set(boxes)) == parts
+        assert all(lo[2] == 0 and hi[2] == 511 for lo, hi in boxes)
+        assert sum(int(np.prod([h - a + 1 for a, h in zip(lo, hi)])) for lo, hi in boxes) == 512 ** 3
+    H = synthetic.lockexchange_hierarchy("c4", 1, 128, 4, 8)
+    for boxes in H["levels"]:
+        own = synthetic.xy_block_owners(boxes, 8)
+        per = np.bincount(own, minlength=8)
+        assert per.min() == per.max() and per.sum() == len(boxes)      # balanced: the same number of 128^3 boxes everywhere
+        # a rank's boxes form one rectangle in (x, y)
+        for r in range(8):
+            mine = [b for b, o in zip(boxes, own) if o == r]
+            xs, ys = sorted({b[0][0] for b in mine}), sorted({b[0][1] for b in mine})
+            assert len(mine) == len(xs) * len(ys)
+    assert synthetic.level_owners(H["levels"][0], 8, "slab") == synthetic.y_slab_owners(H["levels"][0], 8)
+
+
+def test_mt19937_64_field_is_the_standard_generator():
+    """somar_host_fill_mt19937_64 = std::mt19937_64 + std::uniform_real_distribution (host code, no GPU): the C++ standard pins the
+    10000th output of a default-seeded (5489) mt19937_64 to 9981545732273789042; libstdc++ maps one 64-bit draw to [0, 1) by
+    dividing by 2^64"""
+    from somar_amd import api
+    a = api.host_random_field((100, 100, 1), 5489, 0.0, 1.0)
+    assert abs(a.ravel(order="F")[9999] * 2.0 ** 64 - 9981545732273789042) <= 4096      # one ulp of 2^63 is 2048
+    b = api.host_random_field((4, 3, 2), 12345)
+    assert b.min() >= -1.0 and b.max() < 1.0 and b.flags.f_contiguous
+    np.testing.assert_array_equal(b, api.host_random_field((4, 3, 2), 12345))
+
+
 def _oracle_imports_outside(path, allowed_functions):
     """names of the scopes in which `path` imports anything from oracle/, minus the allowed ones"""
     tree = ast.parse(open(path).read())
