@@ -9,6 +9,7 @@
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -27,7 +28,11 @@ struct ShmHeader {
     std::atomic<int> generation;
     int nranks;
     int pad_;
-    long long epoch;  // creation time (seconds): an attaching rank refuses a segment older than a few minutes (a stale one of the same name)
+    long long pad2_;
+    // attach handshake: rank r > 0 writes a random token into hello[r]; only a LIVE rank 0 copies it to echo[r].  A segment of
+    // the same name left behind by an earlier run (opened before this run's rank 0 unlinks it) never answers.
+    std::atomic<long long> hello[16];
+    std::atomic<long long> echo[16];
     // directory: where in src's outbox the message for dst starts, and its length (doubles)
     long long off[16][16];
     long long cnt[16][16];
@@ -182,17 +187,35 @@ Comm* shm_create(const char* name, int rank, int nranks, size_t outbox_bytes)
             c->hdr = reinterpret_cast<ShmHeader*>(m);
             std::memset(static_cast<void*>(c->hdr), 0, sizeof(ShmHeader));
             c->hdr->nranks = nranks;
-            c->hdr->epoch = (long long)time(nullptr);
             std::atomic_thread_fence(std::memory_order_release);
             c->hdr->generation.store(1, std::memory_order_release);  // "initialised"
+            // answer every attaching rank's token (300 s for the slowest peer to get here, the barrier's own limit)
+            const double t0 = ShmComm::now_s();
+            int answered = 0;
+            std::vector<char> done(nranks, 0);
+            while (answered < nranks - 1) {
+                SOMAR_CHECK(ShmComm::now_s() - t0 < 300.0, "shm create: not every rank attached within 300 s");
+                for (int r = 1; r < nranks; ++r) {
+                    if (done[r]) continue;
+                    const long long t = c->hdr->hello[r].load(std::memory_order_acquire);
+                    if (t != 0) {
+                        c->hdr->echo[r].store(t, std::memory_order_release);
+                        done[r] = 1;
+                        ++answered;
+                    }
+                }
+                usleep(200);
+            }
         } else {
             // Attach: the segment must exist, have its full size, be initialised, be made for this many ranks and be
-            // FRESH -- a segment of the same name left by an earlier run (opened before rank 0 unlinks it) is dead
-            // memory on which the barrier below would never complete.  Anything else: drop it and look again.
+            // LIVE -- a segment of the same name left by an earlier run (opened before rank 0 unlinks it) is dead
+            // memory on which the barrier below would never complete.  Liveness is a handshake, not a clock: this rank's
+            // random token must come back from rank 0; while waiting, the name is re-opened now and then, and if it has
+            // come to denote another segment (rank 0 unlinked the stale one and created its own) the attach starts over.
             const double t0 = ShmComm::now_s();
             bool ok = false;
             while (!ok) {
-                SOMAR_CHECK(ShmComm::now_s() - t0 < 60.0, "shm attach timed out (no fresh, fully sized segment of that name appeared)");
+                SOMAR_CHECK(ShmComm::now_s() - t0 < 300.0, "shm attach timed out (no live, fully sized segment of that name appeared)");
                 if (c->base) { munmap(c->base, c->total); c->base = nullptr; c->hdr = nullptr; }
                 if (c->fd >= 0) { close(c->fd); c->fd = -1; }
                 c->fd = shm_open(name, O_RDWR, 0600);
@@ -203,8 +226,29 @@ Comm* shm_create(const char* name, int rank, int nranks, size_t outbox_bytes)
                 c->base = static_cast<char*>(m);
                 c->hdr = reinterpret_cast<ShmHeader*>(m);
                 if (c->hdr->generation.load(std::memory_order_acquire) == 0) { usleep(1000); continue; }
-                const long long age = (long long)time(nullptr) - c->hdr->epoch;
-                if (c->hdr->nranks != nranks || age < -5 || age > 120) { usleep(20000); continue; }
+                if (c->hdr->nranks != nranks) { usleep(20000); continue; }
+                timespec ts;
+                clock_gettime(CLOCK_REALTIME, &ts);
+                long long token = ((long long)getpid() << 32) ^ (long long)ts.tv_nsec ^ ((long long)ts.tv_sec << 20) ^ rank;
+                if (token == 0) token = 1;
+                c->hdr->echo[rank].store(0, std::memory_order_relaxed);
+                c->hdr->hello[rank].store(token, std::memory_order_release);
+                struct stat mine;
+                SOMAR_CHECK(fstat(c->fd, &mine) == 0, "fstat failed");
+                bool stale = false;
+                long polls = 0;
+                while (c->hdr->echo[rank].load(std::memory_order_acquire) != token) {
+                    SOMAR_CHECK(ShmComm::now_s() - t0 < 300.0, "shm attach timed out (rank 0 never answered on a segment of that name)");
+                    usleep(200);
+                    if ((++polls % 100) == 0) {   // every ~20 ms: does the name still denote the segment I mapped?
+                        const int fd2 = shm_open(name, O_RDONLY, 0600);
+                        struct stat now;
+                        const bool same = fd2 >= 0 && fstat(fd2, &now) == 0 && now.st_ino == mine.st_ino && now.st_dev == mine.st_dev;
+                        if (fd2 >= 0) close(fd2);
+                        if (!same) { stale = true; break; }
+                    }
+                }
+                if (stale) continue;
                 ok = true;
             }
         }

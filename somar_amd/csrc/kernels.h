@@ -106,30 +106,6 @@ void launch_incr_copy(hipStream_t st, double* y, double* x, double a, long long 
 void launch_scale(hipStream_t st, double* y, double a, long long n);
 void launch_mul(hipStream_t st, double* y, const double* x, long long n);   // y *= x elementwise
 void launch_axby(hipStream_t st, double* z, const double* x, const double* y, double a, double b, long long n);
-// tiny levels: a list of level operations executed by ONE 1024-thread workgroup in one launch (k_tiny_program, kernels.hip)
-enum { TINY_EXCHANGE = 0, TINY_GSRB = 1, TINY_OP = 2, TINY_DIAG = 3, TINY_SET = 4 };
-constexpr int TINY_MAX_OPS = 24, TINY_MAX_FIELDS = 4;
-struct TinyOp {
-    int type;        // TINY_*
-    int f0, f1, f2;  // indices into TinyProgram::fld: EXCHANGE f0; GSRB phi = f0, rhs = f1, colour = arg; OP out = f0, phi = f1,
-                     // rhs = f2, arg 0: rhs - L[phi], 1: L[phi]; DIAG phi = f0, r = f1 (DIAGPRECOND); SET f0 := a
-    int arg;
-    int pad_;
-    double a;
-};
-struct TinyProgram {
-    const Tile* tiles; int ntiles; int tile_j;
-    const PatchDesc* patches;
-    const CopyItem* items; int nitems;
-    long long field_elems;
-    const double* jg[3]; const double* jinv; const double* lapd;
-    StencilParams P;
-    double* fld[TINY_MAX_FIELDS];
-    TinyOp ops[TINY_MAX_OPS];
-    int nops;
-};
-void launch_tiny_program(hipStream_t st, const LevelDev& L, const CopyItem* items, int nitems, long long field_elems,
-                         double* const* fields, int nfields, const TinyOp* ops, int nops);
 // where a reduction's result is also stored for the host: coherent host memory + a sequence number the host spins on
 // (PressureSolver::fetch_scalars); fused into the reduction's last kernel it saves the separate one-thread publish launch
 struct ScalarPublish { double* host_dst; unsigned long long* host_seq; unsigned long long seq; };

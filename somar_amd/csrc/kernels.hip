@@ -84,7 +84,7 @@ __device__ __forceinline__ void publish_scalars(const double* vals, int n, Scala
 // Thread = one i-pair; exactly one cell of the pair has this colour.
 // ------------------------------------------------------------------------------------
 // bx / tx / ty: the workgroup's tile and the thread's place in it -- the block and thread indices in the kernel of the same
-// name, virtual ones in the single-workgroup program kernel for tiny levels (k_tiny_program)
+// name, virtual ones in the single-workgroup bottom solver of tiny levels (k_tiny_bicgstab)
 __device__ __forceinline__ void gsrb_ortho_body(const Tile* __restrict__ tiles, const PatchDesc* __restrict__ patches,
                                                 double* __restrict__ phi, const double* __restrict__ rhs,
                                                 const double* __restrict__ jgx, const double* __restrict__ jgy,
@@ -1263,76 +1263,6 @@ __global__ __launch_bounds__(256) void k_minmax_valid(const PatchDesc* __restric
 void launch_minmax_valid(hipStream_t st, const LevelDev& L, const double* a, int dir, double* out)
 {
     if (L.npatches) hipLaunchKernelGGL(k_minmax_valid, dim3(L.npatches, MM_CH), dim3(64, 4), 0, st, L.patches, a, dir, out);
-}
-
-// ---- tiny levels: a short PROGRAM of level operations in ONE single-workgroup launch ----------------------------------------
-// Below a few thousand cells every kernel above runs for about a microsecond and costs a launch (4-5 us, graph replay or not),
-// and the reference's bottom solver strings hundreds of them together: on BASELINE C3 2 700 of the 3 400 launches of an AMR
-// V-cycle are BiCGStab's preconditioner sweeps and operator applications on the 4096-cell bottom level.  One 1024-thread
-// workgroup (one CU) executes a list of such operations back to back, __syncthreads() between them standing in for the
-// kernel boundaries: [exchange, colour pass] x 2 x sweeps, the diagonal preconditioner, the operator / residual.  Each
-// operation is the body of the kernel of the same name, run over virtual workgroups of (64 x tile_j) threads: same cells,
-// same arithmetic, same values.  A launch failure or an op the program does not know is the caller's bug: no fallback here.
-__global__ __launch_bounds__(1024) void k_tiny_program(TinyProgram A)
-{
-    const int tid = threadIdx.x;
-    const int vper = 64 * A.tile_j;          // threads of one virtual workgroup
-    const int nvb = 1024 / vper;             // virtual workgroups running side by side
-    const int vb = tid / vper, vt = tid - vb * vper;
-    const int tx = vt & 63, ty = vt >> 6;
-    for (int q = 0; q < A.nops; ++q) {
-        const TinyOp op = A.ops[q];
-        double* f0 = A.fld[op.f0];
-        const double* f1 = A.fld[op.f1];
-        const double* f2 = A.fld[op.f2];
-        if (op.type == TINY_EXCHANGE) {
-            for (int it = vb; it < A.nitems; it += nvb) {
-                const CopyItem ci = A.items[it];
-                const PatchDesc sp = A.patches[ci.src_patch];
-                const PatchDesc dp = A.patches[ci.dst_patch];
-                const int n0 = ci.n[0], n01 = ci.n[0] * ci.n[1];
-                const int cells = n01 * ci.n[2];
-                for (int idx = vt; idx < cells; idx += vper) {
-                    const int k = idx / n01;
-                    const int r = idx - k * n01;
-                    const int j = r / n0, i = r - j * n0;
-                    f0[cidx(dp, ci.dst_lo[0] + i, ci.dst_lo[1] + j, ci.dst_lo[2] + k)] =
-                        f0[cidx(sp, ci.src_lo[0] + i, ci.src_lo[1] + j, ci.src_lo[2] + k)];
-                }
-            }
-        } else if (op.type == TINY_GSRB) {
-            for (int b = vb; b < A.ntiles; b += nvb)
-                gsrb_ortho_body(A.tiles, A.patches, f0, f1, A.jg[0], A.jg[1], A.jg[2], A.jinv, A.lapd, A.P, op.arg, 0, b, tx, ty);
-        } else if (op.type == TINY_OP) {
-            for (int b = vb; b < A.ntiles; b += nvb) {
-                if (op.arg == 0) op_ortho_body<0>(A.tiles, A.patches, f0, f1, f2, A.jg[0], A.jg[1], A.jg[2], A.jinv, A.P, b, tx, ty);
-                else op_ortho_body<1>(A.tiles, A.patches, f0, f1, f2, A.jg[0], A.jg[1], A.jg[2], A.jinv, A.P, b, tx, ty);
-            }
-        } else if (op.type == TINY_DIAG) {
-            for (int b = vb; b < A.ntiles; b += nvb)
-                diag_body<0>(A.tiles, A.patches, f0, f1, A.lapd, A.P.alpha, A.P.beta, b, tx, ty);
-        } else if (op.type == TINY_SET) {
-            for (long long i = tid; i < A.field_elems; i += 1024) f0[i] = op.a;
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-}
-void launch_tiny_program(hipStream_t st, const LevelDev& L, const CopyItem* items, int nitems, long long field_elems,
-                         double* const* fields, int nfields, const TinyOp* ops, int nops)
-{
-    if (nops == 0) return;
-    TinyProgram A;
-    A.tiles = L.tiles; A.ntiles = L.ntiles; A.tile_j = L.tile_j; A.patches = L.patches;
-    A.items = items; A.nitems = nitems; A.field_elems = field_elems;
-    for (int d = 0; d < 3; ++d) A.jg[d] = L.jg[d];
-    A.jinv = L.jinv; A.lapd = L.lapdiag; A.P = L.P;
-    for (int q = 0; q < TINY_MAX_FIELDS; ++q) A.fld[q] = q < nfields ? fields[q] : nullptr;
-    for (int done = 0; done < nops; done += TINY_MAX_OPS) {
-        A.nops = std::min(TINY_MAX_OPS, nops - done);
-        for (int q = 0; q < A.nops; ++q) A.ops[q] = ops[done + q];
-        hipLaunchKernelGGL(k_tiny_program, dim3(1), dim3(1024), 0, st, A);
-    }
 }
 
 // ---- the bottom solver of a tiny level in ONE launch -----------------------------------------------------------------------------

@@ -489,6 +489,8 @@ Level::~Level()
     hipFree(d_ftiles);
     hipFree(d_ftiles_own);
     hipFree(d_ftiles_rem);
+    hipFree(d_rtiles_own);
+    hipFree(d_rtiles_rem);
     hipFree(d_rtiles);
     hipFree(d_qtiles);
     hipFree(d_ctiles);
@@ -643,6 +645,7 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     d_ftiles = to_device(hftiles);
     nftiles = (int)hftiles.size();
     hrtiles = march_tiles(124, 14, 2.0);
+    for (size_t q = 0; q < hrtiles.size(); ++q) hrtiles[q].pad_[2] = (int)q;   // its slot in per-tile partial sums (k_resid_march<2>)
     d_rtiles = to_device(hrtiles);
     nrtiles = (int)hrtiles.size();
     hqtiles = march_tiles(124, full_march_rows() - 2, 2.0, full_march_rows() == 6 ? 512 : 256);   // 6 rows: two workgroups per CU
@@ -687,31 +690,40 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     d_recv_items = to_device(plan.recv_items);
     d_send_off = to_device(plan.send_itemoff);
     d_recv_off = to_device(plan.recv_itemoff);
-    if (!plan.peers.empty() && !hftiles.empty()) {
-        // which fused-sweep tiles read a ghost cell that arrives from another rank?  A tile reads phi two cells around its
-        // columns and planes (the recomputed red ring) -- FRAME deep, as deep as the exchange fills.
+    if (!plan.peers.empty()) {
+        // which marching tiles read a ghost cell that arrives from another rank?  The fused sweep reads phi two cells around
+        // its columns and planes (the recomputed red ring) -- FRAME deep, as deep as the exchange fills; the operator one cell.
         std::vector<std::vector<const CopyItem*>> byDst(hpatches.size());
         for (const CopyItem& it : plan.recv_items) byDst[it.dst_patch].push_back(&it);
-        std::vector<Tile> own, rem;
-        const int rows = fused_rows() - 4;
-        for (const Tile& t : hftiles) {
-            const PatchDesc& p = hpatches[t.patch];
-            const int w = t.pad_[0] > 0 ? t.pad_[0] : 124;
-            const int lo[3] = {t.i0 - FRAME, t.j0 - FRAME, t.k0 - FRAME};
-            const int hi[3] = {std::min(t.i0 + w, p.n[0]) - 1 + FRAME, std::min(t.j0 + rows, p.n[1]) - 1 + FRAME, t.k0 + t.nk - 1 + FRAME};
-            bool hit = false;
-            for (const CopyItem* it : byDst[t.patch]) {
-                bool ov = true;
-                for (int d = 0; d < 3; ++d)
-                    ov = ov && std::max(lo[d], it->dst_lo[d]) <= std::min(hi[d], it->dst_lo[d] + it->n[d] - 1);
-                if (ov) { hit = true; break; }
+        auto split = [&](const std::vector<Tile>& all, int rows, int halo, std::vector<Tile>& own, std::vector<Tile>& rem) {
+            for (const Tile& t : all) {
+                const PatchDesc& p = hpatches[t.patch];
+                const int w = t.pad_[0] > 0 ? t.pad_[0] : 124;
+                const int lo[3] = {t.i0 - halo, t.j0 - halo, t.k0 - halo};
+                const int hi[3] = {std::min(t.i0 + w, p.n[0]) - 1 + halo, std::min(t.j0 + rows, p.n[1]) - 1 + halo, t.k0 + t.nk - 1 + halo};
+                bool hit = false;
+                for (const CopyItem* it : byDst[t.patch]) {
+                    bool ov = true;
+                    for (int d = 0; d < 3; ++d)
+                        ov = ov && std::max(lo[d], it->dst_lo[d]) <= std::min(hi[d], it->dst_lo[d] + it->n[d] - 1);
+                    if (ov) { hit = true; break; }
+                }
+                (hit ? rem : own).push_back(t);
             }
-            (hit ? rem : own).push_back(t);
-        }
+        };
+        std::vector<Tile> own, rem;
+        split(hftiles, fused_rows() - 4, FRAME, own, rem);
         nftiles_own = (int)own.size();
         nftiles_rem = (int)rem.size();
         d_ftiles_own = to_device(own);
         d_ftiles_rem = to_device(rem);
+        own.clear();
+        rem.clear();
+        split(hrtiles, 14, 1, own, rem);
+        nrtiles_own = (int)own.size();
+        nrtiles_rem = (int)rem.size();
+        d_rtiles_own = to_device(own);
+        d_rtiles_rem = to_device(rem);
     }
     if (plan.send_total) SOMAR_HIP(hipMalloc(&d_sendbuf, plan.send_total * sizeof(double)));
     if (plan.recv_total) SOMAR_HIP(hipMalloc(&d_recvbuf, plan.recv_total * sizeof(double)));

@@ -102,6 +102,9 @@ public:
     Tile* d_ftiles_own = nullptr;
     Tile* d_ftiles_rem = nullptr;
     int nftiles_own = 0, nftiles_rem = 0;
+    Tile* d_rtiles_own = nullptr;   // the same split of the marching operator / residual's tiles (they read phi one cell around)
+    Tile* d_rtiles_rem = nullptr;
+    int nrtiles_own = 0, nrtiles_rem = 0;
     std::vector<Tile> hrtiles;   // tiles of the k-marching operator/residual (resid_march.hip): 124 x 14 columns
     Tile* d_rtiles = nullptr;
     int nrtiles = 0;

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
             if (lane == 0 && row == 0) {
                 double tot = red[0];
                 for (int q = 1; q < RM_J; ++q) tot = tot + red[q];
-                volsum[blockIdx.x] = tot;
+                volsum[t.pad_[2]] = tot;   // the tile's place in the level's full tile list: split launches (overlap) keep the order of the sum
             }
         }
     }

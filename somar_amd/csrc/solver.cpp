@@ -28,7 +28,6 @@ PressureSolver::PressureSolver(Comm* comm, hipStream_t shared) : comm_(comm ? co
     if (const char* e = getenv("SOMAR_FUSED_MIN_CELLS")) fused_min_cells_ = atoll(e);
     march_min_cells_ = fused_min_cells_;
     if (const char* e = getenv("SOMAR_MARCH_MIN_CELLS")) march_min_cells_ = atoll(e);
-    if (const char* e = getenv("SOMAR_TINY_MAX_CELLS")) tiny_max_cells_ = atoll(e);
     // levels up to this many cells sum in the reference's serial order (k_reduce_ordered); tests raise it to
     // make whole solves reproduce the oracle's histories to the last bits
     if (const char* e = getenv("SOMAR_ORDERED_REDUCE_MAX")) ordered_max_cells_ = atoll(e);
@@ -689,39 +688,6 @@ void PressureSolver::download_field(const double* field, int depth, int patch, d
 // ------------------------------------------------------------------------------------
 // level operator
 // ------------------------------------------------------------------------------------
-// A level small enough for the single-workgroup program kernel: everything on this rank (no remote halo), the 7-point
-// operator without Dirichlet ghosts or coarse-fine faces, point GSRB
-bool PressureSolver::tiny(int d) const
-{
-    const Level& L = *lev[d];
-    return tiny_max_cells_ > 0 && !full_ && !diri_ && L.ncf == 0 && L.plan.peers.empty() && !profiling_ &&
-           L.valid_cells_global <= tiny_max_cells_ && L.dev.ntiles > 0 && L.dev.tile_j >= 1 && L.dev.tile_j <= 16 &&
-           (1024 % (64 * L.dev.tile_j)) == 0;
-}
-
-void PressureSolver::tiny_run(int d, double* const* fields, int nfields, const std::vector<TinyOp>& ops)
-{
-    Level& L = *lev[d];
-    launch_tiny_program(st_, L.dev, L.d_local_items, (int)L.plan.local.size(), L.field_elems, fields, nfields, ops.data(),
-                        (int)ops.size());
-}
-
-static TinyOp tiny_op(int type, int f0, int f1 = 0, int f2 = 0, int arg = 0, double a = 0.0)
-{
-    TinyOp o;
-    o.type = type; o.f0 = f0; o.f1 = f1; o.f2 = f2; o.arg = arg; o.pad_ = 0; o.a = a;
-    return o;
-}
-// LevelGSRB::relax on a tiny level as program steps: fields[0] = e, fields[1] = res
-static void tiny_push_sweeps(std::vector<TinyOp>& ops, int iters)
-{
-    for (int it = 0; it < iters; ++it)
-        for (int pass = 0; pass < 2; ++pass) {
-            ops.push_back(tiny_op(TINY_EXCHANGE, 0));
-            ops.push_back(tiny_op(TINY_GSRB, 0, 1, 0, pass));
-        }
-}
-
 bool PressureSolver::fused_relax(int d, int iters) const
 {
     const Level& L = *lev[d];
@@ -741,14 +707,6 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
         launch_set(st_, e, L.field_elems, 0.0);
         e_zero = false;
     }
-    if (!fused_path && prm.relaxMode == RELAX_LEVEL_GSRB && tiny(d)) {
-        // the same exchanges and colour passes, one launch (cf_homog: no coarse-fine faces on a tiny() level)
-        std::vector<TinyOp> ops;
-        tiny_push_sweeps(ops, iters);
-        double* fld[2] = {e, const_cast<double*>(res)};
-        tiny_run(d, fld, 2, ops);
-        return;
-    }
     if (fused_path) {
         // LevelGSRB::relax (GSRB.cpp:58-98) as ONE fused red+black launch per sweep (gsrb_fused.hip):
         // same values bit for bit, one ghost exchange per sweep instead of two, ping-pong buffers.
@@ -763,23 +721,12 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
             else if (it == 0 && e_shift) mode = 2;
             if (!zin && fused_overlap(L)) {
                 // the sweep's one exchange in flight on the second stream while the tiles that read none of its cells are swept
-                if (!st_comm_) {
-                    SOMAR_HIP(hipStreamCreateWithFlags(&st_comm_, hipStreamNonBlocking));
-                    SOMAR_HIP(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
-                    SOMAR_HIP(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
-                }
-                SOMAR_HIP(hipEventRecord(ev_ready_, st_));             // cur is final (and alt, which the sweep rewrites, is free)
-                SOMAR_HIP(hipStreamWaitEvent(st_comm_, ev_ready_, 0));
-                L.exchange_local(cur, st_);
+                // (the CF ghosts are other cells, computed from this rank's valid cells: filled before the first tiles run)
                 L.cf_homog_ext(cur, st_);
-                launch_gsrb_fused(st_, L.d_ftiles_own, L.nftiles_own, L.dev, alt, cur, res, mode, e_shift,
-                                  e_plus_level ? &e_plus_level->dev : nullptr, e_plus, L.mgCrseRefRatio);
-                L.exchange_remote(cur, st_comm_);                      // (a host-staged transport may block here: the tiles above are already queued)
-                SOMAR_HIP(hipEventRecord(ev_done_, st_comm_));
-                SOMAR_HIP(hipStreamWaitEvent(st_, ev_done_, 0));
-                launch_gsrb_fused(st_, L.d_ftiles_rem, L.nftiles_rem, L.dev, alt, cur, res, mode, e_shift,
-                                  e_plus_level ? &e_plus_level->dev : nullptr, e_plus, L.mgCrseRefRatio);
-                ++counters[0];
+                overlapped(L, cur, L.d_ftiles_own, L.nftiles_own, L.d_ftiles_rem, L.nftiles_rem, [&](Tile* tl, int nt) {
+                    launch_gsrb_fused(st_, tl, nt, L.dev, alt, cur, res, mode, e_shift, e_plus_level ? &e_plus_level->dev : nullptr,
+                                      e_plus, L.mgCrseRefRatio);
+                });
                 std::swap(cur, alt);
                 continue;
             }
@@ -894,12 +841,6 @@ void PressureSolver::apply_op(int d, double* out, double* phi, bool homogeneous)
 void PressureSolver::residual_i(int d, double* out, double* phi, const double* rhs, bool homogeneous)
 {
     Level& L = *lev[d];
-    if (tiny(d)) {
-        std::vector<TinyOp> ops{tiny_op(TINY_EXCHANGE, 1), tiny_op(TINY_OP, 0, 1, 2, 0)};
-        double* fld[3] = {out, phi, const_cast<double*>(rhs)};
-        tiny_run(d, fld, 3, ops);
-        return;
-    }
     // small levels (direct-load operator): the kernel pulls the ghosts it reads, no copy launch
     const bool pull = !full_ && L.pull_ready() && !(L.valid_cells_global >= march_min_cells_ && L.active[2]);
     if (!pull) xchg(L, phi);  // exchangeComplete, MappedAMRPoissonOp.cpp:2222-2238
@@ -920,12 +861,6 @@ void PressureSolver::residual_i(int d, double* out, double* phi, const double* r
 void PressureSolver::apply_op_i(int d, double* out, double* phi, bool homogeneous)
 {
     Level& L = *lev[d];
-    if (tiny(d)) {
-        std::vector<TinyOp> ops{tiny_op(TINY_EXCHANGE, 1), tiny_op(TINY_OP, 0, 1, 1, 1)};
-        double* fld[2] = {out, phi};
-        tiny_run(d, fld, 2, ops);
-        return;
-    }
     const bool pull = !full_ && L.pull_ready() && !(L.valid_cells_global >= march_min_cells_ && L.active[2]);
     if (!pull) xchg(L, phi);
     if (diri_ && !full_) apply_diri(d, phi, homogeneous);
@@ -978,10 +913,19 @@ void PressureSolver::restrict_residual(int d, double* resCoarse, double* phiFine
     if (F.valid_cells_global >= march_min_cells_ && F.active[2] && !full_) {
         // large level: residual and J-weighted average in one marching pass, the fine residual is never stored
         F.cf_homog(phiFine, st_);
+        const bool want = F.zeroAvg && !ordered(d);  // the fine half of the folded prolongation's mean
+        if (resid_overlap(F)) {
+            overlapped(F, phiFine, F.d_rtiles_own, F.nrtiles_own, F.d_rtiles_rem, F.nrtiles_rem, [&](Tile* tl, int nt) {
+                launch_resid_restrict(st_, tl, nt, F.dev, lev[d + 1]->dev, resCoarse, phiFine, rhsFine, F.mgCrseRefRatio,
+                                      F.dxProduct, want ? d_partials : nullptr);
+            });
+            if (want) launch_sum_partials(st_, d_partials, F.nrtiles, d_fold + 8 * d);
+            sf_valid_[d] = want ? 1 : 0;
+            return;
+        }
         xchg(F, phiFine);
         if (diri_) apply_diri(d, phiFine, true);  // homogeneous Dirichlet ghosts, as residual() fills them
         if (profiling_ && d == 0) prof_begin(1);
-        const bool want = F.zeroAvg && !ordered(d);  // the fine half of the folded prolongation's mean
         launch_resid_restrict(st_, F.d_rtiles, F.nrtiles, F.dev, lev[d + 1]->dev, resCoarse, phiFine, rhsFine,
                               F.mgCrseRefRatio, F.dxProduct, want ? d_partials : nullptr);
         if (want) launch_sum_partials(st_, d_partials, F.nrtiles, d_fold + 8 * d);
@@ -1016,16 +960,6 @@ void PressureSolver::pre_cond(int d, double* phi, const double* rhs)
     Level& L = *lev[d];
     if (prm.num_smooth_precond == 0 || prm.precondMode == PRECOND_NONE) {
         launch_copy(st_, phi, rhs, L.field_elems);
-        return;
-    }
-    if (prm.precondMode != PRECOND_DIAG_LINE_RELAX && prm.relaxMode == RELAX_LEVEL_GSRB && tiny(d) &&
-        !fused_relax(d, prm.num_smooth_precond)) {
-        // DIAGPRECOND + the sweeps in one launch
-        std::vector<TinyOp> ops;
-        ops.push_back(tiny_op(TINY_DIAG, 0, 1));
-        tiny_push_sweeps(ops, prm.num_smooth_precond);
-        double* fld[2] = {phi, const_cast<double*>(rhs)};
-        tiny_run(d, fld, 2, ops);
         return;
     }
     launch_diag(st_, L.dev, phi, rhs, 0);
@@ -1695,7 +1629,7 @@ bool PressureSolver::fold_prolong(int d) const
 // Chombo 3.1 BiCGStabSolver<T>::solve (EXTERNAL to the reference; restated from the published
 // algorithm, same variable names).  Runs on the coarsest MG depth.
 // ------------------------------------------------------------------------------------
-// A bottom level small enough for the one-launch BiCGStab (k_tiny_bicgstab): everything tiny() asks (all boxes on this rank,
+// A bottom level small enough for the one-launch BiCGStab (k_tiny_bicgstab): all boxes on this rank,
 // the 7-point operator, Neumann / periodic sides, no coarse-fine faces, point GSRB) and serial-order sums.
 // SOMAR_FUSED_BOTTOM_MAX_CELLS (default 512, 0 = off) is the A/B switch.
 bool PressureSolver::fused_bottom(int d) const

@@ -241,15 +241,7 @@ private:
     bool own_stream_ = true;
     double dxCrse_[3] = {0, 0, 0};
     std::vector<double*> f_pp;  // per-depth ping-pong buffer of the fused sweep
-    // EXPERIMENT, off by default (SOMAR_TINY_MAX_CELLS=8192 switches it on): levels of at most this many cells run their
-    // sweeps / preconditioner / operator as one single-workgroup program launch (k_tiny_program).  Bit-identical, but measured
-    // SLOWER than the launch-per-operation path it was meant to replace (C3: 91 vs 21 ms per AMR V-cycle): the bodies keep the
-    // tile shape (64 lanes x i-pairs), of which a 4-cell-wide bottom box fills 2 lanes, and one CU runs the 64 boxes in 16
-    // rounds that 64 CUs run at once.  The launch-bound tail needs flat per-cell work lists, not fewer launches of this shape.
-    long long tiny_max_cells_ = 0;
-    bool tiny(int d) const;
     bool fused_bottom(int d) const;   // the whole BiCGStab bottom solve in one single-workgroup launch (k_tiny_bicgstab)
-    void tiny_run(int d, double* const* fields, int nfields, const std::vector<TinyOp>& ops);
     // the BiCGStab bottom solve of a multi-box bottom level as one persistent launch, one workgroup per box (k_box_bicgstab);
     // SOMAR_BOX_BOTTOM=0 is the A/B switch (read once, at construction).  The neighbour table is built at the first use.
     bool box_bottom(int d) const;
@@ -370,6 +362,30 @@ private:
     bool overlap_on_ = true;
     hipStream_t st_comm_ = nullptr;
     hipEvent_t ev_ready_ = nullptr, ev_done_ = nullptr;
+    bool resid_overlap(const Level& L) const
+    {
+        return overlap_on_ && !L.plan.peers.empty() && L.nrtiles_own > 0 && !capturing_ && !profiling_ && !diri_;
+    }
+    // exchange of f with its remote half on the second stream; run(tiles, n) is issued for the tiles that read no remote ghost
+    // first, for the others once the messages have landed
+    template <class Run>
+    void overlapped(const Level& L, double* f, Tile* own, int nown, Tile* rem, int nrem, Run run)
+    {
+        if (!st_comm_) {
+            SOMAR_HIP(hipStreamCreateWithFlags(&st_comm_, hipStreamNonBlocking));
+            SOMAR_HIP(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
+            SOMAR_HIP(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
+        }
+        SOMAR_HIP(hipEventRecord(ev_ready_, st_));
+        SOMAR_HIP(hipStreamWaitEvent(st_comm_, ev_ready_, 0));
+        L.exchange_local(f, st_);
+        run(own, nown);
+        L.exchange_remote(f, st_comm_);   // (a host-staged transport may block here: the tiles above are already queued)
+        SOMAR_HIP(hipEventRecord(ev_done_, st_comm_));
+        SOMAR_HIP(hipStreamWaitEvent(st_, ev_done_, 0));
+        run(rem, nrem);
+        ++counters[0];
+    }
     bool fused_overlap(const Level& L) const
     {
         return overlap_on_ && !L.plan.peers.empty() && L.nftiles_own > 0 && !capturing_ && !profiling_;

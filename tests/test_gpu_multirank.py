@@ -106,6 +106,9 @@ def _worker(rank, nranks, name, mode, q):
             phi = so.random_field(grids, 13, (1, 1, 1), dom.box)
             rhs = so.random_field(grids, 14, (0, 0, 0), dom.box)
             op.relax(phi, rhs, 3)
+            cres = op.create_coarser(rhs)
+            op.restrict_residual(cres, phi, rhs)
+            os.environ["SOMAR_MARCH_MIN_CELLS"] = "1"     # the k-marching residual + restriction on this 64 x 64 x 32 level
             for overlap in (True, False):
                 if overlap:
                     os.environ.pop("SOMAR_NO_OVERLAP", None)
@@ -118,8 +121,12 @@ def _worker(rank, nranks, name, mode, q):
                 g2.relax(0, F.F_PHI, F.F_RHS, 3)
                 assert (g2.counters()["overlapped_sweeps"] == 3) == overlap, g2.counters()
                 mine(download_valid(g2, F.F_PHI, grids), valid_of(phi), "overlapped relax" if overlap else "serial relax")
+                g2.restrictResidual(0, F.FIELD(1, F.F_RES), F.F_PHI, F.F_RHS)
+                assert (g2.counters()["overlapped_sweeps"] == 4) == overlap, g2.counters()
+                mine(download_valid(g2, F.FIELD(1, F.F_RES), cres.grids, 1), valid_of(cres), "residual + restriction")
                 g2.undefine()
             os.environ.pop("SOMAR_NO_OVERLAP", None)
+            os.environ.pop("SOMAR_MARCH_MIN_CELLS", None)
 
         if nranks != 2:
             F.comm_destroy(comm)

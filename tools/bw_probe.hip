@@ -52,6 +52,38 @@ __global__ __launch_bounds__(256) void k_mix6(const v2d* __restrict__ a, const v
     }
 }
 
+// NR read streams + one write stream (how does the achievable rate fall with the number of streams?)
+struct Ptrs { const v2d* r[6]; };
+template <int NR>
+__global__ __launch_bounds__(256) void k_mixn(Ptrs P, v2d* __restrict__ o, long long n)
+{
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
+        v2d v = P.r[0][i];
+#pragma unroll
+        for (int q = 1; q < NR; ++q) v += P.r[q][i];
+        o[i] = v;
+    }
+}
+// the same 48 B read + 8 B written per cell, but the six operands of a cell pair interleaved in ONE array (array of structs,
+// 96 B per lane): one read stream instead of six
+__global__ __launch_bounds__(256) void k_packed6(const v2d* __restrict__ a, v2d* __restrict__ o, long long n)
+{
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
+        const v2d* q = a + 6 * i;
+        o[i] = q[0] + q[1] + q[2] + q[3] + q[4] + q[5];
+    }
+}
+// ... and plane-interleaved: for every row of 128 pairs the six operands' rows follow each other (6 x 2 KB), the layout a
+// k-marching kernel would stream: each wavefront still issues six fully coalesced 1 KB loads, from one 12 KB run
+__global__ __launch_bounds__(256) void k_rowpacked6(const v2d* __restrict__ a, v2d* __restrict__ o, long long n)
+{
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
+        const long long row = i >> 6, lane = i & 63;
+        const v2d* q = a + row * 384 + lane;
+        o[i] = q[0] + q[64] + q[128] + q[192] + q[256] + q[320];
+    }
+}
+
 template <class F>
 static double time_ms(F f, int reps)
 {
@@ -83,6 +115,23 @@ int main(int argc, char** argv)
         first = false;
         fflush(stdout);
     };
+    {
+        v2d* big;
+        CK(hipMalloc(&big, cells * 8 * 6));
+        CK(hipMemset(big, 0, cells * 8 * 6));
+        Ptrs P;
+        for (int q = 0; q < 6; ++q) P.r[q] = p[q];
+        for (int wgs : {1024, 4096}) {
+            rep("mix1r1w", wgs, 16.0 * cells, time_ms([&] { hipLaunchKernelGGL(k_mixn<1>, dim3(wgs), dim3(256), 0, 0, P, p[6], n); }, reps));
+            rep("mix2r1w", wgs, 24.0 * cells, time_ms([&] { hipLaunchKernelGGL(k_mixn<2>, dim3(wgs), dim3(256), 0, 0, P, p[6], n); }, reps));
+            rep("mix3r1w", wgs, 32.0 * cells, time_ms([&] { hipLaunchKernelGGL(k_mixn<3>, dim3(wgs), dim3(256), 0, 0, P, p[6], n); }, reps));
+            rep("mix4r1w", wgs, 40.0 * cells, time_ms([&] { hipLaunchKernelGGL(k_mixn<4>, dim3(wgs), dim3(256), 0, 0, P, p[6], n); }, reps));
+            rep("mix6r1w_again", wgs, 56.0 * cells, time_ms([&] { hipLaunchKernelGGL(k_mixn<6>, dim3(wgs), dim3(256), 0, 0, P, p[6], n); }, reps));
+            rep("packed6r1w", wgs, 56.0 * cells, time_ms([&] { hipLaunchKernelGGL(k_packed6, dim3(wgs), dim3(256), 0, 0, big, p[6], n); }, reps));
+            rep("rowpacked6r1w", wgs, 56.0 * cells, time_ms([&] { hipLaunchKernelGGL(k_rowpacked6, dim3(wgs), dim3(256), 0, 0, big, p[6], n); }, reps));
+        }
+        CK(hipFree(big));
+    }
     for (int wgs : {1024, 2048, 4096, 8192, 32768}) {
         rep("copy", wgs, 16.0 * cells, time_ms([&] { hipLaunchKernelGGL(k_copy<0>, dim3(wgs), dim3(256), 0, 0, p[0], p[6], n); }, reps));
         rep("copy_nt_store", wgs, 16.0 * cells, time_ms([&] { hipLaunchKernelGGL(k_copy<2>, dim3(wgs), dim3(256), 0, 0, p[0], p[6], n); }, reps));
