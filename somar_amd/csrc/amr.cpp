@@ -962,17 +962,23 @@ void AMRSolver::reflux(int l, double* phiFine, double* phi, double* LofPhi)
     if (!K.fluxDefined) return;
     Level& F = S[l + 1]->level(0);
     Level& C = S[l]->level(0);
-    // non-diagonal metric: getFlux = fillExtrap + MAPPEDGETFLUX, evaluated once per level into face fields
-    double* const* flC = S[l]->is_full() ? S[l]->flux_fields(phi) : nullptr;
-    double* const* flF = S[l + 1]->is_full() ? S[l + 1]->flux_fields(phiFine) : nullptr;
+    // non-diagonal metric: getFlux = fillExtrap + MAPPEDGETFLUX.  The register reads the fluxes of its own faces only, so they
+    // are evaluated there (reg_flux19) from the level's extrapolated copy instead of filling three whole face fields per level
+    // (k_flux_full: 1 ms per 16.7 M-cell level, 8 ms of a C5 cycle).  SOMAR_FLUX_FIELDS=1: the face fields, as before (A/B).
+    static const bool fields = getenv("SOMAR_FLUX_FIELDS") != nullptr;
+    double* const* flC = (fields && S[l]->is_full()) ? S[l]->flux_fields(phi) : nullptr;
+    double* const* flF = (fields && S[l + 1]->is_full()) ? S[l + 1]->flux_fields(phiFine) : nullptr;
+    FullFlux ffC, ffF;
+    if (!fields && S[l]->is_full()) S[l]->flux_at_faces(phi, ffC);
+    if (!fields && S[l + 1]->is_full()) S[l + 1]->flux_at_faces(phiFine, ffF);
     launch_fine_register(st_, K.d_reg, K.nreg_local, F.dev.patches, phiFine, F.dev.jg, F.dx, K.sc_fine, K.r, K.d_regvals,
-                         flF);
+                         flF, &ffF);
     if (!K.peers.empty()) {
         launch_gather(st_, K.d_sendidx, K.nsend, K.d_regvals, K.d_sendbuf);
         comm_->neighbor_exchange(K.d_sendbuf, K.d_regvals + K.nreg_local, K.peers, K.soff, K.scount, K.roff, K.rcount, st_);
     }
     launch_reflux(st_, K.d_reflux, K.nreflux, K.d_A, K.d_B, C.dev.patches, phi, C.dev.jg, C.dev.jinv, C.dx, K.d_regvals,
-                  LofPhi, flC);
+                  LofPhi, flC, &ffC);
 }
 
 void AMRSolver::amr_restrict(int l, double* residual, double* correction, const double* coarseCorrection,

@@ -83,14 +83,18 @@ void launch_cf_slopes(hipStream_t st, const QCoarse* cc, int ncc, const QPoint* 
                       const double dxc[3]);
 void launch_cf_quad(hipStream_t st, const QFine* fc, int nfc, const QCoarse* cc, const double* der, const double* buf,
                     double* fine, const double dxf[3], const double dxc[3], const int r[3]);
+// Non-diagonal metric: the face fluxes getFlux would fill a whole FluxBox with (fillExtrap + MAPPEDGETFLUX, beta = 1;
+// MappedAMRPoissonOp.cpp:2048-2122) are evaluated AT THE REGISTER'S FACES ONLY, inside the register kernels: psi = the level's
+// extrapolated copy of phi (ready), J[a][b] = J g^{ab} on a-faces, dxi = 1 / dx of that level.  psi == nullptr: not used.
 void launch_fine_register(hipStream_t st, const FRegCell* cells, int n, const PatchDesc* fpatches, const double* phi,
                           double* const jg[3], const double dxf[3], const double sc[3][2], const int r[3], double* out,
-                          double* const* fluxes = nullptr);
+                          double* const* fluxes = nullptr, const FullFlux* ff = nullptr);
 void launch_gather(hipStream_t st, const int* idx, long long n, const double* src, double* dst);
 void launch_reflux_rescale(hipStream_t st, RefluxA* A, long long n, const double scale[3]);
 void launch_reflux(hipStream_t st, const RefluxCell* cells, int n, const RefluxA* A, const int* B,
                    const PatchDesc* cpatches, const double* phi, double* const jg[3], const double* jinv,
-                   const double dxc[3], const double* freg, double* LofPhi, double* const* fluxes = nullptr);
+                   const double dxc[3], const double* freg, double* LofPhi, double* const* fluxes = nullptr,
+                   const FullFlux* ff = nullptr);
 
 // ---- host side -------------------------------------------------------------------------------------
 // What ties level l (fine) to level l-1 (coarse).

@@ -157,9 +157,24 @@ __global__ void k_cf_quad(const QFine* __restrict__ fc, int nfc, const QCoarse* 
 struct JG3 { const double* v[3]; };
 struct SC6 { double v[3][2]; };
 
-// fl: precomputed face fluxes (getFlux of a non-diagonal metric: PressureSolver::flux_fields) or all null
+// MAPPEDGETFLUX with beta = a_ref = 1 at the face that is the LOW face of cell c in direction a: flux19 of full19.hip, same
+// expression (k_flux_full filled whole face fields with it; the register needs it on its own faces only)
+__device__ __forceinline__ double reg_flux19(const double* __restrict__ phi, const FullFlux& F, long long c, int a,
+                                             const long long st[3])
+{
+    const int b = (a + 1) % 3, cc = (a + 2) % 3;
+    const long long sa = st[a], sb = st[b], sc = st[cc];
+    const double* E = F.psi;
+    const double aScale = 1.0 * F.dxi[a], bScale = 0.25 * 1.0 * F.dxi[b], cScale = 0.25 * 1.0 * F.dxi[cc];
+    return aScale * F.J[a][a][c] * (phi[c] - phi[c - sa]) +
+           bScale * F.J[a][b][c] * (E[c + sb] - E[c - sb] + E[c + sb - sa] - E[c - sb - sa]) +
+           cScale * F.J[a][cc][c] * (E[c + sc] - E[c - sc] + E[c + sc - sa] - E[c - sc - sa]);
+}
+
+// fl: precomputed face fields (the composite divergence's face velocities) or all null; ff.psi: non-diagonal metric, fluxes
+// evaluated here
 __global__ void k_fine_register(const FRegCell* __restrict__ cells, int n, const PatchDesc* __restrict__ fpatches,
-                                const double* __restrict__ phi, JG3 jg, JG3 fl, D3 dxf, SC6 sc, I3 r,
+                                const double* __restrict__ phi, JG3 jg, JG3 fl, FullFlux ff, D3 dxf, SC6 sc, I3 r,
                                 double* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,7 +192,7 @@ __global__ void k_fine_register(const FRegCell* __restrict__ cells, int n, const
         for (int o1 = 0; o1 < n1; ++o1)
             for (int o0 = 0; o0 < n0; ++o0) {
                 const long long f = c.cell0 + o0 + st[1] * o1 + st[2] * o2;
-                const double flux = fl.v[d] ? fl.v[d][f] : J[f] * scale * (phi[f] - phi[f - st[d]]);
+                const double flux = fl.v[d] ? fl.v[d][f] : (ff.psi ? reg_flux19(phi, ff, f, d, st) : J[f] * scale * (phi[f] - phi[f - st[d]]));
                 acc = acc + s * flux;
             }
     out[i] = acc;
@@ -192,7 +207,7 @@ __global__ void k_gather(const int* __restrict__ idx, long long n, const double*
 
 __global__ void k_reflux(const RefluxCell* __restrict__ cells, int n, const RefluxA* __restrict__ A,
                          const int* __restrict__ B, const PatchDesc* __restrict__ cpatches,
-                         const double* __restrict__ phi, JG3 jg, JG3 fl, const double* __restrict__ jinv, D3 dxc,
+                         const double* __restrict__ phi, JG3 jg, JG3 fl, FullFlux ff, const double* __restrict__ jinv, D3 dxc,
                          const double* __restrict__ freg, double* __restrict__ L)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -205,7 +220,8 @@ __global__ void k_reflux(const RefluxCell* __restrict__ cells, int n, const Refl
         const RefluxA e = A[a];
         const double scale = 1.0 / dxc.v[e.dir];
         const double flux = fl.v[e.dir] ? fl.v[e.dir][e.face]
-                                        : jg.v[e.dir][e.face] * scale * (phi[e.face] - phi[e.face - st[e.dir]]);
+                                        : (ff.psi ? reg_flux19(phi, ff, e.face, e.dir, st)
+                                                  : jg.v[e.dir][e.face] * scale * (phi[e.face] - phi[e.face - st[e.dir]]));
         coar = coar + e.sc * flux;
     }
     double inc = 0.0;
@@ -252,7 +268,7 @@ void launch_cf_quad(hipStream_t st, const QFine* fc, int nfc, const QCoarse* cc,
 }
 void launch_fine_register(hipStream_t st, const FRegCell* cells, int n, const PatchDesc* fpatches, const double* phi,
                           double* const jg[3], const double dxf[3], const double sc[3][2], const int r[3], double* out,
-                          double* const* fluxes)
+                          double* const* fluxes, const FullFlux* ff)
 {
     if (n == 0) return;
     JG3 J, FL;
@@ -263,8 +279,8 @@ void launch_fine_register(hipStream_t st, const FRegCell* cells, int n, const Pa
         S.v[d][0] = sc[d][0];
         S.v[d][1] = sc[d][1];
     }
-    hipLaunchKernelGGL(k_fine_register, dim3(grid1(n)), dim3(256), 0, st, cells, n, fpatches, phi, J, FL, d3(dxf), S, i3(r),
-                       out);
+    hipLaunchKernelGGL(k_fine_register, dim3(grid1(n)), dim3(256), 0, st, cells, n, fpatches, phi, J, FL, ff ? *ff : FullFlux(),
+                       d3(dxf), S, i3(r), out);
 }
 // CRSEONESIDEGRAD (calculus/DivCurlGrad/DivCurlGradF.ChF:626-697) over a precomputed face list
 struct G3 { double* v[3]; };
@@ -350,13 +366,13 @@ void launch_reflux_rescale(hipStream_t st, RefluxA* A, long long n, const double
 
 void launch_reflux(hipStream_t st, const RefluxCell* cells, int n, const RefluxA* A, const int* B,
                    const PatchDesc* cpatches, const double* phi, double* const jg[3], const double* jinv,
-                   const double dxc[3], const double* freg, double* LofPhi, double* const* fluxes)
+                   const double dxc[3], const double* freg, double* LofPhi, double* const* fluxes, const FullFlux* ff)
 {
     if (n == 0) return;
     JG3 J, FL;
     for (int d = 0; d < 3; ++d) { J.v[d] = jg[d]; FL.v[d] = fluxes ? fluxes[d] : nullptr; }
-    hipLaunchKernelGGL(k_reflux, dim3(grid1(n)), dim3(256), 0, st, cells, n, A, B, cpatches, phi, J, FL, jinv, d3(dxc),
-                       freg, LofPhi);
+    hipLaunchKernelGGL(k_reflux, dim3(grid1(n)), dim3(256), 0, st, cells, n, A, B, cpatches, phi, J, FL, ff ? *ff : FullFlux(),
+                       jinv, d3(dxc), freg, LofPhi);
 }
 
 }  // namespace somar

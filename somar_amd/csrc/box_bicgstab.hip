@@ -175,10 +175,17 @@ __global__ __launch_bounds__(MAXT) void k_box_bicgstab(BoxBicg A)
         __syncthreads();
     }
 
+    // debug timing (A.dbg != nullptr): thread 0 of workgroup 0 accumulates s_memtime ticks per phase
+    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    const bool timing = A.dbg != nullptr && b == 0 && tid == 0;
+    auto tick = [&]() -> long long { return timing ? (long long)__builtin_amdgcn_s_memtime() : 0ll; };
+
     // ---- device-wide barrier: every workgroup stamps its own flag with the barrier's number (a plain write-through store, no
     // read-modify-write on a shared counter), the first wavefront polls all flags at once, one or two per lane ----
     unsigned epoch = 0;
     auto gsync = [&]() -> bool {
+        const long long t_in = tick();
+        struct Acc { long long& a; long long t0; bool on; __device__ ~Acc() { if (on) a += (long long)__builtin_amdgcn_s_memtime() - t0; } } acc{tk[3], t_in, timing};
         __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's write-through stores have been acknowledged
         __syncthreads();
         if (nwg == 1) return true;
@@ -211,6 +218,7 @@ __global__ __launch_bounds__(MAXT) void k_box_bicgstab(BoxBicg A)
     // ---- 19-point variant: stage the box grown by one cell, run one of its ghost programs on the copy ----
     // zf's valid cells are current everywhere (a device-wide barrier has passed since they were written)
     auto stage_fab = [&](const double* zf, int which) {
+        const long long t0 = tick();
         const int* src = A.fab_src + A.fab_start[b];
         for (int q = tid; q < mtot; q += nth) {
             const int so = src[q];
@@ -219,13 +227,13 @@ __global__ __launch_bounds__(MAXT) void k_box_bicgstab(BoxBicg A)
             Fe[q] = v;                                            // psi := phi
         }
         __syncthreads();
+        const long long t1 = tick();
+        tk[0] += t1 - t0;
         const int wave = tid >> 6, lane = tid & 63, nwaves = nth >> 6;
         const long long stg[3] = {1, (long long)p.pj, p.pk};
         int q = 0;
         while (q < nops[which]) {
-            const int stage = sops[which][q].pad_;
-            int e = q + 1;
-            while (e < nops[which] && sops[which][e].pad_ == stage) ++e;
+            const int e = q + 1 + (sops[which][q].pad_ >> 16);   // pad_ = stage | (ops of this stage that follow) << 16
             for (int o = q + wave; o < e; o += nwaves) {
                 const GhostOp op = sops[which][o];
                 const int n0 = op.n[0], n01 = op.n[0] * op.n[1];
@@ -259,6 +267,8 @@ __global__ __launch_bounds__(MAXT) void k_box_bicgstab(BoxBicg A)
             __syncthreads();
             q = e;
         }
+        tk[1] += tick() - t1;
+        ++tk[5];
     };
     // one GSRB point update, 19-point: GSRBITER3D / GSRBBOUNDARYITER3D in k_gsrb_full's expression order, operands from the LDS copy
     auto relax_cell_full = [&](int q, double rhsv) {
@@ -427,6 +437,8 @@ __global__ __launch_bounds__(MAXT) void k_box_bicgstab(BoxBicg A)
     };
     // the terms of up to two sums are in X (and Y); -> the two totals.  false: the barrier gave up
     auto finish_sums = [&](bool two, double& ra, double& rb) -> bool {
+        const long long ts0 = tick();
+        struct AccS { long long& a; long long& g; long long t0, g0; bool on; __device__ ~AccS() { if (on) a += ((long long)__builtin_amdgcn_s_memtime() - t0) - (g - g0); } } accs{tk[4], tk[3], ts0, tk[3], timing};
         __syncthreads();
         double* mine = A.sums + (nred & 1) * 2 * BOX_MAX_WG;
         ++nred;
@@ -541,6 +553,7 @@ __global__ __launch_bounds__(MAXT) void k_box_bicgstab(BoxBicg A)
         return true;
     };
     auto finish = [&](int iters, int exit_code) {
+        if (timing) for (int q = 0; q < 6; ++q) A.dbg[q] = tk[q];
         if (b == 0 && tid == 0) {
             const double vals[2] = {(double)iters, (double)exit_code};
             A.info[0] = vals[0];

@@ -102,7 +102,7 @@ __global__ void k_ghost_ops(const GhostOp* __restrict__ ops, const PatchDesc* __
 // A whole ghost program in ONE launch, one workgroup per box.  Every op of a program reads and writes the storage of its own
 // box only (the exchange that feeds it has already run), so the stage boundaries of the dependence schedule -- kernel boundaries
 // in the staged form, 12-20 launches per application -- need only a workgroup barrier.  box_ops: the ops of box b, sorted by
-// stage (GhostOp::pad_), are box_ops[box_first[b] .. box_first[b + 1]).  For the SMALL levels (boxes of at most a few thousand
+// stage (GhostOp::pad_ & 0xffff; the upper half counts the ops of the same stage that follow), are box_ops[box_first[b] .. box_first[b + 1]).  For the SMALL levels (boxes of at most a few thousand
 // cells: a face is a few hundred cells, one 256-thread workgroup is plenty): on BASELINE C5 5 500 of the 7 700 dispatches of an
 // AMR V-cycle were staged ghost ops of such levels, three quarters of them inside the bottom solver.
 constexpr int GP_MAX_OPS = 160;   // ops of one box staged in LDS (10 KB); a longer program walks the rest from global memory
@@ -139,9 +139,8 @@ __global__ __launch_bounds__(512) void k_ghost_program(const GhostOp* __restrict
     const int wave = tid >> 6, lane = tid & 63, nwaves = nth >> 6;
     int q = 0;
     while (q < nops) {
-        const int stage = q < GP_MAX_OPS ? sops[q].pad_ : box_ops[first + q].pad_;
-        int e = q + 1;
-        while (e < nops && (e < GP_MAX_OPS ? sops[e].pad_ : box_ops[first + e].pad_) == stage) ++e;
+        // pad_ = stage | (ops of this stage that follow) << 16 (PressureSolver::upload_program)
+        const int e = q + 1 + ((q < GP_MAX_OPS ? sops[q].pad_ : box_ops[first + q].pad_) >> 16);
         for (int o = q + wave; o < e; o += nwaves) {
             const GhostOp op = o < GP_MAX_OPS ? sops[o] : box_ops[first + o];
             ghost_op_body<REDIRECT>(op, p, phi, psi, J, P, lane, 64);

@@ -25,6 +25,9 @@ struct LevelDev {
     StencilParams P;
 };
 
+// operands of MAPPEDGETFLUX with a non-diagonal metric, evaluated where a flux register needs it (amr_kernels.hip: reg_flux19)
+struct FullFlux { const double* psi = nullptr; const double* J[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}; double dxi[3] = {0, 0, 0}; };
+
 // 19-point path (full19.hip)
 // redirect: a read of psi that lands INSIDE the box's valid region takes phi instead (psi is then maintained in the
 // boxes' frames only -- the frame-only programs of the marching 19-point kernels, full19_march.hip)
@@ -152,6 +155,7 @@ struct BoxBicg {
     const double* jgf[3][3];
     const int* fab_src; const int* fab_start;
     const GhostOp* ops[2]; const int* ops_first[2];
+    long long* dbg;      // optional (SOMAR_BOX_TIMING=1): workgroup 0's clock ticks in {staging loads, ghost program, stencil, barrier, sums, count}
     int serial;          // sums in the reference's serial order (levels of at most ordered_max cells) or by a fixed tree per box
     double* info;        // device: iterations, exit code
     ScalarPublish pub;

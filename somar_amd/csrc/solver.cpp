@@ -1715,7 +1715,7 @@ void PressureSolver::build_box_tables(int d)
     }
     SOMAR_HIP(hipMalloc(&d_box_nb_, nb.size() * sizeof(int)));
     SOMAR_HIP(hipMalloc(&d_box_cstart_, cstart.size() * sizeof(int)));
-    SOMAR_HIP(hipMalloc(&d_box_sums_, (size_t)4 * BOX_MAX_WG * sizeof(double)));
+    SOMAR_HIP(hipMalloc(&d_box_sums_, ((size_t)4 * BOX_MAX_WG + 8) * sizeof(double)));   // + 6 debug counters (SOMAR_BOX_TIMING)
     SOMAR_HIP(hipMalloc(&d_box_sync_, (BOX_MAX_WG + 1) * sizeof(unsigned)));
     if (full_) {
         // the box grown by one cell: where each of its cells' values comes from
@@ -1770,6 +1770,8 @@ void PressureSolver::bottom_solve(double* phi, const double* rhs)
         A.sums = d_box_sums_;
         A.sync = d_box_sync_;
         A.serial = ordered(d) ? 1 : 0;
+        static const bool box_timing = getenv("SOMAR_BOX_TIMING") != nullptr;
+        A.dbg = box_timing ? reinterpret_cast<long long*>(d_box_sums_ + 4 * BOX_MAX_WG) : nullptr;
         A.full = full_ ? 1 : 0;
         if (full_) {
             A.fab_src = d_box_fab_;
@@ -1783,6 +1785,12 @@ void PressureSolver::bottom_solve(double* phi, const double* rhs)
         bottom_iters = (int)h_scalars[SLOT_TMP];
         bottom_exit = (int)h_scalars[SLOT_TMP + 1];
         bottom_kind = 2;
+        if (box_timing) {
+            long long t[6];
+            SOMAR_HIP(hipMemcpy(t, A.dbg, sizeof(t), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[somar box timing] iterations %d: ticks staging %lld, program %lld, barrier %lld, sums %lld, stagings %lld (100 MHz s_memtime)\n",
+                    bottom_iters, t[0], t[1], t[3], t[4], t[5]);
+        }
         return;
     }
     if (fused_bottom(d)) {

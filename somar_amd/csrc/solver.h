@@ -131,6 +131,7 @@ public:
     //   on every face of depth 0, for the flux register (reflux, :1615-1707)
     void cf_ev(int d, double* phi);
     double* const* flux_fields(double* phi);
+    void flux_at_faces(double* phi, FullFlux& ff);   // getFlux's operands for the register kernels: fillExtrap run, nothing stored
     void mac_grad_full(double* phi);  // f_flux := MAC gradient of phi, non-diagonal metric (phi exchanged)
     // the MAC gradient G^a = J g^{ab} d_b(phi) on every a-face of depth 0, STORED (either metric; phi exchanged, CF ghosts
     // filled by the caller): levelGradientMAC's per-box part (Gradient.cpp:124-160)

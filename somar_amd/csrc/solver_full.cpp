@@ -318,7 +318,18 @@ void PressureSolver::upload_program(FullProgram& P, const std::vector<std::vecto
     std::vector<int> first(npatches + 1, 0);
     for (int b = 0; b < npatches; ++b) {
         first[b] = (int)sorted.size();
-        sorted.insert(sorted.end(), byBox[b].begin(), byBox[b].end());   // stage order is kept: stages were walked in order
+        // stage order is kept (stages were walked in order).  pad_ of the box-sorted copy = stage | (how many ops of the same
+        // stage FOLLOW this one in the box's list) << 16: a kernel finds the end of a stage without walking the list
+        std::vector<GhostOp>& v = byBox[b];
+        for (size_t q = 0; q < v.size(); ++q) {
+            size_t e = q + 1;
+            while (e < v.size() && v[e].pad_ == v[q].pad_) ++e;
+            SOMAR_CHECK(v[q].pad_ < 65536 && e - q - 1 < 32768, "ghost program too long for its stage encoding");
+            const int st = v[q].pad_;
+            for (size_t r = q; r < e; ++r) v[r].pad_ = st | (int)((e - r - 1) << 16);
+            q = e - 1;
+        }
+        sorted.insert(sorted.end(), v.begin(), v.end());
     }
     first[npatches] = (int)sorted.size();
     P.max_box_ops = 0;
@@ -444,6 +455,18 @@ double* const* PressureSolver::flux_fields(double* phi)
     run_program(0, full_prog_[0][2], phi, f_psi[0], true, false, true);
     launch_flux_full(st_, L.dev, f_flux, phi, f_psi[0]);
     return f_flux;
+}
+
+void PressureSolver::flux_at_faces(double* phi, FullFlux& ff)
+{
+    SOMAR_CHECK(full_ && finalized, "flux_at_faces is for the non-diagonal path");
+    Level& L = *lev[0];
+    run_program(0, full_prog_[0][2], phi, f_psi[0], true, false, true);   // psi := phi, then fillExtrap (order 2)
+    ff.psi = f_psi[0];
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) ff.J[a][b] = L.dev.jgf[a][b];
+        ff.dxi[a] = 1.0 / L.dx[a];
+    }
 }
 
 void PressureSolver::mac_grad_full(double* phi)
