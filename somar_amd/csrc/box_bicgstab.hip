@@ -63,7 +63,11 @@ __global__ __launch_bounds__(MAXT) void k_box_bicgstab(BoxBicg A)
     static_assert(!FULL || CPT == 1, "the 19-point variant keeps one cell per thread");
     __shared__ double X[BOX_MAX_CELLS], Y[BOX_MAX_CELLS];
     __shared__ double Fp[FULL ? BOX_FAB_MAX : 1], Fe[FULL ? BOX_FAB_MAX : 1];   // the box grown by one cell: phi and its extrapolated copy
-    __shared__ GhostOp sops[FULL ? 2 : 1][FULL ? BOX_MAX_OPS : 1];               // the box's programs: [0] operator, [1] smoother
+    // the box's ghost programs ([0] operator, [1] smoother) as per-cell entries, their stage starts, and the coefficient triples
+    // (J g^{ab}, J g^{ac}, J g^{aa} on the boundary face) of their cross-term Neumann ghost cells
+    __shared__ BoxProgEntry E[FULL ? 2 : 1][FULL ? BOX_MAX_ENT : 1];
+    __shared__ int ST[FULL ? 2 : 1][FULL ? BOX_MAX_STAGES + 1 : 1];
+    __shared__ double NJ[FULL ? 2 : 1][FULL ? BOX_MAX_NEUM : 1][3];
     __shared__ double S[2][BOX_MAX_WG];
     __shared__ double M[16];
     __shared__ int s_ok;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(MAXT) void k_box_bicgstab(BoxBicg A)
     int fc[CPT];                 // own cell in the LDS copy
     double cj[CPT][3][3][2];     // J g^{ab} on the low / high a-face of the cell
     double dgF[CPT];             // GSRBBOUNDARYITER3D's denominator (its diagonal takes the faces in the order x-, x+, y-, y+, z-, z+)
-    int nops[2] = {0, 0};
+    int nstages[2] = {0, 0};
     const double xyScale = 0.25 / (P.dx[0] * P.dx[1]), yzScale = 0.25 / (P.dx[1] * P.dx[2]), zxScale = 0.25 / (P.dx[2] * P.dx[0]);
     if (FULL) {
 #pragma unroll
@@ -165,12 +169,25 @@ __global__ __launch_bounds__(MAXT) void k_box_bicgstab(BoxBicg A)
             dgF[q] = (f & 64u) ? P.alpha + P.beta * ld : dd[q];
         }
         for (int w = 0; w < 2; ++w) {
-            if (!A.ops_first[w]) continue;   // a program without ops (no wall anywhere: every ghost comes from the exchange)
-            const int first = A.ops_first[w][b];
-            nops[w] = A.ops_first[w][b + 1] - first;
-            const int4* src = reinterpret_cast<const int4*>(A.ops[w] + first);
-            int4* dst = reinterpret_cast<int4*>(sops[w]);
-            for (int q = tid; q < nops[w] * (int)(sizeof(GhostOp) / 16); q += nth) dst[q] = src[q];
+            if (!A.ent_first[w]) continue;   // a program without entries (no wall anywhere: every ghost comes from the exchange)
+            const int e0 = A.ent_first[w][b], ne = A.ent_first[w][b + 1] - e0;
+            const int s0 = A.stg_first[w][b], ns = A.stg_first[w][b + 1] - s0;   // stage starts: one more than stages
+            const int g0 = A.nfg_first[w][b], ng = A.nfg_first[w][b + 1] - g0;
+            nstages[w] = ns > 0 ? ns - 1 : 0;
+            const int* src = reinterpret_cast<const int*>(A.ent[w] + e0);       // 12-byte entries, 4-byte aligned
+            int* dst = reinterpret_cast<int*>(E[w]);
+            for (int q = tid; q < 3 * ne; q += nth) dst[q] = src[q];
+            for (int q = tid; q < ns; q += nth) ST[w][q] = A.stg[w][s0 + q];
+            for (int q = tid; q < ng; q += nth) {
+                // entry order = slot order within the box: (direction, side) travel with the entry; the face with the table
+                const long long fg = A.nfg[w][g0 + q];
+                const int a = (int)(fg & 3);
+                const long long face = fg >> 2;
+                const int bb = (a + 1) % 3, cc = (a + 2) % 3;
+                NJ[w][q][0] = A.jgf[a][bb][face];
+                NJ[w][q][1] = A.jgf[a][cc][face];
+                NJ[w][q][2] = A.jgf[a][a][face];
+            }
         }
         __syncthreads();
     }
@@ -229,43 +246,35 @@ __global__ __launch_bounds__(MAXT) void k_box_bicgstab(BoxBicg A)
         __syncthreads();
         const long long t1 = tick();
         tk[0] += t1 - t0;
-        const int wave = tid >> 6, lane = tid & 63, nwaves = nth >> 6;
-        const long long stg[3] = {1, (long long)p.pj, p.pk};
-        int q = 0;
-        while (q < nops[which]) {
-            const int e = q + 1 + (sops[which][q].pad_ >> 16);   // pad_ = stage | (ops of this stage that follow) << 16
-            for (int o = q + wave; o < e; o += nwaves) {
-                const GhostOp op = sops[which][o];
-                const int n0 = op.n[0], n01 = op.n[0] * op.n[1];
-                const int ncell = n01 * op.n[2];
-                double* dst = op.dstf ? Fe : Fp;
-                const double* sr = op.srcf ? Fe : Fp;
-                for (int idx = lane; idx < ncell; idx += 64) {
-                    const int k = idx / n01, r = idx - k * n01;
-                    const int j = r / n0, i = r - j * n0;
-                    const int l0 = op.lo[0] + i, l1 = op.lo[1] + j, l2 = op.lo[2] + k;
-                    const int f = (l0 + 1) + m0 * (l1 + 1) + m01 * (l2 + 1);
-                    if (op.type == GHOST_COPY) {
-                        dst[f] = sr[f];
-                    } else if (op.type == GHOST_EXTRAP) {
-                        const int d = -op.sgn * fs[op.dir];   // values come from 1, 2, 3 steps back along dir
-                        if (op.order == 0) dst[f] = sr[f + d];
-                        else if (op.order == 1) dst[f] = 2.0 * sr[f + d] - sr[f + 2 * d];
-                        else dst[f] = 3.0 * (sr[f + d] - sr[f + 2 * d]) + sr[f + 3 * d];
-                    } else {   // GHOST_NEUM (k_ghost_ops, full19.hip): the phi ghost that makes the boundary flux, cross terms included, zero
-                        const int a = op.dir, bb = (a + 1) % 3, cc = (a + 2) % 3;
-                        const int v = f - op.sgn * fs[a];
-                        const long long fg = cidx(p, l0, l1, l2) + ((op.sgn < 0) ? stg[a] : 0);   // the boundary face in the coefficient arrays
-                        const double idxb = -0.25 / P.dx[bb], idxc = -0.25 / P.dx[cc];
-                        const int bk = -op.sgn * fs[a];
-                        const double cross = (Fe[f + fs[bb]] - Fe[f - fs[bb]] + Fe[f + bk + fs[bb]] - Fe[f + bk - fs[bb]]) * A.jgf[a][bb][fg] * idxb +
-                                             (Fe[f + fs[cc]] - Fe[f - fs[cc]] + Fe[f + bk + fs[cc]] - Fe[f + bk - fs[cc]]) * A.jgf[a][cc][fg] * idxc;
-                        Fp[f] = Fp[v] + (0.0 - cross) * P.dx[a] / A.jgf[a][a][fg];
-                    }
+        // stage by stage: every entry of a stage is independent of the others -- one thread each, a workgroup barrier between
+        for (int sg = 0; sg < nstages[which]; ++sg) {
+            const int e1 = ST[which][sg + 1];
+            for (int q = ST[which][sg] + tid; q < e1; q += nth) {
+                const BoxProgEntry en = E[which][q];
+                double* dst = (en.flags & 1) ? Fe : Fp;
+                const double* sr = (en.flags & 2) ? Fe : Fp;
+                const int f = en.dst;
+                if (en.kind == 0) {
+                    dst[f] = sr[f];
+                } else if (en.kind == 1) {
+                    dst[f] = sr[en.s1];
+                } else if (en.kind == 2) {
+                    dst[f] = 2.0 * sr[en.s1] - sr[en.s2];
+                } else if (en.kind == 3) {
+                    dst[f] = 3.0 * (sr[en.s1] - sr[en.s2]) + sr[en.s3];
+                } else {   // the cross-term Neumann ghost (k_ghost_ops, full19.hip): the phi ghost that makes the boundary flux zero
+                    const int a = (en.flags >> 2) & 3, bb = (a + 1) % 3, cc = (a + 2) % 3;
+                    const int sgn = (en.flags & 16) ? 1 : -1;
+                    const int v = f - sgn * fs[a];
+                    const double idxb = -0.25 / P.dx[bb], idxc = -0.25 / P.dx[cc];
+                    const int bk = -sgn * fs[a];
+                    const double* nj = NJ[which][en.nslot];
+                    const double cross = (Fe[f + fs[bb]] - Fe[f - fs[bb]] + Fe[f + bk + fs[bb]] - Fe[f + bk - fs[bb]]) * nj[0] * idxb +
+                                         (Fe[f + fs[cc]] - Fe[f - fs[cc]] + Fe[f + bk + fs[cc]] - Fe[f + bk - fs[cc]]) * nj[1] * idxc;
+                    Fp[f] = Fp[v] + (0.0 - cross) * P.dx[a] / nj[2];
                 }
             }
             __syncthreads();
-            q = e;
         }
         tk[1] += tick() - t1;
         ++tk[5];

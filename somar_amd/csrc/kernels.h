@@ -135,7 +135,17 @@ void launch_tiny_bicgstab(hipStream_t st, const LevelDev& L, const CopyItem* ite
 // six cells its stencil reads (x-, x+, y-, y+, z-, z+): the neighbour itself, or -- across a box edge -- the valid cell the ghost
 // exchange would have copied from (built on the host from the level's exchange plan), so no ghost cell is ever filled.
 constexpr int BOX_MAX_WG = 128, BOX_MAX_CELLS = 2048;
-constexpr int BOX_FAB_MAX = 2048, BOX_MAX_OPS = 512;   // 19-point variant: cells of a box grown by one cell; ops of one of its ghost programs
+// 19-point variant: cells of a box grown by one cell; per box and ghost program the entries (one per written cell), stages and
+// cross-term Neumann ghost cells the kernel keeps in LDS
+constexpr int BOX_FAB_MAX = 2048, BOX_MAX_ENT = 2048, BOX_MAX_STAGES = 63, BOX_MAX_NEUM = 512;
+// One written cell of a ghost program, compiled on the host from the box's GhostOps (PressureSolver::build_box_tables): indices
+// into the LDS copy of the box grown by one cell.  kind 0: dst := src (the other field); 1 / 2 / 3: extrapolation of order
+// 0 / 1 / 2 from s1, s2, s3; 4: the cross-term Neumann ghost (flags: direction and side; nslot: its coefficient triple).
+struct alignas(4) BoxProgEntry {
+    unsigned short dst, s1, s2, s3;
+    unsigned char kind, flags;   // flags: bit 0 dst field (1 = psi), bit 1 src field, bits 2-3 direction, bit 4 high side
+    unsigned short nslot;
+};
 struct BoxBicg {
     const PatchDesc* patches; int npatches;
     const int* nb; const int* cstart;
@@ -149,12 +159,16 @@ struct BoxBicg {
     unsigned* sync;      // BOX_MAX_WG + 1: per workgroup the number of the last barrier it reached; abort flag (a barrier gave up); zeroed per launch
     // 19-point variant (non-diagonal metric, 3-D, boxes of at most 256 cells): all J g^{ab}; for every cell of box b grown by one
     // cell (x fastest, box b starts at fab_start[b]) the field offset its value comes from -- the cell itself, the valid cell
-    // the ghost exchange copies there, or -1 (a ghost beyond a wall: the program fills it); the box-sorted ghost programs
-    // [0] operator, [1] smoother (GhostOp::pad_ = stage; box b owns ops[w][ops_first[w][b] .. ops_first[w][b + 1]))
+    // the ghost exchange copies there, or -1 (a ghost beyond a wall: the program fills it); the ghost programs [0] operator,
+    // [1] smoother compiled into per-cell entries: box b owns ent[w][ent_first[w][b] .. ent_first[w][b + 1]), sorted by stage;
+    // stg[w][stg_first[w][b] ..]: where each of its stages starts (relative to the box's first entry; one more than stages);
+    // nfg[w][nfg_first[w][b] ..]: the boundary face (field offset) of each of its cross-term Neumann ghost cells
     int full;
     const double* jgf[3][3];
     const int* fab_src; const int* fab_start;
-    const GhostOp* ops[2]; const int* ops_first[2];
+    const BoxProgEntry* ent[2]; const int* ent_first[2];
+    const int* stg[2]; const int* stg_first[2];
+    const int* nfg[2]; const int* nfg_first[2];
     long long* dbg;      // optional (SOMAR_BOX_TIMING=1): workgroup 0's clock ticks in {staging loads, ghost program, stencil, barrier, sums, count}
     int serial;          // sums in the reference's serial order (levels of at most ordered_max cells) or by a fixed tree per box
     double* info;        // device: iterations, exit code

@@ -73,6 +73,7 @@ PressureSolver::~PressureSolver()
     hipFree(f_phi); hipFree(f_rhs); hipFree(f_uberRes); hipFree(f_uberCorr); hipFree(f_best);
     for (double* f : bicg) hipFree(f);
     hipFree(d_box_nb_); hipFree(d_box_cstart_); hipFree(d_box_sums_); hipFree(d_box_sync_); hipFree(d_box_fab_); hipFree(d_box_fabstart_);
+    for (int w = 0; w < 2; ++w) { hipFree(d_box_ent_[w]); hipFree(d_box_entfirst_[w]); hipFree(d_box_stg_[w]); hipFree(d_box_stgfirst_[w]); hipFree(d_box_nfg_[w]); hipFree(d_box_nfgfirst_[w]); }
     hipFree(d_partials);
     hipFree(d_scalars);
     for (Prof& p : prof_) {
@@ -1668,11 +1669,7 @@ bool PressureSolver::box_bottom(int d) const
             if ((long long)p.n[0] * p.n[1] * p.n[2] > 256 || p.n[0] < 2 || p.n[1] < 2 || p.n[2] < 2) return false;
             if ((long long)(p.n[0] + 2) * (p.n[1] + 2) * (p.n[2] + 2) > BOX_FAB_MAX) return false;
         }
-        for (int w = 0; w < 2; ++w) {
-            const FullProgram& Pg = full_prog_[d][w];
-            if (!Pg.d_box_ops && !Pg.first.empty()) return false;
-            if (Pg.max_box_ops > BOX_MAX_OPS) return false;
-        }
+        if (box_depth_ == d && !box_full_ok_) return false;   // (tables built: a program did not fit the kernel's LDS arrays)
     }
     return true;
 }
@@ -1736,6 +1733,76 @@ void PressureSolver::build_box_tables(int d)
         SOMAR_HIP(hipMalloc(&d_box_fabstart_, fstart.size() * sizeof(int)));
         SOMAR_HIP(hipMemcpy(d_box_fab_, fab.data(), fab.size() * sizeof(int), hipMemcpyHostToDevice));
         SOMAR_HIP(hipMemcpy(d_box_fabstart_, fstart.data(), fstart.size() * sizeof(int), hipMemcpyHostToDevice));
+        // the two ghost programs ([0] operator, [1] smoother), one entry per written cell, stage after stage: what the kernel
+        // runs on its LDS copy with one thread per entry (decoding ops and their regions there cost 20 us per program)
+        box_full_ok_ = true;
+        for (int w = 0; w < 2; ++w) {
+            const FullProgram& Pg = full_prog_[d][w];
+            std::vector<BoxProgEntry> ent;
+            std::vector<int> efirst(L.hpatches.size() + 1, 0), stg, sfirst(L.hpatches.size() + 1, 0), nfg, nfirst(L.hpatches.size() + 1, 0);
+            for (size_t b = 0; b < L.hpatches.size(); ++b) {
+                const PatchDesc& p = L.hpatches[b];
+                const int m0 = p.n[0] + 2, m01 = m0 * (p.n[1] + 2);
+                const int fs[3] = {1, m0, m01};
+                const long long gst[3] = {1, (long long)p.pj, p.pk};
+                efirst[b] = (int)ent.size();
+                sfirst[b] = (int)stg.size();
+                nfirst[b] = (int)nfg.size();
+                int cur = -1;
+                const int o0 = Pg.h_box_first.empty() ? 0 : Pg.h_box_first[b], o1 = Pg.h_box_first.empty() ? 0 : Pg.h_box_first[b + 1];
+                for (int o = o0; o < o1; ++o) {
+                    const GhostOp& op = Pg.h_box_ops[o];
+                    const int stage = op.pad_ & 0xffff;
+                    if (stage != cur) { stg.push_back((int)ent.size() - efirst[b]); cur = stage; }
+                    SOMAR_CHECK(op.type != GHOST_DIRI, "k_box_bicgstab: Dirichlet ghosts are not compiled (levels with Dirichlet sides take the launch path)");
+                    for (int k = 0; k < op.n[2]; ++k)
+                        for (int j = 0; j < op.n[1]; ++j)
+                            for (int i = 0; i < op.n[0]; ++i) {
+                                const int l0 = op.lo[0] + i, l1 = op.lo[1] + j, l2 = op.lo[2] + k;
+                                const int f = (l0 + 1) + m0 * (l1 + 1) + m01 * (l2 + 1);
+                                BoxProgEntry en;
+                                std::memset(&en, 0, sizeof(en));
+                                en.dst = (unsigned short)f;
+                                en.flags = (unsigned char)((op.dstf ? 1 : 0) | (op.srcf ? 2 : 0));
+                                if (op.type == GHOST_COPY) {
+                                    en.kind = 0;
+                                } else if (op.type == GHOST_EXTRAP) {
+                                    const int dd = -op.sgn * fs[op.dir];
+                                    en.kind = (unsigned char)(1 + op.order);
+                                    en.s1 = (unsigned short)(f + dd);
+                                    en.s2 = (unsigned short)(f + 2 * dd);
+                                    en.s3 = (unsigned short)(f + 3 * dd);
+                                } else {   // GHOST_NEUM: writes phi, reads psi around the face and the first valid cell of phi
+                                    en.kind = 4;
+                                    en.flags = (unsigned char)((op.dir << 2) | (op.sgn > 0 ? 16 : 0));
+                                    en.nslot = (unsigned short)((int)nfg.size() - nfirst[b]);
+                                    const long long face = at(p, l0, l1, l2) + (op.sgn < 0 ? gst[op.dir] : 0);
+                                    nfg.push_back((int)((face << 2) | op.dir));
+                                }
+                                ent.push_back(en);
+                            }
+                }
+                stg.push_back((int)ent.size() - efirst[b]);
+                if ((int)ent.size() - efirst[b] > BOX_MAX_ENT || (int)stg.size() - sfirst[b] > BOX_MAX_STAGES + 1 ||
+                    (int)nfg.size() - nfirst[b] > BOX_MAX_NEUM || L.field_elems >= (1ll << 28))
+                    box_full_ok_ = false;
+            }
+            efirst[L.hpatches.size()] = (int)ent.size();
+            sfirst[L.hpatches.size()] = (int)stg.size();
+            nfirst[L.hpatches.size()] = (int)nfg.size();
+            auto up = [](auto*& dptr, const auto& v) {
+                using T = typename std::remove_reference<decltype(v)>::type::value_type;
+                const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+                SOMAR_HIP(hipMalloc(&dptr, bytes));
+                if (!v.empty()) SOMAR_HIP(hipMemcpy(dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+            };
+            up(d_box_ent_[w], ent);
+            up(d_box_entfirst_[w], efirst);
+            up(d_box_stg_[w], stg);
+            up(d_box_stgfirst_[w], sfirst);
+            up(d_box_nfg_[w], nfg);
+            up(d_box_nfgfirst_[w], nfirst);
+        }
     }
     SOMAR_HIP(hipMemcpy(d_box_nb_, nb.data(), nb.size() * sizeof(int), hipMemcpyHostToDevice));
     SOMAR_HIP(hipMemcpy(d_box_cstart_, cstart.data(), cstart.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1747,8 +1814,8 @@ void PressureSolver::bottom_solve(double* phi, const double* rhs)
     ++counters[3];
     const int d = (int)lev.size() - 1;
     const long long n = lev[d]->field_elems;
+    if (!fused_bottom(d) && box_bottom(d)) build_box_tables(d);   // (the 19-point tables may turn out not to fit: asked again below)
     if (!fused_bottom(d) && box_bottom(d)) {
-        build_box_tables(d);
         Level& L = *lev[d];
         BoxBicg A;
         std::memset(&A, 0, sizeof(A));
@@ -1776,7 +1843,11 @@ void PressureSolver::bottom_solve(double* phi, const double* rhs)
         if (full_) {
             A.fab_src = d_box_fab_;
             A.fab_start = d_box_fabstart_;
-            for (int w = 0; w < 2; ++w) { A.ops[w] = full_prog_[d][w].d_box_ops; A.ops_first[w] = full_prog_[d][w].d_box_first; }
+            for (int w = 0; w < 2; ++w) {
+                A.ent[w] = d_box_ent_[w]; A.ent_first[w] = d_box_entfirst_[w];
+                A.stg[w] = d_box_stg_[w]; A.stg_first[w] = d_box_stgfirst_[w];
+                A.nfg[w] = d_box_nfg_[w]; A.nfg_first[w] = d_box_nfgfirst_[w];
+            }
         }
         A.info = d_scalars + SLOT_TMP;
         A.pub = ScalarPublish{h_scalars + SLOT_TMP, h_seq_, ++fetch_seq_};

@@ -252,6 +252,11 @@ private:
     long long box_min_cells_ = 513;      // smaller single-workgroup bottoms stay with k_tiny_bicgstab
     int box_depth_ = -1, box_max_cells_ = 0;
     int *d_box_nb_ = nullptr, *d_box_cstart_ = nullptr, *d_box_fab_ = nullptr, *d_box_fabstart_ = nullptr;
+    // 19-point variant: the two ghost programs compiled into per-cell entries (kernels.h: BoxProgEntry), per box
+    BoxProgEntry* d_box_ent_[2] = {nullptr, nullptr};
+    int *d_box_entfirst_[2] = {nullptr, nullptr}, *d_box_stg_[2] = {nullptr, nullptr}, *d_box_stgfirst_[2] = {nullptr, nullptr};
+    int *d_box_nfg_[2] = {nullptr, nullptr}, *d_box_nfgfirst_[2] = {nullptr, nullptr};
+    bool box_full_ok_ = false;   // the compiled programs fit the kernel's LDS tables
     double* d_box_sums_ = nullptr;
     unsigned* d_box_sync_ = nullptr;
     long long fused_min_cells_ = 262144;
@@ -291,7 +296,8 @@ private:
     // ---- non-diagonal metric (19-point) path, solver_full.cpp ----
     // d_ops: the ops stage by stage (first / count per stage) for the staged form, one launch per stage; d_box_ops / d_box_first:
     // the same ops sorted by box, then stage (GhostOp::pad_), for the one-launch form (k_ghost_program, small levels)
-    struct FullProgram { GhostOp* d_ops = nullptr; std::vector<int> first, count; GhostOp* d_box_ops = nullptr; int* d_box_first = nullptr; int max_box_ops = 0; };
+    struct FullProgram { GhostOp* d_ops = nullptr; std::vector<int> first, count; GhostOp* d_box_ops = nullptr; int* d_box_first = nullptr; int max_box_ops = 0;
+                         std::vector<GhostOp> h_box_ops; std::vector<int> h_box_first; };   // host copy of the box-sorted list (k_box_bicgstab's tables)
     void upload_program(FullProgram& P, const std::vector<std::vector<GhostOp>>& stages, int npatches);
     static void free_program(FullProgram& P);
     // small levels run a ghost program as ONE launch, one workgroup per box (SOMAR_GHOST_STAGED=1: always stage by stage)

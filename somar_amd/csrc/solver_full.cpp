@@ -303,6 +303,8 @@ void PressureSolver::upload_program(FullProgram& P, const std::vector<std::vecto
     std::vector<GhostOp> flat;
     P.first.clear();
     P.count.clear();
+    P.h_box_ops.clear();
+    P.h_box_first.assign(npatches + 1, 0);
     std::vector<std::vector<GhostOp>> byBox(npatches);
     for (size_t s = 0; s < stages.size(); ++s) {
         P.first.push_back((int)flat.size());
@@ -338,6 +340,8 @@ void PressureSolver::upload_program(FullProgram& P, const std::vector<std::vecto
     SOMAR_HIP(hipMemcpy(P.d_ops, flat.data(), flat.size() * sizeof(GhostOp), hipMemcpyHostToDevice));
     SOMAR_HIP(hipMalloc(&P.d_box_ops, sorted.size() * sizeof(GhostOp)));
     SOMAR_HIP(hipMemcpy(P.d_box_ops, sorted.data(), sorted.size() * sizeof(GhostOp), hipMemcpyHostToDevice));
+    P.h_box_ops = sorted;
+    P.h_box_first = first;
     SOMAR_HIP(hipMalloc(&P.d_box_first, first.size() * sizeof(int)));
     SOMAR_HIP(hipMemcpy(P.d_box_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
 }
