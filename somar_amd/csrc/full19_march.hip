@@ -28,7 +28,6 @@
 
 namespace somar {
 
-constexpr int FM_I = 128;  // region width (64 lanes x double2) = 124-cell tile + 2 low + 2 high
 // region rows FM_J = tile rows + 1 low + 1 high, a template parameter: 8 (6-row tile, 512 threads, 64 KB LDS; at 160 VGPRs
 // a SIMD holds 3 waves, so ONE such workgroup fits a CU: 8 waves per CU) or 6 (4-row tile, 384 threads, 48 KB LDS: TWO
 // workgroups per CU = 12 waves, the occupancy limit, for 1.5 instead of 1.33 times the phi / psi halo traffic -- 1.4 B/cell
@@ -56,22 +55,28 @@ __device__ __forceinline__ double fm_pick(const double2& v, int s) { return s ? 
 // ZXY: J g^{xy} on x-faces and J g^{yx} on y-faces are identically zero (StencilParams::zero_xy): those two planes are not
 // streamed -- three of the pass's thirteen coefficient loads per plane -- and zeros stand in for them; the products are the
 // zeros the stored planes would give (up to the sign of zero).
-template <int MODE, int FM_J, bool ZXY = false>
-__global__ __launch_bounds__(64 * FM_J) void k_full_march(const Tile* __restrict__ tiles,
-                                                          const PatchDesc* __restrict__ patches,
-                                                          double* __restrict__ out, const double* __restrict__ phi,
-                                                          const double* __restrict__ psi,
-                                                          const double* __restrict__ rhs, JgFullM J,
-                                                          const double* __restrict__ jinv, StencilParams P, int color)
+// CLS: the tile's lane class (Tile::pad_[1], Level::define): a wavefront covers 2^CLS region rows of 128 >> CLS columns each.
+// CLS 0 = one 128-column row per wavefront (124 output columns); CLS 1 = two 64-column rows (60 output columns: a 64-wide
+// box is one such tile + a 4-wide one instead of a tile that leaves 30 of 64 lanes idle); CLS 4 = sixteen 8-column rows (the
+// 4-column remainder of a box, 128 -> 124 + 4).  Region rows of a wavefront have the same parity (row = 2^(CLS+1) (y / 2) +
+// (y & 1) + 2 sub), which the 7-point fused sweep needs and the others share.  Same arithmetic on the same values: same bits.
+template <int MODE, int FM_J, bool ZXY, int CLS>
+__device__ __forceinline__ void full_march_body(double* __restrict__ SP, double* __restrict__ SE, const Tile& t,
+                                                const PatchDesc& p, double* __restrict__ out,
+                                                const double* __restrict__ phi, const double* __restrict__ psi,
+                                                const double* __restrict__ rhs, const JgFullM& J,
+                                                const double* __restrict__ jinv, const StencilParams& P, int color)
 {
-    __shared__ __attribute__((aligned(16))) double SP[FM_S][FM_J][FM_I];  // phi
-    __shared__ __attribute__((aligned(16))) double SE[FM_S][FM_J][FM_I];  // E: phi inside the box, psi in its frame
-    const Tile t = tiles[blockIdx.x];
-    const PatchDesc p = patches[t.patch];
-    const int lane = threadIdx.x, row = threadIdx.y;
+    constexpr int LPR = 64 >> CLS;                 // lanes per region row
+    constexpr int NR = FM_J << CLS;                // region rows of the workgroup
+    constexpr int PITCH = 2 * LPR + (CLS >= 2 ? 2 : 0);   // LDS row pitch; narrow rows padded against bank conflicts
+#define SPx(slot, r, c) SP[((slot) * NR + (r)) * PITCH + (c)]
+#define SEx(slot, r, c) SE[((slot) * NR + (r)) * PITCH + (c)]
+    const int lane = threadIdx.x & (LPR - 1);
+    const int row = ((threadIdx.y >> 1) << (CLS + 1)) + (threadIdx.y & 1) + 2 * (threadIdx.x >> (6 - CLS));
     const int ri = 2 * lane;
     const int li = t.i0 - 2 + ri;  // even: rows are 16-byte aligned
-    const int wi = t.pad_[0] > 0 ? t.pad_[0] : FM_I - 4;
+    const int wi = t.pad_[0] > 0 ? t.pad_[0] : 2 * LPR - 4;
     const int lj = t.j0 - 1 + row;
     const int gj = p.lo[1] + lj;
 
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(64 * FM_J) void k_full_march(const Tile* __restrict
     const bool inj = (lj >= 0) && (lj < p.n[1]);
     const bool in0 = inj && (li >= 0) && (li < p.n[0]);          // inside the box (in i, j): E = phi there
     const bool in1 = inj && (li + 1 >= 0) && (li + 1 < p.n[0]);
-    const bool own_j = inj && (row >= 1) && (row <= FM_J - 2) && (lj < t.j0 + (FM_J - 2));
+    const bool own_j = inj && (row >= 1) && (row <= NR - 2) && (lj < t.j0 + (NR - 2));
     bool o[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -118,8 +123,8 @@ __global__ __launch_bounds__(64 * FM_J) void k_full_march(const Tile* __restrict
     };
     auto store_plane = [&](int kp, const double2& vp, const double2& ve) {
         const int slot = kp & (FM_S - 1);
-        *reinterpret_cast<double2*>(&SP[slot][row][ri]) = vp;
-        *reinterpret_cast<double2*>(&SE[slot][row][ri]) = ve;
+        *reinterpret_cast<double2*>(&SPx(slot, row, ri)) = vp;
+        *reinterpret_cast<double2*>(&SEx(slot, row, ri)) = ve;
     };
 
     int k = t.k0;
@@ -169,13 +174,13 @@ __global__ __launch_bounds__(64 * FM_J) void k_full_march(const Tile* __restrict
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int rc = ri + s;
-                const double pc = SP[sc][row][rc];
+                const double pc = SPx(sc, row, rc);
                 if (MODE == 2 && s != csel) { res[s] = pc; continue; }
                 if (!o[s]) continue;
                 const int gi = p.lo[0] + li + s;
                 // neighbours: Pn(di,dj,dk) = phi, En(di,dj,dk) = E
-#define Pn(di, dj, dk) SP[(dk) < 0 ? sm : ((dk) > 0 ? sp : sc)][row + (dj)][rc + (di)]
-#define En(di, dj, dk) SE[(dk) < 0 ? sm : ((dk) > 0 ? sp : sc)][row + (dj)][rc + (di)]
+#define Pn(di, dj, dk) SPx((dk) < 0 ? sm : ((dk) > 0 ? sp : sc), row + (dj), rc + (di))
+#define En(di, dj, dk) SEx((dk) < 0 ? sm : ((dk) > 0 ? sp : sc), row + (dj), rc + (di))
                 // coefficients on the low / high face of this cell
                 const double jx0l = s ? Jx0.y : Jx0.x, jx0h = s ? jx0n : Jx0.y;
                 const double jx1l = s ? Jx1.y : Jx1.x, jx1h = s ? jx1n : Jx1.y;
@@ -304,6 +309,27 @@ __global__ __launch_bounds__(64 * FM_J) void k_full_march(const Tile* __restrict
         Jz1c = Jz1p;
         Jz2c = Jz2p;
     }
+#undef SPx
+#undef SEx
+}
+
+template <int MODE, int FM_J, bool ZXY = false>
+__global__ __launch_bounds__(64 * FM_J) void k_full_march(const Tile* __restrict__ tiles,
+                                                          const PatchDesc* __restrict__ patches,
+                                                          double* __restrict__ out, const double* __restrict__ phi,
+                                                          const double* __restrict__ psi,
+                                                          const double* __restrict__ rhs, JgFullM J,
+                                                          const double* __restrict__ jinv, StencilParams P, int color)
+{
+    // one slot = the largest class's region: 16 FM_J rows of 8 + 2 columns
+    __shared__ __attribute__((aligned(16))) double SP[FM_S * FM_J * 160];  // phi
+    __shared__ __attribute__((aligned(16))) double SE[FM_S * FM_J * 160];  // E: phi inside the box, psi in its frame
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int cls = FM_J == 8 ? t.pad_[1] : 0;   // Level::define hands the 6-row kernels (SOMAR_FULL_ROWS=6) class-0 tiles only
+    if (cls == 0) full_march_body<MODE, FM_J, ZXY, 0>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color);
+    else if (cls == 1) full_march_body<MODE, FM_J, ZXY, 1>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color);
+    else full_march_body<MODE, FM_J, ZXY, 4>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color);
 }
 
 int full_march_rows()

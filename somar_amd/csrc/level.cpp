@@ -590,20 +590,43 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     // ---- tiles of the k-marching kernels: (FT_I x FT_J) columns, k split into chunks so that the launch
     // fills the 256 CUs evenly (one 1024-thread workgroup per CU at a time); `halo` = planes a chunk reads
     // beyond its own (fused red-black sweep: 3, marching residual: 2) ----------------------------------
-    auto march_tiles = [&](int FT_I, int FT_J, double halo, int slots = 256) {
+    // Tile columns and their lane class (Tile::pad_[1], see full19_march.hip): class 0 = 124 output columns, one region row
+    // per wavefront; class 1 = 60 columns, two rows per wavefront; class 4 = 4 columns, sixteen rows per wavefront.  A box
+    // is cut into 124-wide columns and its remainder into the narrow classes (128 -> 124 + 4, 64 -> 60 + 4, 512 -> 4 x 124 +
+    // 4 x 4), so that a remainder column costs a sixteenth (a half) of a workgroup-march instead of a whole one.
+    // `classes` off (SOMAR_NO_NARROW_TILES, the 6-/8-row A/B variants): columns of equal width, all class 0 (128 -> 2 x 64,
+    // 512 -> 5 x 104).  region_rows = blockDim.y of the kernel, hrows = region rows that are halo.
+    struct ColSpec { int i0, w, cls; };
+    static const bool narrow_on = getenv("SOMAR_NO_NARROW_TILES") == nullptr;   // A/B switch
+    auto march_tiles = [&](int FT_I, int region_rows, int hrows, double halo, int slots, bool classes) {
+        const int FT_J = region_rows - hrows;
+        classes = classes && narrow_on;
+        static const bool balanced = getenv("SOMAR_NO_BALANCED_TILES") == nullptr;  // A/B switch
+        auto columns = [&](int n0) {
+            std::vector<ColSpec> v;
+            if (!classes || (n0 & 1)) {
+                int w = FT_I;
+                if (balanced) {
+                    const int ncol = (n0 + FT_I - 1) / FT_I;
+                    w = (n0 + ncol - 1) / ncol;
+                    w += w & 1;
+                    w = std::min(w, FT_I);
+                }
+                for (int i0 = 0; i0 < n0; i0 += w) v.push_back({i0, w, 0});
+                return v;
+            }
+            int i0 = 0, rem = n0;
+            while (rem >= FT_I) { v.push_back({i0, FT_I, 0}); i0 += FT_I; rem -= FT_I; }
+            if (rem > 76) { v.push_back({i0, rem, 0}); rem = 0; }
+            if (rem > 16) { const int w = std::min(rem, 60); v.push_back({i0, w, 1}); i0 += w; rem -= w; }
+            while (rem > 0) { const int w = std::min(rem, 4); v.push_back({i0, w, 4}); i0 += w; rem -= w; }
+            return v;
+        };
+        auto rows_of = [&](int cls) { return (region_rows << cls) - hrows; };
         long long cols = 0;
         int maxn2 = 1;
-        // tile columns of equal (even) width per box: 128 cells -> 2 x 64, 512 -> 5 x 104 (104,104,104,104,96), never
-        // a nearly empty last column (a 4-wide remainder tile marches all planes for 3 % of the work)
-        auto tile_w = [&](int n0) {
-            const int ncol = (n0 + FT_I - 1) / FT_I;
-            int w = (n0 + ncol - 1) / ncol;
-            w += w & 1;
-            return std::min(w, FT_I);
-        };
-        static const bool balanced = getenv("SOMAR_NO_BALANCED_TILES") == nullptr;  // A/B switch
         for (const PatchDesc& p : hpatches) {
-            cols += (long long)((p.n[0] + FT_I - 1) / FT_I) * ((p.n[1] + FT_J - 1) / FT_J);
+            for (const ColSpec& c : columns(p.n[0])) cols += (p.n[1] + rows_of(c.cls) - 1) / rows_of(c.cls);
             maxn2 = std::max(maxn2, p.n[2]);
         }
         int best = 1;
@@ -620,17 +643,25 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
             const PatchDesc& p = hpatches[pi];
             int nk = (p.n[2] + best - 1) / best;
             nk += nk & 1;  // even chunks: a chunk never splits the two planes of a coarse cell (fused restriction)
-            const int wstep = balanced ? tile_w(p.n[0]) : FT_I;
-            for (int k0 = 0; k0 < p.n[2]; k0 += nk)
-                for (int j0 = 0; j0 < p.n[1]; j0 += FT_J)
-                    for (int i0 = 0; i0 < p.n[0]; i0 += wstep) {
-                        Tile t;
-                        std::memset(&t, 0, sizeof(t));
-                        t.patch = pi; t.i0 = i0; t.j0 = j0; t.k0 = k0;
-                        t.nk = std::min(nk, p.n[2] - k0);
-                        t.pad_[0] = wstep;
-                        fnat.push_back(t);
-                    }
+            const std::vector<ColSpec> cs = columns(p.n[0]);
+            auto add = [&](const ColSpec& c, int j0, int k0) {
+                Tile t;
+                std::memset(&t, 0, sizeof(t));
+                t.patch = pi; t.i0 = c.i0; t.j0 = j0; t.k0 = k0;
+                t.nk = std::min(nk, p.n[2] - k0);
+                t.pad_[0] = c.w;
+                t.pad_[1] = c.cls;
+                fnat.push_back(t);
+            };
+            for (int k0 = 0; k0 < p.n[2]; k0 += nk) {
+                if (!classes) {   // one class: rows outside, columns inside (the natural order; partial sums per tile keep it)
+                    for (int j0 = 0; j0 < p.n[1]; j0 += FT_J)
+                        for (const ColSpec& c : cs) add(c, j0, k0);
+                } else {
+                    for (const ColSpec& c : cs)
+                        for (int j0 = 0; j0 < p.n[1]; j0 += rows_of(c.cls)) add(c, j0, k0);
+                }
+            }
         }
         const int NF = (int)fnat.size();
         std::vector<Tile> perm(NF);
@@ -641,14 +672,14 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
         for (int b = 0; b < NF; ++b) perm[b] = fnat[start[b % NX] + b / NX];
         return perm;
     };
-    hftiles = march_tiles(124, fused_rows() - 4, 3.0);
+    hftiles = march_tiles(124, fused_rows(), 4, 3.0, 256, false);
     d_ftiles = to_device(hftiles);
     nftiles = (int)hftiles.size();
-    hrtiles = march_tiles(124, 14, 2.0);
+    hrtiles = march_tiles(124, 16, 2, 2.0, 256, false);
     for (size_t q = 0; q < hrtiles.size(); ++q) hrtiles[q].pad_[2] = (int)q;   // its slot in per-tile partial sums (k_resid_march<2>)
     d_rtiles = to_device(hrtiles);
     nrtiles = (int)hrtiles.size();
-    hqtiles = march_tiles(124, full_march_rows() - 2, 2.0, full_march_rows() == 6 ? 512 : 256);   // 6 rows: two workgroups per CU
+    hqtiles = march_tiles(124, full_march_rows(), 2, 2.0, full_march_rows() == 6 ? 512 : 256, full_march_rows() == 8);   // 6 rows: two workgroups per CU
     d_qtiles = to_device(hqtiles);
     nqtiles = (int)hqtiles.size();
 
@@ -695,10 +726,11 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
         // its columns and planes (the recomputed red ring) -- FRAME deep, as deep as the exchange fills; the operator one cell.
         std::vector<std::vector<const CopyItem*>> byDst(hpatches.size());
         for (const CopyItem& it : plan.recv_items) byDst[it.dst_patch].push_back(&it);
-        auto split = [&](const std::vector<Tile>& all, int rows, int halo, std::vector<Tile>& own, std::vector<Tile>& rem) {
+        auto split = [&](const std::vector<Tile>& all, int region_rows, int hrows, int halo, std::vector<Tile>& own, std::vector<Tile>& rem) {
             for (const Tile& t : all) {
                 const PatchDesc& p = hpatches[t.patch];
                 const int w = t.pad_[0] > 0 ? t.pad_[0] : 124;
+                const int rows = (region_rows << t.pad_[1]) - hrows;
                 const int lo[3] = {t.i0 - halo, t.j0 - halo, t.k0 - halo};
                 const int hi[3] = {std::min(t.i0 + w, p.n[0]) - 1 + halo, std::min(t.j0 + rows, p.n[1]) - 1 + halo, t.k0 + t.nk - 1 + halo};
                 bool hit = false;
@@ -712,14 +744,14 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
             }
         };
         std::vector<Tile> own, rem;
-        split(hftiles, fused_rows() - 4, FRAME, own, rem);
+        split(hftiles, fused_rows(), 4, FRAME, own, rem);
         nftiles_own = (int)own.size();
         nftiles_rem = (int)rem.size();
         d_ftiles_own = to_device(own);
         d_ftiles_rem = to_device(rem);
         own.clear();
         rem.clear();
-        split(hrtiles, 14, 1, own, rem);
+        split(hrtiles, 16, 2, 1, own, rem);
         nrtiles_own = (int)own.size();
         nrtiles_rem = (int)rem.size();
         d_rtiles_own = to_device(own);
