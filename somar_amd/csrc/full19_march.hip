@@ -72,8 +72,10 @@ __device__ __forceinline__ void full_march_body(double* __restrict__ SP, double*
     constexpr int PITCH = 2 * LPR + (CLS >= 2 ? 2 : 0);   // LDS row pitch; narrow rows padded against bank conflicts
 #define SPx(slot, r, c) SP[((slot) * NR + (r)) * PITCH + (c)]
 #define SEx(slot, r, c) SE[((slot) * NR + (r)) * PITCH + (c)]
-    const int lane = threadIdx.x & (LPR - 1);
-    const int row = ((threadIdx.y >> 1) << (CLS + 1)) + (threadIdx.y & 1) + 2 * (threadIdx.x >> (6 - CLS));
+    // class 0: the region row is the wavefront's index, a scalar -- everything derived from it stays in scalar registers
+    const int lane = CLS == 0 ? (int)threadIdx.x : (int)(threadIdx.x & (LPR - 1));
+    const int row = CLS == 0 ? (int)threadIdx.y
+                             : (int)(((threadIdx.y >> 1) << (CLS + 1)) + (threadIdx.y & 1) + 2 * (threadIdx.x >> (6 - CLS)));
     const int ri = 2 * lane;
     const int li = t.i0 - 2 + ri;  // even: rows are 16-byte aligned
     const int wi = t.pad_[0] > 0 ? t.pad_[0] : 2 * LPR - 4;
@@ -314,7 +316,7 @@ __device__ __forceinline__ void full_march_body(double* __restrict__ SP, double*
 }
 
 template <int MODE, int FM_J, bool ZXY = false>
-__global__ __launch_bounds__(64 * FM_J) void k_full_march(const Tile* __restrict__ tiles,
+__global__ __launch_bounds__(64 * FM_J, 3) void k_full_march(const Tile* __restrict__ tiles,
                                                           const PatchDesc* __restrict__ patches,
                                                           double* __restrict__ out, const double* __restrict__ phi,
                                                           const double* __restrict__ psi,

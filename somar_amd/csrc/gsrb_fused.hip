@@ -33,7 +33,6 @@
 
 namespace somar {
 
-constexpr int FR_I = 128;  // region width  (64 lanes x double2) = tile + 4
 
 __device__ __forceinline__ double pick(const double2& v, int s) { return s ? v.y : v.x; }
 
@@ -131,8 +130,10 @@ __device__ __forceinline__ double gsrb_point(const StencilParams& P, double xxS,
 // in x and y -- over 90 % of the tiles of a large level -- so everything that classifies a cell against those per lane
 // is compiled out (gsrb_point<.., INT>, the ring's existence tests, the coarse-fine ghosts of x and y).  Same arithmetic on
 // the same values: same bits.
-template <int FR_J, int INMODE, bool DIRI, bool UNI, bool INT>
-__device__ __forceinline__ void gsrb_fused_body(double (&S)[3][FR_J][FR_I], const Tile& t, const PatchDesc& p,
+// CLS: the tile's lane class (see full19_march.hip): a wavefront covers 2^CLS region rows of 128 >> CLS columns, all of the
+// same parity, so the colour column c stays wave-uniform.
+template <int FR_J, int INMODE, bool DIRI, bool UNI, bool INT, int CLS>
+__device__ __forceinline__ void gsrb_fused_body(double* __restrict__ S, const Tile& t, const PatchDesc& p,
                                                 double* __restrict__ phi_out,
                                                 const double* __restrict__ phi_in,
                                                 const double* __restrict__ rhs,
@@ -145,12 +146,18 @@ __device__ __forceinline__ void gsrb_fused_body(double (&S)[3][FR_J][FR_I], cons
                                                 const double* __restrict__ crse, int r0, int r1, int r2)
 {
     const double avg = (INMODE == 2 || INMODE == 4) ? sums[0] / sums[1] : 0.0;
-    const int lane = threadIdx.x, row = threadIdx.y;
+    constexpr int LPR = 64 >> CLS;                 // lanes per region row
+    constexpr int NR = FR_J << CLS;                // region rows of the workgroup
+    constexpr int PITCH = 2 * LPR + (CLS >= 2 ? 2 : 0);
+#define Sx(slot, r, c) S[((slot) * NR + (r)) * PITCH + (c)]
+    // class 0: the region row is the wavefront's index, a scalar -- everything derived from it stays in scalar registers
+    const int lane = CLS == 0 ? (int)threadIdx.x : (int)(threadIdx.x & (LPR - 1));
+    const int row = CLS == 0 ? (int)threadIdx.y
+                             : (int)(((threadIdx.y >> 1) << (CLS + 1)) + (threadIdx.y & 1) + 2 * (threadIdx.x >> (6 - CLS)));
     const int ri = 2 * lane;       // region column of the pair's first cell
     const int li = t.i0 - 2 + ri;  // local i of the pair's first cell (even: rows are 16-byte aligned)
-    // output columns of this tile (even, <= FR_I - 4): boxes are split into EQUAL tile columns (a 128-wide box into
-    // 2 x 64, not 124 + 4), so the region beyond wi + 4 columns is neither loaded nor computed
-    const int wi = t.pad_[0] > 0 ? t.pad_[0] : FR_I - 4;
+    // output columns of this tile (even, <= region width - 4); the region beyond wi + 4 columns is neither loaded nor computed
+    const int wi = t.pad_[0] > 0 ? t.pad_[0] : 2 * LPR - 4;
     const int lj = t.j0 - 2 + row;
     // INMODE 3/4: where this pair's coarse parents live (floor division: ghosts map to coarse ghosts)
     long long cbase = 0, cpk = 0, coff = 0;
@@ -193,7 +200,7 @@ __device__ __forceinline__ void gsrb_fused_body(double (&S)[3][FR_J][FR_I], cons
     const bool f0 = fj && (li >= -FRAME) && (li < p.n[0] + FRAME) && (ri < wi + 4);
     const bool f1 = fj && (li + 1 >= -FRAME) && (li + 1 < p.n[0] + FRAME) && (ri + 1 < wi + 4);
     // the outermost region rows only supply phi to the red ring: they need no coefficients
-    const bool cf = (row >= 1) && (row <= FR_J - 2);
+    const bool cf = (row >= 1) && (row <= NR - 2);
     const bool c0 = f0 && cf, c1 = f1 && cf;
     // red is computed on the tile grown by one cell, restricted to cells that exist: a cell beyond a
     // non-periodic (Neumann) domain face does not; a periodic image or a neighbour box's cell does
@@ -203,7 +210,7 @@ __device__ __forceinline__ void gsrb_fused_body(double (&S)[3][FR_J][FR_I], cons
     for (int s = 0; s < 2; ++s) {
         const int l = li + s, g = p.lo[0] + l, r = ri + s;
         bool cmp = (l >= -1) && (l <= p.n[0]) && (r >= 1) && (r <= wi + 2) && (lj >= -1) && (lj <= p.n[1]) &&
-                   (row >= 1) && (row <= FR_J - 2);
+                   (row >= 1) && (row <= NR - 2);
         if (!INT) {
             if ((g < P.dom_lo[0] && (P.neum[0][0] || (DIRI && P.diri[0][0]))) ||
                 (g > P.dom_hi[0] && (P.neum[0][1] || (DIRI && P.diri[0][1]))))
@@ -218,7 +225,7 @@ __device__ __forceinline__ void gsrb_fused_body(double (&S)[3][FR_J][FR_I], cons
         }
         comp_ij[s] = cmp;
         out_ij[s] = (l >= 0) && (l < p.n[0]) && (lj >= 0) && (lj < p.n[1]) && (r >= 2) && (r < wi + 2) &&
-                    (row >= 2) && (row < FR_J - 2);
+                    (row >= 2) && (row < NR - 2);
     }
     const long long sj = p.pj, sk = p.pk;
     const long long base = p.off + li + sj * lj;
@@ -279,7 +286,7 @@ __device__ __forceinline__ void gsrb_fused_body(double (&S)[3][FR_J][FR_I], cons
         //   slot k%3 was last read two steps ago (black of plane k-3); every wave has passed the
         //   previous barrier since, so overwriting it is safe.
         const int slot = ((k % 3) + 3) % 3;
-        *reinterpret_cast<double2*>(&S[slot][row][ri]) = Pc;
+        *reinterpret_cast<double2*>(&Sx(slot, row, ri)) = Pc;
         __syncthreads();
 
         // ---- red(k) at column c: reads only black cells of the plane, writes only red ones ---------
@@ -293,12 +300,12 @@ __device__ __forceinline__ void gsrb_fused_body(double (&S)[3][FR_J][FR_I], cons
                 comp = false;
             if ((k < 0 && (p.cf & 16)) || (k >= p.n[2] && (p.cf & 32))) comp = false;
             if (comp) {
-                const double pxl = S[slot][row][rc - 1], pxh = S[slot][row][rc + 1];
-                const double pyl = S[slot][row - 1][rc], pyh = S[slot][row + 1][rc];
+                const double pxl = Sx(slot, row, rc - 1), pxh = Sx(slot, row, rc + 1);
+                const double pyl = Sx(slot, row - 1, rc), pyh = Sx(slot, row + 1, rc);
                 red = gsrb_point<DIRI, INT>(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, gk, pxl, pxh, pyl, pyh, pick(Pm, c),
                                  pick(Pp, c), c ? Gx.y : Gx.x, c ? gx_next : Gx.y, pick(Gy, c), pick(Gyh, c),
                                  pick(Gzc, c), pick(Gzp, c), pick(Ji, c), pick(Rh, c), red);
-                S[slot][row][rc] = red;  // visible to the black phase of the NEXT step (after its barrier)
+                Sx(slot, row, rc) = red;  // visible to the black phase of the NEXT step (after its barrier)
             }
         }
 
@@ -310,14 +317,14 @@ __device__ __forceinline__ void gsrb_fused_body(double (&S)[3][FR_J][FR_I], cons
                 const int sb = ((kb % 3) + 3) % 3;
                 double black = 0.0;
                 if (out_ij[c]) {
-                    double pxl = S[sb][row][rc - 1], pxh = S[sb][row][rc + 1];
-                    double pyl = S[sb][row - 1][rc], pyh = S[sb][row + 1][rc];
+                    double pxl = Sx(sb, row, rc - 1), pxh = Sx(sb, row, rc + 1);
+                    double pyl = Sx(sb, row - 1, rc), pyh = Sx(sb, row + 1, rc);
                     double pzl = redPrev2, pzh = red;
                     if (INT ? (p.cf & 48) != 0 : p.cf != 0) {
                         // homogeneousCFInterp between the colours (LevelGSRB refills the CF ghosts before the
                         // black pass): ghost = c1 * first valid cell (this black cell, old value) + c2 * second
                         // valid cell (its opposite neighbour, a NEW red value)
-                        const double own = S[sb][row][rc];
+                        const double own = Sx(sb, row, rc);
                         const int l = li + c;
                         const double xl = pxl, xh = pxh, yl = pyl, yh = pyh, zl = pzl, zh = pzh;
                         if (!INT) {
@@ -331,7 +338,7 @@ __device__ __forceinline__ void gsrb_fused_body(double (&S)[3][FR_J][FR_I], cons
                     }
                     black = gsrb_point<DIRI, INT>(P, xxS, yyS, zzS, p.lo[0] + li + c, gj, p.lo[2] + kb, pxl, pxh, pyl, pyh,
                                        pzl, pzh, b_gxl, b_gxh, b_gyl, b_gyh, b_gzl, pick(Gzc, c), b_ji, b_rhs,
-                                       S[sb][row][rc]);
+                                       Sx(sb, row, rc));
                 }
                 // plane k-1: column c is the new black, column c^1 is red(k-1) (= redPrev1)
                 double* dst = phi_out + base + sk * kb;
@@ -379,9 +386,12 @@ __device__ __forceinline__ void gsrb_fused_body(double (&S)[3][FR_J][FR_I], cons
             ++k;
         }
     }
+#undef Sx
 }
 
-template <int FR_J, int INMODE, bool DIRI = false, bool UNI = false>
+// NARROW: the tile table holds narrow lane classes (uniform-metric depths, or SOMAR_NARROW_7PT=1); the instantiation without
+// them is the one-body kernel with 48 KB of LDS that the HBM-bound streaming sweep was tuned as.
+template <int FR_J, int INMODE, bool DIRI = false, bool UNI = false, bool NARROW = false>
 __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict__ tiles,
                                                      const PatchDesc* __restrict__ patches,
                                                      double* __restrict__ phi_out,
@@ -395,25 +405,34 @@ __global__ __launch_bounds__(64 * FR_J) void k_gsrb_fused(const Tile* __restrict
                                                      const PatchDesc* __restrict__ cpatches,
                                                      const double* __restrict__ crse, int r0, int r1, int r2, int lean_ok)
 {
-    __shared__ __attribute__((aligned(16))) double S[3][FR_J][FR_I];
+    // one slot = the largest class's region: FR_J rows of 128, or 16 FR_J rows of 8 + 2
+    __shared__ __attribute__((aligned(16))) double S[3 * FR_J * (NARROW ? 160 : 128)];
     const Tile t = tiles[blockIdx.x];
     const PatchDesc p = patches[t.patch];
+    const int cls = NARROW ? t.pad_[1] : 0;
+    bool lean = false;
     if (UNI && !DIRI) {
         // does the tile grown by its red ring stay clear of every domain face (periodic seams included: the boundary form of
         // the update applies there too) and of every coarse-fine face, in x and y?  One scalar test per workgroup.
-        const int wi = t.pad_[0] > 0 ? t.pad_[0] : FR_I - 4;
-        const int ilo = t.i0 - 1, ihi = min(t.i0 + wi, p.n[0]), jlo = t.j0 - 1, jhi = min(t.j0 + FR_J - 4, p.n[1]);
-        const bool lean = lean_ok && p.lo[0] + ilo > P.dom_lo[0] && p.lo[0] + ihi < P.dom_hi[0] && p.lo[1] + jlo > P.dom_lo[1] &&
-                          p.lo[1] + jhi < P.dom_hi[1] && !((p.cf & 1) && ilo < 0) && !((p.cf & 2) && ihi >= p.n[0]) &&
-                          !((p.cf & 4) && jlo < 0) && !((p.cf & 8) && jhi >= p.n[1]);
-        if (lean) {
-            gsrb_fused_body<FR_J, INMODE, DIRI, UNI, UNI && !DIRI>(S, t, p, phi_out, phi_in, rhs, jgx, jgy, jgz, jinv, P, sums,
-                                                                  cpatches, crse, r0, r1, r2);
-            return;
-        }
+        const int wi = t.pad_[0] > 0 ? t.pad_[0] : 124;
+        const int ilo = t.i0 - 1, ihi = min(t.i0 + wi, p.n[0]), jlo = t.j0 - 1, jhi = min(t.j0 + (FR_J << cls) - 4, p.n[1]);
+        lean = lean_ok && p.lo[0] + ilo > P.dom_lo[0] && p.lo[0] + ihi < P.dom_hi[0] && p.lo[1] + jlo > P.dom_lo[1] &&
+               p.lo[1] + jhi < P.dom_hi[1] && !((p.cf & 1) && ilo < 0) && !((p.cf & 2) && ihi >= p.n[0]) &&
+               !((p.cf & 4) && jlo < 0) && !((p.cf & 8) && jhi >= p.n[1]);
     }
-    gsrb_fused_body<FR_J, INMODE, DIRI, UNI, false>(S, t, p, phi_out, phi_in, rhs, jgx, jgy, jgz, jinv, P, sums, cpatches, crse,
-                                                    r0, r1, r2);
+#define SOMAR_FUSED_BODY(INT_, CLS_)                                                                                          \
+    gsrb_fused_body<FR_J, INMODE, DIRI, UNI, INT_, CLS_>(S, t, p, phi_out, phi_in, rhs, jgx, jgy, jgz, jinv, P, sums, cpatches, \
+                                                        crse, r0, r1, r2)
+    if (!NARROW || cls == 0) {
+        if (lean) SOMAR_FUSED_BODY(UNI && !DIRI, 0);
+        else SOMAR_FUSED_BODY(false, 0);
+    } else if (cls == 1) {
+        if (lean) SOMAR_FUSED_BODY(UNI && !DIRI, NARROW ? 1 : 0);
+        else SOMAR_FUSED_BODY(false, NARROW ? 1 : 0);
+    } else {
+        SOMAR_FUSED_BODY(false, NARROW ? 4 : 0);   // remainder columns sit on a box edge: never clear of it
+    }
+#undef SOMAR_FUSED_BODY
 }
 
 void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* phi_out,
@@ -424,54 +443,43 @@ void launch_gsrb_fused(hipStream_t st, const Tile* tiles, int ntiles, const Leve
     const PatchDesc* cpatches = C ? C->patches : nullptr;
     const int r0 = r ? r[0] : 1, r1 = r ? r[1] : 1, r2 = r ? r[2] : 1;
     static const int lean_ok = getenv("SOMAR_NO_LEAN_TILES") == nullptr;   // A/B switch: interior tiles take the general path too
-#define SOMAR_LAUNCH_FUSED(ROWS, M)                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gsrb_fused<ROWS, M>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
-                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2, lean_ok)
-#define SOMAR_LAUNCH_FUSED_MODES(ROWS)                 \
-    switch (in_mode) {                                 \
-        case 1: SOMAR_LAUNCH_FUSED(ROWS, 1); break;    \
-        case 2: SOMAR_LAUNCH_FUSED(ROWS, 2); break;    \
-        case 3: SOMAR_LAUNCH_FUSED(ROWS, 3); break;    \
-        case 4: SOMAR_LAUNCH_FUSED(ROWS, 4); break;    \
-        default: SOMAR_LAUNCH_FUSED(ROWS, 0);          \
-    }
     SOMAR_CHECK(in_mode < 3 || ((r0 == 1 || r0 == 2) && (r1 == 1 || r1 == 2) && (r2 == 1 || r2 == 2)),
                 "internal: the prolongation folded into a sweep takes multigrid ratios of 1 or 2 per direction");
+    auto go = [&](auto kern, int rows) {
+        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(64, rows, 1), 0, st, tiles, L.patches, phi_out, phi_in, rhs, L.jg[0], L.jg[1],
+                           L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2, lean_ok);
+    };
+    // (rows, mode, Dirichlet sides, uniform metric, narrow lane classes in the tile table)
+#define SOMAR_FUSED_MODES(ROWS, D, U, N, M0, M1, M2, M3, M4)                    \
+    switch (in_mode) {                                                          \
+        case 1: go(k_gsrb_fused<ROWS, M1, D, U, N>, ROWS); break;               \
+        case 2: go(k_gsrb_fused<ROWS, M2, D, U, N>, ROWS); break;               \
+        case 3: go(k_gsrb_fused<ROWS, M3, D, U, N>, ROWS); break;               \
+        case 4: go(k_gsrb_fused<ROWS, M4, D, U, N>, ROWS); break;               \
+        default: go(k_gsrb_fused<ROWS, M0, D, U, N>, ROWS);                     \
+    }
+    const bool rows16 = fused_rows() == 16;
+    const bool narrow = L.narrow7 != 0 && rows16;   // Level::build_march_tiles hands the 8-row kernels class-0 tiles only
     bool diri = false;
     for (int d = 0; d < 3; ++d) diri = diri || L.P.diri[d][0] || L.P.diri[d][1];
     if (diri) {
-        // Dirichlet sides: no null space, hence never a mean removal (modes 2 / 4)
-#define SOMAR_LAUNCH_FUSED_D(ROWS, M)                                                                                       \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gsrb_fused<ROWS, M, true>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
-                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2, lean_ok)
+        // Dirichlet sides: no null space, hence never a mean removal (modes 2 / 4 fall back to 0 / 3 in the table below; checked)
         SOMAR_CHECK(in_mode == 0 || in_mode == 1 || in_mode == 3, "internal: mean removal on a level with Dirichlet sides");
-        if (fused_rows() == 8) {
-            if (in_mode == 1) SOMAR_LAUNCH_FUSED_D(8, 1); else if (in_mode == 3) SOMAR_LAUNCH_FUSED_D(8, 3); else SOMAR_LAUNCH_FUSED_D(8, 0);
-        } else {
-            if (in_mode == 1) SOMAR_LAUNCH_FUSED_D(16, 1); else if (in_mode == 3) SOMAR_LAUNCH_FUSED_D(16, 3); else SOMAR_LAUNCH_FUSED_D(16, 0);
-        }
-#undef SOMAR_LAUNCH_FUSED_D
+        if (!rows16) { SOMAR_FUSED_MODES(8, true, false, false, 0, 1, 0, 3, 3) }
+        else if (narrow) { SOMAR_FUSED_MODES(16, true, false, true, 0, 1, 0, 3, 3) }
+        else { SOMAR_FUSED_MODES(16, true, false, false, 0, 1, 0, 3, 3) }
         return;
     }
-    if (L.P.uniform && fused_rows() == 16) {
+    if (L.P.uniform && rows16) {
         // uniform metric: the four coefficient streams come from StencilParams
-#define SOMAR_LAUNCH_FUSED_U(M)                                                                                                 \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gsrb_fused<16, M, false, true>), dim3(ntiles), dim3(64, 16, 1), 0, st, tiles, L.patches, \
-                       phi_out, phi_in, rhs, L.jg[0], L.jg[1], L.jg[2], L.jinv, L.P, sums, cpatches, crse, r0, r1, r2, lean_ok)
-        switch (in_mode) {
-            case 1: SOMAR_LAUNCH_FUSED_U(1); break;
-            case 2: SOMAR_LAUNCH_FUSED_U(2); break;
-            case 3: SOMAR_LAUNCH_FUSED_U(3); break;
-            case 4: SOMAR_LAUNCH_FUSED_U(4); break;
-            default: SOMAR_LAUNCH_FUSED_U(0);
-        }
-#undef SOMAR_LAUNCH_FUSED_U
+        if (narrow) { SOMAR_FUSED_MODES(16, false, true, true, 0, 1, 2, 3, 4) }
+        else { SOMAR_FUSED_MODES(16, false, true, false, 0, 1, 2, 3, 4) }
         return;
     }
-    if (fused_rows() == 8) { SOMAR_LAUNCH_FUSED_MODES(8) }
-    else { SOMAR_LAUNCH_FUSED_MODES(16) }
-#undef SOMAR_LAUNCH_FUSED_MODES
-#undef SOMAR_LAUNCH_FUSED
+    if (!rows16) { SOMAR_FUSED_MODES(8, false, false, false, 0, 1, 2, 3, 4) }
+    else if (narrow) { SOMAR_FUSED_MODES(16, false, false, true, 0, 1, 2, 3, 4) }
+    else { SOMAR_FUSED_MODES(16, false, false, false, 0, 1, 2, 3, 4) }
+#undef SOMAR_FUSED_MODES
 }
 
 // region rows per workgroup of the fused sweep (tile rows = rows - 4); SOMAR_FUSED_ROWS = 8 | 16

@@ -23,6 +23,7 @@ struct LevelDev {
     // non-diagonal metric: all components J g^{ab} on a-faces, jgf[a][b]; jgf[a][a] aliases jg[a]
     double* jgf[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     StencilParams P;
+    int narrow7 = 0;                    // the 7-point marching kernels' tile tables hold narrow lane classes (Level::build_march_tiles)
 };
 
 // operands of MAPPEDGETFLUX with a non-diagonal metric, evaluated where a flux register needs it (amr_kernels.hip: reg_flux19)

@@ -509,6 +509,157 @@ Level::~Level()
     hipFree(dev.lapdiag);
 }
 
+// Tile tables of the k-marching kernels (fused 7-point sweep, 7-point operator / residual, 19-point kernels) and, on a sharded
+// level, their split into tiles that read no remote ghost cell and the rest.  narrow7: the 7-point tables use the narrow lane
+// classes for remainder columns.  That pays where the kernels are latency-bound -- a uniform metric, two or three streams
+// (C4: 158 -> 112 ms per AMR V-cycle, c2_cartesian 134 -> 159 V-cycles/s) -- and costs where six streams are HBM-bound
+// (512^3 stretched: residual 1.52 -> 2.00 ms: 64-byte row segments of six arrays), so PressureSolver::finalize asks for it
+// on the depths whose metric it found uniform; the 19-point tables always use the classes.
+void Level::build_march_tiles(bool narrow7)
+{
+    for (Tile** q : {&d_ftiles, &d_ftiles_own, &d_ftiles_rem, &d_rtiles, &d_rtiles_own, &d_rtiles_rem, &d_qtiles}) {
+        hipFree(*q);
+        *q = nullptr;
+    }
+    nftiles_own = nftiles_rem = nrtiles_own = nrtiles_rem = 0;
+    narrow7_ = narrow7;
+    dev.narrow7 = narrow7 ? 1 : 0;
+    // ---- tiles of the k-marching kernels: (FT_I x FT_J) columns, k split into chunks so that the launch
+    // fills the 256 CUs evenly (one 1024-thread workgroup per CU at a time); `halo` = planes a chunk reads
+    // beyond its own (fused red-black sweep: 3, marching residual: 2) ----------------------------------
+    // Tile columns and their lane class (Tile::pad_[1], see full19_march.hip): class 0 = 124 output columns, one region row
+    // per wavefront; class 1 = 60 columns, two rows per wavefront; class 4 = 4 columns, sixteen rows per wavefront.  A box
+    // is cut into 124-wide columns and its remainder into the narrow classes (128 -> 124 + 4, 64 -> 60 + 4, 512 -> 4 x 124 +
+    // 4 x 4), so that a remainder column costs a sixteenth (a half) of a workgroup-march instead of a whole one.
+    // `classes` off (SOMAR_NO_NARROW_TILES, the 6-/8-row A/B variants): columns of equal width, all class 0 (128 -> 2 x 64,
+    // 512 -> 5 x 104).  region_rows = blockDim.y of the kernel, hrows = region rows that are halo.
+    struct ColSpec { int i0, w, cls; };
+    static const bool narrow_on = getenv("SOMAR_NO_NARROW_TILES") == nullptr;   // A/B switch
+    auto march_tiles = [&](int FT_I, int region_rows, int hrows, double halo, int slots, bool classes) {
+        const int FT_J = region_rows - hrows;
+        classes = classes && narrow_on;
+        static const bool balanced = getenv("SOMAR_NO_BALANCED_TILES") == nullptr;  // A/B switch
+        auto columns = [&](int n0) {
+            std::vector<ColSpec> v;
+            if (!classes || (n0 & 1)) {
+                int w = FT_I;
+                if (balanced) {
+                    const int ncol = (n0 + FT_I - 1) / FT_I;
+                    w = (n0 + ncol - 1) / ncol;
+                    w += w & 1;
+                    w = std::min(w, FT_I);
+                }
+                for (int i0 = 0; i0 < n0; i0 += w) v.push_back({i0, w, 0});
+                return v;
+            }
+            int i0 = 0, rem = n0;
+            while (rem >= FT_I) { v.push_back({i0, FT_I, 0}); i0 += FT_I; rem -= FT_I; }
+            if (rem > 76) { v.push_back({i0, rem, 0}); rem = 0; }
+            if (rem > 16) { const int w = std::min(rem, 60); v.push_back({i0, w, 1}); i0 += w; rem -= w; }
+            while (rem > 0) { const int w = std::min(rem, 4); v.push_back({i0, w, 4}); i0 += w; rem -= w; }
+            return v;
+        };
+        auto rows_of = [&](int cls) { return (region_rows << cls) - hrows; };
+        long long cols = 0;
+        int maxn2 = 1;
+        for (const PatchDesc& p : hpatches) {
+            for (const ColSpec& c : columns(p.n[0])) cols += (p.n[1] + rows_of(c.cls) - 1) / rows_of(c.cls);
+            maxn2 = std::max(maxn2, p.n[2]);
+        }
+        int best = 1;
+        double best_eff = -1.0;
+        for (int nch = 1; nch <= 64 && (nch == 1 || maxn2 / nch >= 4); ++nch) {  // small levels: short chunks, more workgroups
+            const long long blocks = cols * nch;
+            const long long rounds = (blocks + slots - 1) / slots;
+            const double nk = (double)maxn2 / nch;
+            const double eff = (double)blocks / (double)(rounds * slots) * nk / (nk + halo);
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = nch; }
+        }
+        std::vector<Tile> fnat;
+        for (int pi = 0; pi < (int)hpatches.size(); ++pi) {
+            const PatchDesc& p = hpatches[pi];
+            int nk = (p.n[2] + best - 1) / best;
+            nk += nk & 1;  // even chunks: a chunk never splits the two planes of a coarse cell (fused restriction)
+            const std::vector<ColSpec> cs = columns(p.n[0]);
+            auto add = [&](const ColSpec& c, int j0, int k0) {
+                Tile t;
+                std::memset(&t, 0, sizeof(t));
+                t.patch = pi; t.i0 = c.i0; t.j0 = j0; t.k0 = k0;
+                t.nk = std::min(nk, p.n[2] - k0);
+                t.pad_[0] = c.w;
+                t.pad_[1] = c.cls;
+                fnat.push_back(t);
+            };
+            for (int k0 = 0; k0 < p.n[2]; k0 += nk) {
+                if (!classes) {   // one class: rows outside, columns inside (the natural order; partial sums per tile keep it)
+                    for (int j0 = 0; j0 < p.n[1]; j0 += FT_J)
+                        for (const ColSpec& c : cs) add(c, j0, k0);
+                } else {
+                    // narrow columns first: their workgroups run longest (sixteen rows of short segments per wavefront) and
+                    // must not be the ones the launch waits for at its end
+                    for (auto c = cs.rbegin(); c != cs.rend(); ++c)
+                        for (int j0 = 0; j0 < p.n[1]; j0 += rows_of(c->cls)) add(*c, j0, k0);
+                }
+            }
+        }
+        const int NF = (int)fnat.size();
+        std::vector<Tile> perm(NF);
+        const int NX = 8;
+        int start[NX + 1];
+        start[0] = 0;
+        for (int x = 0; x < NX; ++x) start[x + 1] = start[x] + (NF - x + NX - 1) / NX;
+        for (int b = 0; b < NF; ++b) perm[b] = fnat[start[b % NX] + b / NX];
+        return perm;
+    };
+    hftiles = march_tiles(124, fused_rows(), 4, 3.0, 256, narrow7 && fused_rows() == 16);
+    d_ftiles = to_device(hftiles);
+    nftiles = (int)hftiles.size();
+    hrtiles = march_tiles(124, 16, 2, 2.0, 256, narrow7);
+    for (size_t q = 0; q < hrtiles.size(); ++q) hrtiles[q].pad_[2] = (int)q;   // its slot in per-tile partial sums (k_resid_march<2>)
+    d_rtiles = to_device(hrtiles);
+    nrtiles = (int)hrtiles.size();
+    hqtiles = march_tiles(124, full_march_rows(), 2, 2.0, full_march_rows() == 6 ? 512 : 256, full_march_rows() == 8);   // 6 rows: two workgroups per CU
+    d_qtiles = to_device(hqtiles);
+    nqtiles = (int)hqtiles.size();
+
+    if (!plan.peers.empty()) {
+        // which marching tiles read a ghost cell that arrives from another rank?  The fused sweep reads phi two cells around
+        // its columns and planes (the recomputed red ring) -- FRAME deep, as deep as the exchange fills; the operator one cell.
+        std::vector<std::vector<const CopyItem*>> byDst(hpatches.size());
+        for (const CopyItem& it : plan.recv_items) byDst[it.dst_patch].push_back(&it);
+        auto split = [&](const std::vector<Tile>& all, int region_rows, int hrows, int halo, std::vector<Tile>& own, std::vector<Tile>& rem) {
+            for (const Tile& t : all) {
+                const PatchDesc& p = hpatches[t.patch];
+                const int w = t.pad_[0] > 0 ? t.pad_[0] : 124;
+                const int rows = (region_rows << t.pad_[1]) - hrows;
+                const int lo[3] = {t.i0 - halo, t.j0 - halo, t.k0 - halo};
+                const int hi[3] = {std::min(t.i0 + w, p.n[0]) - 1 + halo, std::min(t.j0 + rows, p.n[1]) - 1 + halo, t.k0 + t.nk - 1 + halo};
+                bool hit = false;
+                for (const CopyItem* it : byDst[t.patch]) {
+                    bool ov = true;
+                    for (int d = 0; d < 3; ++d)
+                        ov = ov && std::max(lo[d], it->dst_lo[d]) <= std::min(hi[d], it->dst_lo[d] + it->n[d] - 1);
+                    if (ov) { hit = true; break; }
+                }
+                (hit ? rem : own).push_back(t);
+            }
+        };
+        std::vector<Tile> own, rem;
+        split(hftiles, fused_rows(), 4, FRAME, own, rem);
+        nftiles_own = (int)own.size();
+        nftiles_rem = (int)rem.size();
+        d_ftiles_own = to_device(own);
+        d_ftiles_rem = to_device(rem);
+        own.clear();
+        rem.clear();
+        split(hrtiles, 16, 2, 1, own, rem);
+        nrtiles_own = (int)own.size();
+        nrtiles_rem = (int)rem.size();
+        d_rtiles_own = to_device(own);
+        d_rtiles_rem = to_device(rem);
+    }
+}
+
 void Level::define(const IBox& dom, const bool per[3], const double dx_[3], const int bct[3][2],
                    const std::vector<IBox>& bx, const std::vector<int>& own, Comm* c)
 {
@@ -587,102 +738,6 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
         for (int b = 0; b < N; ++b) htiles[b] = nat[start[b % NX] + b / NX];
     }
 
-    // ---- tiles of the k-marching kernels: (FT_I x FT_J) columns, k split into chunks so that the launch
-    // fills the 256 CUs evenly (one 1024-thread workgroup per CU at a time); `halo` = planes a chunk reads
-    // beyond its own (fused red-black sweep: 3, marching residual: 2) ----------------------------------
-    // Tile columns and their lane class (Tile::pad_[1], see full19_march.hip): class 0 = 124 output columns, one region row
-    // per wavefront; class 1 = 60 columns, two rows per wavefront; class 4 = 4 columns, sixteen rows per wavefront.  A box
-    // is cut into 124-wide columns and its remainder into the narrow classes (128 -> 124 + 4, 64 -> 60 + 4, 512 -> 4 x 124 +
-    // 4 x 4), so that a remainder column costs a sixteenth (a half) of a workgroup-march instead of a whole one.
-    // `classes` off (SOMAR_NO_NARROW_TILES, the 6-/8-row A/B variants): columns of equal width, all class 0 (128 -> 2 x 64,
-    // 512 -> 5 x 104).  region_rows = blockDim.y of the kernel, hrows = region rows that are halo.
-    struct ColSpec { int i0, w, cls; };
-    static const bool narrow_on = getenv("SOMAR_NO_NARROW_TILES") == nullptr;   // A/B switch
-    auto march_tiles = [&](int FT_I, int region_rows, int hrows, double halo, int slots, bool classes) {
-        const int FT_J = region_rows - hrows;
-        classes = classes && narrow_on;
-        static const bool balanced = getenv("SOMAR_NO_BALANCED_TILES") == nullptr;  // A/B switch
-        auto columns = [&](int n0) {
-            std::vector<ColSpec> v;
-            if (!classes || (n0 & 1)) {
-                int w = FT_I;
-                if (balanced) {
-                    const int ncol = (n0 + FT_I - 1) / FT_I;
-                    w = (n0 + ncol - 1) / ncol;
-                    w += w & 1;
-                    w = std::min(w, FT_I);
-                }
-                for (int i0 = 0; i0 < n0; i0 += w) v.push_back({i0, w, 0});
-                return v;
-            }
-            int i0 = 0, rem = n0;
-            while (rem >= FT_I) { v.push_back({i0, FT_I, 0}); i0 += FT_I; rem -= FT_I; }
-            if (rem > 76) { v.push_back({i0, rem, 0}); rem = 0; }
-            if (rem > 16) { const int w = std::min(rem, 60); v.push_back({i0, w, 1}); i0 += w; rem -= w; }
-            while (rem > 0) { const int w = std::min(rem, 4); v.push_back({i0, w, 4}); i0 += w; rem -= w; }
-            return v;
-        };
-        auto rows_of = [&](int cls) { return (region_rows << cls) - hrows; };
-        long long cols = 0;
-        int maxn2 = 1;
-        for (const PatchDesc& p : hpatches) {
-            for (const ColSpec& c : columns(p.n[0])) cols += (p.n[1] + rows_of(c.cls) - 1) / rows_of(c.cls);
-            maxn2 = std::max(maxn2, p.n[2]);
-        }
-        int best = 1;
-        double best_eff = -1.0;
-        for (int nch = 1; nch <= 64 && (nch == 1 || maxn2 / nch >= 4); ++nch) {  // small levels: short chunks, more workgroups
-            const long long blocks = cols * nch;
-            const long long rounds = (blocks + slots - 1) / slots;
-            const double nk = (double)maxn2 / nch;
-            const double eff = (double)blocks / (double)(rounds * slots) * nk / (nk + halo);
-            if (eff > best_eff + 1e-9) { best_eff = eff; best = nch; }
-        }
-        std::vector<Tile> fnat;
-        for (int pi = 0; pi < (int)hpatches.size(); ++pi) {
-            const PatchDesc& p = hpatches[pi];
-            int nk = (p.n[2] + best - 1) / best;
-            nk += nk & 1;  // even chunks: a chunk never splits the two planes of a coarse cell (fused restriction)
-            const std::vector<ColSpec> cs = columns(p.n[0]);
-            auto add = [&](const ColSpec& c, int j0, int k0) {
-                Tile t;
-                std::memset(&t, 0, sizeof(t));
-                t.patch = pi; t.i0 = c.i0; t.j0 = j0; t.k0 = k0;
-                t.nk = std::min(nk, p.n[2] - k0);
-                t.pad_[0] = c.w;
-                t.pad_[1] = c.cls;
-                fnat.push_back(t);
-            };
-            for (int k0 = 0; k0 < p.n[2]; k0 += nk) {
-                if (!classes) {   // one class: rows outside, columns inside (the natural order; partial sums per tile keep it)
-                    for (int j0 = 0; j0 < p.n[1]; j0 += FT_J)
-                        for (const ColSpec& c : cs) add(c, j0, k0);
-                } else {
-                    for (const ColSpec& c : cs)
-                        for (int j0 = 0; j0 < p.n[1]; j0 += rows_of(c.cls)) add(c, j0, k0);
-                }
-            }
-        }
-        const int NF = (int)fnat.size();
-        std::vector<Tile> perm(NF);
-        const int NX = 8;
-        int start[NX + 1];
-        start[0] = 0;
-        for (int x = 0; x < NX; ++x) start[x + 1] = start[x] + (NF - x + NX - 1) / NX;
-        for (int b = 0; b < NF; ++b) perm[b] = fnat[start[b % NX] + b / NX];
-        return perm;
-    };
-    hftiles = march_tiles(124, fused_rows(), 4, 3.0, 256, false);
-    d_ftiles = to_device(hftiles);
-    nftiles = (int)hftiles.size();
-    hrtiles = march_tiles(124, 16, 2, 2.0, 256, false);
-    for (size_t q = 0; q < hrtiles.size(); ++q) hrtiles[q].pad_[2] = (int)q;   // its slot in per-tile partial sums (k_resid_march<2>)
-    d_rtiles = to_device(hrtiles);
-    nrtiles = (int)hrtiles.size();
-    hqtiles = march_tiles(124, full_march_rows(), 2, 2.0, full_march_rows() == 6 ? 512 : 256, full_march_rows() == 8);   // 6 rows: two workgroups per CU
-    d_qtiles = to_device(hqtiles);
-    nqtiles = (int)hqtiles.size();
-
     // ---- whole-column tiles for line relaxation (one lane per (i-pair, j) column) ---------------
     {
         for (int pi = 0; pi < (int)hpatches.size(); ++pi) {
@@ -721,42 +776,7 @@ void Level::define(const IBox& dom, const bool per[3], const double dx_[3], cons
     d_recv_items = to_device(plan.recv_items);
     d_send_off = to_device(plan.send_itemoff);
     d_recv_off = to_device(plan.recv_itemoff);
-    if (!plan.peers.empty()) {
-        // which marching tiles read a ghost cell that arrives from another rank?  The fused sweep reads phi two cells around
-        // its columns and planes (the recomputed red ring) -- FRAME deep, as deep as the exchange fills; the operator one cell.
-        std::vector<std::vector<const CopyItem*>> byDst(hpatches.size());
-        for (const CopyItem& it : plan.recv_items) byDst[it.dst_patch].push_back(&it);
-        auto split = [&](const std::vector<Tile>& all, int region_rows, int hrows, int halo, std::vector<Tile>& own, std::vector<Tile>& rem) {
-            for (const Tile& t : all) {
-                const PatchDesc& p = hpatches[t.patch];
-                const int w = t.pad_[0] > 0 ? t.pad_[0] : 124;
-                const int rows = (region_rows << t.pad_[1]) - hrows;
-                const int lo[3] = {t.i0 - halo, t.j0 - halo, t.k0 - halo};
-                const int hi[3] = {std::min(t.i0 + w, p.n[0]) - 1 + halo, std::min(t.j0 + rows, p.n[1]) - 1 + halo, t.k0 + t.nk - 1 + halo};
-                bool hit = false;
-                for (const CopyItem* it : byDst[t.patch]) {
-                    bool ov = true;
-                    for (int d = 0; d < 3; ++d)
-                        ov = ov && std::max(lo[d], it->dst_lo[d]) <= std::min(hi[d], it->dst_lo[d] + it->n[d] - 1);
-                    if (ov) { hit = true; break; }
-                }
-                (hit ? rem : own).push_back(t);
-            }
-        };
-        std::vector<Tile> own, rem;
-        split(hftiles, fused_rows(), 4, FRAME, own, rem);
-        nftiles_own = (int)own.size();
-        nftiles_rem = (int)rem.size();
-        d_ftiles_own = to_device(own);
-        d_ftiles_rem = to_device(rem);
-        own.clear();
-        rem.clear();
-        split(hrtiles, 16, 2, 1, own, rem);
-        nrtiles_own = (int)own.size();
-        nrtiles_rem = (int)rem.size();
-        d_rtiles_own = to_device(own);
-        d_rtiles_rem = to_device(rem);
-    }
+    build_march_tiles(false);
     if (plan.send_total) SOMAR_HIP(hipMalloc(&d_sendbuf, plan.send_total * sizeof(double)));
     if (plan.recv_total) SOMAR_HIP(hipMalloc(&d_recvbuf, plan.recv_total * sizeof(double)));
 

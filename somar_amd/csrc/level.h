@@ -94,6 +94,8 @@ public:
     std::vector<int> local;    // global box index of each local patch
     std::vector<PatchDesc> hpatches;
     std::vector<Tile> htiles;
+    void build_march_tiles(bool narrow7);   // (re)builds the marching kernels' tile tables below
+    bool narrow7_ = false;
     std::vector<Tile> hftiles;   // tiles of the fused red-black sweep (gsrb_fused.hip)
     Tile* d_ftiles = nullptr;
     int nftiles = 0;

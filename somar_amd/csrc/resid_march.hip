@@ -16,7 +16,6 @@
 
 namespace somar {
 
-constexpr int RM_I = 128;  // region width (64 lanes x double2) = 124-cell tile + 2 low + 2 high
 constexpr int RM_J = 16;   // region rows = 14-row tile + 1 low + 1 high
 
 __device__ __forceinline__ double2 rm_ld2(const double* __restrict__ a, long long idx, bool ok0, bool ok1,
@@ -40,28 +39,28 @@ __device__ __forceinline__ double2 rm_ld2(const double* __restrict__ a, long lon
 __device__ __forceinline__ double2 rm_uni2(double c, bool, bool) { return make_double2(c, c); }
 
 // UNI: uniform metric, the four coefficient arrays are not read (StencilParams::uc)
-template <int MODE, bool UNI = false>
-__global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restrict__ tiles,
-                                                           const PatchDesc* __restrict__ patches,
-                                                           double* __restrict__ out,
-                                                           const double* __restrict__ phi,
-                                                           const double* __restrict__ rhs,
-                                                           const double* __restrict__ jgx,
-                                                           const double* __restrict__ jgy,
-                                                           const double* __restrict__ jgz,
-                                                           const double* __restrict__ jinv, StencilParams P,
-                                                           const PatchDesc* __restrict__ cpatches, int r0, int r1,
-                                                           int r2, double dxProduct, double* __restrict__ volsum)
+// CLS: the tile's lane class (see full19_march.hip): a wavefront covers 2^CLS region rows of 128 >> CLS columns
+template <int MODE, bool UNI, int CLS>
+__device__ __forceinline__ void resid_march_body(double* __restrict__ S, double* __restrict__ T, const Tile& t,
+                                                 const PatchDesc& p, double* __restrict__ out,
+                                                 const double* __restrict__ phi, const double* __restrict__ rhs,
+                                                 const double* __restrict__ jgx, const double* __restrict__ jgy,
+                                                 const double* __restrict__ jgz, const double* __restrict__ jinv,
+                                                 const StencilParams& P, const PatchDesc* __restrict__ cpatches, int r0,
+                                                 int r1, int r2, double dxProduct, double* __restrict__ volsum)
 {
-    __shared__ __attribute__((aligned(16))) double S[2][RM_J][RM_I];
-    // MODE 2: (res/J, 1/J) of both cells of every pair, handed from the odd row of a coarse cell to the even one
-    __shared__ __attribute__((aligned(16))) double T[MODE == 2 ? 2 : 1][MODE == 2 ? RM_J : 1][MODE == 2 ? 64 : 1][4];
-    const Tile t = tiles[blockIdx.x];
-    const PatchDesc p = patches[t.patch];
-    const int lane = threadIdx.x, row = threadIdx.y;
+    constexpr int LPR = 64 >> CLS;                 // lanes per region row
+    constexpr int NR = RM_J << CLS;                // region rows of the workgroup
+    constexpr int PITCH = 2 * LPR + (CLS >= 2 ? 2 : 0);
+#define Sx(slot, r, c) S[((slot) * NR + (r)) * PITCH + (c)]
+#define Tx(slot, r, l) (T + ((((slot) * NR + (r)) * LPR + (l)) << 2))
+    // class 0: the region row is the wavefront's index, a scalar -- everything derived from it stays in scalar registers
+    const int lane = CLS == 0 ? (int)threadIdx.x : (int)(threadIdx.x & (LPR - 1));
+    const int row = CLS == 0 ? (int)threadIdx.y
+                             : (int)(((threadIdx.y >> 1) << (CLS + 1)) + (threadIdx.y & 1) + 2 * (threadIdx.x >> (6 - CLS)));
     const int ri = 2 * lane;
     const int li = t.i0 - 2 + ri;  // even: rows are 16-byte aligned
-    const int wi = t.pad_[0] > 0 ? t.pad_[0] : RM_I - 4;  // output columns of this tile (see gsrb_fused.hip)
+    const int wi = t.pad_[0] > 0 ? t.pad_[0] : 2 * LPR - 4;  // output columns of this tile (see gsrb_fused.hip)
     const int lj = t.j0 - 1 + row;
     const int gj = p.lo[1] + lj;
     const double sx = 1.0 / P.dx[0], sy = 1.0 / P.dx[1], sz = 1.0 / P.dx[2];
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
     const bool fj = (lj >= -1) && (lj <= p.n[1]);
     const bool f0 = fj && (li >= -1) && (li <= p.n[0]) && (ri < wi + 4);
     const bool f1 = fj && (li + 1 >= -1) && (li + 1 <= p.n[0]) && (ri + 1 < wi + 4);
-    const bool own_j = (lj >= 0) && (lj < p.n[1]) && (row >= 1) && (row <= RM_J - 2) && (lj < t.j0 + (RM_J - 2));
+    const bool own_j = (lj >= 0) && (lj < p.n[1]) && (row >= 1) && (row <= NR - 2) && (lj < t.j0 + (NR - 2));
     bool o[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -106,7 +105,7 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
         if (first) { cs[0] = cs[1] = 0.0; cjs[0] = cjs[1] = 0.0; }
         double q[4] = {0.0, 0.0, 0.0, 0.0};
         if (r1 == 2) {
-            const double* src = T[kp & 1][row + 1][lane];
+            const double* src = Tx(kp & 1, row + 1, lane);
             q[0] = src[0]; q[1] = src[1]; q[2] = src[2]; q[3] = src[3];
         }
         if (r0 == 2) {
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
 
         // ---- stage plane k; slot k&1 was last read two steps ago, one barrier per plane suffices ----
         const int slot = k & 1;
-        *reinterpret_cast<double2*>(&S[slot][row][ri]) = Pc;
+        *reinterpret_cast<double2*>(&Sx(slot, row, ri)) = Pc;
         __syncthreads();
         if (MODE == 2 && k > t.k0) accumulate(k - 1);
 
@@ -174,9 +173,9 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
                 if (!o[s]) continue;
                 const int rc = ri + s;
                 const double pc = s ? Pc.y : Pc.x;
-                const double pxl = s ? Pc.x : S[slot][row][rc - 1];
-                const double pxh = s ? S[slot][row][rc + 1] : Pc.y;
-                const double pyl = S[slot][row - 1][rc], pyh = S[slot][row + 1][rc];
+                const double pxl = s ? Pc.x : Sx(slot, row, rc - 1);
+                const double pxh = s ? Sx(slot, row, rc + 1) : Pc.y;
+                const double pyl = Sx(slot, row - 1, rc), pyh = Sx(slot, row + 1, rc);
                 const double gxl = s ? Gx.y : Gx.x, gxh = s ? gx_next : Gx.y;
                 double fxl = gxl * sx * (pc - pxl);
                 double fxh = gxh * sx * (pxh - pc);
@@ -206,7 +205,7 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
                     if (o[1]) vsum = vsum + dxProduct * pv[3] * Pc.y;
                 }
                 if (r1 == 2) {
-                    double* dstT = T[k & 1][row][lane];
+                    double* dstT = Tx(k & 1, row, lane);
                     *reinterpret_cast<double2*>(dstT) = make_double2(pv[0], pv[1]);
                     *reinterpret_cast<double2*>(dstT + 2) = make_double2(pv[2], pv[3]);
                 }
@@ -227,15 +226,42 @@ __global__ __launch_bounds__(64 * RM_J) void k_resid_march(const Tile* __restric
         if (volsum) {
             __shared__ double red[RM_J];
             for (int o2 = 32; o2 > 0; o2 >>= 1) vsum += __shfl_down(vsum, o2, 64);
-            if (lane == 0) red[row] = vsum;
+            if (threadIdx.x == 0) red[threadIdx.y] = vsum;
             __syncthreads();
-            if (lane == 0 && row == 0) {
+            if (threadIdx.x == 0 && threadIdx.y == 0) {
                 double tot = red[0];
                 for (int q = 1; q < RM_J; ++q) tot = tot + red[q];
                 volsum[t.pad_[2]] = tot;   // the tile's place in the level's full tile list: split launches (overlap) keep the order of the sum
             }
         }
     }
+#undef Sx
+#undef Tx
+}
+
+template <int MODE, bool UNI = false>
+// uniform metric, plain output: 64 VGPRs, two workgroups per CU (the narrow classes' per-lane row arithmetic must not cost that)
+__global__ __launch_bounds__(64 * RM_J, (UNI && MODE != 2) ? 8 : 4) void k_resid_march(const Tile* __restrict__ tiles,
+                                                           const PatchDesc* __restrict__ patches,
+                                                           double* __restrict__ out,
+                                                           const double* __restrict__ phi,
+                                                           const double* __restrict__ rhs,
+                                                           const double* __restrict__ jgx,
+                                                           const double* __restrict__ jgy,
+                                                           const double* __restrict__ jgz,
+                                                           const double* __restrict__ jinv, StencilParams P,
+                                                           const PatchDesc* __restrict__ cpatches, int r0, int r1,
+                                                           int r2, double dxProduct, double* __restrict__ volsum)
+{
+    __shared__ __attribute__((aligned(16))) double S[2 * RM_J * 160];   // one slot = the largest class's region (16 RM_J rows of 8 + 2)
+    // MODE 2: (res/J, 1/J) of both cells of every pair, handed from the odd row of a coarse cell to the even one
+    __shared__ __attribute__((aligned(16))) double T[MODE == 2 ? 2 * RM_J * 64 * 4 : 4];
+    const Tile t = tiles[blockIdx.x];
+    const PatchDesc p = patches[t.patch];
+    const int cls = t.pad_[1];
+    if (cls == 0) resid_march_body<MODE, UNI, 0>(S, T, t, p, out, phi, rhs, jgx, jgy, jgz, jinv, P, cpatches, r0, r1, r2, dxProduct, volsum);
+    else if (cls == 1) resid_march_body<MODE, UNI, 1>(S, T, t, p, out, phi, rhs, jgx, jgy, jgz, jinv, P, cpatches, r0, r1, r2, dxProduct, volsum);
+    else resid_march_body<MODE, UNI, 4>(S, T, t, p, out, phi, rhs, jgx, jgy, jgz, jinv, P, cpatches, r0, r1, r2, dxProduct, volsum);
 }
 
 void launch_resid_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out,

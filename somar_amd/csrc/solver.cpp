@@ -514,6 +514,15 @@ void PressureSolver::finalize()
     const auto t1 = now();
     detect_uniform_metric();
     detect_zero_planes();
+    {
+        // narrow lane classes for the 7-point marching kernels where the metric is uniform (Level::build_march_tiles says why);
+        // SOMAR_NARROW_7PT = 0 | 1 forces never / always (A/B)
+        const char* e = getenv("SOMAR_NARROW_7PT");
+        for (auto& Lp : lev) {
+            const bool want = e ? atoi(e) != 0 : Lp->dev.P.uniform != 0;
+            if (want != Lp->narrow7_) Lp->build_march_tiles(want);
+        }
+    }
     const auto t2 = now();
     struct Report {
         bool on; std::chrono::steady_clock::time_point t0, t1, t2; long long cells;
