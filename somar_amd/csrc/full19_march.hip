@@ -315,23 +315,27 @@ __device__ __forceinline__ void full_march_body(double* __restrict__ SP, double*
 #undef SEx
 }
 
-template <int MODE, int FM_J, bool ZXY = false>
-__global__ __launch_bounds__(64 * FM_J, 3) void k_full_march(const Tile* __restrict__ tiles,
-                                                          const PatchDesc* __restrict__ patches,
-                                                          double* __restrict__ out, const double* __restrict__ phi,
-                                                          const double* __restrict__ psi,
-                                                          const double* __restrict__ rhs, JgFullM J,
-                                                          const double* __restrict__ jinv, StencilParams P, int color)
+// NARROW: the tile table holds narrow lane classes; the instantiation without them is the one-body kernel with 64 KB of LDS
+// (one 512-wide box: colour pass 3.02 ms against 3.24 with the three-body kernel on the same class-0 tiles).
+template <int MODE, int FM_J, bool ZXY, bool NARROW>
+// (an occupancy hint of 3 waves per SIMD on every instantiation changed the scheduling of those that need none: 512^3 colour pass
+// 3.02 -> 3.29 ms, C5 53.1 -> 55.8 ms; only the three-body operator without zero planes would otherwise take 169 VGPRs)
+__global__ __launch_bounds__(64 * FM_J, (NARROW && !ZXY && MODE == 1) ? 3 : 1) void k_full_march(const Tile* __restrict__ tiles,
+                                                             const PatchDesc* __restrict__ patches,
+                                                             double* __restrict__ out, const double* __restrict__ phi,
+                                                             const double* __restrict__ psi,
+                                                             const double* __restrict__ rhs, JgFullM J,
+                                                             const double* __restrict__ jinv, StencilParams P, int color)
 {
-    // one slot = the largest class's region: 16 FM_J rows of 8 + 2 columns
-    __shared__ __attribute__((aligned(16))) double SP[FM_S * FM_J * 160];  // phi
-    __shared__ __attribute__((aligned(16))) double SE[FM_S * FM_J * 160];  // E: phi inside the box, psi in its frame
+    // one slot = the largest class's region: FM_J rows of 128, or 16 FM_J rows of 8 + 2 columns
+    __shared__ __attribute__((aligned(16))) double SP[FM_S * FM_J * (NARROW ? 160 : 128)];  // phi
+    __shared__ __attribute__((aligned(16))) double SE[FM_S * FM_J * (NARROW ? 160 : 128)];  // E: phi inside the box, psi in its frame
     const Tile t = tiles[blockIdx.x];
     const PatchDesc p = patches[t.patch];
-    const int cls = FM_J == 8 ? t.pad_[1] : 0;   // Level::define hands the 6-row kernels (SOMAR_FULL_ROWS=6) class-0 tiles only
-    if (cls == 0) full_march_body<MODE, FM_J, ZXY, 0>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color);
-    else if (cls == 1) full_march_body<MODE, FM_J, ZXY, 1>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color);
-    else full_march_body<MODE, FM_J, ZXY, 4>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color);
+    const int cls = NARROW ? t.pad_[1] : 0;
+    if (!NARROW || cls == 0) full_march_body<MODE, FM_J, ZXY, 0>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color);
+    else if (cls == 1) full_march_body<MODE, FM_J, ZXY, NARROW ? 1 : 0>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color);
+    else full_march_body<MODE, FM_J, ZXY, NARROW ? 4 : 0>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color);
 }
 
 int full_march_rows()
@@ -357,12 +361,13 @@ template <int MODE>
 static void launch_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out, const double* phi,
                          const double* psi, const double* rhs, int color)
 {
-    const bool six = full_march_rows() == 6, z = L.P.zero_xy != 0;
-#define SOMAR_FM(ROWS, Z)                                                                                                   \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<MODE, ROWS, Z>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
+    const bool six = full_march_rows() == 6, z = L.P.zero_xy != 0, nw = L.narrowq != 0;   // (6-row tables never hold narrow classes)
+#define SOMAR_FM(ROWS, Z, N)                                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<MODE, ROWS, Z, N>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
                        out, phi, psi, rhs, jgfullm(L), L.jinv, L.P, color)
-    if (six) { if (z) SOMAR_FM(6, true); else SOMAR_FM(6, false); }
-    else { if (z) SOMAR_FM(8, true); else SOMAR_FM(8, false); }
+    if (six) { if (z) SOMAR_FM(6, true, false); else SOMAR_FM(6, false, false); }
+    else if (nw) { if (z) SOMAR_FM(8, true, true); else SOMAR_FM(8, false, true); }
+    else { if (z) SOMAR_FM(8, true, false); else SOMAR_FM(8, false, false); }
 #undef SOMAR_FM
 }
 

@@ -24,6 +24,7 @@ struct LevelDev {
     double* jgf[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     StencilParams P;
     int narrow7 = 0;                    // the 7-point marching kernels' tile tables hold narrow lane classes (Level::build_march_tiles)
+    int narrowq = 0;                    // the 19-point marching kernels' tile table does
 };
 
 // operands of MAPPEDGETFLUX with a non-diagonal metric, evaluated where a flux register needs it (amr_kernels.hip: reg_flux19)

@@ -535,13 +535,14 @@ void Level::build_march_tiles(bool narrow7)
     // 512 -> 5 x 104).  region_rows = blockDim.y of the kernel, hrows = region rows that are halo.
     struct ColSpec { int i0, w, cls; };
     static const bool narrow_on = getenv("SOMAR_NO_NARROW_TILES") == nullptr;   // A/B switch
-    auto march_tiles = [&](int FT_I, int region_rows, int hrows, double halo, int slots, bool classes) {
-        const int FT_J = region_rows - hrows;
+    auto march_tiles = [&](int FT_I, int region_rows, int hrows, double halo, int slots, bool classes, double min_gain = 1.0) {
         classes = classes && narrow_on;
         static const bool balanced = getenv("SOMAR_NO_BALANCED_TILES") == nullptr;  // A/B switch
+        // min_gain: the narrow decomposition is taken only where it costs at most that fraction of the equal columns' workgroup-
+        // marches (a class-4 workgroup counted as a quarter: it runs long; a class-1 one as a half).  1.0 = always.
         auto columns = [&](int n0) {
-            std::vector<ColSpec> v;
-            if (!classes || (n0 & 1)) {
+            std::vector<ColSpec> eq, v;
+            {
                 int w = FT_I;
                 if (balanced) {
                     const int ncol = (n0 + FT_I - 1) / FT_I;
@@ -549,15 +550,16 @@ void Level::build_march_tiles(bool narrow7)
                     w += w & 1;
                     w = std::min(w, FT_I);
                 }
-                for (int i0 = 0; i0 < n0; i0 += w) v.push_back({i0, w, 0});
-                return v;
+                for (int i0 = 0; i0 < n0; i0 += w) eq.push_back({i0, w, 0});
             }
+            if (!classes || (n0 & 1)) return eq;
             int i0 = 0, rem = n0;
-            while (rem >= FT_I) { v.push_back({i0, FT_I, 0}); i0 += FT_I; rem -= FT_I; }
-            if (rem > 76) { v.push_back({i0, rem, 0}); rem = 0; }
-            if (rem > 16) { const int w = std::min(rem, 60); v.push_back({i0, w, 1}); i0 += w; rem -= w; }
-            while (rem > 0) { const int w = std::min(rem, 4); v.push_back({i0, w, 4}); i0 += w; rem -= w; }
-            return v;
+            double cost = 0.0;
+            while (rem >= FT_I) { v.push_back({i0, FT_I, 0}); i0 += FT_I; rem -= FT_I; cost += 1.0; }
+            if (rem > 76) { v.push_back({i0, rem, 0}); rem = 0; cost += 1.0; }
+            if (rem > 16) { const int w = std::min(rem, 60); v.push_back({i0, w, 1}); i0 += w; rem -= w; cost += 0.5; }
+            while (rem > 0) { const int w = std::min(rem, 4); v.push_back({i0, w, 4}); i0 += w; rem -= w; cost += 0.25; }
+            return cost <= min_gain * (double)eq.size() ? v : eq;
         };
         auto rows_of = [&](int cls) { return (region_rows << cls) - hrows; };
         long long cols = 0;
@@ -591,15 +593,14 @@ void Level::build_march_tiles(bool narrow7)
                 fnat.push_back(t);
             };
             for (int k0 = 0; k0 < p.n[2]; k0 += nk) {
-                if (!classes) {   // one class: rows outside, columns inside (the natural order; partial sums per tile keep it)
-                    for (int j0 = 0; j0 < p.n[1]; j0 += FT_J)
-                        for (const ColSpec& c : cs) add(c, j0, k0);
-                } else {
-                    // narrow columns first: their workgroups run longest (sixteen rows of short segments per wavefront) and
-                    // must not be the ones the launch waits for at its end
-                    for (auto c = cs.rbegin(); c != cs.rend(); ++c)
-                        for (int j0 = 0; j0 < p.n[1]; j0 += rows_of(c->cls)) add(*c, j0, k0);
-                }
+                // rows outside, columns inside (the natural order: a 512-wide box's 19-point colour pass takes 3.07 ms so, 3.23 ms
+                // with the columns outside); a narrow column's tall tile goes where its first row is
+                const size_t first = fnat.size();
+                for (const ColSpec& c : cs)
+                    for (int j0 = 0; j0 < p.n[1]; j0 += rows_of(c.cls)) add(c, j0, k0);
+                std::stable_sort(fnat.begin() + first, fnat.end(), [](const Tile& a, const Tile& b) {
+                    return a.j0 != b.j0 ? a.j0 < b.j0 : a.i0 < b.i0;
+                });
             }
         }
         const int NF = (int)fnat.size();
@@ -611,16 +612,21 @@ void Level::build_march_tiles(bool narrow7)
         for (int b = 0; b < NF; ++b) perm[b] = fnat[start[b % NX] + b / NX];
         return perm;
     };
-    hftiles = march_tiles(124, fused_rows(), 4, 3.0, 256, narrow7 && fused_rows() == 16);
+    hftiles = march_tiles(124, fused_rows(), 4, 3.0, 256, narrow7 && fused_rows() == 16, 0.85);
     d_ftiles = to_device(hftiles);
     nftiles = (int)hftiles.size();
-    hrtiles = march_tiles(124, 16, 2, 2.0, 256, narrow7);
+    hrtiles = march_tiles(124, 16, 2, 2.0, 256, narrow7, 0.85);
     for (size_t q = 0; q < hrtiles.size(); ++q) hrtiles[q].pad_[2] = (int)q;   // its slot in per-tile partial sums (k_resid_march<2>)
     d_rtiles = to_device(hrtiles);
     nrtiles = (int)hrtiles.size();
-    hqtiles = march_tiles(124, full_march_rows(), 2, 2.0, full_march_rows() == 6 ? 512 : 256, full_march_rows() == 8);   // 6 rows: two workgroups per CU
+    // every table: narrow classes where they save at least 15 % of the workgroup-marches (64-wide boxes: C5 62.8 -> 53.1 ms per
+    // AMR V-cycle; 128-wide: C4 136.8 -> 111.6).  One 512-wide box, 5 equal columns against 4 + 4 narrow, is a wash or worse:
+    // 19-point colour pass 3.02 -> 3.07 ms, residual 3.17 -> 3.42; c2_cartesian 151 -> 149-158 V-cycles/s depending on tile order)
+    hqtiles = march_tiles(124, full_march_rows(), 2, 2.0, full_march_rows() == 6 ? 512 : 256, full_march_rows() == 8, 0.85);   // 6 rows: two workgroups per CU
     d_qtiles = to_device(hqtiles);
     nqtiles = (int)hqtiles.size();
+    dev.narrowq = 0;
+    for (const Tile& t : hqtiles) if (t.pad_[1]) dev.narrowq = 1;
 
     if (!plan.peers.empty()) {
         // which marching tiles read a ghost cell that arrives from another rank?  The fused sweep reads phi two cells around

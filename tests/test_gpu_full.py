@@ -20,10 +20,10 @@ CASES = [
     ((16, 16, 16), 8, (True, True, True), (1.0, 1.0, 1.0)),
     ((16, 16, 8), 8, (False, True, False), (2.0, 1.0, 0.5)),
     ((24, 16, 8), (12, 8, 8), (False, False, False), (1.5, 1.0, 0.5)),
-    # tile columns of every lane class of the marching kernels (Level::define): 72 = 60 (two rows per wavefront) + 3 x 4
-    # (sixteen rows per wavefront); 136 = 124 (one row per wavefront) + 3 x 4
-    ((72, 8, 8), (72, 8, 8), (False, True, False), (2.0, 1.0, 0.5)),
-    ((136, 6, 4), (136, 6, 4), (True, False, False), (4.0, 1.0, 0.5)),
+    # tile columns of every lane class of the marching kernels (Level::build_march_tiles): 64 = 60 (two region rows per
+    # wavefront) + 4 (sixteen); 128 = 124 (one row per wavefront) + 4
+    ((64, 8, 8), (64, 8, 8), (False, True, False), (2.0, 1.0, 0.5)),
+    ((128, 6, 4), (128, 6, 4), (True, False, False), (4.0, 1.0, 0.5)),
 ]
 
 

@@ -21,10 +21,10 @@ CASES = [
     ((64, 32, 16), 16, "stretched", (False, True, False), (4.0, 1.0, 0.5)),
     ((48, 24, 24), (24, 12, 8), "stretched", (True, True, True), (1.0, 2.0, 1.0)),
     ((36, 20, 12), (12, 20, 4), "stretched", (False, False, True), (1.0, 1.0, 3.0)),   # ragged / odd box counts
-    # tile columns of every lane class of the marching kernels (Level::define; the cases above give 32- / 24-wide class-1 and
-    # 4-wide class-4 columns): 72 = 60 (two region rows per wavefront) + 3 x 4 (sixteen), 136 = 124 (one) + 3 x 4
-    ((72, 16, 8), (72, 8, 8), "stretched", (False, True, False), (2.0, 1.0, 0.5)),
-    ((136, 8, 8), (136, 8, 8), "stretched", (True, False, False), (4.0, 1.0, 1.0)),
+    # tile columns of every lane class of the marching kernels (Level::build_march_tiles; the cases above give 32- / 24-wide
+    # class-1 and 4-wide class-4 columns): 64 = 60 (two region rows per wavefront) + 4 (sixteen), 128 = 124 (one) + 4
+    ((64, 16, 8), (64, 8, 8), "stretched", (False, True, False), (2.0, 1.0, 0.5)),
+    ((128, 8, 8), (128, 8, 8), "stretched", (True, False, False), (4.0, 1.0, 1.0)),
 ]
 
 
@@ -287,7 +287,7 @@ def test_one_launch_bottom_solver_equals_the_launch_by_launch_one(oracle, case, 
 _ORACLE_SOLVES = {}   # (case, smooth) -> the oracle's solve: shared by the two sweep-kernel variants of the test below
 
 
-@pytest.mark.parametrize("case", CASES[:6])   # (the 136 x 8 x 8 bar's histories agree to 7e-10 only: its kernels are covered above)
+@pytest.mark.parametrize("case", CASES[:6])   # (the 128 x 8 x 8 bar: its kernels are covered above)
 @pytest.mark.parametrize("smooth", [(2, 2, 2), (4, 4, 2)])
 def test_full_solve_history_matches(oracle, case, smooth, gsrb_mode):
     so = oracle
