@@ -49,7 +49,7 @@ extern "C" {
  * 6: + somar_amr_tga_step (composite MappedAMRTGA::oneStep); composite operations with heat coefficients installed no
  *    longer fail (the flux-register scales follow beta); somar_solver_set_vel_bc (inflow / outflow sides); somar_solver_set_metric_map (cylindrical and bathymetric
  *    metric producers on the device); somar_k_fillmappedlapdiag3d, somar_k_mappedaverage2 (kernel-level hooks); additions only */
-#define SOMAR_AMD_ABI_VERSION 7
+#define SOMAR_AMD_ABI_VERSION 8
 
 /* BCType codes, calculus/BCInterface/BCDescriptor.H:34-39 */
 #define SOMAR_BC_NONE (-1)
@@ -203,6 +203,9 @@ int somar_bottom_kind(somar_solver_t* s, int* kind);
  * is the one that ran): out4 = {fused sweeps whose ghost exchange travelled on the second stream under their interior tiles,
  * ghost programs executed as one launch (a workgroup per box), ghost programs executed stage by stage, bottom solves} */
 int somar_solver_counters(somar_solver_t* s, long long* out4);
+/* sweeps of LevelGSRB with a non-diagonal metric (GSRB.cpp:58-98 with GSRBITER3D) that ran as ONE red+black marching launch plus
+ * a shell pass (levels of large boxes; csrc/full19_fused.hip) instead of two colour passes */
+int somar_solver_fused19_sweeps(somar_solver_t* s, long long* n);
 
 /* MAC level projection of a face-centred velocity given in flux form (J u^a on a-faces, one host array per
  * local patch spanning faces(valid, a)):  rhs = div(U)/dt ; solve ; U -= dt * Jg^{aa} d_a(phi).

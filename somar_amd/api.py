@@ -103,6 +103,7 @@ _SIGS = {
     "somar_bottom_solve": [_H, C.c_int, C.c_int, _PI, _PI],
     "somar_bottom_kind": [_H, _PI],
     "somar_solver_counters": [_H, C.POINTER(C.c_longlong)],
+    "somar_solver_fused19_sweeps": [_H, C.POINTER(C.c_longlong)],
     "somar_last_history": [_PD, C.c_int, _PI],
     "somar_host_fill_mt19937_64": [_PD, C.c_longlong, C.c_ulonglong, C.c_double, C.c_double],
     "somar_vel_upload": [_H, C.c_int, C.c_int, _PD],
@@ -637,6 +638,12 @@ class AMRPressureSolver:
         c = (C.c_longlong * 4)()
         _ck(lib().somar_solver_counters(self._h, c))
         return {"overlapped_sweeps": c[0], "ghost_programs_one_launch": c[1], "ghost_programs_staged": c[2], "bottom_solves": c[3]}
+
+    def fused19Sweeps(self):
+        """19-point LevelGSRB sweeps that ran as one red+black launch plus a shell pass (levels of large boxes)"""
+        n = C.c_longlong()
+        _ck(lib().somar_solver_fused19_sweeps(self._h, C.byref(n)))
+        return n.value
 
     def bottomKind(self):
         """how the last bottom solve ran: 0 launch by launch, 1 one single-workgroup launch, 2 one persistent launch, a workgroup per box"""

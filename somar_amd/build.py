@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsomar_amd.so")
-SOURCES = ["kernels.hip", "box_bicgstab.hip", "gsrb_fused.hip", "resid_march.hip", "full19.hip", "full19_march.hip", "projection.hip", "line_gsrb.hip", "amr_kernels.hip", "leptic_kernels.hip", "maps.hip", "level.cpp", "solver.cpp", "solver_full.cpp", "amr.cpp", "leptic.cpp", "comm_rccl.cpp", "comm_shm.cpp", "capi.cpp"]
+SOURCES = ["kernels.hip", "box_bicgstab.hip", "gsrb_fused.hip", "resid_march.hip", "full19.hip", "full19_march.hip", "full19_fused.hip", "projection.hip", "line_gsrb.hip", "amr_kernels.hip", "leptic_kernels.hip", "maps.hip", "level.cpp", "solver.cpp", "solver_full.cpp", "amr.cpp", "leptic.cpp", "comm_rccl.cpp", "comm_shm.cpp", "capi.cpp"]
 HEADERS = ["common.h", "kernels.h", "level.h", "solver.h", "amr.h", "leptic.h", os.path.join("..", "..", "include", "somar_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -556,6 +556,13 @@ int somar_solver_counters(somar_solver_t* s, long long* out4)
     API_END
 }
 
+int somar_solver_fused19_sweeps(somar_solver_t* s, long long* n)
+{
+    API_BEGIN
+    *n = s->ps->counters[4];
+    API_END
+}
+
 int somar_vel_upload(somar_solver_t* s, int dir, int patch, const double* host)
 {
     API_BEGIN

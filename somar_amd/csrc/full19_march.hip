@@ -52,6 +52,7 @@ __device__ __forceinline__ double2 fm_ld2(const double* __restrict__ a, long lon
 __device__ __forceinline__ double fm_pick(const double2& v, int s) { return s ? v.y : v.x; }
 
 // MODE 0: out = rhs - L[phi]   MODE 1: out = L[phi]   MODE 2: out = phi with the cells of `color` relaxed (one GSRB pass)
+// MODE 3: the colour pass on the cells of the three outer layers of each box only, in place, after k_full_fused (see there)
 // ZXY: J g^{xy} on x-faces and J g^{yx} on y-faces are identically zero (StencilParams::zero_xy): those two planes are not
 // streamed -- three of the pass's thirteen coefficient loads per plane -- and zeros stand in for them; the products are the
 // zeros the stored planes would give (up to the sign of zero).
@@ -65,7 +66,8 @@ __device__ __forceinline__ void full_march_body(double* __restrict__ SP, double*
                                                 const PatchDesc& p, double* __restrict__ out,
                                                 const double* __restrict__ phi, const double* __restrict__ psi,
                                                 const double* __restrict__ rhs, const JgFullM& J,
-                                                const double* __restrict__ jinv, const StencilParams& P, int color)
+                                                const double* __restrict__ jinv, const StencilParams& P, int color,
+                                                const double* __restrict__ phi2)
 {
     constexpr int LPR = 64 >> CLS;                 // lanes per region row
     constexpr int NR = FM_J << CLS;                // region rows of the workgroup
@@ -119,6 +121,14 @@ __device__ __forceinline__ void full_march_body(double* __restrict__ SP, double*
         const bool ink = (kp >= 0) && (kp < p.n[2]);
         const long long idx = base + sk * kp;
         vp = fm_ld2(phi, idx, f0 && fk, f1 && fk, p.off);
+        if (MODE == 3) {
+            // the pass's colour INSIDE the box comes from phi2 (the sweep's input: the pre-pass value of a cell the fused kernel
+            // may already have relaxed), everything else -- the other colour, every ghost cell -- from phi
+            const int cs = (p.lo[0] + li + gj + p.lo[2] + kp + color) & 1;
+            const bool m0 = in0 && ink && cs == 0, m1 = in1 && ink && cs == 1;
+            const double2 vq = fm_ld2(phi2, idx, m0, m1, p.off);
+            vp = make_double2(m0 ? vq.x : vp.x, m1 ? vq.y : vp.y);
+        }
         const bool e0 = f0 && fk && !(in0 && ink), e1 = f1 && fk && !(in1 && ink);   // frame cells: E = psi
         const double2 vs = fm_ld2(psi, idx, e0, e1, p.off);
         ve = make_double2(e0 ? vs.x : vp.x, e1 ? vs.y : vp.y);
@@ -172,13 +182,18 @@ __device__ __forceinline__ void full_march_body(double* __restrict__ SP, double*
         if (any) {
             const int sm = (k - 1) & (FM_S - 1), sc = k & (FM_S - 1), sp = (k + 1) & (FM_S - 1);
             double res[2] = {0.0, 0.0};
+            bool o3 = true;
             const int csel = (p.lo[0] + li + gj + gk + color) & 1;   // MODE 2: the cell of the pair that has this colour
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int rc = ri + s;
                 const double pc = SPx(sc, row, rc);
-                if (MODE == 2 && s != csel) { res[s] = pc; continue; }
+                if (MODE >= 2 && s != csel) { res[s] = pc; continue; }
                 if (!o[s]) continue;
+                if (MODE == 3 && min(min(min(li + s, p.n[0] - 1 - (li + s)), min(lj, p.n[1] - 1 - lj)), min(k, p.n[2] - 1 - k)) >= 3) {
+                    o3 = false;   // three layers inside the box: k_full_fused relaxed this cell
+                    continue;
+                }
                 const int gi = p.lo[0] + li + s;
                 // neighbours: Pn(di,dj,dk) = phi, En(di,dj,dk) = E
 #define Pn(di, dj, dk) SPx((dk) < 0 ? sm : ((dk) > 0 ? sp : sc), row + (dj), rc + (di))
@@ -194,7 +209,7 @@ __device__ __forceinline__ void full_march_body(double* __restrict__ SP, double*
                 const double jz1l = fm_pick(Jz1c, s), jz1h = fm_pick(Jz1p, s);
                 const double jz2l = fm_pick(Jz2c, s), jz2h = fm_pick(Jz2p, s);
                 const double ji = fm_pick(Ji, s);
-                if (MODE != 2) {
+                if (MODE < 2) {
                     // flux19 (full19.hip) at the six faces: direction a, then b = a+1, c = a+2 (cyclic)
                     double fxl = a0 * jx0l * (pc - Pn(-1, 0, 0)) +
                                  q1 * jx1l * (En(0, 1, 0) - En(0, -1, 0) + En(-1, 1, 0) - En(-1, -1, 0)) +
@@ -303,7 +318,9 @@ __device__ __forceinline__ void full_march_body(double* __restrict__ SP, double*
 #undef En
             }
             double* dst = out + base + sk * k;
-            if (o[0] && o[1]) *reinterpret_cast<double2*>(dst) = make_double2(res[0], res[1]);
+            if (MODE == 3) {
+                if (o[csel] && o3) dst[csel] = res[csel];   // in place: only the shell cells of the colour
+            } else if (o[0] && o[1]) *reinterpret_cast<double2*>(dst) = make_double2(res[0], res[1]);
             else if (o[0]) dst[0] = res[0];
             else dst[1] = res[1];
         }
@@ -325,7 +342,8 @@ __global__ __launch_bounds__(64 * FM_J, (NARROW && !ZXY && MODE == 1) ? 3 : 1) v
                                                              double* __restrict__ out, const double* __restrict__ phi,
                                                              const double* __restrict__ psi,
                                                              const double* __restrict__ rhs, JgFullM J,
-                                                             const double* __restrict__ jinv, StencilParams P, int color)
+                                                             const double* __restrict__ jinv, StencilParams P, int color,
+                                                          const double* __restrict__ phi2)
 {
     // one slot = the largest class's region: FM_J rows of 128, or 16 FM_J rows of 8 + 2 columns
     __shared__ __attribute__((aligned(16))) double SP[FM_S * FM_J * (NARROW ? 160 : 128)];  // phi
@@ -333,9 +351,9 @@ __global__ __launch_bounds__(64 * FM_J, (NARROW && !ZXY && MODE == 1) ? 3 : 1) v
     const Tile t = tiles[blockIdx.x];
     const PatchDesc p = patches[t.patch];
     const int cls = NARROW ? t.pad_[1] : 0;
-    if (!NARROW || cls == 0) full_march_body<MODE, FM_J, ZXY, 0>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color);
-    else if (cls == 1) full_march_body<MODE, FM_J, ZXY, NARROW ? 1 : 0>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color);
-    else full_march_body<MODE, FM_J, ZXY, NARROW ? 4 : 0>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color);
+    if (!NARROW || cls == 0) full_march_body<MODE, FM_J, ZXY, 0>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color, phi2);
+    else if (cls == 1) full_march_body<MODE, FM_J, ZXY, NARROW ? 1 : 0>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color, phi2);
+    else full_march_body<MODE, FM_J, ZXY, NARROW ? 4 : 0>(SP, SE, t, p, out, phi, psi, rhs, J, jinv, P, color, phi2);
 }
 
 int full_march_rows()
@@ -359,12 +377,12 @@ static JgFullM jgfullm(const LevelDev& L)
 // mode 0: out = rhs - L[phi], 1: out = L[phi], 2: one GSRB colour pass.  psi needs to be right only in the one-cell frame of every box.
 template <int MODE>
 static void launch_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out, const double* phi,
-                         const double* psi, const double* rhs, int color)
+                         const double* psi, const double* rhs, int color, const double* phi2 = nullptr, bool narrow = false)
 {
-    const bool six = full_march_rows() == 6, z = L.P.zero_xy != 0, nw = L.narrowq != 0;   // (6-row tables never hold narrow classes)
+    const bool six = full_march_rows() == 6, z = L.P.zero_xy != 0, nw = L.narrowq != 0 || narrow;   // (6-row tables never hold narrow classes)
 #define SOMAR_FM(ROWS, Z, N)                                                                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_full_march<MODE, ROWS, Z, N>), dim3(ntiles), dim3(64, ROWS, 1), 0, st, tiles, L.patches, \
-                       out, phi, psi, rhs, jgfullm(L), L.jinv, L.P, color)
+                       out, phi, psi, rhs, jgfullm(L), L.jinv, L.P, color, phi2)
     if (six) { if (z) SOMAR_FM(6, true, false); else SOMAR_FM(6, false, false); }
     else if (nw) { if (z) SOMAR_FM(8, true, true); else SOMAR_FM(8, false, true); }
     else { if (z) SOMAR_FM(8, true, false); else SOMAR_FM(8, false, false); }
@@ -387,4 +405,16 @@ void launch_gsrb_full_march(hipStream_t st, const Tile* tiles, int ntiles, const
     launch_march<2>(st, tiles, ntiles, L, out, phi, psi, rhs, color);
 }
 
+}  // namespace somar
+
+namespace somar {
+// the black cells of the three outer layers of every box after k_full_fused (full19_fused.hip): in place on phi, their same-colour
+// neighbours from phi_in (the sweep's input); tiles = Level::d_stiles (box faces only, narrow classes on the x faces)
+void launch_gsrb_full_shell(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* phi, const double* phi_in,
+                            const double* psi, const double* rhs)
+{
+    if (ntiles == 0) return;
+    SOMAR_CHECK(full_march_rows() == 8, "internal: the shell pass uses the 8-row marching kernels");
+    launch_march<3>(st, tiles, ntiles, L, phi, phi, psi, rhs, 1, phi_in, true);
+}
 }  // namespace somar

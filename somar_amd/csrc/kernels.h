@@ -46,6 +46,12 @@ void launch_full_march(hipStream_t st, const Tile* tiles, int ntiles, const Leve
 void launch_gsrb_full_march(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out,
                             const double* phi, const double* psi, const double* rhs, int color);
 int full_march_rows();
+// red + black in one launch for the cells three layers inside their box (full19_fused.hip), then -- after the between-colour
+// ghost work on `out` -- the black cells of the outer layers in place (full19_march.hip, MODE 3)
+void launch_full_fused(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* out, const double* phi,
+                       const double* psi, const double* rhs);
+void launch_gsrb_full_shell(hipStream_t st, const Tile* tiles, int ntiles, const LevelDev& L, double* phi, const double* phi_in,
+                            const double* psi, const double* rhs);
 void launch_flux_full(hipStream_t st, const LevelDev& L, double* const out[3], const double* phi, const double* psi);
 void launch_op_full(hipStream_t st, const LevelDev& L, double* out, const double* phi, const double* psi,
                     const double* rhs, int mode);

@@ -493,6 +493,8 @@ Level::~Level()
     hipFree(d_rtiles_rem);
     hipFree(d_rtiles);
     hipFree(d_qtiles);
+    hipFree(d_gtiles);
+    hipFree(d_stiles);
     hipFree(d_ctiles);
     hipFree(d_local_items);
     hipFree(d_red_counter);
@@ -517,7 +519,7 @@ Level::~Level()
 // on the depths whose metric it found uniform; the 19-point tables always use the classes.
 void Level::build_march_tiles(bool narrow7)
 {
-    for (Tile** q : {&d_ftiles, &d_ftiles_own, &d_ftiles_rem, &d_rtiles, &d_rtiles_own, &d_rtiles_rem, &d_qtiles}) {
+    for (Tile** q : {&d_ftiles, &d_ftiles_own, &d_ftiles_rem, &d_rtiles, &d_rtiles_own, &d_rtiles_rem, &d_qtiles, &d_gtiles, &d_stiles}) {
         hipFree(*q);
         *q = nullptr;
     }
@@ -627,6 +629,46 @@ void Level::build_march_tiles(bool narrow7)
     nqtiles = (int)hqtiles.size();
     dev.narrowq = 0;
     for (const Tile& t : hqtiles) if (t.pad_[1]) dev.narrowq = 1;
+    ngtiles = nstiles = 0;
+    if (want_fused19_) {
+        const std::vector<Tile> g = march_tiles(124, 8, 4, 3.0, 256, false);
+        d_gtiles = to_device(g);
+        ngtiles = (int)g.size();
+        // shell pass: per box the two x faces (4-wide class-4 columns, 126 rows each), the two y faces (one 6-row band of class-0
+        // columns each) in k-chunks of 32 planes, and the two z faces (3 planes over every class-0 tile).  The sets overlap at
+        // the box edges: a cell relaxed twice gets the same value twice (its inputs are not written by the pass).
+        std::vector<Tile> sh;
+        const int KC = 32;
+        for (int pi = 0; pi < (int)hpatches.size(); ++pi) {
+            const PatchDesc& p = hpatches[pi];
+            auto add = [&](int i0, int w, int cls, int j0, int k0, int nk) {
+                Tile t;
+                std::memset(&t, 0, sizeof(t));
+                t.patch = pi; t.i0 = i0; t.j0 = j0; t.k0 = k0; t.nk = nk;
+                t.pad_[0] = w; t.pad_[1] = cls;
+                sh.push_back(t);
+            };
+            int wcol = 124;
+            {
+                const int ncol = (p.n[0] + 123) / 124;
+                wcol = (p.n[0] + ncol - 1) / ncol;
+                wcol += wcol & 1;
+                wcol = std::min(wcol, 124);
+            }
+            for (int k0 = 0; k0 < p.n[2]; k0 += KC) {
+                const int nk = std::min(KC, p.n[2] - k0);
+                for (int xi : {0, std::max(0, p.n[0] - 4)})
+                    for (int j0 = 0; j0 < p.n[1]; j0 += 126) add(xi, 4, 4, j0, k0, nk);
+                for (int yj : {0, std::max(0, p.n[1] - 6)})
+                    for (int i0 = 0; i0 < p.n[0]; i0 += wcol) add(i0, wcol, 0, yj, k0, nk);
+            }
+            for (int zk : {0, std::max(0, p.n[2] - 3)})
+                for (int j0 = 0; j0 < p.n[1]; j0 += 6)
+                    for (int i0 = 0; i0 < p.n[0]; i0 += wcol) add(i0, wcol, 0, j0, zk, std::min(3, p.n[2] - zk));
+        }
+        d_stiles = to_device(sh);
+        nstiles = (int)sh.size();
+    }
 
     if (!plan.peers.empty()) {
         // which marching tiles read a ghost cell that arrives from another rank?  The fused sweep reads phi two cells around

@@ -113,6 +113,12 @@ public:
     std::vector<Tile> hqtiles;   // tiles of the k-marching 19-point kernels (full19_march.hip): 124 x (rows - 2) columns
     Tile* d_qtiles = nullptr;
     int nqtiles = 0;
+    // fused red+black 19-point sweep (full19_fused.hip), built when PressureSolver asks (want_fused19_): its 124 x 4 column tiles
+    // and the tiles of the shell pass that follows it (the three outer cell layers of every box)
+    bool want_fused19_ = false;
+    Tile* d_gtiles = nullptr;
+    Tile* d_stiles = nullptr;
+    int ngtiles = 0, nstiles = 0;
     std::vector<Tile> hctiles;   // whole-column tiles (line relaxation): 128 x ctile_j columns, all of k
     Tile* d_ctiles = nullptr;
     int nctiles = 0, ctile_j = 2;

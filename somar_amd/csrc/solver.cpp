@@ -515,6 +515,22 @@ void PressureSolver::finalize()
     detect_uniform_metric();
     detect_zero_planes();
     {
+        // the fused red+black 19-point sweep on levels of large boxes
+        if (const char* e = getenv("SOMAR_FUSED19_MIN_BOX")) fused19_min_box_ = atoi(e);
+        fused19_.assign(lev.size(), 0);
+        for (size_t d = 0; d < lev.size(); ++d) {
+            Level& L = *lev[d];
+            bool ok = full_ && fused19_min_box_ >= 0 && full_march((int)d) && full_march_rows() == 8 && !L.boxes.empty();
+            for (const IBox& b : L.boxes)
+                for (int a = 0; a < 3; ++a) ok = ok && b.size(a) >= std::max(fused19_min_box_, 8) && (a != 0 || b.size(a) % 2 == 0);
+            fused19_[d] = ok ? 1 : 0;
+            if (ok != L.want_fused19_) {
+                L.want_fused19_ = ok;
+                L.build_march_tiles(L.narrow7_);
+            }
+        }
+    }
+    {
         // narrow lane classes for the 7-point marching kernels where the metric is uniform (Level::build_march_tiles says why);
         // SOMAR_NARROW_7PT = 0 | 1 forces never / always (A/B)
         const char* e = getenv("SOMAR_NARROW_7PT");
@@ -748,6 +764,32 @@ void PressureSolver::relax(int d, double* e, const double* res, int iters, bool 
             launch_gsrb_fused(st_, L.d_ftiles, L.nftiles, L.dev, alt, cur, res, mode, e_shift,
                               e_plus_level ? &e_plus_level->dev : nullptr, e_plus, L.mgCrseRefRatio);
             if (profiling_ && d == 0) prof_end(0);
+            std::swap(cur, alt);
+        }
+        if (cur != e) launch_copy(st_, e, cur, L.field_elems);
+        return;
+    }
+    if (prm.relaxMode == RELAX_LEVEL_GSRB && full_march(d) && fused19(d)) {
+        // LevelGSRB::relax with a non-diagonal metric on a level of large boxes: red everywhere and black three layers inside
+        // every box in ONE marching launch (full19_fused.hip), the between-colour ghost work on its output exactly as in the
+        // two-pass form below, then the black cells of the outer layers in place (k_full_march<3>).  Same values, same bits.
+        double* cur = e;
+        double* alt = f_pp[d];
+        for (int it = 0; it < iters; ++it) {
+            L.cf_homog(cur, st_);
+            xchg(L, cur);
+            run_full_program_frames(d, 1, cur);
+            copy_frames(d, cur, alt);
+            if (profiling_ && d == 0) prof_begin(0);
+            launch_full_fused(st_, L.d_gtiles, L.ngtiles, L.dev, alt, cur, f_psi[d], res);
+            if (profiling_ && d == 0) prof_end(0);
+            L.cf_homog(alt, st_);
+            xchg(L, alt);
+            run_full_program_frames(d, 1, alt);
+            if (profiling_ && d == 0) prof_begin(0);   // (slot 0 then holds two launches per sweep, as in the two-pass form)
+            launch_gsrb_full_shell(st_, L.d_stiles, L.nstiles, L.dev, alt, cur, f_psi[d], res);
+            if (profiling_ && d == 0) prof_end(0);
+            ++counters[4];
             std::swap(cur, alt);
         }
         if (cur != e) launch_copy(st_, e, cur, L.field_elems);

@@ -209,7 +209,7 @@ public:
     // bottom-solver state shared with MappedAMRMultiGrid (setConvergenceMetrics)
     double bottom_metric = -1.0, bottom_eps_eff = 1e-6;
     int bottom_iters = 0, bottom_exit = 0;
-    long long counters[4] = {0, 0, 0, 0};   // overlapped sweeps, one-launch ghost programs, staged ghost programs, bottom solves
+    long long counters[5] = {0, 0, 0, 0, 0};   // overlapped sweeps, one-launch ghost programs, staged ghost programs, bottom solves, fused 19-point sweeps
     int bottom_kind = 0;   // how the last bottom solve ran: 0 launch by launch, 1 k_tiny_bicgstab, 2 k_box_bicgstab
     std::vector<std::array<int, 3>> mgRefRatios;
 
@@ -322,6 +322,13 @@ private:
         const Level& L = *lev[d];
         return full_ && L.active[2] && L.valid_cells_global >= march_min_cells_;
     }
+    // ... or, where every box of the level is at least fused19_min_box_ cells wide in every direction, red + black in one launch
+    // plus a shell pass (full19_fused.hip).  OFF by default (negative): measured on one MI355X it loses at every box size --
+    // 512^3 in one box: 9.1 ms (fused) + 0.38 ms (shell) against 2 x 2.85 ms; boxes of 128: 14.9 against 6.6 ms; of 64: 16.0
+    // against 6.0 (profiles/r03_fused19.txt).  SOMAR_FUSED19_MIN_BOX = 0 forces it onto every marching level (tests, A/B).
+    int fused19_min_box_ = -1;
+    std::vector<char> fused19_;   // per depth, decided in finalize
+    bool fused19(int d) const { return d < (int)fused19_.size() && fused19_[d] != 0; }
     std::unique_ptr<PressureSolver> coarse_;   // replicated tail of the hierarchy (agglomeration)
     int agglom_depth_ = -1;
     long long agglom_cells_ = 2097152;  // 128^3: below this a level costs less to replicate (~0.2 ms of sweeps) than to exchange (~8 x 60 us)

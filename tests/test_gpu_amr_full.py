@@ -10,11 +10,14 @@ from helpers import download_valid, make_full_amr_levels, make_gpu_amr, max_rel_
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["direct", "march"])
+@pytest.fixture(autouse=True, params=["direct", "march", "fused"])
 def kernel_path(request, monkeypatch):
     """direct: k_op_full / k_gsrb_full (small levels); march: the k-marching LDS kernels of large levels
     (full19_march.hip, psi kept in the boxes' frames only), forced onto these small cases.  Same bits either way."""
-    monkeypatch.setenv("SOMAR_MARCH_MIN_CELLS", "0" if request.param == "march" else "1000000000000")
+    monkeypatch.setenv("SOMAR_MARCH_MIN_CELLS", "0" if request.param != "direct" else "1000000000000")
+    # fused: red + black in one marching launch three layers inside every box, then a shell pass (full19_fused.hip), forced onto
+    # every level whose boxes are at least 8 cells wide (the default takes it on boxes of 192 and more)
+    monkeypatch.setenv("SOMAR_FUSED19_MIN_BOX", "0" if request.param == "fused" else "-1")
     return request.param
 
 LAYOUTS = [

@@ -85,8 +85,9 @@ def test_c5_small_parity_with_the_oracle(oracle, am, monkeypatch):
         for f in p_.fabs:
             f.a[...] = phi_in[q]
             q += 1
-    for path in ("direct", "march"):
-        monkeypatch.setenv("SOMAR_MARCH_MIN_CELLS", "0" if path == "march" else "1000000000000")
+    for path in ("direct", "march", "fused"):
+        monkeypatch.setenv("SOMAR_MARCH_MIN_CELLS", "0" if path != "direct" else "1000000000000")
+        monkeypatch.setenv("SOMAR_FUSED19_MIN_BOX", "0" if path == "fused" else "-1")   # red + black in one launch + shell pass
         gpu = make_gpu_amr(levels, ratios, full=True)
         try:
             for l, v in enumerate(gpu.levels):

@@ -9,11 +9,14 @@ from helpers import download_valid, max_rel_diff, upload, valid_of
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["direct", "march"])
+@pytest.fixture(autouse=True, params=["direct", "march", "fused"])
 def kernel_path(request, monkeypatch):
     """direct: k_op_full / k_gsrb_full (small levels); march: the k-marching LDS kernels of large levels
     (full19_march.hip, psi kept in the boxes' frames only), forced onto these small cases.  Same bits either way."""
-    monkeypatch.setenv("SOMAR_MARCH_MIN_CELLS", "0" if request.param == "march" else "1000000000000")
+    monkeypatch.setenv("SOMAR_MARCH_MIN_CELLS", "0" if request.param != "direct" else "1000000000000")
+    # fused: red + black in one marching launch three layers inside every box, then a shell pass (full19_fused.hip), forced onto
+    # every level whose boxes are at least 8 cells wide (the default takes it on boxes of 192 and more)
+    monkeypatch.setenv("SOMAR_FUSED19_MIN_BOX", "0" if request.param == "fused" else "-1")
     return request.param
 
 CASES = [
@@ -24,6 +27,8 @@ CASES = [
     # wavefront) + 4 (sixteen); 128 = 124 (one row per wavefront) + 4
     ((64, 8, 8), (64, 8, 8), (False, True, False), (2.0, 1.0, 0.5)),
     ((128, 6, 4), (128, 6, 4), (True, False, False), (4.0, 1.0, 0.5)),
+    # boxes with cells more than three layers inside them (the fused red+black kernel's own black updates)
+    ((32, 16, 16), (16, 16, 16), (False, True, False), (2.0, 1.0, 1.0)),
 ]
 
 
@@ -48,7 +53,7 @@ def _setup(so, case, **kw):
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_full_operator_and_gsrb_bit_exact(oracle, case):
+def test_full_operator_and_gsrb_bit_exact(oracle, case, kernel_path):
     from somar_amd import api as F
     so = oracle
     dom, grids, fac, gpu = _setup(so, case)
@@ -70,9 +75,14 @@ def test_full_operator_and_gsrb_bit_exact(oracle, case):
             for a, b in zip(download_valid(gpu, fs, g, d), valid_of(res)):
                 np.testing.assert_array_equal(a, b)
             op.relax(phi, rhs, 2)
+            n_fused = gpu.fused19Sweeps()
             gpu.relax(d, fc, fr, 2)
             for a, b in zip(download_valid(gpu, fc, g, d), valid_of(phi)):
                 np.testing.assert_array_equal(a, b)
+            if kernel_path == "fused" and all(min(b_.size()) >= 8 and b_.size()[0] % 2 == 0 for b_ in g):
+                assert gpu.fused19Sweeps() == n_fused + 2     # the path under test is the one that ran
+            else:
+                assert gpu.fused19Sweeps() == n_fused
     finally:
         gpu.undefine()
 
@@ -152,9 +162,14 @@ def test_2d_full_operator_and_gsrb_bit_exact(oracle, case):
             for a, b in zip(download_valid(gpu, fs, g, d), valid_of(res)):
                 np.testing.assert_array_equal(a, b)
             op.relax(phi, rhs, 2)
+            n_fused = gpu.fused19Sweeps()
             gpu.relax(d, fc, fr, 2)
             for a, b in zip(download_valid(gpu, fc, g, d), valid_of(phi)):
                 np.testing.assert_array_equal(a, b)
+            if kernel_path == "fused" and all(min(b_.size()) >= 8 and b_.size()[0] % 2 == 0 for b_ in g):
+                assert gpu.fused19Sweeps() == n_fused + 2     # the path under test is the one that ran
+            else:
+                assert gpu.fused19Sweeps() == n_fused
     finally:
         gpu.undefine()
 

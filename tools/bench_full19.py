@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--path", default="march", choices=["march", "direct"])
     ap.add_argument("--metric", default="sheared", choices=["sheared", "bathy"],
                     help="bathy: BathymetricBaseMap of a bump, produced on the device (no host arrays)")
+    ap.add_argument("--box", type=int, default=0, help="cut the n^3 domain into boxes of this many cells per side (default: one box)")
     args = ap.parse_args()
     if args.path == "direct":
         os.environ["SOMAR_MARCH_MIN_CELLS"] = "1000000000000"
@@ -74,8 +75,11 @@ def main():
     p = s._p
     s.setAMRMGParameters(p.imin, p.imax, p.eps, -1, p.num_smooth_precond, 2, 2, 2, p.precond_mode, 1, p.num_mg, p.hang,
                          p.norm_thresh, 0)
-    s.define((0, 0, 0), (n - 1,) * 3, (False, False, False), dx, [((0, 0, 0), (n - 1,) * 3)])
+    bs = args.box or n
+    boxes = [((i, j, k), (i + bs - 1, j + bs - 1, k + bs - 1)) for k in range(0, n, bs) for j in range(0, n, bs) for i in range(0, n, bs)]
+    s.define((0, 0, 0), (n - 1,) * 3, (False, False, False), dx, boxes)
     if args.metric == "sheared":
+        assert len(boxes) == 1, "--box needs --metric bathy (the map is evaluated per box on the device)"
         s.setMetricFull(0, jg[0], jg[1], jg[2], jinv)
         del jg, jinv
     else:
@@ -116,7 +120,7 @@ def main():
     cells = n ** 3
     pass_ms = ms_g / max(n_g, 1)
     res_ms = ms_r / max(n_r, 1)
-    out = {"n": n, "path": args.path, "metric": args.metric, "rows": os.environ.get("SOMAR_FULL_ROWS", "8"), "cells": cells, "metric_seconds": t_metric, "mg_depth": s.depth(),
+    out = {"n": n, "box": bs, "fused19_sweeps": s.fused19Sweeps(), "path": args.path, "metric": args.metric, "rows": os.environ.get("SOMAR_FULL_ROWS", "8"), "cells": cells, "metric_seconds": t_metric, "mg_depth": s.depth(),
            "gsrb_colour_pass_ms": pass_ms, "gsrb_sweep_kernel_ms": 2 * pass_ms, "residual_kernel_ms": res_ms,
            "gsrb_sweep_wall_ms": t_sweep * 1e3, "residual_wall_ms": t_res * 1e3,
            "gsrb_sweep_alg_GBs": 120.0 * cells / (2 * pass_ms * 1e-3) / 1e9,
