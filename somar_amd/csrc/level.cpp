@@ -525,7 +525,6 @@ void Level::build_march_tiles(bool narrow7)
     }
     nftiles_own = nftiles_rem = nrtiles_own = nrtiles_rem = 0;
     narrow7_ = narrow7;
-    dev.narrow7 = narrow7 ? 1 : 0;
     // ---- tiles of the k-marching kernels: (FT_I x FT_J) columns, k split into chunks so that the launch
     // fills the 256 CUs evenly (one 1024-thread workgroup per CU at a time); `halo` = planes a chunk reads
     // beyond its own (fused red-black sweep: 3, marching residual: 2) ----------------------------------
@@ -621,6 +620,10 @@ void Level::build_march_tiles(bool narrow7)
     for (size_t q = 0; q < hrtiles.size(); ++q) hrtiles[q].pad_[2] = (int)q;   // its slot in per-tile partial sums (k_resid_march<2>)
     d_rtiles = to_device(hrtiles);
     nrtiles = (int)hrtiles.size();
+    // the three-body instantiation of the fused sweep only where the table really holds a narrow tile (on class-0 tiles alone it
+    // is the slower kernel: c2_cartesian 151 -> 140 V-cycles/s)
+    dev.narrow7 = 0;
+    for (const Tile& t : hftiles) if (t.pad_[1]) dev.narrow7 = 1;
     // every table: narrow classes where they save at least 15 % of the workgroup-marches (64-wide boxes: C5 62.8 -> 53.1 ms per
     // AMR V-cycle; 128-wide: C4 136.8 -> 111.6).  One 512-wide box, 5 equal columns against 4 + 4 narrow, is a wash or worse:
     // 19-point colour pass 3.02 -> 3.07 ms, residual 3.17 -> 3.42; c2_cartesian 151 -> 149-158 V-cycles/s depending on tile order)
