@@ -435,9 +435,12 @@ def main():
     achieved = b_launch * cells_local / t_gsrb / 1e9
     t_sweep = t_gsrb if fused else 2 * t_gsrb
     traffic = None
+    traffic_src = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf) and n == N_FINE and world == 1:
-        traffic = json.load(open(tf)).get("k_gsrb_fused_bytes_per_launch" if fused else "k_gsrb_ortho_bytes_per_launch")
+        tj = json.load(open(tf))
+        traffic = tj.get("k_gsrb_fused_bytes_per_launch" if fused else "k_gsrb_ortho_bytes_per_launch")
+        traffic_src = tj.get("source")
     unit_t = t_sweep + t_op                       # one red+black sweep + one residual (north-star unit)
     out = {
         "metric": "pressure-Poisson V-cycles/sec", "value": value, "unit": "V-cycles/s", "n_gpus": world,
@@ -450,8 +453,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/traffic.json: HBM bytes per launch of this kernel from separate rocprofv3 --pmc "
-                                       "FETCH_SIZE / WRITE_SIZE passes of an EARLIER run (round 2, same kernel source); cited, "
-                                       "not measured in this run",
+                                       "FETCH_SIZE / WRITE_SIZE passes of an EARLIER run of this bench command (%s); cited, "
+                                       "not measured in this run" % (traffic_src or "see the file's note"),
                      "algorithmic_bytes_per_launch": b_launch * cells_local, "launches": n_gsrb,
                      "avg_launch_ms": t_gsrb * 1e3, "measured_copy_GBs": copy_gbs,
                      "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,

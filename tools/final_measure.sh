@@ -27,4 +27,11 @@ for cnt in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/prof_summary.py pmc $o/pmc_FETCH_SIZE $o/pmc_WRITE_SIZE $o/${tag}_full19_pmc_traffic_raw.json $((384*384*384)) "k_full_march<0,k_full_march<2,k_ghost_ops" > /dev/null
 rm -rf $o/pmc_FETCH_SIZE $o/pmc_WRITE_SIZE
+# the same two passes over the bench command: HBM bytes per launch of the headline kernels (profiles/traffic.json is written from this)
+for cnt in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $o/pmcb_$cnt
+  rocprofv3 --pmc $cnt -d $o/pmcb_$cnt -o pmc --output-format csv -- python3 bench.py --no-c4 --no-c5 --no-cpu-baseline --no-cartesian --steps 3 --warmup 1 > $o/${tag}_pmcb_$cnt.log 2>&1
+done
+python3 tools/prof_summary.py pmc $o/pmcb_FETCH_SIZE $o/pmcb_WRITE_SIZE $o/${tag}_c2_pmc_traffic_raw.json $((512*512*512)) > /dev/null
+rm -rf $o/pmcb_FETCH_SIZE $o/pmcb_WRITE_SIZE
 ls $o | grep $tag
