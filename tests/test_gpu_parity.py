@@ -290,6 +290,8 @@ _ORACLE_SOLVES = {}   # (case, smooth) -> the oracle's solve: shared by the two 
 @pytest.mark.parametrize("case", CASES[:6])   # (the 128 x 8 x 8 bar: its kernels are covered above)
 @pytest.mark.parametrize("smooth", [(2, 2, 2), (4, 4, 2)])
 def test_full_solve_history_matches(oracle, case, smooth, gsrb_mode):
+    if gsrb_mode == "fused-narrow" and case not in (CASES[1], CASES[5]):
+        pytest.skip("the narrow lane classes are covered kernel by kernel above; whole solves run them on two of the cases")
     so = oracle
     pre, post, bottom = smooth
     n, boxsz, variant, periodic, L = case
