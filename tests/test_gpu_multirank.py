@@ -98,7 +98,9 @@ def _worker(rank, nranks, name, mode, q):
         if mode == "fused":
             # ---- exchange / compute overlap: boxes large enough to have tiles that read no remote ghost cell; the sweeps'
             #      exchanges travel on the second stream under those tiles (fused_overlap, solver.cpp).  Same bits.
-            dom, grids, dx, Jgup, Jinv = make_problem(so, (64, 32 * nranks, 32), (64, 32, 32), "stretched", (False, True, False),
+            # (64 rows per box: with two region rows per wavefront a class-1 tile is 28 rows tall, and one of them must lie between the
+            # two y faces)
+            dom, grids, dx, Jgup, Jinv = make_problem(so, (64, 64 * nranks, 32), (64, 64, 32), "stretched", (False, True, False),
                                                       (2.0, 1.0, 1.0))
             assert len(grids) == nranks
             owner = list(range(nranks))
@@ -108,12 +110,18 @@ def _worker(rank, nranks, name, mode, q):
             op.relax(phi, rhs, 3)
             cres = op.create_coarser(rhs)
             op.restrict_residual(cres, phi, rhs)
-            os.environ["SOMAR_MARCH_MIN_CELLS"] = "1"     # the k-marching residual + restriction on this 64 x 64 x 32 level
-            for overlap in (True, False):
+            os.environ["SOMAR_MARCH_MIN_CELLS"] = "1"     # the k-marching residual + restriction on this level
+            # (narrow: the tile tables hold the narrow lane classes -- 64 = 60 + 4 columns -- so the split into tiles that read no
+            # remote ghost cell and the rest sees tiles of every class)
+            for overlap, narrow in ((True, False), (False, False), (True, True)):
                 if overlap:
                     os.environ.pop("SOMAR_NO_OVERLAP", None)
                 else:
                     os.environ["SOMAR_NO_OVERLAP"] = "1"
+                if narrow:
+                    os.environ["SOMAR_NARROW_7PT"] = "1"
+                else:
+                    os.environ.pop("SOMAR_NARROW_7PT", None)
                 g2 = make_gpu_solver(dom, grids, dx, Mine(Jgup), Mine(Jinv), owner=owner, comm=comm)
                 p0 = so.random_field(grids, 13, (1, 1, 1), dom.box)
                 upload(g2, F.F_PHI, p0)
@@ -126,6 +134,7 @@ def _worker(rank, nranks, name, mode, q):
                 mine(download_valid(g2, F.FIELD(1, F.F_RES), cres.grids, 1), valid_of(cres), "residual + restriction")
                 g2.undefine()
             os.environ.pop("SOMAR_NO_OVERLAP", None)
+            os.environ.pop("SOMAR_NARROW_7PT", None)
             os.environ.pop("SOMAR_MARCH_MIN_CELLS", None)
 
         if nranks != 2:
