@@ -178,6 +178,7 @@ void AMRSolver::build_link(int l)
     K->resC = K->cfl->alloc_field();
     const int g2[3] = {2, 2, 2}, g0[3] = {0, 0, 0};
     K->gather.define(C.domain, C.periodic, C, *K->cfl, g2, comm_);
+    K->gather_ring.define(C.domain, C.periodic, C, *K->cfl, g2, comm_, true);
     K->scatter.define(C.domain, C.periodic, *K->cfl, C, g0, comm_);
     // zeroCovered: the coarse cells under the fine level
     std::vector<FillItem> cover;
@@ -706,7 +707,10 @@ void AMRSolver::interp_cf(int l, double* phiFine, const double* phiCoarse, bool 
     Level& F = S[l]->level(0);
     double dxc[3];
     for (int d = 0; d < 3; ++d) dxc[d] = F.dx[d] * (double)K.r[d];  // m_dxCrse of MappedQuadCFInterp::define
-    K.gather.run(phiCoarse, K.buf, st_);
+    // MappedQuadCFInterp copies the coarse data onto the whole coarsened-fine layout and reads its ghost ring; here only the ring
+    // travels (the stencils' points, K.d_pts / K.d_cc, all lie outside the coarsened fine boxes)
+    static const bool full_gather = getenv("SOMAR_CF_FULL_GATHER") != nullptr;
+    (full_gather ? K.gather : K.gather_ring).run(phiCoarse, K.buf, st_);
     launch_cf_slopes(st_, K.d_cc, K.ncc, K.d_pts, K.buf, K.d_der, dxc);
     launch_cf_quad(st_, K.d_fc, K.nfc, K.d_cc, K.d_der, K.buf, phiFine, F.dx, dxc, K.r);
     if (ev) S[l]->cf_ev(0, phiFine);  // ExtrapolateCFEV: non-diagonal metric only (interpCFGhosts, MappedAMRPoissonOp.cpp:2193-2216)

@@ -104,6 +104,8 @@ struct AMRLink {
     double* buf = nullptr;       // coarse values under and around the fine boxes (2 ghosts)
     double* resC = nullptr;      // restricted fine residual
     Copier gather;               // coarse level -> buf (valid + 2 ghosts, periodic)
+    Copier gather_ring;          // the same onto the 2-cell ring around each coarsened fine box only: all the coarse-fine
+                                 // interpolation reads (a 64 x 64 x 128 box: 86 K of 610 K cells; SOMAR_CF_FULL_GATHER=1: A/B)
     Copier scatter;              // resC valid -> coarse level valid
     // quadratic CF interpolation
     bool hasCF = false;          // false: the fine level covers the whole domain

@@ -292,7 +292,7 @@ void Level::define_cf(const double dxCrse[3])
 // same order, so the i-th item of a send message is the i-th item of the matching receive message.
 ExchangePlan build_copy_plan(const IBox& domain, const bool periodic[3], const std::vector<IBox>& srcBoxes,
                              const std::vector<int>& srcOwner, const std::vector<IBox>& dstBoxes,
-                             const std::vector<int>& dstOwner, const int ghost[3], int myrank)
+                             const std::vector<int>& dstOwner, const int ghost[3], int myrank, bool ring_only)
 {
     ExchangePlan plan;
     const auto shifts = periodic_shifts(domain, periodic);
@@ -304,20 +304,39 @@ ExchangePlan build_copy_plan(const IBox& domain, const bool periodic[3], const s
             const bool dl = dstOwner[di] == myrank, sl = srcOwner[si] == myrank;
             if (!dl && !sl) continue;
             for (const auto& sh : shifts) {
-                const IBox r = gbox & srcBoxes[si].shift(sh.data());
-                if (r.empty()) continue;
-                CopyItem it;
-                std::memset(&it, 0, sizeof(it));
-                it.src_patch = (int)si;
-                it.dst_patch = (int)di;
-                for (int d = 0; d < 3; ++d) {
-                    it.n[d] = r.size(d);
-                    it.dst_lo[d] = r.lo[d] - dstBoxes[di].lo[d];
-                    it.src_lo[d] = r.lo[d] - sh[d] - srcBoxes[si].lo[d];
+                const IBox r0 = gbox & srcBoxes[si].shift(sh.data());
+                if (r0.empty()) continue;
+                // ring_only: the part of the region outside the destination box (its ghost ring), as up to six slabs in a fixed
+                // order -- every rank derives the same pieces, so sends and receives still pair up
+                std::vector<IBox> pieces;
+                if (!ring_only) pieces.push_back(r0);
+                else {
+                    IBox rest = r0;
+                    const IBox& V = dstBoxes[di];
+                    for (int d = 2; d >= 0 && !rest.empty(); --d) {
+                        IBox lo = rest, hi = rest;
+                        lo.hi[d] = std::min(rest.hi[d], V.lo[d] - 1);
+                        hi.lo[d] = std::max(rest.lo[d], V.hi[d] + 1);
+                        if (!lo.empty()) pieces.push_back(lo);
+                        if (!hi.empty()) pieces.push_back(hi);
+                        rest.lo[d] = std::max(rest.lo[d], V.lo[d]);
+                        rest.hi[d] = std::min(rest.hi[d], V.hi[d]);
+                    }
                 }
-                if (dl && sl) plan.local.push_back(it);
-                else if (sl) sends.push_back({dstOwner[di], it});
-                else recvs.push_back({srcOwner[si], it});
+                for (const IBox& r : pieces) {
+                    CopyItem it;
+                    std::memset(&it, 0, sizeof(it));
+                    it.src_patch = (int)si;
+                    it.dst_patch = (int)di;
+                    for (int d = 0; d < 3; ++d) {
+                        it.n[d] = r.size(d);
+                        it.dst_lo[d] = r.lo[d] - dstBoxes[di].lo[d];
+                        it.src_lo[d] = r.lo[d] - sh[d] - srcBoxes[si].lo[d];
+                    }
+                    if (dl && sl) plan.local.push_back(it);
+                    else if (sl) sends.push_back({dstOwner[di], it});
+                    else recvs.push_back({srcOwner[si], it});
+                }
             }
         }
     }
@@ -352,13 +371,13 @@ Copier::~Copier()
 }
 
 void Copier::define(const IBox& domain, const bool periodic[3], const Level& src, const Level& dst, const int ghost[3],
-                    Comm* comm)
+                    Comm* comm, bool ring_only)
 {
     src_ = &src;
     dst_ = &dst;
     comm_ = comm;
     for (int d = 0; d < 3; ++d) SOMAR_CHECK(ghost[d] <= FRAME, "copier ghost wider than the device frame");
-    plan = build_copy_plan(domain, periodic, src.boxes, src.owner, dst.boxes, dst.owner, ghost, comm ? comm->rank : 0);
+    plan = build_copy_plan(domain, periodic, src.boxes, src.owner, dst.boxes, dst.owner, ghost, comm ? comm->rank : 0, ring_only);
     std::vector<int> sp(src.boxes.size(), -1), dp(dst.boxes.size(), -1);
     for (int pi = 0; pi < (int)src.local.size(); ++pi) sp[src.local[pi]] = pi;
     for (int pi = 0; pi < (int)dst.local.size(); ++pi) dp[dst.local[pi]] = pi;
@@ -380,7 +399,7 @@ void Copier::define_faces(const IBox& domain, const bool periodic[3], const Leve
     comm_ = comm;
     std::vector<IBox> fb = L.boxes;
     for (IBox& b : fb) b.hi[dir] += 1;
-    plan = build_copy_plan(domain, periodic, fb, L.owner, L.boxes, L.owner, ghost, comm ? comm->rank : 0);
+    plan = build_copy_plan(domain, periodic, fb, L.owner, L.boxes, L.owner, ghost, comm ? comm->rank : 0, false);
     std::vector<int> lp(L.boxes.size(), -1);
     for (int pi = 0; pi < (int)L.local.size(); ++pi) lp[L.local[pi]] = pi;
     for (CopyItem& it : plan.local) { it.src_patch = lp[it.src_patch]; it.dst_patch = lp[it.dst_patch]; }

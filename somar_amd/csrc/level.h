@@ -216,8 +216,9 @@ public:
 class Copier {
 public:
     ~Copier();
+    // ring_only: only the part of each destination box's grown region that lies OUTSIDE the box (its ghost ring)
     void define(const IBox& domain, const bool periodic[3], const Level& src, const Level& dst, const int ghost[3],
-                Comm* comm);
+                Comm* comm, bool ring_only = false);
     void define_allgather(const Level& src, const Level& dst, int grow, Comm* comm);
     void define_faces(const IBox& domain, const bool periodic[3], const Level& L, int dir, const int ghost[3],
                       Comm* comm);
@@ -236,7 +237,7 @@ private:
 
 ExchangePlan build_copy_plan(const IBox& domain, const bool periodic[3], const std::vector<IBox>& srcBoxes,
                              const std::vector<int>& srcOwner, const std::vector<IBox>& dstBoxes,
-                             const std::vector<int>& dstOwner, const int ghost[3], int myrank);
+                             const std::vector<int>& dstOwner, const int ghost[3], int myrank, bool ring_only = false);
 // every rank gets every box (grown): items carry GLOBAL box indices on both sides
 ExchangePlan build_allgather_plan(const std::vector<IBox>& boxes, const std::vector<int>& owner, int grow, int myrank,
                                   int nranks);
