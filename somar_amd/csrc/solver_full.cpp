@@ -143,10 +143,103 @@ static std::vector<std::vector<GhostOp>> schedule_stages(const std::vector<std::
     return stages;
 }
 
+// Dead ops of a FRAME program (the marching kernels' form: psi is read in the boxes' one-cell frames only, and "psi" inside a box
+// is phi).  The reference's sequence writes some regions more than once before anything reads them -- on a box under a Neumann
+// wall the smoother's own order-1 extrapolation of the whole ghost face is overwritten by the order-2 extrapolation the Neumann
+// ghost wants, and the copy of the first valid layer into psi lands where nobody looks -- and each such op is a launch (a stage)
+// on a large level.  Backward liveness over the cells of each box's FAB: at the end phi is live everywhere, psi in the frame only;
+// an op none of whose cells is live is dropped; a kept op kills what it writes and revives what it reads.  Same final values.
+namespace {
+struct ReadOff { int o[3]; int field; };
+void reads_offsets(const GhostOp& op, std::vector<ReadOff>& rd)
+{
+    rd.clear();
+    if (op.type == GHOST_COPY) rd.push_back({{0, 0, 0}, op.srcf});
+    else if (op.type == GHOST_EXTRAP || op.type == GHOST_DIRI) {
+        const int far = op.type == GHOST_DIRI ? 1 : (op.order == 2 ? 3 : (op.order == 1 ? 2 : 1));
+        for (int k = 1; k <= far; ++k) {
+            ReadOff r{{0, 0, 0}, op.srcf};
+            r.o[op.dir] = -op.sgn * k;
+            rd.push_back(r);
+        }
+    } else {  // GHOST_NEUM: psi on the ghost layer and the first valid layer, one cell wider tangentially; phi on the valid layer
+        const int a = op.dir, b = (a + 1) % 3, c = (a + 2) % 3;
+        for (int da = 0; da < 2; ++da)
+            for (int tb = -1; tb <= 1; ++tb)
+                for (int tc = -1; tc <= 1; ++tc) {
+                    ReadOff r{{0, 0, 0}, 1};
+                    r.o[a] = da ? -op.sgn : 0;
+                    r.o[b] = tb;
+                    r.o[c] = tc;
+                    rd.push_back(r);
+                }
+        ReadOff v{{0, 0, 0}, 0};
+        v.o[a] = -op.sgn;
+        rd.push_back(v);
+    }
+}
+}  // namespace
+
+static void drop_dead_frame_ops(const Level& L, std::vector<std::vector<GhostOp>>& perPatch)
+{
+    std::vector<ReadOff> rd;
+    for (int pi = 0; pi < L.npatches(); ++pi) {
+        const IBox valid = L.boxes[L.local[pi]];
+        // the FAB grown once more: reads may reach one cell beyond it (they are clipped away below)
+        int n[3], g[3];
+        for (int d = 0; d < 3; ++d) { g[d] = L.active[d] ? 1 : 0; n[d] = valid.size(d) + 2 * g[d]; }
+        const long long tot = (long long)n[0] * n[1] * n[2];
+        auto inside = [&](int i, int j, int k) {   // local coordinates relative to the valid low corner
+            return i >= -g[0] && i < n[0] - g[0] && j >= -g[1] && j < n[1] - g[1] && k >= -g[2] && k < n[2] - g[2];
+        };
+        auto at = [&](int i, int j, int k) { return (long long)(i + g[0]) + (long long)n[0] * ((j + g[1]) + (long long)n[1] * (k + g[2])); };
+        std::vector<char> live[2];
+        live[0].assign(tot, 1);                    // phi: anything may be read later
+        live[1].assign(tot, 0);                    // psi: the frame only
+        for (int k = -g[2]; k < n[2] - g[2]; ++k)
+            for (int j = -g[1]; j < n[1] - g[1]; ++j)
+                for (int i = -g[0]; i < n[0] - g[0]; ++i) {
+                    const bool in_valid = i >= 0 && i < valid.size(0) && j >= 0 && j < valid.size(1) && k >= 0 && k < valid.size(2);
+                    if (!in_valid) live[1][at(i, j, k)] = 1;
+                }
+        std::vector<GhostOp>& ops = perPatch[pi];
+        std::vector<char> keep(ops.size(), 1);
+        for (size_t q = ops.size(); q-- > 0;) {
+            const GhostOp& op = ops[q];
+            const int wf = (op.type == GHOST_NEUM || op.type == GHOST_DIRI) ? 0 : op.dstf;
+            bool any = false;
+            for (int k = op.lo[2]; k < op.lo[2] + op.n[2] && !any; ++k)
+                for (int j = op.lo[1]; j < op.lo[1] + op.n[1] && !any; ++j)
+                    for (int i = op.lo[0]; i < op.lo[0] + op.n[0]; ++i)
+                        if (inside(i, j, k) && live[wf][at(i, j, k)]) { any = true; break; }
+            if (!any) { keep[q] = 0; continue; }
+            reads_offsets(op, rd);
+            // kill first (an op never reads what it writes), then revive the inputs
+            for (int k = op.lo[2]; k < op.lo[2] + op.n[2]; ++k)
+                for (int j = op.lo[1]; j < op.lo[1] + op.n[1]; ++j)
+                    for (int i = op.lo[0]; i < op.lo[0] + op.n[0]; ++i)
+                        if (inside(i, j, k)) live[wf][at(i, j, k)] = 0;
+            for (const ReadOff& r : rd)
+                for (int k = op.lo[2]; k < op.lo[2] + op.n[2]; ++k)
+                    for (int j = op.lo[1]; j < op.lo[1] + op.n[1]; ++j)
+                        for (int i = op.lo[0]; i < op.lo[0] + op.n[0]; ++i) {
+                            const int a = i + r.o[0], b = j + r.o[1], c = k + r.o[2];
+                            if (!inside(a, b, c)) continue;
+                            // a read of psi inside the box is a read of phi (k_ghost_ops<true>)
+                            const bool in_valid = a >= 0 && a < valid.size(0) && b >= 0 && b < valid.size(1) && c >= 0 && c < valid.size(2);
+                            live[(r.field == 1 && in_valid) ? 0 : r.field][at(a, b, c)] = 1;
+                        }
+        }
+        std::vector<GhostOp> kept;
+        for (size_t q = 0; q < ops.size(); ++q) if (keep[q]) kept.push_back(ops[q]);
+        ops.swap(kept);
+    }
+}
+
 // Programs of one level.  which = 0: operator (fillExtrap order 2, then the Neumann ghosts of phi);
 // which = 1: smoother (extrapolation order 1 from the domain box, then the Neumann ghosts of phi).
 // The leading full copy psi := phi is done by the caller with one flat copy.
-static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which, const double bcv[3][2])
+static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which, const double bcv[3][2], bool frames = false)
 {
     std::vector<std::vector<GhostOp>> perPatch(L.npatches());
     if (which == 3) {
@@ -253,6 +346,8 @@ static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which
             }
         }
     }
+    static const bool dce = getenv("SOMAR_NO_GHOST_DCE") == nullptr;   // A/B switch
+    if (frames && dce) drop_dead_frame_ops(L, perPatch);
     return schedule_stages(perPatch);
 }
 
@@ -372,7 +467,7 @@ void PressureSolver::build_full_programs(int d)
         if (which == 3 && !hasCF_) continue;
         if (which >= 4 && !full_march(d)) continue;   // [4] / [5]: [0] / [1] for the marching kernels (psi in frames only)
         FullProgram& P = full_prog_[d][which];
-        auto stages = build_program(L, which >= 4 ? which - 4 : which, bc_value_);
+        auto stages = build_program(L, which >= 4 ? which - 4 : which, bc_value_, which >= 4);
         if (which >= 4) stages.insert(stages.begin(), frame_copy_stage(L));
         upload_program(P, stages, L.npatches());
     }
