@@ -143,11 +143,12 @@ static std::vector<std::vector<GhostOp>> schedule_stages(const std::vector<std::
     return stages;
 }
 
-// Dead ops of a FRAME program (the marching kernels' form: psi is read in the boxes' one-cell frames only, and "psi" inside a box
-// is phi).  The reference's sequence writes some regions more than once before anything reads them -- on a box under a Neumann
+// Dead ops of a program.  (Frame programs -- the marching kernels' form -- read psi in the boxes' one-cell frames only, and "psi"
+// inside a box is phi; the other programs leave all of psi to the direct kernels.)  The reference's sequence writes some regions more than once before anything reads them -- on a box under a Neumann
 // wall the smoother's own order-1 extrapolation of the whole ghost face is overwritten by the order-2 extrapolation the Neumann
 // ghost wants, and the copy of the first valid layer into psi lands where nobody looks -- and each such op is a launch (a stage)
-// on a large level.  Backward liveness over the cells of each box's FAB: at the end phi is live everywhere, psi in the frame only;
+// on a large level.  Backward liveness over the cells of each box's FAB: at the end phi is live everywhere, psi in the frame only
+// (frame programs) or everywhere;
 // an op none of whose cells is live is dropped; a kept op kills what it writes and revives what it reads.  Same final values.
 namespace {
 struct ReadOff { int o[3]; int field; };
@@ -180,7 +181,7 @@ void reads_offsets(const GhostOp& op, std::vector<ReadOff>& rd)
 }
 }  // namespace
 
-static void drop_dead_frame_ops(const Level& L, std::vector<std::vector<GhostOp>>& perPatch)
+static void drop_dead_ops(const Level& L, std::vector<std::vector<GhostOp>>& perPatch, bool frames)
 {
     std::vector<ReadOff> rd;
     for (int pi = 0; pi < L.npatches(); ++pi) {
@@ -195,8 +196,8 @@ static void drop_dead_frame_ops(const Level& L, std::vector<std::vector<GhostOp>
         auto at = [&](int i, int j, int k) { return (long long)(i + g[0]) + (long long)n[0] * ((j + g[1]) + (long long)n[1] * (k + g[2])); };
         std::vector<char> live[2];
         live[0].assign(tot, 1);                    // phi: anything may be read later
-        live[1].assign(tot, 0);                    // psi: the frame only
-        for (int k = -g[2]; k < n[2] - g[2]; ++k)
+        live[1].assign(tot, frames ? 0 : 1);       // psi: the frame only (frame programs) / everything (the direct kernels read it all)
+        for (int k = -g[2]; frames && k < n[2] - g[2]; ++k)
             for (int j = -g[1]; j < n[1] - g[1]; ++j)
                 for (int i = -g[0]; i < n[0] - g[0]; ++i) {
                     const bool in_valid = i >= 0 && i < valid.size(0) && j >= 0 && j < valid.size(1) && k >= 0 && k < valid.size(2);
@@ -227,7 +228,7 @@ static void drop_dead_frame_ops(const Level& L, std::vector<std::vector<GhostOp>
                             if (!inside(a, b, c)) continue;
                             // a read of psi inside the box is a read of phi (k_ghost_ops<true>)
                             const bool in_valid = a >= 0 && a < valid.size(0) && b >= 0 && b < valid.size(1) && c >= 0 && c < valid.size(2);
-                            live[(r.field == 1 && in_valid) ? 0 : r.field][at(a, b, c)] = 1;
+                            live[(frames && r.field == 1 && in_valid) ? 0 : r.field][at(a, b, c)] = 1;
                         }
         }
         std::vector<GhostOp> kept;
@@ -347,7 +348,7 @@ static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which
         }
     }
     static const bool dce = getenv("SOMAR_NO_GHOST_DCE") == nullptr;   // A/B switch
-    if (frames && dce) drop_dead_frame_ops(L, perPatch);
+    if (dce) drop_dead_ops(L, perPatch, frames);
     return schedule_stages(perPatch);
 }
 
