@@ -309,7 +309,7 @@ private:
     // per depth: [0] operator, [1] smoother, [2] fillExtrap alone (getFlux of the flux register), [3] ExtrapolateCFEV
     FullProgram aux_prog_[2];
     bool aux_built_[2] = {false, false};
-    std::vector<std::array<FullProgram, 6>> full_prog_;   // + [4] / [5]: [0] / [1] writing psi in the boxes' frames only (marching kernels)
+    std::vector<std::array<FullProgram, 7>> full_prog_;   // + [4] / [5]: [0] / [1] writing psi in the boxes' frames only (marching kernels); [6]: the plain frame copy (copy_frames)
     double* f_flux[3] = {nullptr, nullptr, nullptr};  // face fluxes of depth 0 (refluxing with a non-diagonal metric)
     void alloc_full_metric(Level& L);
     void build_full_programs(int d);

@@ -309,6 +309,24 @@ static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which
     for (int pi = 0; pi < L.npatches(); ++pi) {
         const IBox valid = L.boxes[L.local[pi]];
         Builder B{valid, valid.grow(g1), pi, perPatch[pi]};
+        if (frames) {
+            // the frame copy psi := phi as the FIRST ops of the box, cut into the frame's 26 pieces (faces, edges, corners): the
+            // pieces a later op overwrites before anything reads them are dead (drop_dead_ops), the others conflict with nothing
+            // and share the first launch with the first real ops -- no launch of its own for the copy
+            const IBox fab = valid.grow(g1);
+            for (int c = 0; c < 27; ++c) {
+                const int t[3] = {c % 3, (c / 3) % 3, c / 9};   // 0: low ghost layer, 1: valid range, 2: high ghost layer
+                if (t[0] == 1 && t[1] == 1 && t[2] == 1) continue;
+                IBox piece = valid;
+                bool ok = true;
+                for (int d = 0; d < 3; ++d) {
+                    if (t[d] == 1) continue;
+                    if (!L.active[d]) { ok = false; break; }
+                    piece.lo[d] = piece.hi[d] = t[d] == 0 ? valid.lo[d] - 1 : valid.hi[d] + 1;
+                }
+                if (ok) B.push(GHOST_COPY, piece & fab, 0, 0, 0, 1, 0);
+            }
+        }
         if (which == 0 || which == 2) {
             IBox validPhi = B.fab & validDomain;
             for (int fdir = 0; fdir < 3; ++fdir) {
@@ -352,8 +370,8 @@ static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which
     return schedule_stages(perPatch);
 }
 
-// Stage 0 of a frame-only program: psi := phi in the one-cell frame of every box (all six slabs of all boxes in ONE
-// launch: they overlap only in edge / corner cells, where they write the same values).
+// copy_frames: psi := phi in the one-cell frame of every box (all six slabs of all boxes in ONE launch: they overlap only in
+// edge / corner cells, where they write the same values).  (The frame programs carry their own copy, piece by piece.)
 static std::vector<GhostOp> frame_copy_stage(const Level& L)
 {
     std::vector<GhostOp> out;
@@ -469,9 +487,9 @@ void PressureSolver::build_full_programs(int d)
         if (which >= 4 && !full_march(d)) continue;   // [4] / [5]: [0] / [1] for the marching kernels (psi in frames only)
         FullProgram& P = full_prog_[d][which];
         auto stages = build_program(L, which >= 4 ? which - 4 : which, bc_value_, which >= 4);
-        if (which >= 4) stages.insert(stages.begin(), frame_copy_stage(L));
         upload_program(P, stages, L.npatches());
     }
+    if (full_march(d)) upload_program(full_prog_[d][6], {frame_copy_stage(L)}, L.npatches());
     SOMAR_HIP(hipDeviceSynchronize());
 }
 
@@ -488,11 +506,11 @@ void PressureSolver::run_full_program_frames(int d, int which, double* phi, bool
     run_program(d, full_prog_[d][which + 4], phi, f_psi[d], homogeneous, true, false);
 }
 
-// stage 0 of the frame-only programs with (src, dst) in the roles of (phi, psi)
+// the frame copy (six slabs per box, one launch) with (src, dst) in the roles of (phi, psi)
 void PressureSolver::copy_frames(int d, const double* src, double* dst)
 {
     Level& L = *lev[d];
-    const FullProgram& P = full_prog_[d][5];
+    const FullProgram& P = full_prog_[d][6];
     if (P.first.empty()) return;
     launch_ghost_ops(st_, L.dev, P.d_ops + P.first[0], P.count[0], const_cast<double*>(src), dst, true, false);
 }
