@@ -103,14 +103,20 @@ static std::vector<std::vector<GhostOp>> schedule_stages(const std::vector<std::
             if (op.sgn > 0) { b.lo[op.dir] = r.lo[op.dir] - far; b.hi[op.dir] = r.hi[op.dir] - 1; }
             else { b.lo[op.dir] = r.lo[op.dir] + 1; b.hi[op.dir] = r.hi[op.dir] + far; }
             rd.push_back({b, op.srcf});
-        } else {  // GHOST_NEUM: psi on the ghost layer and the first valid layer, one cell wider tangentially; phi on the valid layer
+        } else {  // GHOST_NEUM: psi on the ghost layer and the first valid layer at +-1 along each tangential direction (no diagonal:
+                  // ghost_op_body), phi on the valid layer
             IBox b = r;
             if (op.sgn > 0) b.lo[op.dir] -= 1; else b.hi[op.dir] += 1;
-            IBox v = b;
-            for (int d = 0; d < 3; ++d)
-                if (d != op.dir) { b.lo[d] -= 1; b.hi[d] += 1; }
-            rd.push_back({b, 1});
-            rd.push_back({v, 0});
+            for (int t = 1; t <= 2; ++t) {
+                const int d = (op.dir + t) % 3;
+                for (int sg = -1; sg <= 1; sg += 2) {
+                    IBox q = b;
+                    q.lo[d] += sg;
+                    q.hi[d] += sg;
+                    rd.push_back({q, 1});
+                }
+            }
+            rd.push_back({b, 0});
         }
     };
     size_t ns = 0;
@@ -163,15 +169,15 @@ void reads_offsets(const GhostOp& op, std::vector<ReadOff>& rd)
             r.o[op.dir] = -op.sgn * k;
             rd.push_back(r);
         }
-    } else {  // GHOST_NEUM: psi on the ghost layer and the first valid layer, one cell wider tangentially; phi on the valid layer
-        const int a = op.dir, b = (a + 1) % 3, c = (a + 2) % 3;
+    } else {  // GHOST_NEUM (ghost_op_body): psi on the ghost layer and the first valid layer at +-1 along each tangential direction
+              // (no diagonal), phi on the valid layer
+        const int a = op.dir;
         for (int da = 0; da < 2; ++da)
-            for (int tb = -1; tb <= 1; ++tb)
-                for (int tc = -1; tc <= 1; ++tc) {
+            for (int t = 1; t <= 2; ++t)
+                for (int sg = -1; sg <= 1; sg += 2) {
                     ReadOff r{{0, 0, 0}, 1};
                     r.o[a] = da ? -op.sgn : 0;
-                    r.o[b] = tb;
-                    r.o[c] = tc;
+                    r.o[(a + t) % 3] = sg;
                     rd.push_back(r);
                 }
         ReadOff v{{0, 0, 0}, 0};
@@ -201,7 +207,9 @@ static void drop_dead_ops(const Level& L, std::vector<std::vector<GhostOp>>& per
             for (int j = -g[1]; j < n[1] - g[1]; ++j)
                 for (int i = -g[0]; i < n[0] - g[0]; ++i) {
                     const bool in_valid = i >= 0 && i < valid.size(0) && j >= 0 && j < valid.size(1) && k >= 0 && k < valid.size(2);
-                    if (!in_valid) live[1][at(i, j, k)] = 1;
+                    // ... minus its eight corner cells: a 19-point stencil reads no body diagonal
+                    const bool corner = (i < 0 || i >= valid.size(0)) && (j < 0 || j >= valid.size(1)) && (k < 0 || k >= valid.size(2));
+                    if (!in_valid && !corner) live[1][at(i, j, k)] = 1;
                 }
         std::vector<GhostOp>& ops = perPatch[pi];
         std::vector<char> keep(ops.size(), 1);
@@ -366,6 +374,35 @@ static std::vector<std::vector<GhostOp>> build_program(const Level& L, int which
         }
     }
     static const bool dce = getenv("SOMAR_NO_GHOST_DCE") == nullptr;   // A/B switch
+    if (dce && frames) {
+        // every op cut along the faces of its box (low ghost layer | valid range | high ghost layer, per direction): dependences
+        // and liveness are then judged piece by piece -- an edge strip no longer waits for the strip that only feeds its corner
+        // cell, and the corner pieces, which nothing reads, die
+        for (int pi = 0; pi < L.npatches(); ++pi) {
+            const IBox valid = L.boxes[L.local[pi]];
+            std::vector<GhostOp> cut;
+            for (const GhostOp& op : perPatch[pi]) {
+                int lo[3][3], hi[3][3], np[3];
+                for (int d = 0; d < 3; ++d) {
+                    // local coordinates: the valid range is [0, n)
+                    const int a = op.lo[d], b = op.lo[d] + op.n[d] - 1, n = valid.size(d);
+                    np[d] = 0;
+                    if (a < 0) { lo[d][np[d]] = a; hi[d][np[d]] = std::min(b, -1); ++np[d]; }
+                    if (b >= 0 && a < n) { lo[d][np[d]] = std::max(a, 0); hi[d][np[d]] = std::min(b, n - 1); ++np[d]; }
+                    if (b >= n) { lo[d][np[d]] = std::max(a, n); hi[d][np[d]] = b; ++np[d]; }
+                }
+                for (int z = 0; z < np[2]; ++z)
+                    for (int y = 0; y < np[1]; ++y)
+                        for (int x = 0; x < np[0]; ++x) {
+                            GhostOp o = op;
+                            const int q[3] = {x, y, z};
+                            for (int d = 0; d < 3; ++d) { o.lo[d] = lo[d][q[d]]; o.n[d] = hi[d][q[d]] - lo[d][q[d]] + 1; }
+                            cut.push_back(o);
+                        }
+            }
+            perPatch[pi].swap(cut);
+        }
+    }
     if (dce) drop_dead_ops(L, perPatch, frames);
     return schedule_stages(perPatch);
 }
