@@ -467,6 +467,15 @@ void PressureSolver::upload_program(FullProgram& P, const std::vector<std::vecto
         }
     }
     if (flat.empty()) return;
+    if (getenv("SOMAR_TIMING") && atoi(getenv("SOMAR_TIMING")) > 1) {
+        fprintf(stderr, "[somar timing] ghost program: %zu stages, %zu ops, %d boxes; ops per stage:", stages.size(), flat.size(), npatches);
+        for (size_t q = 0; q < stages.size(); ++q) {
+            long long cells = 0;
+            for (const GhostOp& o : stages[q]) cells += (long long)o.n[0] * o.n[1] * o.n[2];
+            fprintf(stderr, " %zu (%lld cells)", stages[q].size(), cells);
+        }
+        fprintf(stderr, "\n");
+    }
     std::vector<GhostOp> sorted;
     std::vector<int> first(npatches + 1, 0);
     for (int b = 0; b < npatches; ++b) {
