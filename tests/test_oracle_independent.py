@@ -66,9 +66,12 @@ def lapdiag_formula(jg, jinv, dx):
     return -jinv * s
 
 
-def apply_19pt(phi, jgf, jinv, dx, periodic):
+def apply_19pt(phi, jgf, jinv, dx, periodic, smoother=False):
     """the 19-point operator by array slices.  jgf[a][..., b] = J g^{ab} on a-faces.  psi = phi with one ghost layer:
-    periodic wrap, or the quadratic extrapolation 3 (p1 - p2) + p3 beyond a wall."""
+    periodic wrap, or the quadratic extrapolation 3 (p1 - p2) + p3 beyond a wall.
+    smoother: the cross terms see the SMOOTHER's copy instead (RelaxationMethod::fillGhostsAndExtrapolate,
+    RelaxationMethod.cpp:376-435): linear extrapolation 2 p1 - p2 beyond EVERY face of the domain
+    box, a periodic one included, direction after direction; the normal differences keep the periodic images."""
     n = phi.shape
     psi = np.zeros(tuple(m + 2 for m in n))
     psi[1:-1, 1:-1, 1:-1] = phi
@@ -81,11 +84,20 @@ def apply_19pt(phi, jgf, jinv, dx, periodic):
         else:
             psi[sl(0)] = 3.0 * (psi[sl(1)] - psi[sl(2)]) + psi[sl(3)]
             psi[sl(n[d] + 1)] = 3.0 * (psi[sl(n[d])] - psi[sl(n[d] - 1)]) + psi[sl(n[d] - 2)]
+    ext = psi
+    if smoother:
+        ext = np.zeros_like(psi)
+        ext[1:-1, 1:-1, 1:-1] = phi
+        for d in range(3):
+            def sl(i):
+                return tuple(i if e == d else slice(None) for e in range(3))
+            ext[sl(0)] = 2.0 * ext[sl(1)] - ext[sl(2)]
+            ext[sl(n[d] + 1)] = 2.0 * ext[sl(n[d])] - ext[sl(n[d] - 1)]
 
     out = np.zeros(n)
     for a in range(3):
         # faces 0 .. n_a along a; the face's high cell has padded index f + 1, its low cell f
-        def at(cell_side, shift_dir=None, shift=0):
+        def at(cell_side, shift_dir=None, shift=0, src=psi):
             ix = []
             for e in range(3):
                 if e == a:
@@ -94,12 +106,12 @@ def apply_19pt(phi, jgf, jinv, dx, periodic):
                     ix.append(slice(1 + shift, 1 + shift + n[e]))
                 else:
                     ix.append(slice(1, 1 + n[e]))
-            return psi[tuple(ix)]
+            return src[tuple(ix)]
         F = jgf[a][..., a] * (at(1) - at(0)) / dx[a]
         for b in range(3):
             if b == a:
                 continue
-            F = F + jgf[a][..., b] / (4.0 * dx[b]) * (at(1, b, 1) - at(1, b, -1) + at(0, b, 1) - at(0, b, -1))
+            F = F + jgf[a][..., b] / (4.0 * dx[b]) * (at(1, b, 1, ext) - at(1, b, -1, ext) + at(0, b, 1, ext) - at(0, b, -1, ext))
         if not periodic[a]:
             F[tuple(0 if e == a else slice(None) for e in range(3))] = 0.0
             F[tuple(n[a] if e == a else slice(None) for e in range(3))] = 0.0
@@ -319,6 +331,34 @@ def test_nineteen_point_operator_equals_the_sliced_formula(oracle, per, metric):
         assert np.abs(got - want)[junction].max() > 1e-3 * np.abs(want).max()   # the quirk is there, and only there
     lap = op.lapDiag[0].view(grids[0])[..., 0]
     np.testing.assert_allclose(lap, lapdiag_formula([jgf[a][..., a] for a in range(3)], jinv, dx), rtol=1e-14, atol=0)
+
+
+def test_nineteen_point_level_gsrb_is_a_coloured_jacobi_step_on_the_pre_pass_field(oracle):
+    """LevelGSRB with a non-diagonal metric (GSRBITER3D, GSRBF.ChF:36-282): a colour pass takes EVERY neighbour -- the six
+    of the other colour and the twelve diagonal ones of its own colour, which the reference reads from the snapshot
+    `extrap` -- at its value before the pass.  As a formula: phi += mask_colour * (rhs - L~[phi]) / (alpha + beta lapDiag), with L~ the
+    sliced 19-point operator above whose cross terms see the smoother's linearly extrapolated copy (apply_19pt(smoother=True)).
+    Fully periodic box (no wall forms), sheared metric, two sweeps."""
+    so = oracle
+    n, L, per = (12, 8, 8), (2.0, 1.0, 0.5), (True, True, True)
+    dom, grids, dx = _one_box(so, n, per, L)
+    Jg, Ji = so.make_full_metric(grids, dx, L, dom)
+    jgf, jinv = _full_arrays(Jg, Ji)
+    op = so.Factory(dom, grids, dx, so.BCHolder(), Jg, Ji, isDiagonal=False, maxDepth=0).mg_new_op(0, None)
+    rng = np.random.default_rng(23)
+    x, b = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    phi = _field(so, grids, x)
+    rhs = _field(so, grids, b, ghost=(0, 0, 0))
+    op.relax(phi, rhs, 2)
+    got = phi[0].view(grids[0])[..., 0]
+    diag = lapdiag_formula([jgf[a][..., a] for a in range(3)], jinv, dx)       # alpha = 0, beta = 1
+    I = np.meshgrid(*[np.arange(m) for m in n], indexing="ij")
+    want = x.copy()
+    for _ in range(2):
+        for colour in (0, 1):
+            mask = ((I[0] + I[1] + I[2] + colour) % 2) == 0
+            want = want + mask * (b - apply_19pt(want, jgf, jinv, dx, per, smoother=True)) / diag
+    assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
 
 
 @pytest.mark.parametrize("variant", ["stretched", "cartesian"])
