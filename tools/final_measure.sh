@@ -16,8 +16,8 @@ for c in c3 c4 c5; do
   python3 tools/bench_amr.py --config $c --steps 5 > $o/${tag}_$c.json 2>/dev/null
 done
 tools/prof_cycle.sh c3 11 $o/${tag}_c3_cycle.txt 50 > /dev/null
-tools/prof_cycle.sh c4 115 $o/${tag}_c4_cycle.txt 100 > /dev/null
-tools/prof_cycle.sh c5 56 $o/${tag}_c5_cycle.txt 100 > /dev/null
+tools/prof_cycle.sh c4 110 $o/${tag}_c4_cycle.txt 100 > /dev/null
+tools/prof_cycle.sh c5 51 $o/${tag}_c5_cycle.txt 100 > /dev/null
 python3 tools/bench_full19.py --n 512 --metric bathy > $o/${tag}_full19_bathy_512.json 2>/dev/null
 python3 tools/bench_full19.py --n 384 --metric sheared > $o/${tag}_full19_sheared_384.json 2>/dev/null
 # PMC: separate passes, counters only (no trace domains)
