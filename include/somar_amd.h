@@ -576,13 +576,18 @@ int somar_solver_set_metric_uniform(somar_solver_t* s, const double* c4);
  *      SOMAR_MAP_TWISTED      TwistedMap with m_twistType 0 (geometry/maps/TwistedMap.cpp:160-260, TwistedMapF.ChF:
  *          TWISTED0_FILL_DXDXI, TWISTED0_FILL_J), non-diagonal: x^mu = xi^mu + pert_mu sin(2 pi xi^nu) sin(2 pi xi^sigma);
  *          L = the three amplitudes m_pert, depth unused.
+ *      SOMAR_MAP_TWISTED1     TwistedMap with m_twistType 1: analytic coordinate functions (TWISTED1_FILL_PHYSCOOR,
+ *          TwistedMapF.ChF:356-430; domain lengths m_L = dx * cells of the level's domain), dx/dXi and J from
+ *          GeoSourceInterface's defaults: staggered differences of the coordinates (GeoSourceInterface.cpp:65-113,
+ *          SIMPLECCDERIV / SIMPLEFCDERIV) and DEFAULT_FILL_J_3D with Chombo's CellToEdge average on faces (:122-202).
+ *          L = the three amplitudes m_pert, depth unused.
  *    All run GeoSourceInterface::fill_Jgup / fill_Jinv's generic algebra per point at the point's own centring, as
- *    LevelGeometry does.  Maps not listed (TwistedMap's m_twistType 1, which goes through the generic finite differences of
- *    GeoSourceInterface, NewBeamGenerator's spline, the DEM interpolation itself) stay with the caller through
- *    somar_solver_set_metric_full or somar_metric_jgup_from_dxdxi. */
+ *    LevelGeometry does.  Maps not listed (NewBeamGenerator's spline, the DEM interpolation itself) stay with the caller
+ *    through somar_solver_set_metric_full or somar_metric_jgup_from_dxdxi. */
 #define SOMAR_MAP_CYLINDRICAL 1
 #define SOMAR_MAP_BATHYMETRIC 2
 #define SOMAR_MAP_TWISTED 3
+#define SOMAR_MAP_TWISTED1 4
 int somar_solver_set_metric_map(somar_solver_t* s, int kind, const double* L, const double* depth, const int* depth_lo,
                                 const int* depth_n);
 

@@ -180,6 +180,68 @@ class TwistedMap:
         return np.broadcast_to(v, np.broadcast(I, J, K).shape).copy()
 
 
+class TwistedMap1:
+    """TwistedMap with m_twistType 1 (geometry/maps/TwistedMap.cpp:99-113, 160-260): only the coordinate functions are analytic
+    (TWISTED1_FILL_PHYSCOOR, TwistedMapF.ChF:356-430); fill_dxdXi and fill_J are GeoSourceInterface's defaults
+    (GeoSourceInterface.cpp:65-113, 122-202): x^mu on the box staggered in nu, differenced by SIMPLECCDERIV / SIMPLEFCDERIV
+    (GeoSourceInterfaceF.ChF:195-246); J cell-centred from the face coordinates (DEFAULT_FILL_J_3D, :67-105), on a box that is
+    face-centred in one direction the average of the two cells beside the face (Chombo CellToEdge), times scale / prod(dXi)."""
+    diagonal = False
+
+    def __init__(self, dXi, pert, L):
+        self.dXi = tuple(float(x) for x in dXi)
+        self.pert = tuple(float(x) for x in pert)
+        self.L = tuple(float(x) for x in L)
+
+    def x(self, mu, Tc, I, J, K):
+        Pi = np.pi
+        Xi0 = self.dXi[0] * (I + (1.0 - Tc[0]) * 0.5)
+        Xi1 = self.dXi[1] * (J + (1.0 - Tc[1]) * 0.5)
+        Xi2 = self.dXi[2] * (K + (1.0 - Tc[2]) * 0.5)
+        k0, k1, k2 = Pi / self.L[0], Pi / self.L[1], Pi / self.L[2]
+        phi0 = phi1 = phi2 = 0.25 * Pi
+        pert = self.pert[mu]
+        if mu == 0:
+            return Xi0 + pert * np.sin(k0 * Xi0) * np.cos(2.0 * k1 * Xi1 + phi1) * np.cos(2.0 * k2 * Xi2 + phi2)
+        if mu == 1:
+            return Xi1 + pert * np.cos(2.0 * k0 * Xi0 + phi0) * np.sin(k1 * Xi1) * np.cos(2.0 * k2 * Xi2 + phi2)
+        return Xi2 + pert * np.cos(2.0 * k0 * Xi0 + phi0) * np.cos(2.0 * k1 * Xi1 + phi1) * np.sin(k2 * Xi2)
+
+    def dxdXi(self, mu, nu, T, I, J, K, scale=1.0):
+        Tx = list(T)
+        Tx[nu] = 1 - T[nu]
+        e = [1 if d == nu else 0 for d in range(3)]
+        scaleOnDXi = scale / self.dXi[nu]
+        if T[nu] == 0:
+            v = (self.x(mu, Tx, I + e[0], J + e[1], K + e[2]) - self.x(mu, Tx, I, J, K)) * scaleOnDXi
+        else:
+            v = (self.x(mu, Tx, I, J, K) - self.x(mu, Tx, I - e[0], J - e[1], K - e[2])) * scaleOnDXi
+        return np.broadcast_to(v, np.broadcast(I, J, K).shape).copy()
+
+    def _ccj(self, I, J, K):
+        d = [[None] * 3 for _ in range(3)]
+        for nu in range(3):
+            Tf = [0, 0, 0]
+            Tf[nu] = 1
+            e = [1 if q == nu else 0 for q in range(3)]
+            for mu in range(3):
+                d[nu][mu] = self.x(mu, Tf, I + e[0], J + e[1], K + e[2]) - self.x(mu, Tf, I, J, K)
+        xXi, yXi, zXi = d[0]
+        xNu, yNu, zNu = d[1]
+        xZeta, yZeta, zZeta = d[2]
+        return xXi * (yNu * zZeta - yZeta * zNu) + xNu * (yZeta * zXi - yXi * zZeta) + xZeta * (yXi * zNu - yNu * zXi)
+
+    def J(self, T, I, J, K, scale=1.0):
+        f = 0 if T[0] else (1 if T[1] else (2 if T[2] else -1))
+        if f < 0:
+            v = self._ccj(I, J, K)
+        else:
+            e = [1 if q == f else 0 for q in range(3)]
+            v = 0.5 * (self._ccj(I, J, K) + self._ccj(I - e[0], J - e[1], K - e[2]))
+        v = v * (scale / (self.dXi[0] * self.dXi[1] * self.dXi[2]))
+        return np.broadcast_to(v, np.broadcast(I, J, K).shape).copy()
+
+
 def fill_jgup(m, valid, mu):
     """LevelGeometry's FC J g^{mu nu} on faces(valid, mu): -> array (faces..., 3) (for a diagonal map the nu != mu
     components are zero, GeoSourceInterface.cpp:431-436)"""

@@ -14,7 +14,7 @@ _LIB = None
 
 BC_NONE, BC_NEUM, BC_DIRI = -1, 0, 1
 F_PHI, F_RHS, F_RES, F_CORR, F_BEST, F_SCRATCH, F_AMR_CORR, F_AMR_RES, F_HEAT_OLD, F_HEAT_SRC = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
-MAP_CYLINDRICAL, MAP_BATHYMETRIC, MAP_TWISTED = 1, 2, 3   # SOMAR_MAP_* of include/somar_amd.h
+MAP_CYLINDRICAL, MAP_BATHYMETRIC, MAP_TWISTED, MAP_TWISTED1 = 1, 2, 3, 4   # SOMAR_MAP_* of include/somar_amd.h
 MAX_HISTORY = 64
 COMM_ID_BYTES = 128
 

@@ -211,7 +211,7 @@ void launch_mac_correct(hipStream_t st, const LevelDev& L, double* const vel[3],
 void launch_face_wall(hipStream_t st, const LevelDev& L, double* const edge[3]);  // zero normal flux on solid walls (null = skip)
 // coordinate maps' metric producers (maps.hip): kind 1 cylindrical (diagonal), 2 bathymetric (non-diagonal, nodal depth)
 void launch_map_metric(hipStream_t st, const LevelDev& L, int kind, const double dXi[3], const double Lc[3],
-                       const double* d_depth, const int dlo[2], const int dn[2], bool diagonal);
+                       const double* d_depth, const int dlo[2], const int dn[2], bool diagonal, const double* domLen = nullptr);
 void launch_face_bc(hipStream_t st, const LevelDev& L, double* const edge[3], const int kind[6], const double value[6]);
 void launch_cell_to_edge(hipStream_t st, const LevelDev& L, double* const edge[3], double* const cc[3], bool wall);
 void launch_cc_correct(hipStream_t st, const LevelDev& L, double* const cc[3], const double* phi, double dtScale);

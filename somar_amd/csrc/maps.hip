@@ -26,9 +26,10 @@
 namespace somar {
 
 struct MapParams {
-    int kind;            // 1 cylindrical, 2 bathymetric, 3 twisted (type 0)
+    int kind;            // 1 cylindrical, 2 bathymetric, 3 twisted (type 0), 4 twisted (type 1)
     double dXi[3];
     double L[3];         // bathymetric: domain lengths; twisted: the perturbation amplitudes m_pert
+    double dom[3];       // twisted type 1: the domain lengths m_L
     const double* depth; // nodes [dlo, dlo + dn), i fastest
     int dlo[2], dn[2];
 };
@@ -66,8 +67,48 @@ struct MapEval {
         return 0.125 * s;
     }
 
+    // TWISTED1_FILL_PHYSCOOR (TwistedMapF.ChF:356-430): x^mu at index (i, j, k) of a box of type Tc
+    __device__ double twisted1_x(int mu, const int* Tc, int i, int j, int k) const
+    {
+        const double Pi = M_PI;
+        const double Xi0 = M.dXi[0] * (i + (1.0 - Tc[0]) * 0.5);
+        const double Xi1 = M.dXi[1] * (j + (1.0 - Tc[1]) * 0.5);
+        const double Xi2 = M.dXi[2] * (k + (1.0 - Tc[2]) * 0.5);
+        const double k0 = Pi / M.dom[0], k1 = Pi / M.dom[1], k2 = Pi / M.dom[2];
+        const double phi0 = 0.25 * Pi, phi1 = 0.25 * Pi, phi2 = 0.25 * Pi;
+        const double pert = M.L[mu];
+        if (mu == 0) return Xi0 + pert * sin(k0 * Xi0) * cos(2.0 * k1 * Xi1 + phi1) * cos(2.0 * k2 * Xi2 + phi2);
+        if (mu == 1) return Xi1 + pert * cos(2.0 * k0 * Xi0 + phi0) * sin(k1 * Xi1) * cos(2.0 * k2 * Xi2 + phi2);
+        return Xi2 + pert * cos(2.0 * k0 * Xi0 + phi0) * cos(2.0 * k1 * Xi1 + phi1) * sin(k2 * Xi2);
+    }
+    // DEFAULT_FILL_J_3D (GeoSourceInterfaceF.ChF:67-105) at the CELL (i, j, k): differences of the face-centred coordinates
+    __device__ double twisted1_ccj(int i, int j, int k) const
+    {
+        double d[3][3];   // d[nu][mu] = x^mu(face nu high) - x^mu(face nu low)
+        for (int nu = 0; nu < 3; ++nu) {
+            int Tf[3] = {0, 0, 0};
+            Tf[nu] = 1;
+            const int e0 = nu == 0, e1 = nu == 1, e2 = nu == 2;
+            for (int mu = 0; mu < 3; ++mu) d[nu][mu] = twisted1_x(mu, Tf, i + e0, j + e1, k + e2) - twisted1_x(mu, Tf, i, j, k);
+        }
+        const double xXi = d[0][0], yXi = d[0][1], zXi = d[0][2];
+        const double xNu = d[1][0], yNu = d[1][1], zNu = d[1][2];
+        const double xZeta = d[2][0], yZeta = d[2][1], zZeta = d[2][2];
+        return xXi * (yNu * zZeta - yZeta * zNu) + xNu * (yZeta * zXi - yXi * zZeta) + xZeta * (yXi * zNu - yNu * zXi);
+    }
+
     __device__ double dxdXi(int mu, int nu, const int* T, int i, int j, int k, double scale) const
     {
+        if (M.kind == 4) {
+            // GeoSourceInterface::fill_dxdXi (GeoSourceInterface.cpp:65-113): x^mu on the box staggered in nu, then
+            // SIMPLECCDERIV (src(i + e) - src(i)) or SIMPLEFCDERIV (src(i) - src(i - e)), times scale / dXi_nu
+            int Tx[3] = {T[0], T[1], T[2]};
+            Tx[nu] = 1 - T[nu];
+            const int e0 = nu == 0, e1 = nu == 1, e2 = nu == 2;
+            const double scaleOnDXi = scale / M.dXi[nu];
+            if (T[nu] == 0) return (twisted1_x(mu, Tx, i + e0, j + e1, k + e2) - twisted1_x(mu, Tx, i, j, k)) * scaleOnDXi;
+            return (twisted1_x(mu, Tx, i, j, k) - twisted1_x(mu, Tx, i - e0, j - e1, k - e2)) * scaleOnDXi;
+        }
         if (M.kind == 1) {
             if (mu == 2 || nu == 2) return mu == nu ? scale : 0.0;
             const double off0 = (1.0 - T[0]) * 0.5, off1 = (1.0 - T[1]) * 0.5;
@@ -121,6 +162,19 @@ struct MapEval {
 
     __device__ double detJ(const int* T, int i, int j, int k) const
     {
+        if (M.kind == 4) {
+            // GeoSourceInterface::fill_J (GeoSourceInterface.cpp:122-202): cell-centred from the face coordinates; on a box that
+            // is face-centred in ONE direction the cell-centred J of the two cells beside the face, averaged (Chombo CellToEdge);
+            // then times scale / (dXi0 dXi1 dXi2)
+            const int f = T[0] ? 0 : (T[1] ? 1 : (T[2] ? 2 : -1));
+            double v;
+            if (f < 0) v = twisted1_ccj(i, j, k);
+            else {
+                const int e0 = f == 0, e1 = f == 1, e2 = f == 2;
+                v = 0.5 * (twisted1_ccj(i, j, k) + twisted1_ccj(i - e0, j - e1, k - e2));
+            }
+            return v * (1.0 / (M.dXi[0] * M.dXi[1] * M.dXi[2]));
+        }
         if (M.kind == 1) {
             const double off0 = (1.0 - T[0]) * 0.5;
             const double scaleDXi0 = 1.0 * M.dXi[0];
@@ -197,12 +251,12 @@ __global__ void k_map_metric(const PatchDesc* __restrict__ patches, int npatches
 }
 
 void launch_map_metric(hipStream_t st, const LevelDev& L, int kind, const double dXi[3], const double Lc[3],
-                       const double* d_depth, const int dlo[2], const int dn[2], bool diagonal)
+                       const double* d_depth, const int dlo[2], const int dn[2], bool diagonal, const double* domLen)
 {
     if (L.npatches == 0) return;
     MapParams M;
     M.kind = kind;
-    for (int d = 0; d < 3; ++d) { M.dXi[d] = dXi[d]; M.L[d] = Lc[d]; }
+    for (int d = 0; d < 3; ++d) { M.dXi[d] = dXi[d]; M.L[d] = Lc[d]; M.dom[d] = domLen ? domLen[d] : 0.0; }
     M.depth = d_depth;
     for (int d = 0; d < 2; ++d) { M.dlo[d] = dlo[d]; M.dn[d] = dn[d]; }
     MapOut O;

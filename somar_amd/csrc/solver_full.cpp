@@ -707,7 +707,7 @@ void PressureSolver::set_metric_map(int kind, const double Lc[3], const double* 
 {
     SOMAR_CHECK(!lev.empty() && !finalized, "set_metric before define / after finalize");
     SOMAR_CHECK(prm.spaceDim == 3, "the map producers restate the CH_SPACEDIM = 3 algebra (GeoSourceInterface.cpp:236-291)");
-    SOMAR_CHECK(kind >= 1 && kind <= 3, "map kind: 1 cylindrical, 2 bathymetric, 3 twisted");
+    SOMAR_CHECK(kind >= 1 && kind <= 4, "map kind: 1 cylindrical, 2 bathymetric, 3 twisted (type 0), 4 twisted (type 1)");
     Level& L = *lev[0];
     SOMAR_CHECK(L.npatches() < 65536, "too many local patches for one launch");
     double* d_depth = nullptr;
@@ -728,8 +728,10 @@ void PressureSolver::set_metric_map(int kind, const double Lc[3], const double* 
         for (int d = 0; d < 2; ++d) { lo[d] = dlo[d]; n[d] = dn[d]; }
         full_ = true;
         alloc_full_metric(L);
-    } else if (kind == 3) {
-        // TwistedMap, m_twistType 0: Lc = the amplitudes m_pert; 2 pi |pert| < 1 keeps the Jacobian positive
+    } else if (kind == 3 || kind == 4) {
+        // TwistedMap, m_twistType 0 / 1: Lc = the amplitudes m_pert; 2 pi |pert| < 1 keeps the Jacobian positive.  Type 1 takes its
+        // derivatives and its Jacobian from differences of the coordinate functions (GeoSourceInterface's defaults) over the domain
+        // lengths m_L = dx * cells
         full_ = true;
         alloc_full_metric(L);
     } else {
@@ -737,7 +739,9 @@ void PressureSolver::set_metric_map(int kind, const double Lc[3], const double* 
         // r = dXi0 (i + offset) > 0 on every face / cell the level owns
         SOMAR_CHECK(L.domain.lo[0] >= 0, "the cylindrical map needs r >= 0: domain index 0 starts below zero");
     }
-    launch_map_metric(st_, L.dev, kind, L.dx, Lc, d_depth, lo, n, kind == 1);
+    double domLen[3];
+    for (int d = 0; d < 3; ++d) domLen[d] = L.dx[d] * (double)L.domain.size(d);
+    launch_map_metric(st_, L.dev, kind, L.dx, Lc, d_depth, lo, n, kind == 1, domLen);
     sync();
     if (d_depth) hipFree(d_depth);
 }

@@ -203,6 +203,35 @@ def test_twisted_map_on_the_device_matches_the_oracle_metric():
         b.undefine()
 
 
+def test_twisted_map_type_1_on_the_device_matches_the_oracle_metric():
+    """TwistedMap with m_twistType 1: analytic coordinates, dx/dXi and J from GeoSourceInterface's finite-difference defaults
+    (staggered coordinate differences, DEFAULT_FILL_J_3D + CellToEdge).  Device libm against numpy's: 1e-12 of the operator."""
+    from oracle import somar_maps as sm
+    from somar_amd import api as F
+    n, bs = (16, 16, 8), 8
+    L = (1.0, 2.0, 0.5)
+    dom = so.Domain(so.Box((0, 0, 0), tuple(a - 1 for a in n)), (False, False, False))
+    grids = so.split_domain(dom.box, bs)
+    dx = tuple(L[d] / n[d] for d in range(3))
+    pert = (0.05, 0.08, 0.02)
+    m = sm.TwistedMap1(dx, pert, L)
+
+    def upload_metric(s):
+        for q in range(s.num_local_patches):
+            _, _, gi = s.patch_box(q)
+            g = grids[gi]
+            jg = [np.asfortranarray(sm.fill_jgup(m, g, mu)) for mu in range(3)]
+            s.setMetricFull(q, jg[0], jg[1], jg[2], np.asfortranarray(sm.fill_jinv(m, g)))
+
+    a = _twin(dom, grids, dx, upload_metric)
+    b = _twin(dom, grids, dx, lambda s: s.setMetricMap(F.MAP_TWISTED1, pert))
+    try:
+        _compare_operators(a, b, grids, dom, exact=False)
+    finally:
+        a.undefine()
+        b.undefine()
+
+
 def test_map_producer_argument_checks():
     from somar_amd import SomarError
     from somar_amd import api as F

@@ -148,3 +148,32 @@ def test_twisted_map_jacobian_is_the_determinant_of_its_dxdxi(oracle, sm):
     # the diagonal component is positive
     for mu in range(3):
         assert sm.fill_jgup(m, valid, mu)[..., mu].min() > 0.0
+
+
+def test_twisted_map_type_1_defaults_converge_to_the_analytic_jacobian(oracle, sm):
+    """m_twistType 1 goes through GeoSourceInterface's finite-difference defaults: the differenced dx/dXi must approach the analytic
+    derivative of TWISTED1_FILL_PHYSCOOR's coordinates at second order (16^3 -> 32^3: about four times smaller), and the default J
+    (face-coordinate differences) is the determinant of those differenced derivatives."""
+    L, pert = (1.0, 2.0, 0.5), (0.05, 0.08, 0.02)
+    errs = []
+    for n in (16, 32):
+        dXi = tuple(L[d] / n for d in range(3))
+        m = sm.TwistedMap1(dXi, pert, L)
+        I, J, K = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+        T = (0, 0, 0)
+        Xi = [dXi[0] * (I + 0.5), dXi[1] * (J + 0.5), dXi[2] * (K + 0.5)]
+        k = [np.pi / L[d] for d in range(3)]
+        ph = 0.25 * np.pi
+        # analytic d x^0 / d Xi^0 and d x^0 / d Xi^1 of x^0 = Xi0 + p0 sin(k0 Xi0) cos(2 k1 Xi1 + ph) cos(2 k2 Xi2 + ph)
+        d00 = 1.0 + pert[0] * k[0] * np.cos(k[0] * Xi[0]) * np.cos(2 * k[1] * Xi[1] + ph) * np.cos(2 * k[2] * Xi[2] + ph)
+        d01 = -pert[0] * 2 * k[1] * np.sin(k[0] * Xi[0]) * np.sin(2 * k[1] * Xi[1] + ph) * np.cos(2 * k[2] * Xi[2] + ph)
+        e = max(np.abs(m.dxdXi(0, 0, T, I, J, K) - d00).max(), np.abs(m.dxdXi(0, 1, T, I, J, K) - d01).max())
+        A = np.empty(I.shape + (3, 3))
+        for r in range(3):
+            for s_ in range(3):
+                A[..., r, s_] = m.dxdXi(r, s_, T, I, J, K)
+        eJ = np.abs(m.J(T, I, J, K) - np.linalg.det(A)).max()
+        errs.append((e, eJ))
+    assert errs[1][0] < 0.3 * errs[0][0] and errs[1][0] < 1e-3
+    # cell-centred, the default J IS the determinant of the differenced dx/dXi (the same face-coordinate differences)
+    assert errs[0][1] < 1e-13 and errs[1][1] < 1e-13
