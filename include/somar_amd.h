@@ -49,7 +49,7 @@ extern "C" {
  * 6: + somar_amr_tga_step (composite MappedAMRTGA::oneStep); composite operations with heat coefficients installed no
  *    longer fail (the flux-register scales follow beta); somar_solver_set_vel_bc (inflow / outflow sides); somar_solver_set_metric_map (cylindrical and bathymetric
  *    metric producers on the device); somar_k_fillmappedlapdiag3d, somar_k_mappedaverage2 (kernel-level hooks); additions only */
-#define SOMAR_AMD_ABI_VERSION 8
+#define SOMAR_AMD_ABI_VERSION 9
 
 /* BCType codes, calculus/BCInterface/BCDescriptor.H:34-39 */
 #define SOMAR_BC_NONE (-1)
@@ -590,6 +590,17 @@ int somar_solver_set_metric_uniform(somar_solver_t* s, const double* c4);
 #define SOMAR_MAP_TWISTED1 4
 int somar_solver_set_metric_map(somar_solver_t* s, int kind, const double* L, const double* depth, const int* depth_lo,
                                 const int* depth_n);
+/* The nodal "depth" of the reference's analytic bathymetric maps, for SOMAR_MAP_BATHYMETRIC (host arithmetic, no GPU; x, y: the
+ * Cartesian coordinates of the nodes, for these maps x = dXi0 * i, y = dXi1 * j):
+ *   LedgeMap::fill_bathymetry            geometry/maps/LedgeMap.cpp:38-60, 98-164   order 1 / 3: h_l left of x_l, h_r right of x_r,
+ *        a linear / cubic transition between (y = NULL); the 3-D build's Gaussian bump exp(-((x - x_l) / h_l)^2 - ((y - x_r) / h_r)^2)
+ *        when y is given (order ignored, as in the reference's CH_SPACEDIM == 3 branch)
+ *   BeamGeneratorMap::fill_bathymetry    geometry/maps/BeamGeneratorMap.cpp:73-93, BeamGeneratorMapF.ChF:51-166   the smoothed
+ *        triangular ridge of critical slope `angle` centred at x = 0 (Masoud's lab-scale proportions, the compiled-in set), Lx = the
+ *        domain length in x */
+int somar_bathymetry_ledge(double* out, long long n, const double* x, const double* y, int order, double hl, double hr, double xl,
+                           double xr);
+int somar_bathymetry_beam_generator(double* out, long long n, const double* x, double Lx, double angle);
 
 /* Diagnostics, no reference counterpart: what this device streams for a given mix of streams, in GB/s of algorithmic bytes
  * -- kind 0 copy (16 B/cell), 1 read (8 B/cell), 2 six reads + one write (56 B/cell: the fused GSRB sweep's mix without

@@ -267,3 +267,46 @@ def fill_jinv(m, valid):
     """fill_Jinv = fill_J then FArrayBox::invert(1.0) on the cell-centred valid box"""
     I, J, K = _idx(valid.lo, valid.hi)
     return 1.0 / m.J((0, 0, 0), I, J, K)
+
+
+def ledge_bathymetry(x, order, hl, hr, xl, xr):
+    """LedgeMap::fill_bathymetry, CH_SPACEDIM == 2 branch (geometry/maps/LedgeMap.cpp:38-60, 118-160)"""
+    x = np.asarray(x, dtype=np.float64)
+    dh, dx = hr - hl, xr - xl
+    invdx3 = dx ** -3.0
+    if order == 1:
+        mid = (hr - xr * dh / dx) + x * (dh / dx)
+    else:
+        c0 = hr + dh * (3.0 * xl - xr) * xr * xr * invdx3
+        c1 = -6.0 * dh * xl * xr * invdx3
+        c2 = 3.0 * dh * (xl + xr) * invdx3
+        c3 = -2.0 * dh * invdx3
+        mid = c0 + x * (c1 + x * (c2 + x * c3))
+    return np.where(x < xl, hl, np.where(x > xr, hr, mid))
+
+
+def beam_generator_bathymetry(x, Lx, angle):
+    """FILL_BeamGeneratorMapBATHYMETRY (geometry/maps/BeamGeneratorMapF.ChF:51-166), Masoud's lab-scale PARAMETER set"""
+    x = np.asarray(x, dtype=np.float64)
+    lp, Bp, Pp = 0.009714, 0.01173, 0.0183542
+    sa, ca, ta = np.sin(angle), np.cos(angle), np.tan(angle)
+    l, B, P = lp * Lx, Bp * Lx, Pp * Lx
+    lstar = l + (B + P) / ca
+    C1, C2, C3, C4, C5, C6 = -lstar * ca - B, -lstar * ca + B, -P, P, lstar * ca - B, lstar * ca + B
+    b0 = 0.25 * ta * (B + lstar * ca) * (B + lstar * ca) / B
+    b1 = -0.5 * ta * (B + lstar * ca) / B
+    b2 = 0.25 * ta / B
+    p0 = lstar * sa - 0.5 * ta * P
+    p2 = -0.5 * ta / P
+    out = np.zeros_like(x)
+    m = (C1 < x) & (x < C2)
+    out[m] = b2 * x[m] * x[m] - b1 * x[m] + b0
+    m = (C2 <= x) & (x <= C3)
+    out[m] = lstar * sa + ta * x[m]
+    m = (C3 < x) & (x < C4)
+    out[m] = p2 * x[m] * x[m] + p0
+    m = (C4 <= x) & (x <= C5)
+    out[m] = lstar * sa - ta * x[m]
+    m = (C5 < x) & (x < C6)
+    out[m] = b2 * x[m] * x[m] + b1 * x[m] + b0
+    return out

@@ -106,6 +106,8 @@ _SIGS = {
     "somar_solver_fused19_sweeps": [_H, C.POINTER(C.c_longlong)],
     "somar_last_history": [_PD, C.c_int, _PI],
     "somar_host_fill_mt19937_64": [_PD, C.c_longlong, C.c_ulonglong, C.c_double, C.c_double],
+    "somar_bathymetry_ledge": [_PD, C.c_longlong, _PD, _PD, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double],
+    "somar_bathymetry_beam_generator": [_PD, C.c_longlong, _PD, C.c_double, C.c_double],
     "somar_vel_upload": [_H, C.c_int, C.c_int, _PD],
     "somar_vel_download": [_H, C.c_int, C.c_int, _PD],
     "somar_vel_wall_bc": [_H],
@@ -925,6 +927,24 @@ def plan_exchange(domain_lo, domain_hi, periodic, boxes, owner, rank, ghost=2, m
                           "peer": o[11]})
         out.append(items)
     return tuple(out)
+
+
+def ledge_bathymetry(x, y=None, order=3, hl=1.0, hr=0.5, xl=0.0, xr=1.0):
+    """LedgeMap::fill_bathymetry at the nodes' Cartesian coordinates (y given: the 3-D build's Gaussian bump)"""
+    xa = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(xa)
+    ya = None if y is None else np.ascontiguousarray(np.broadcast_to(y, xa.shape), dtype=np.float64)
+    _ck(lib().somar_bathymetry_ledge(out.ctypes.data_as(_PD), xa.size, xa.ctypes.data_as(_PD),
+                                     None if ya is None else ya.ctypes.data_as(_PD), int(order), hl, hr, xl, xr))
+    return out
+
+
+def beam_generator_bathymetry(x, Lx, angle):
+    """BeamGeneratorMap::fill_bathymetry (elevation of the smoothed ridge of critical slope `angle`, radians) at the nodes' x"""
+    xa = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(xa)
+    _ck(lib().somar_bathymetry_beam_generator(out.ctypes.data_as(_PD), xa.size, xa.ctypes.data_as(_PD), float(Lx), float(angle)))
+    return out
 
 
 def host_random_field(shape, seed, lo=-1.0, hi=1.0):

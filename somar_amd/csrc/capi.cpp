@@ -1,4 +1,5 @@
 // somar_amd/csrc/capi.cpp -- extern "C" boundary of libsomar_amd.so (include/somar_amd.h).
+#include <cmath>
 #include <random>
 #include <cstring>
 #include <string>
@@ -73,6 +74,70 @@ int somar_host_fill_mt19937_64(double* out, long long n, unsigned long long seed
     std::mt19937_64 gen(seed);
     std::uniform_real_distribution<double> dist(lo, hi);
     for (long long i = 0; i < n; ++i) out[i] = dist(gen);
+    API_END
+}
+
+// LedgeMap::fill_bathymetry (geometry/maps/LedgeMap.cpp:38-60 the coefficients, :98-164 the branches)
+int somar_bathymetry_ledge(double* out, long long n, const double* x, const double* y, int order, double hl, double hr, double xl,
+                           double xr)
+{
+    API_BEGIN
+    SOMAR_CHECK(out && x && n >= 0, "somar_bathymetry_ledge: bad arguments");
+    if (y) {   // the CH_SPACEDIM == 3 branch: "Alberto's Gaussian bump"
+        for (long long i = 0; i < n; ++i) {
+            const double a = (x[i] - xl) / hl, b = (y[i] - xr) / hr;
+            const double R2 = a * a + b * b;
+            out[i] = std::exp(-R2);
+        }
+    } else {
+        SOMAR_CHECK(order == 1 || order == 3, "LedgeMap::m_transitionOrder must be 1 or 3");
+        const double dh = hr - hl, dx = xr - xl;
+        const double invdx3 = std::pow(dx, -3.0);
+        double c0, c1, c2 = 0.0, c3 = 0.0;
+        if (order == 1) {
+            c0 = hr - xr * dh / dx;
+            c1 = dh / dx;
+        } else {
+            c0 = hr + dh * (3.0 * xl - xr) * xr * xr * invdx3;
+            c1 = -6.0 * dh * xl * xr * invdx3;
+            c2 = 3.0 * dh * (xl + xr) * invdx3;
+            c3 = -2.0 * dh * invdx3;
+        }
+        for (long long i = 0; i < n; ++i) {
+            const double v = x[i];
+            if (v < xl) out[i] = hl;
+            else if (v > xr) out[i] = hr;
+            else out[i] = order == 1 ? c0 + v * c1 : c0 + v * (c1 + v * (c2 + v * c3));
+        }
+    }
+    API_END
+}
+
+// FILL_BeamGeneratorMapBATHYMETRY (geometry/maps/BeamGeneratorMapF.ChF:51-166)
+int somar_bathymetry_beam_generator(double* out, long long n, const double* x, double Lx, double angle)
+{
+    API_BEGIN
+    SOMAR_CHECK(out && x && n >= 0 && Lx > 0.0, "somar_bathymetry_beam_generator: bad arguments");
+    const double lp = 0.009714, Bp = 0.01173, Pp = 0.0183542;   // Masoud's lab-scale ridge, the compiled-in PARAMETER set
+    const double sa = std::sin(angle), ca = std::cos(angle), ta = std::tan(angle);
+    const double l = lp * Lx, B = Bp * Lx, P = Pp * Lx;
+    const double lstar = l + (B + P) / ca;
+    const double C1 = -lstar * ca - B, C2 = -lstar * ca + B, C3 = -P, C4 = P, C5 = lstar * ca - B, C6 = lstar * ca + B;
+    const double b0 = 0.25 * ta * (B + lstar * ca) * (B + lstar * ca) / B;
+    const double b1 = -0.5 * ta * (B + lstar * ca) / B;
+    const double b2 = 0.25 * ta / B;
+    const double p0 = lstar * sa - 0.5 * ta * P;
+    const double p2 = -0.5 * ta / P;
+    for (long long i = 0; i < n; ++i) {
+        const double v = x[i];
+        if (v <= C1) out[i] = 0.0;
+        else if (C1 < v && v < C2) out[i] = b2 * v * v - b1 * v + b0;
+        else if (C2 <= v && v <= C3) out[i] = lstar * sa + ta * v;
+        else if (C3 < v && v < C4) out[i] = p2 * v * v + p0;
+        else if (C4 <= v && v <= C5) out[i] = lstar * sa - ta * v;
+        else if (C5 < v && v < C6) out[i] = b2 * v * v + b1 * v + b0;
+        else out[i] = 0.0;
+    }
     API_END
 }
 

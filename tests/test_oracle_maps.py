@@ -177,3 +177,28 @@ def test_twisted_map_type_1_defaults_converge_to_the_analytic_jacobian(oracle, s
     assert errs[1][0] < 0.3 * errs[0][0] and errs[1][0] < 1e-3
     # cell-centred, the default J IS the determinant of the differenced dx/dXi (the same face-coordinate differences)
     assert errs[0][1] < 1e-13 and errs[1][1] < 1e-13
+
+
+def test_analytic_bathymetries_of_ledge_and_beam_generator_maps(sm):
+    """The host helpers behind SOMAR_MAP_BATHYMETRIC's nodal depth (somar_bathymetry_ledge / _beam_generator, no GPU involved)
+    against the numpy restatement, plus what the shapes must satisfy: the ledge's cubic meets both plateaus with zero slope, the
+    ridge is even in x, continuous at its six break points, zero outside and peaks at l* sin(angle) - tan(angle) P / 2."""
+    from somar_amd import api as F
+    x = np.linspace(-0.3, 1.4, 3001)
+    for order in (1, 3):
+        got = F.ledge_bathymetry(x, None, order, 1.0, 0.4, 0.2, 0.9)
+        np.testing.assert_allclose(got, sm.ledge_bathymetry(x, order, 1.0, 0.4, 0.2, 0.9), rtol=1e-15, atol=0)
+        assert got[0] == 1.0 and got[-1] == 0.4 and np.abs(np.diff(got)).max() < 2e-3
+    cub = F.ledge_bathymetry(np.array([0.2, 0.2 + 1e-6, 0.9 - 1e-6, 0.9]), None, 3, 1.0, 0.4, 0.2, 0.9)
+    assert abs(cub[1] - cub[0]) < 1e-10 and abs(cub[3] - cub[2]) < 1e-10      # zero slope where the cubic meets the plateaus
+    bump = F.ledge_bathymetry(np.array([0.2, 0.7]), np.array([0.9, 0.9]), 3, 0.5, 0.4, 0.2, 0.9)
+    np.testing.assert_allclose(bump, [1.0, np.exp(-1.0)], rtol=1e-15)
+    Lx, ang = 40.5, np.deg2rad(21.0)
+    xs = np.linspace(-3.0, 3.0, 6001)
+    r = F.beam_generator_bathymetry(xs, Lx, ang)
+    np.testing.assert_allclose(r, sm.beam_generator_bathymetry(xs, Lx, ang), rtol=1e-15, atol=0)
+    np.testing.assert_allclose(r, r[::-1], rtol=0, atol=1e-14)                   # even
+    assert r[0] == 0.0 and r[-1] == 0.0 and np.abs(np.diff(r)).max() < 1e-3      # flat outside, continuous
+    lp, Bp, Pp = 0.009714, 0.01173, 0.0183542
+    lstar = lp * Lx + (Bp * Lx + Pp * Lx) / np.cos(ang)
+    assert abs(r.max() - (lstar * np.sin(ang) - 0.5 * np.tan(ang) * Pp * Lx)) < 1e-12
