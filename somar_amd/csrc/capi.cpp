@@ -3,6 +3,7 @@
 #include <random>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/somar_amd.h"
 #include "amr.h"
@@ -137,6 +138,74 @@ int somar_bathymetry_beam_generator(double* out, long long n, const double* x, d
         else if (C4 <= v && v <= C5) out[i] = lstar * sa - ta * v;
         else if (C5 < v && v < C6) out[i] = b2 * v * v + b1 * v + b0;
         else out[i] = 0.0;
+    }
+    API_END
+}
+
+// CubicSpline::solve (natural end conditions: lofbc = hifbc = 1e50) + CubicSpline::interp
+// (calculus/interpolation/CubicSpline.cpp:57-143, CubicSplineF.ChF:46-112)
+int somar_dem_cubic_spline(double* out, long long n, const double* x, int nd, const double* xd, const double* fd)
+{
+    API_BEGIN
+    SOMAR_CHECK(out && x && xd && fd && n >= 0 && nd >= 2, "somar_dem_cubic_spline: bad arguments");
+    std::vector<double> d2f(nd), u(nd);
+    const int hi = nd - 1;
+    u[0] = 0.0;
+    d2f[0] = 0.0;
+    for (int i = 1; i <= hi - 1; ++i) {
+        const double dxl = xd[i] - xd[i - 1], dxr = xd[i + 1] - xd[i];
+        const double dfl = fd[i] - fd[i - 1], dfr = fd[i + 1] - fd[i];
+        const double sig = dxl / (dxr + dxl);
+        const double p = sig * d2f[i - 1] + 2.0;
+        d2f[i] = (sig - 1.0) / p;
+        u[i] = (6.0 * (dfr / dxr - dfl / dxl) / (dxr + dxl) - sig * u[i - 1]) / p;
+    }
+    u[hi] = 0.0;
+    d2f[hi] = 0.0;
+    d2f[hi] = (u[hi] - d2f[hi] * u[hi - 1]) / (d2f[hi] * d2f[hi - 1] + 1.0);
+    for (int i = hi - 1; i >= 0; --i) d2f[i] = d2f[i] * d2f[i + 1] + u[i];
+    for (long long q = 0; q < n; ++q) {
+        const double v = x[q];
+        int klo = 0, khi = nd - 1;
+        while (khi - klo > 1) {
+            const int k = (khi + klo) >> 1;
+            if (xd[k] > v) khi = k; else klo = k;
+        }
+        const double xlo = xd[klo], xhi = xd[khi], dx = xhi - xlo;
+        SOMAR_CHECK(dx != 0.0, "somar_dem_cubic_spline: repeated abscissa");
+        const double A = (xhi - v) / dx, B = (v - xlo) / dx;
+        double f = A * fd[klo] + B * fd[khi];
+        const double C = A * (A * A - 1.0), D = B * (B * B - 1.0);
+        f += (C * d2f[klo] + D * d2f[khi]) * dx * dx / 6.0;
+        out[q] = f;
+    }
+    API_END
+}
+
+// BilinearInterp2DF (calculus/interpolation/BilinearInterpF.ChF), xdir = 0, ydir = 1
+int somar_dem_bilinear(double* out, long long n, const double* x, const double* y, int nx, int ny, const double* xd,
+                       const double* yd, const double* fd)
+{
+    API_BEGIN
+    SOMAR_CHECK(out && x && y && xd && yd && fd && n >= 0 && nx >= 1 && ny >= 1, "somar_dem_bilinear: bad arguments");
+    for (long long q = 0; q < n; ++q) {
+        const double xi = x[q], yj = y[q];
+        int ilo = 0, ihi = nx - 1;
+        while (ihi - ilo > 1) {
+            const int i = (ihi + ilo) / 2;
+            if (xd[i] > xi) ihi = i; else ilo = i;
+        }
+        int jlo = 0, jhi = ny - 1;
+        while (jhi - jlo > 1) {
+            const int j = (jhi + jlo) / 2;
+            if (yd[j] > yj) jhi = j; else jlo = j;
+        }
+        const double xlo = xd[ilo], xhi = xd[ihi], ylo = yd[jlo], yhi = yd[jhi];
+        const double fA = fd[ilo + (long long)nx * jlo], fB = fd[ihi + (long long)nx * jlo];
+        const double fC = fd[ilo + (long long)nx * jhi], fD = fd[ihi + (long long)nx * jhi];
+        const double u = xlo == xhi ? xi - xlo : (xi - xlo) / (xhi - xlo);
+        const double v = ylo == yhi ? yj - ylo : (yj - ylo) / (yhi - ylo);
+        out[q] = fA * (1 - u) * (1 - v) + fB * u * (1 - v) + fC * (1 - u) * v + fD * u * v;
     }
     API_END
 }

@@ -202,3 +202,25 @@ def test_analytic_bathymetries_of_ledge_and_beam_generator_maps(sm):
     lp, Bp, Pp = 0.009714, 0.01173, 0.0183542
     lstar = lp * Lx + (Bp * Lx + Pp * Lx) / np.cos(ang)
     assert abs(r.max() - (lstar * np.sin(ang) - 0.5 * np.tan(ang) * Pp * Lx)) < 1e-12
+
+
+def test_dem_interpolators_against_scipy():
+    """DEMMap's interpolation cores as host helpers: the natural cubic spline (CubicSpline::solve / interp, the Numerical
+    Recipes tridiagonal solve) against scipy's CubicSpline(bc_type="natural"), BilinearInterp2D against scipy's
+    RegularGridInterpolator -- independent implementations of the same mathematics; nodes reproduce the data exactly."""
+    from scipy.interpolate import CubicSpline, RegularGridInterpolator
+    from somar_amd import api as F
+    rng = np.random.default_rng(5)
+    xd = np.cumsum(rng.uniform(0.5, 1.5, 40))
+    fd = np.sin(0.3 * xd) + 0.1 * rng.standard_normal(40)
+    x = np.sort(rng.uniform(xd[0], xd[-1], 500))
+    got = F.dem_cubic_spline(x, xd, fd)
+    np.testing.assert_allclose(got, CubicSpline(xd, fd, bc_type="natural")(x), rtol=0, atol=2e-13)
+    np.testing.assert_allclose(F.dem_cubic_spline(xd, xd, fd), fd, rtol=0, atol=1e-15)
+    yd = np.cumsum(rng.uniform(0.5, 1.5, 30))
+    f2 = rng.standard_normal((40, 30))
+    px, py = rng.uniform(xd[0], xd[-1], 400), rng.uniform(yd[0], yd[-1], 400)
+    want = RegularGridInterpolator((xd, yd), f2, method="linear")(np.stack([px, py], axis=1))
+    np.testing.assert_allclose(F.dem_bilinear(px, py, xd, yd, f2), want, rtol=0, atol=2e-14)
+    gx, gy = np.meshgrid(xd, yd, indexing="ij")
+    np.testing.assert_allclose(F.dem_bilinear(gx.ravel(), gy.ravel(), xd, yd, f2), f2.ravel(), rtol=0, atol=1e-15)
