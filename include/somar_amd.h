@@ -49,7 +49,7 @@ extern "C" {
  * 6: + somar_amr_tga_step (composite MappedAMRTGA::oneStep); composite operations with heat coefficients installed no
  *    longer fail (the flux-register scales follow beta); somar_solver_set_vel_bc (inflow / outflow sides); somar_solver_set_metric_map (cylindrical and bathymetric
  *    metric producers on the device); somar_k_fillmappedlapdiag3d, somar_k_mappedaverage2 (kernel-level hooks); additions only */
-#define SOMAR_AMD_ABI_VERSION 10
+#define SOMAR_AMD_ABI_VERSION 11
 
 /* BCType codes, calculus/BCInterface/BCDescriptor.H:34-39 */
 #define SOMAR_BC_NONE (-1)
@@ -607,10 +607,16 @@ int somar_bathymetry_beam_generator(double* out, long long n, const double* x, d
  *        through (xd[q], fd[q]), q < nd (xd ascending), evaluated at x[0 .. n)   (Create_Level_DEM_2D)
  *   BilinearInterp2D              calculus/interpolation/BilinearInterp.cpp:37-119, BilinearInterpF.ChF   f on the tensor grid
  *        xd[0 .. nx) x yd[0 .. ny) (fd[i + nx * j]) evaluated at the points (x[q], y[q])   (Create_Level_DEM_3D, interpOrder 0)
- * HermiteInterp2D (interpOrder > 0) and the HDF5 reader stay with the caller. */
+ *   HermiteInterp2D               calculus/interpolation/HermiteInterp.cpp:28-146, HermiteInterpF.ChF:38-215   the same grid with
+ *        interpOrder > 0: df/dx, df/dy by the centred (one-sided at the ends) differences of Create_Level_DEM_3D
+ *        (DEMMap.cpp:222-289), then the "simplified Hermite interpolant" as written (the nodal derivatives enter the cubic basis
+ *        functions unscaled by the cell width)
+ * The HDF5 reader stays with the caller. */
 int somar_dem_cubic_spline(double* out, long long n, const double* x, int nd, const double* xd, const double* fd);
 int somar_dem_bilinear(double* out, long long n, const double* x, const double* y, int nx, int ny, const double* xd,
                        const double* yd, const double* fd);
+int somar_dem_hermite(double* out, long long n, const double* x, const double* y, int nx, int ny, const double* xd,
+                      const double* yd, const double* fd);
 
 /* Diagnostics, no reference counterpart: what this device streams for a given mix of streams, in GB/s of algorithmic bytes
  * -- kind 0 copy (16 B/cell), 1 read (8 B/cell), 2 six reads + one write (56 B/cell: the fused GSRB sweep's mix without

@@ -110,6 +110,7 @@ _SIGS = {
     "somar_bathymetry_beam_generator": [_PD, C.c_longlong, _PD, C.c_double, C.c_double],
     "somar_dem_cubic_spline": [_PD, C.c_longlong, _PD, C.c_int, _PD, _PD],
     "somar_dem_bilinear": [_PD, C.c_longlong, _PD, _PD, C.c_int, C.c_int, _PD, _PD, _PD],
+    "somar_dem_hermite": [_PD, C.c_longlong, _PD, _PD, C.c_int, C.c_int, _PD, _PD, _PD],
     "somar_vel_upload": [_H, C.c_int, C.c_int, _PD],
     "somar_vel_download": [_H, C.c_int, C.c_int, _PD],
     "somar_vel_wall_bc": [_H],
@@ -959,16 +960,18 @@ def dem_cubic_spline(x, xd, fd):
     return out
 
 
-def dem_bilinear(x, y, xd, yd, fd):
-    """DEMMap's 3-D path with interpOrder 0: BilinearInterp2D of fd[i, j] on the tensor grid xd x yd at the points (x, y)"""
+def dem_bilinear(x, y, xd, yd, fd, hermite=False):
+    """DEMMap's 3-D path: BilinearInterp2D (interpOrder 0) or, hermite=True, Create_Level_DEM_3D's difference tables + HermiteInterp2D
+    (interpOrder > 0) of fd[i, j] on the tensor grid xd x yd at the points (x, y)"""
     xa = np.ascontiguousarray(x, dtype=np.float64)
     ya = np.ascontiguousarray(np.broadcast_to(y, xa.shape), dtype=np.float64)
     xda, yda = np.ascontiguousarray(xd, dtype=np.float64), np.ascontiguousarray(yd, dtype=np.float64)
     fda = np.asfortranarray(fd, dtype=np.float64)          # i fastest
     assert fda.shape == (xda.size, yda.size)
     out = np.empty_like(xa)
-    _ck(lib().somar_dem_bilinear(out.ctypes.data_as(_PD), xa.size, xa.ctypes.data_as(_PD), ya.ctypes.data_as(_PD), xda.size,
-                                 yda.size, xda.ctypes.data_as(_PD), yda.ctypes.data_as(_PD), fda.ctypes.data_as(_PD)))
+    fn = lib().somar_dem_hermite if hermite else lib().somar_dem_bilinear
+    _ck(fn(out.ctypes.data_as(_PD), xa.size, xa.ctypes.data_as(_PD), ya.ctypes.data_as(_PD), xda.size,
+           yda.size, xda.ctypes.data_as(_PD), yda.ctypes.data_as(_PD), fda.ctypes.data_as(_PD)))
     return out
 
 

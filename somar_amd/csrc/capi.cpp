@@ -210,6 +210,54 @@ int somar_dem_bilinear(double* out, long long n, const double* x, const double* 
     API_END
 }
 
+// Create_Level_DEM_3D's derivative tables (DEMMap.cpp:222-289) + HermiteInterp2DF (HermiteInterpF.ChF:38-215), xdir = 0, ydir = 1
+int somar_dem_hermite(double* out, long long n, const double* x, const double* y, int nx, int ny, const double* xd,
+                      const double* yd, const double* fd)
+{
+    API_BEGIN
+    SOMAR_CHECK(out && x && y && xd && yd && fd && n >= 0 && nx >= 2 && ny >= 2, "somar_dem_hermite: bad arguments");
+    auto F = [&](int i, int j) { return fd[i + (long long)nx * j]; };
+    std::vector<double> fx((size_t)nx * ny), fy((size_t)nx * ny);
+    for (int j = 0; j < ny; ++j) {
+        fx[0 + (size_t)nx * j] = (F(1, j) - F(0, j)) / (xd[1] - xd[0]);
+        for (int i = 1; i < nx - 1; ++i) fx[i + (size_t)nx * j] = (F(i + 1, j) - F(i - 1, j)) / (xd[i + 1] - xd[i - 1]);
+        fx[nx - 1 + (size_t)nx * j] = (F(nx - 1, j) - F(nx - 2, j)) / (xd[nx - 1] - xd[nx - 2]);
+    }
+    for (int i = 0; i < nx; ++i) {
+        fy[i] = (F(i, 1) - F(i, 0)) / (yd[1] - yd[0]);
+        for (int j = 1; j < ny - 1; ++j) fy[i + (size_t)nx * j] = (F(i, j + 1) - F(i, j - 1)) / (yd[j + 1] - yd[j - 1]);
+        fy[i + (size_t)nx * (ny - 1)] = (F(i, ny - 1) - F(i, ny - 2)) / (yd[ny - 1] - yd[ny - 2]);
+    }
+    for (long long q = 0; q < n; ++q) {
+        const double xi = x[q], yj = y[q];
+        int ilo = 0, ihi = nx - 1;
+        while (ihi - ilo > 1) {
+            const int i = (ihi + ilo) / 2;
+            if (xd[i] > xi) ihi = i; else ilo = i;
+        }
+        int jlo = 0, jhi = ny - 1;
+        while (jhi - jlo > 1) {
+            const int j = (jhi + jlo) / 2;
+            if (yd[j] > yj) jhi = j; else jlo = j;
+        }
+        const double xlo = xd[ilo], xhi = xd[ihi], ylo = yd[jlo], yhi = yd[jhi];
+        const size_t A = ilo + (size_t)nx * jlo, B = ihi + (size_t)nx * jlo, C = ilo + (size_t)nx * jhi, D = ihi + (size_t)nx * jhi;
+        const double fA = fd[A], fB = fd[B], fC = fd[C], fD = fd[D];
+        const double fxA = fx[A], fxB = fx[B], fxC = fx[C], fxD = fx[D];
+        const double fyA = fy[A], fyB = fy[B], fyC = fy[C], fyD = fy[D];
+        const double u = xlo == xhi ? xi - xlo : (xi - xlo) / (xhi - xlo);
+        const double h4u = (u - 1.0) * u * u, h3u = ((u - 2.0) * u + 1.0) * u, h2u = (3.0 - 2.0 * u) * u * u, h1u = 1.0 - h2u;
+        const double v = ylo == yhi ? yj - ylo : (yj - ylo) / (yhi - ylo);
+        const double h4v = (v - 1.0) * v * v, h3v = ((v - 2.0) * v + 1.0) * v, h2v = (3.0 - 2.0 * v) * v * v, h1v = 1.0 - h2v;
+        const double fAB = fA * h1u + fB * h2u + fxA * h3u + fxB * h4u;
+        const double fCD = fC * h1u + fD * h2u + fxC * h3u + fxD * h4u;
+        const double fAC = fA * h1v + fC * h2v + fyA * h3v + fyC * h4v;
+        const double fBD = fB * h1v + fD * h2v + fyB * h3v + fyD * h4v;
+        out[q] = fAB * h1v + fCD * h2v + fAC * h1u + fBD * h2u - fA * h1u * h1v - fB * h2u * h1v - fC * h1u * h2v - fD * h2u * h2v;
+    }
+    API_END
+}
+
 int somar_device_count(int* count)
 {
     API_BEGIN

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = C.CDLL(built_lib)
     for name in _header_functions():
         assert hasattr(lib, name), "missing export " + name
-    assert lib.somar_abi_version() == 10
+    assert lib.somar_abi_version() == 11
 
 
 def test_no_cpu_fallback_without_gpu(built_lib):

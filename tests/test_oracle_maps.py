@@ -224,3 +224,39 @@ def test_dem_interpolators_against_scipy():
     np.testing.assert_allclose(F.dem_bilinear(px, py, xd, yd, f2), want, rtol=0, atol=2e-14)
     gx, gy = np.meshgrid(xd, yd, indexing="ij")
     np.testing.assert_allclose(F.dem_bilinear(gx.ravel(), gy.ravel(), xd, yd, f2), f2.ravel(), rtol=0, atol=1e-15)
+
+
+def test_dem_hermite_interpolant_as_the_reference_writes_it():
+    """HermiteInterp2D with Create_Level_DEM_3D's difference tables: nodes reproduce the data; on a UNIT-spaced grid (where the
+    reference's unscaled nodal derivatives are the right ones) a plane a + b x + c y is reproduced exactly (the simplified
+    interpolant blends its cubic Hermite edges with smoothstep weights, so a twist term x y is not); and a numpy restatement of the same
+    statements agrees to roundoff on a ragged grid."""
+    from somar_amd import api as F
+    rng = np.random.default_rng(8)
+    xd, yd = np.arange(12.0), np.arange(9.0)
+    gx, gy = np.meshgrid(xd, yd, indexing="ij")
+    f = 1.5 - 0.7 * gx + 0.3 * gy
+    px, py = rng.uniform(0, 11, 300), rng.uniform(0, 8, 300)
+    np.testing.assert_allclose(F.dem_bilinear(px, py, xd, yd, f, hermite=True), 1.5 - 0.7 * px + 0.3 * py, rtol=0, atol=1e-13)
+    xr, yr = np.cumsum(rng.uniform(0.5, 1.5, 14)), np.cumsum(rng.uniform(0.5, 1.5, 11))
+    g = rng.standard_normal((14, 11))
+    rx, ry = np.meshgrid(xr, yr, indexing="ij")
+    np.testing.assert_allclose(F.dem_bilinear(rx.ravel(), ry.ravel(), xr, yr, g, hermite=True), g.ravel(), rtol=0, atol=1e-14)
+    # the same statements in numpy
+    fx, fy = np.empty_like(g), np.empty_like(g)
+    fx[0] = (g[1] - g[0]) / (xr[1] - xr[0]); fx[-1] = (g[-1] - g[-2]) / (xr[-1] - xr[-2])
+    fx[1:-1] = (g[2:] - g[:-2]) / (xr[2:] - xr[:-2])[:, None]
+    fy[:, 0] = (g[:, 1] - g[:, 0]) / (yr[1] - yr[0]); fy[:, -1] = (g[:, -1] - g[:, -2]) / (yr[-1] - yr[-2])
+    fy[:, 1:-1] = (g[:, 2:] - g[:, :-2]) / (yr[2:] - yr[:-2])[None, :]
+    qx, qy = rng.uniform(xr[0], xr[-1], 200), rng.uniform(yr[0], yr[-1], 200)
+    il = np.clip(np.searchsorted(xr, qx, side="right") - 1, 0, 12); jl = np.clip(np.searchsorted(yr, qy, side="right") - 1, 0, 9)
+    u = (qx - xr[il]) / (xr[il + 1] - xr[il]); v = (qy - yr[jl]) / (yr[jl + 1] - yr[jl])
+    h = lambda t: (1.0 - (3.0 - 2.0 * t) * t * t, (3.0 - 2.0 * t) * t * t, ((t - 2.0) * t + 1.0) * t, (t - 1.0) * t * t)
+    h1u, h2u, h3u, h4u = h(u); h1v, h2v, h3v, h4v = h(v)
+    A, B, Cc, D = (il, jl), (il + 1, jl), (il, jl + 1), (il + 1, jl + 1)
+    fAB = g[A] * h1u + g[B] * h2u + fx[A] * h3u + fx[B] * h4u
+    fCD = g[Cc] * h1u + g[D] * h2u + fx[Cc] * h3u + fx[D] * h4u
+    fAC = g[A] * h1v + g[Cc] * h2v + fy[A] * h3v + fy[Cc] * h4v
+    fBD = g[B] * h1v + g[D] * h2v + fy[B] * h3v + fy[D] * h4v
+    want = fAB * h1v + fCD * h2v + fAC * h1u + fBD * h2u - g[A] * h1u * h1v - g[B] * h2u * h1v - g[Cc] * h1u * h2v - g[D] * h2u * h2v
+    np.testing.assert_allclose(F.dem_bilinear(qx, qy, xr, yr, g, hermite=True), want, rtol=0, atol=1e-13)
